@@ -1,0 +1,165 @@
+"""Seeded synthetic inputs: a counter-based RNG defined here, so the GPU box and
+the build container generate bit-identical waveforms, labels and filler weights without relying on
+torch/NumPy generator internals.
+
+No network => no real checkpoint (`model_weights/` holds LFS stubs) and no dataset; every parity
+test and the benchmark run on these.
+"""
+import zlib
+
+import numpy as np
+import torch
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+    z = x
+    z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+    z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+    return z ^ (z >> np.uint64(31))
+
+
+def uniform(key, n, seed=0):
+    """n doubles in (0,1), a pure function of (key, seed, index)."""
+    with np.errstate(over='ignore'):
+        base = np.uint64(zlib.crc32(str(key).encode()) & 0xFFFFFFFF) * np.uint64(0x100000001B3) + np.uint64(seed)
+        idx = np.arange(n, dtype=np.uint64)
+        h = _splitmix64(_splitmix64(base) + idx)
+    return ((h >> np.uint64(11)).astype(np.float64) + 0.5) * (1.0 / 9007199254740992.0)
+
+
+def normal(key, n, seed=0):
+    """n standard normals (Box-Muller on two independent counter streams)."""
+    u1 = uniform(('n1', key), n, seed)
+    u2 = uniform(('n2', key), n, seed)
+    return np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+
+
+# --------------------------------------------------------------------------- waveforms
+def clip_pcm16(index, n_samples=66150, sr=22050):
+    """One synthetic 3 s mono clip as int16 PCM: low-level pink-ish noise plus 1-3 tones/chirps
+    between 1 and 10 kHz, seed = clip index."""
+    t = np.arange(n_samples) / sr
+    from scipy.signal import lfilter
+    white = normal(('w', index), n_samples)
+    a = 0.85
+    lp = lfilter([1 - a], [1, -a], white)          # one-pole low-pass => gently falling spectrum
+    y = 0.03 * white + 0.06 * lp
+    u = uniform(('c', index), 16)
+    n_calls = 1 + int(u[0] * 3)
+    for j in range(n_calls):
+        f0 = 1000 + 8000 * u[1 + 4 * j]
+        f1 = f0 * (0.8 + 0.5 * u[2 + 4 * j])
+        t0 = 0.2 + 2.2 * u[3 + 4 * j]
+        dur = 0.08 + 0.3 * u[4 + 4 * j]
+        env = np.exp(-0.5 * ((t - t0) / (dur / 2.5)) ** 2)
+        ph = 2 * np.pi * (f0 * (t - t0) + 0.5 * (f1 - f0) / dur * (t - t0) ** 2)
+        y = y + 0.35 * env * np.sin(ph)
+    y = np.clip(y, -0.999, 0.999)
+    return np.round(y * 32767.0).astype(np.int16)
+
+
+def clip_batch_pcm16(start, count, n_samples=66150, sr=22050):
+    return np.stack([clip_pcm16(start + i, n_samples, sr) for i in range(count)])
+
+
+def write_wav(path, pcm16, sr=22050):
+    import wave
+    with wave.open(path, 'wb') as f:
+        f.setnchannels(1), f.setsampwidth(2), f.setframerate(sr)
+        f.writeframes(np.asarray(pcm16, dtype='<i2').tobytes())
+
+
+# --------------------------------------------------------------------------- images / labels
+def image_batch(start, count, h=375, w=1024):
+    """Synthetic [0,1] spectrogram-like images for detector-only tests (no front end)."""
+    out = np.empty((count, h, w), dtype=np.float32)
+    for i in range(count):
+        base = uniform(('img', start + i), h * w).reshape(h, w)
+        yy, xx = np.mgrid[0:h, 0:w]
+        u = uniform(('blob', start + i), 12)
+        img = 0.25 * base
+        for j in range(3):
+            cx, cy = 60 + 900 * u[4 * j], 30 + 300 * u[4 * j + 1]
+            sx, sy = 15 + 60 * u[4 * j + 2], 8 + 30 * u[4 * j + 3]
+            img = img + 0.7 * np.exp(-0.5 * (((xx - cx) / sx) ** 2 + ((yy - cy) / sy) ** 2))
+        out[i] = np.clip(img, 0, 1).astype(np.float32)
+    return out
+
+
+def label_batch(start, count, num_classes=150, img_w=1024, img_h=375):
+    """1-3 boxes per clip: x1 in [0,900], y1 in [0,300], w in [20,120], h in [20,70], class in 1..nc.
+    Returns (bb_coord f32 [sum,4], bird_ids f32 [sum], lengths list) like `collate_fn`
+    (reference nets_utils.py:159-166; class ids are float, Appendix C-10)."""
+    boxes, ids, lengths = [], [], []
+    for i in range(count):
+        u = uniform(('lab', start + i), 16)
+        n = 1 + int(u[0] * 3)
+        for j in range(n):
+            x1 = np.floor(900 * u[1 + 5 * j])
+            y1 = np.floor(300 * u[2 + 5 * j])
+            w = np.floor(20 + 100 * u[3 + 5 * j])
+            h = np.floor(20 + 50 * u[4 + 5 * j])
+            boxes.append([x1, y1, min(x1 + w, img_w - 1), min(y1 + h, img_h - 1)])
+            ids.append(1 + int(u[5 + 5 * j] * num_classes) % num_classes)
+        lengths.append(n)
+    return (torch.tensor(boxes, dtype=torch.float32), torch.tensor(ids, dtype=torch.float32), lengths)
+
+
+# --------------------------------------------------------------------------- filler weights
+def fill_state_dict(shapes, seed=0):
+    """Deterministic filler for a {name: shape} mapping (SURVEY Appendix B layout): conv/linear
+    weights ~ N(0, gain/fan_in), BatchNorm weight ~ 1, running_var ~ 1, small biases/means; the last
+    norm of every residual branch is damped so activations stay O(1) through 16 bottlenecks.
+    Returns {name: torch.float32 tensor} (int64 for num_batches_tracked)."""
+    out = {}
+    for name, shape in shapes.items():
+        shape = tuple(shape)
+        n = int(np.prod(shape)) if len(shape) else 1
+        if name.endswith('num_batches_tracked'):
+            out[name] = torch.zeros((), dtype=torch.int64)
+            continue
+        leaf = name.rsplit('.', 1)[-1]
+        parent = name.rsplit('.', 1)[0]
+        is_norm = ('.bn' in name or '.norm' in name or 'downsample.1' in name)
+        if is_norm:
+            if leaf == 'weight':
+                scale = 0.35 if parent.endswith('bn3') else 1.0
+                v = scale * (1.0 + 0.1 * normal(name, n, seed))
+            elif leaf == 'bias':
+                v = 0.05 * normal(name, n, seed)
+            elif leaf == 'running_mean':
+                v = 0.05 * normal(name, n, seed)
+            else:  # running_var
+                v = 0.9 + 0.2 * uniform(name, n, seed)
+        elif leaf == 'bias':
+            v = 0.02 * normal(name, n, seed)
+            if 'bbox_classif_layer' in name:
+                v = 0.5 * normal(name, n, seed)
+                v[0] += 2.5                              # a fair share of RoIs should come out as background
+        else:
+            fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
+            gain = 2.0
+            if 'init_conv' in name:
+                v = 1.0 + 0.2 * normal(name, n, seed)
+                out[name] = torch.from_numpy(v.astype(np.float32).reshape(shape))
+                continue
+            if 'attention_modules' in name:
+                gain = 1.0
+            if 'final_projection' in name:
+                gain = 0.25
+            if 'fpn.pt_wise' in name:
+                gain = 0.5
+            if 'fpn.out_convs' in name:
+                gain = 0.1
+            if 'cls_score' in name:
+                gain = 1.5
+            if 'bbox_reg' in name:
+                gain = 0.04
+            if 'bbox_classif_layer' in name:
+                gain = 12.0
+            v = np.sqrt(gain / fan_in) * normal(name, n, seed)
+        out[name] = torch.from_numpy(np.asarray(v, dtype=np.float32).reshape(shape))
+    return out

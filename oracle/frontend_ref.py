@@ -1,0 +1,162 @@
+"""TEST INFRASTRUCTURE ONLY — CPU restatement (numpy, float64) of the spectrogram front end.
+
+Follows reference nbm_model/nbm_datasets/prepare_dataset.py `File_Processor`
+(:92-294): load -> [resample to 44.1 kHz] -> STFT(n_fft=win=1324, hop=132, periodic Hann,
+center=True) -> |.| -> 20 log10(max(floor, .)) -> rows [16:391] -> per-file min/max normalise
+-> 1024-column windows, hop 819, last one reflect-padded.
+
+PARITY UNPINNED for two third-party steps that are absent from /root/reference and from this
+image:
+  * `librosa.stft` (prepare_dataset.py:237; version unpinned; pad_mode default 'constant' in
+    librosa >= 0.10, 'reflect' before).  Restated from its documented semantics; pinned only by
+    analytic known-answer tests (pure tone -> peak row, Parseval, silence -> NaN) in
+    tests/test_frontend_oracle.py.  `pad_mode` is a switch; default 'constant'.
+  * the `ffmpeg -ar 44100 -acodec pcm_s16le` resample (prepare_dataset.py:175-178).  The build
+    owns a documented 2x half-band polyphase up-sampler in exact integer arithmetic
+    (`upsample2x_pcm16`), bit-reproducible on any device.
+Only tests, `__graft_entry__.smoke()` and `bench.py`'s cpu_baseline leg may import this module.
+"""
+import wave
+
+import numpy as np
+import scipy.fft
+
+FREQ = 44100          # prepare_dataset.py:98
+H_PIX = 375           # :96
+LOW_FREQ = 500        # :97
+
+
+def constants(freq_accuracy=33.3, dt=0.003, overlap_spectro=0.2, w_pix=1024):
+    """process_file constants, prepare_dataset.py:114-138."""
+    c = {}
+    c['W_PIX'] = w_pix
+    c['HOP_SPECTRO'] = int((1 - overlap_spectro) * w_pix)
+    c['WIN_LENGTH'] = int(FREQ / freq_accuracy)
+    c['HOP_LENGTH'] = int(FREQ * dt)
+    overlap_fft = np.round(1 - c['HOP_LENGTH'] / c['WIN_LENGTH'], 3)
+    c['FREQ_ACCURACY'] = FREQ / c['WIN_LENGTH']
+    c['DT'] = int((1 - overlap_fft) * c['WIN_LENGTH']) / FREQ
+    c['LOW_IDX'] = 1 + int(LOW_FREQ / c['FREQ_ACCURACY'])
+    c['HIGH_IDX'] = c['LOW_IDX'] + H_PIX
+    c['LOW_FREQ'] = (c['LOW_IDX'] - 1) * c['FREQ_ACCURACY']
+    c['HIGH_FREQ'] = (c['HIGH_IDX'] - 1) * c['FREQ_ACCURACY']
+    return c
+
+
+# --------------------------------------------------------------------------- F1: load (+ resample)
+def read_wav_pcm16(path):
+    """mono/stereo 16-bit PCM wav -> (int16 [n] (channel mean, as librosa.load mono=True), sr)."""
+    with wave.open(path, 'rb') as f:
+        assert f.getsampwidth() == 2, 'only 16-bit PCM is supported'
+        sr, nch, n = f.getframerate(), f.getnchannels(), f.getnframes()
+        x = np.frombuffer(f.readframes(n), dtype='<i2').reshape(-1, nch)
+    return (x[:, 0] if nch == 1 else np.round(x.astype(np.float64).mean(1)).astype(np.int16)), sr
+
+
+UP_TAPS = 16
+
+
+def upsample2x_coeffs():
+    """Q15 odd-phase coefficients of the half-band windowed-sinc interpolator: h[k] =
+    sinc(k+1/2) * kaiser(beta=8), k = 0..15 (symmetric), scaled so that 2*sum(h) = 32768."""
+    k = np.arange(UP_TAPS, dtype=np.float64) + 0.5
+    h = np.sinc(k) * np.i0(8.0 * np.sqrt(1 - (k / UP_TAPS) ** 2)) / np.i0(8.0)
+    h = h / (2 * h.sum())
+    q = np.round(h * 32768).astype(np.int64)
+    q[0] += 16384 - q.sum()                                   # exact unity DC gain
+    return q
+
+
+def upsample2x_pcm16(x):
+    """22.05 kHz -> 44.1 kHz.  Even output samples are the input samples; odd ones are the
+    half-band interpolation in exact integer arithmetic: (sum_k hq[k]*(x[n-k]+x[n+1+k]) + 2^14) >> 15,
+    saturated to int16.  Samples outside the clip are zero."""
+    x = np.asarray(x, dtype=np.int64)
+    n = len(x)
+    hq = upsample2x_coeffs()
+    xp = np.concatenate([np.zeros(UP_TAPS, np.int64), x, np.zeros(UP_TAPS + 1, np.int64)])
+    acc = np.zeros(n, dtype=np.int64)
+    for k in range(UP_TAPS):
+        acc += hq[k] * (xp[UP_TAPS - k:UP_TAPS - k + n] + xp[UP_TAPS + 1 + k:UP_TAPS + 1 + k + n])
+    odd = np.clip((acc + 16384) >> 15, -32768, 32767)
+    out = np.empty(2 * n, dtype=np.int16)
+    out[0::2] = x
+    out[1::2] = odd
+    return out
+
+
+def load(path):
+    """File_Processor.load prepare_dataset.py:160-184 -> float32 in [-1,1) at 44.1 kHz."""
+    pcm, sr = read_wav_pcm16(path)
+    if sr == FREQ:
+        pass
+    elif sr * 2 == FREQ:
+        pcm = upsample2x_pcm16(pcm)
+    else:
+        raise NotImplementedError(f'sample rate {sr}: only 44100 and 22050 Hz are supported')
+    return pcm.astype(np.float32) / np.float32(32768.0)
+
+
+# --------------------------------------------------------------------------- F3: spectrogram
+def hann_periodic(n):
+    return 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n) / n)
+
+
+def stft_mag(y, n_fft, hop, pad_mode='constant'):
+    """|librosa.stft(y, n_fft, hop_length=hop)| with librosa defaults (win_length=n_fft, periodic Hann,
+    center=True): [1+n_fft//2, 1+len(y)//hop] float64."""
+    y = np.asarray(y, dtype=np.float64)
+    yp = np.pad(y, n_fft // 2, mode=pad_mode)
+    n_frames = 1 + (len(yp) - n_fft) // hop
+    idx = np.arange(n_fft)[None, :] + hop * np.arange(n_frames)[:, None]
+    frames = yp[idx] * hann_periodic(n_fft)[None, :]
+    return np.abs(scipy.fft.rfft(frames, axis=1)).T
+
+
+def amp_to_db(x, min_level_db=-100):
+    """prepare_dataset.py:228-230 (floor = exp(-100/20*ln10) = 9.99999999999998e-06, Appendix C-7)."""
+    min_level = np.exp(min_level_db / 20 * np.log(10))
+    return 20 * np.log10(np.maximum(min_level, x))
+
+
+def spectrogram(y, c, pad_mode='constant'):
+    """File_Processor.spectrogram prepare_dataset.py:233-252: STFT in chunks of 5e7 samples, dB, crop,
+    min/max over the WHOLE file.  Returns list of float64 [375, L_k] in [0,1]."""
+    max_l = int(5e7)
+    parts = []
+    for k in range(int(len(y) / max_l) + 1):
+        m = stft_mag(y[k * max_l:(k + 1) * max_l], c['WIN_LENGTH'], c['HOP_LENGTH'], pad_mode)
+        parts.append(amp_to_db(m)[c['LOW_IDX']:c['HIGH_IDX'], :])
+    s_max = max(p.max() for p in parts)
+    s_min = min(p.min() for p in parts)
+    with np.errstate(invalid='ignore', divide='ignore'):
+        return [(p - s_min) / (s_max - s_min) for p in parts]
+
+
+# --------------------------------------------------------------------------- F4: windows
+def split_power_spec(parts, c):
+    """File_Processor.split_power_spec prepare_dataset.py:255-294 (labels=None branch)."""
+    spec = np.concatenate(parts, axis=1)            # chunk-boundary bookkeeping (:263-278) == slicing the concat
+    L = spec.shape[1]
+    W, hop = c['W_PIX'], c['HOP_SPECTRO']
+    imgs = [spec[:, k * hop:k * hop + W] for k in range(max(1, int(1 + np.ceil((L - W) / hop))))]
+    if imgs[-1].shape[1] < W:
+        empty = L - (L - W)                         # max_pix = max_l - W_PIX (:285) => empty_width = W_PIX
+        while imgs[-1].shape[1] < W:
+            pad = max(1, min(empty, W - imgs[-1].shape[1]))
+            imgs[-1] = np.pad(imgs[-1], ((0, 0), (0, pad)), mode='reflect')
+            empty += pad
+    return imgs
+
+
+def process_waveform(y, pad_mode='constant', **kw):
+    """process_file prepare_dataset.py:108-157 from an already loaded 44.1 kHz float waveform.
+    Returns (list of float32 [375,1024], meta dict with W_PIX, HOP_SPECTRO, spectrogram_length)."""
+    c = constants(**kw)
+    parts = spectrogram(y, c, pad_mode)
+    c['spectrogram_length'] = int(sum(p.shape[1] for p in parts))
+    return [im.astype(np.float32) for im in split_power_spec(parts, c)], c
+
+
+def process_file(path, pad_mode='constant', **kw):
+    return process_waveform(load(path), pad_mode, **kw)
