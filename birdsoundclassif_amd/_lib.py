@@ -1,0 +1,102 @@
+"""ctypes binding of libnbm_hip.so (C ABI: include/nbm_hip.h).
+
+There is NO fallback: if the shared library is missing or a symbol cannot be resolved the import of
+the op layer fails loudly (a silent eager/CPU path would void every parity claim).
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libnbm_hip.so')
+CSRC = os.path.join(_HERE, 'csrc')
+
+_lib = None
+
+
+class GemmDesc(C.Structure):
+    """struct nbm_gemm_desc (include/nbm_hip.h)."""
+    _fields_ = [('x', C.c_void_p), ('w', C.c_void_p), ('y', C.c_void_p),
+                ('scale', C.c_void_p), ('shift', C.c_void_p), ('residual', C.c_void_p),
+                ('x_gs', C.c_int64), ('w_gs', C.c_int64), ('y_gs', C.c_int64), ('res_gs', C.c_int64),
+                ('groups', C.c_int),
+                ('B', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cin', C.c_int),
+                ('N', C.c_int),
+                ('kh', C.c_int), ('kw', C.c_int), ('stride', C.c_int), ('pad', C.c_int),
+                ('Ho', C.c_int), ('Wo', C.c_int),
+                ('x_ld', C.c_int), ('w_ld', C.c_int), ('y_ld', C.c_int), ('res_ld', C.c_int),
+                ('alpha', C.c_float), ('act', C.c_int), ('shift_per_row', C.c_int)]
+
+
+class RoiDesc(C.Structure):
+    """struct nbm_roi_desc (include/nbm_hip.h)."""
+    _fields_ = [('fmap', C.c_void_p * 5), ('fh', C.c_int * 5), ('fw', C.c_int * 5),
+                ('n_levels', C.c_int), ('C', C.c_int),
+                ('rois', C.c_void_p), ('n_roi', C.c_void_p), ('B', C.c_int), ('roi_cap', C.c_int),
+                ('pe_f', C.c_void_p), ('pe_t', C.c_void_p), ('img_h', C.c_int), ('img_w', C.c_int),
+                ('pool', C.c_void_p), ('pe', C.c_void_p), ('level', C.c_void_p)]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> argtypes (restype is int unless noted); must list every symbol of include/nbm_hip.h
+SIGNATURES = {
+    'nbm_gemm_conv': [C.POINTER(GemmDesc), _P],
+    'nbm_pcm16_to_wave': [_P, _L, _I, _I, _I, _P, _P, _L, _I, _P],
+    'nbm_minmax_init': [_P, _I, _P],
+    'nbm_stft_db': [_P, _L, _I, _I, _I, _P, _I, _I, _I, _F, _P, _L, _I, _P, _P],
+    'nbm_spec_windows': [_P, _L, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P],
+    'nbm_init_conv': [_P, _L, _P, _P, _I, _P, _P],
+    'nbm_maxpool3x3s2': [_P, _I, _I, _I, _I, _P, _I, _I, _P],
+    'nbm_upsample_bilinear_add': [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P],
+    'nbm_softmax_rows': [_P, _L, _I, _L, _P],
+    'nbm_dwconv3x3': [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _L, _P, _I, _I, _P],
+    'nbm_silu': [_P, _P, _L, _P],
+    'nbm_pair_softmax': [_P, _L, _I, _I, _P, _I, _P],
+    'nbm_rpn_decode': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
+    'nbm_rpn_select': [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P],
+    'nbm_nms_batched': [_P, _P, _P, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P],
+    'nbm_roi_pool': [C.POINTER(RoiDesc), _P],
+    'nbm_rcnn_post': [_P, _P, _I, _I, _P, _P, _I, _I, _I, _F, _F, _I, _P, _P, _P],
+}
+
+
+def build(verbose=False):
+    """Compile libnbm_hip.so in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(['make', '-C', CSRC, '-j4'], capture_output=True, text=True)
+    if verbose or r.returncode:
+        print(r.stdout[-4000:], r.stderr[-4000:])
+    if r.returncode:
+        raise RuntimeError('building libnbm_hip.so failed')
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                           '(the NBM hot path has no CPU / eager fallback)')
+    lib = C.CDLL(LIB_PATH)
+    lib.nbm_version.restype = C.c_char_p
+    lib.nbm_version.argtypes = []
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)            # AttributeError => loud failure on a missing symbol
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+class NbmHipError(RuntimeError):
+    pass
+
+
+_CODES = {-1: 'NBM_EINVAL (bad argument / shape)', -2: 'NBM_EALIGN (pointer or pitch not 16-byte aligned)',
+          -3: 'NBM_EUNSUPPORTED'}
+
+
+def check(rc, name):
+    if rc != 0:
+        raise NbmHipError(f'{name} failed: {_CODES.get(rc, f"hipError_t {rc}")}')

@@ -1,0 +1,463 @@
+// Proposal / RoI / detection stages of the NBM detector on device: box decoding, top-N selection,
+// greedy NMS, RoI pooling (+ separable positional encoding) and the FastRCNN eval post-processing.
+// Integer / sort / index work: results are bit-exact against the oracle for identical inputs, so
+// floating-point contraction is disabled wherever a value is rounded to a pixel coordinate or compared
+// with a threshold (torch CPU evaluates a*b+c as two rounded operations).
+#include "nbm_common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+// bbox_reg_to_coord (reference nets_utils.py:169-186) + clip (layers.py:279-280)
+__device__ __forceinline__ void decode_clip(const float* d, const float* a, int img_w, int img_h, float* o) {
+  const float wa = (a[2] - a[0]) + 1.0f, ha = (a[3] - a[1]) + 1.0f;
+  const float xa = a[0] + 0.5f * wa, ya = a[1] + 0.5f * ha;
+  const float x = (d[0] * wa) + xa, y = (d[1] * ha) + ya;
+  const float w = expf(d[2]) * wa, h = expf(d[3]) * ha;
+  const float xm = (float)(img_w - 1), ym = (float)(img_h - 1);
+  o[0] = fminf(fmaxf(rintf(x - 0.5f * w), 0.f), xm);
+  o[1] = fminf(fmaxf(rintf(y - 0.5f * h), 0.f), ym);
+  o[2] = fminf(fmaxf(rintf(x + 0.5f * w), 0.f), xm);
+  o[3] = fminf(fmaxf(rintf(y + 0.5f * h), 0.f), ym);
+}
+
+// IoU with the inclusive-pixel convention (reference nets_utils.py:189-207)
+__device__ __forceinline__ float iou_incl(const float* a, const float* b) {
+  const float xi = fmaxf((fminf(a[2], b[2]) - fmaxf(a[0], b[0])) + 1.0f, 0.f);
+  const float yi = fmaxf((fminf(a[3], b[3]) - fmaxf(a[1], b[1])) + 1.0f, 0.f);
+  const float inter = xi * yi;
+  const float aa = ((a[2] - a[0]) + 1.0f) * ((a[3] - a[1]) + 1.0f);
+  const float ab = ((b[2] - b[0]) + 1.0f) * ((b[3] - b[1]) + 1.0f);
+  return inter / ((aa + ab) - inter);
+}
+
+// ------------------------------------------------------------------ RPN decode
+__global__ void rpn_decode_kernel(const float* __restrict__ cls, const float* __restrict__ reg,
+                                  const float* __restrict__ anchors, int KA, int n_anchor, int img_w, int img_h,
+                                  float min_size, float* __restrict__ boxes, uint32_t* __restrict__ keys,
+                                  int* __restrict__ keep_count) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int kept = 0;
+  if (i < KA) {
+    const int k = i / n_anchor, a = i - k * n_anchor;
+    const long long pix = (long long)b * (KA / n_anchor) + k;
+    const float score = cls[pix * (2 * n_anchor) + 2 * a + 1];
+    float d[4], an[4], o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { d[e] = reg[pix * (4 * n_anchor) + 4 * a + e]; an[e] = anchors[i * 4 + e]; }
+    decode_clip(d, an, img_w, img_h, o);
+    const bool keep = ((o[2] - o[0]) + 1.0f >= min_size) && ((o[3] - o[1]) + 1.0f >= min_size);
+    float* ob = boxes + ((long long)b * KA + i) * 4;
+    ob[0] = o[0]; ob[1] = o[1]; ob[2] = o[2]; ob[3] = o[3];
+    keys[(long long)b * KA + i] = keep ? nbm_f2key(score) : 0u;
+    kept = keep ? 1 : 0;
+  }
+  const unsigned long long m = __ballot(kept);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(keep_count + b, __popcll(m));
+}
+
+// ------------------------------------------------------------------ top-N selection (radix select + bitonic sort)
+// composite key = (score_key << 32) | ~index : unique, descending order == (score desc, index asc)
+constexpr int SEL_THREADS = 1024;
+
+__global__ __launch_bounds__(SEL_THREADS) void rpn_select_kernel(
+    const float* __restrict__ boxes, const uint32_t* __restrict__ keys, const int* __restrict__ keep_count, int B,
+    int KA, int top_n, int fail_below, int cap, float* __restrict__ sel_boxes, float* __restrict__ sel_scores,
+    int* __restrict__ n_sel) {
+  extern __shared__ unsigned long long sm[];  // [cap] sort buffer, then 256 histogram counters + scalars
+  unsigned long long* buf = sm;
+  unsigned int* hist = reinterpret_cast<unsigned int*>(sm + cap);
+  __shared__ unsigned long long s_prefix;
+  __shared__ int s_need, s_count, s_N;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const uint32_t* kb = keys + (long long)b * KA;
+
+  if (tid == 0) {
+    int mn = 0x7fffffff;
+    for (int i = 0; i < B; ++i) mn = min(mn, keep_count[i]);
+    int N = min(top_n, mn);
+    if (N < fail_below) N = 0;
+    s_N = N; s_need = N; s_prefix = 0ull; s_count = 0;
+    if (b == 0) n_sel[0] = N;
+  }
+  __syncthreads();
+  const int N = s_N;
+  for (int i = tid; i < cap; i += SEL_THREADS) buf[i] = 0ull;
+  if (N > 0) {
+    // 8 passes of 8 bits, MSB first: find the N-th largest composite key
+    for (int pass = 7; pass >= 0; --pass) {
+      for (int i = tid; i < 256; i += SEL_THREADS) hist[i] = 0u;
+      __syncthreads();
+      const int shift = pass * 8;
+      const unsigned long long prefix = s_prefix;
+      const unsigned long long himask = pass == 7 ? 0ull : (~0ull << (shift + 8));
+      for (int i = tid; i < KA; i += SEL_THREADS) {
+        const unsigned long long c = ((unsigned long long)kb[i] << 32) | (unsigned int)(~(unsigned int)i);
+        if ((c & himask) == prefix) atomicAdd(&hist[(c >> shift) & 255ull], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int need = s_need, d = 255;
+        for (; d > 0; --d) { if ((int)hist[d] >= need) break; need -= (int)hist[d]; }
+        s_need = need;
+        s_prefix = prefix | ((unsigned long long)d << shift);
+      }
+      __syncthreads();
+    }
+    const unsigned long long thr = s_prefix;  // exactly N composites are >= thr
+    for (int i = tid; i < KA; i += SEL_THREADS) {
+      const unsigned long long c = ((unsigned long long)kb[i] << 32) | (unsigned int)(~(unsigned int)i);
+      if (c >= thr) { const int pos = atomicAdd(&s_count, 1); if (pos < cap) buf[pos] = c; }
+    }
+  }
+  __syncthreads();
+  // bitonic sort, descending
+  for (int k = 2; k <= cap; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < cap; i += SEL_THREADS) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long x = buf[i], y = buf[ixj];
+          const bool desc = (i & k) == 0;
+          if (desc ? (x < y) : (x > y)) { buf[i] = y; buf[ixj] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int r = tid; r < cap; r += SEL_THREADS) {
+    float* ob = sel_boxes + ((long long)b * cap + r) * 4;
+    if (r < N) {
+      const unsigned long long c = buf[r];
+      const int idx = (int)(~(unsigned int)(c & 0xffffffffull));
+      const float* ib = boxes + ((long long)b * KA + idx) * 4;
+      ob[0] = ib[0]; ob[1] = ib[1]; ob[2] = ib[2]; ob[3] = ib[3];
+      sel_scores[(long long)b * cap + r] = nbm_key2f((uint32_t)(c >> 32));
+    } else {
+      ob[0] = ob[1] = ob[2] = ob[3] = 0.f;
+      sel_scores[(long long)b * cap + r] = 0.f;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ NMS
+__global__ void nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ n_in, int cap, int words,
+                                float thresh, unsigned long long* __restrict__ mask) {
+  const int n = n_in[0];
+  const int b = blockIdx.z, rb = blockIdx.y, cb = blockIdx.x;
+  if (rb * 64 >= n || cb * 64 >= n || cb < rb) return;
+  __shared__ float cbox[64][4];
+  const int t = threadIdx.x;
+  const float* bb = boxes + (long long)b * cap * 4;
+  {
+    const int j = cb * 64 + t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) cbox[t][e] = j < n ? bb[j * 4 + e] : 0.f;
+  }
+  __syncthreads();
+  const int i = rb * 64 + t;
+  if (i >= n) return;
+  float me[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) me[e] = bb[i * 4 + e];
+  unsigned long long bits = 0ull;
+  const int jn = min(64, n - cb * 64);
+  for (int jj = 0; jj < jn; ++jj) {
+    const int j = cb * 64 + jj;
+    if (j > i && iou_incl(me, cbox[jj]) >= thresh) bits |= 1ull << jj;
+  }
+  mask[((long long)b * cap + i) * words + cb] = bits;
+}
+
+// one wave per image: lane w owns removed-word w (cap <= 4096)
+__global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* __restrict__ mask,
+                                                      const int* __restrict__ n_in, int cap, int words,
+                                                      int* __restrict__ keep_idx, int* __restrict__ keep_cnt) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int n = n_in[0];
+  const int nwords = (n + 63) >> 6;
+  unsigned long long removed = 0ull;
+  int cnt = 0;
+  const unsigned long long* mb = mask + (long long)b * cap * words;
+  for (int i = 0; i < n; ++i) {
+    const int wi = i >> 6;
+    const unsigned long long rw = __shfl(removed, wi);
+    if (!((rw >> (i & 63)) & 1ull)) {
+      if (lane == 0) keep_idx[(long long)b * cap + cnt] = i;
+      ++cnt;
+      // row i only has valid words for column blocks >= i/64 (upper triangle)
+      if (lane < nwords && lane >= wi) removed |= mb[(long long)i * words + lane];
+    }
+  }
+  if (lane == 0) keep_cnt[b] = cnt;
+}
+
+__global__ void nms_gather_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                  const int* __restrict__ keep_idx, const int* __restrict__ keep_cnt, int B, int cap,
+                                  int post_n, float* __restrict__ rois, float* __restrict__ roi_scores,
+                                  int* __restrict__ n_out) {
+  const int b = blockIdx.x;
+  int mn = 0x7fffffff;
+  for (int i = 0; i < B; ++i) mn = min(mn, keep_cnt[i]);
+  const int R = min(post_n, mn);
+  if (b == 0 && threadIdx.x == 0) n_out[0] = R;
+  for (int r = threadIdx.x; r < post_n; r += blockDim.x) {
+    float* o = rois + ((long long)b * post_n + r) * 4;
+    if (r < R) {
+      const int idx = keep_idx[(long long)b * cap + r];
+      const float* ib = boxes + ((long long)b * cap + idx) * 4;
+      o[0] = ib[0]; o[1] = ib[1]; o[2] = ib[2]; o[3] = ib[3];
+      roi_scores[(long long)b * post_n + r] = scores[(long long)b * cap + idx];
+    } else {
+      o[0] = o[1] = o[2] = o[3] = 0.f;
+      roi_scores[(long long)b * post_n + r] = 0.f;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ RoI pooling (+ positional encoding)
+struct RoiParams {
+  const float* fmap[5]; int fh[5], fw[5]; int n_levels, C;
+  const float* rois; const int* n_roi; int B, roi_cap;
+  const float* pe_f; const float* pe_t; int img_h, img_w;
+  float* pool; float* pe; int* level;
+};
+
+__global__ void roi_pool_kernel(const RoiParams p) {
+  const int slot = blockIdx.x;                 // b * roi_cap + r
+  const int b = slot / p.roi_cap, r = slot - b * p.roi_cap;
+  if (r >= p.n_roi[0]) return;
+  const float* roi = p.rois + (long long)slot * 4;
+  // level assignment, layers.py:408-417 (sizes WITHOUT the +1)
+  const float size = sqrtf((roi[2] - roi[0]) * (roi[3] - roi[1]));
+  const float lf = logf(size * 0.1f) / 0.6931471805599453f;
+  int lvl = (lf != lf) ? (int)0x80000000 : (lf <= -2147483648.f ? (int)0x80000000 : (lf >= 2147483648.f ? (int)0x80000000 : (int)lf));
+  lvl = min(max(lvl, 0), p.n_levels - 1);
+  const float stride = (float)(2 << lvl);
+  int x1 = (int)rintf(roi[0] / stride), y1 = (int)rintf(roi[1] / stride);
+  int x2 = (int)rintf(roi[2] / stride), y2 = (int)rintf(roi[3] / stride);
+  const int H = p.fh[lvl], W = p.fw[lvl];
+  y2 = min(y2, H - 1);
+  while (y2 - y1 + 1 < 2) { y1 = max(0, y1 - 1); y2 = min(H - 1, y2 + 1); }
+  while (x2 - x1 + 1 < 2) { x1 = max(0, x1 - 1); x2 = min(W - 1, x2 + 1); }
+  if (threadIdx.x == 0) p.level[slot] = lvl;
+  const int C = p.C, half = C >> 1;
+  const float* fm = p.fmap[lvl];
+  const int h = y2 - y1 + 1, w = x2 - x1 + 1;
+  const int s = 2 << lvl;
+  const int f0 = s * y1, f1 = min(s * y2, p.img_h), hf = f1 - f0;         // pe_frequency[s*y1 : s*y2]
+  const int wt = min(s * (x2 - x1), p.img_w);                              // pe_time[: s*(x2-x1)]
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ya = (i * h) / 2, yb = ((i + 1) * h + 1) / 2;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int xa = (j * w) / 2, xb = ((j + 1) * w + 1) / 2;
+        float sum = 0.f;
+        for (int yy = ya; yy < yb; ++yy)
+          for (int xx = xa; xx < xb; ++xx)
+            sum += fm[(((long long)b * H + y1 + yy) * W + x1 + xx) * C + c];
+        p.pool[((long long)slot * 4 + i * 2 + j) * C + c] = sum / (float)((yb - ya) * (xb - xa));
+      }
+    }
+    if (c < half) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ra = (i * hf) / 2, rb = ((i + 1) * hf + 1) / 2;
+        double acc = 0.0;
+        for (int q = ra; q < rb; ++q) acc += (double)p.pe_f[(long long)(f0 + q) * half + c];
+        const float v = (float)(acc / (double)(rb - ra));
+        p.pe[((long long)slot * 4 + i * 2 + 0) * C + c] = v;
+        p.pe[((long long)slot * 4 + i * 2 + 1) * C + c] = v;
+      }
+    } else {
+      const int cc = c - half;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ca = (j * wt) / 2, cb = ((j + 1) * wt + 1) / 2;
+        double acc = 0.0;
+        for (int q = ca; q < cb; ++q) acc += (double)p.pe_t[(long long)q * half + cc];
+        const float v = (float)(acc / (double)(cb - ca));
+        p.pe[((long long)slot * 4 + 0 * 2 + j) * C + c] = v;
+        p.pe[((long long)slot * 4 + 1 * 2 + j) * C + c] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ FastRCNN eval post-processing
+constexpr int POST_MAX = 1024;
+
+__global__ __launch_bounds__(256) void rcnn_post_kernel(const float* __restrict__ rois, const int* __restrict__ n_roi,
+                                                        int roi_cap, const float* __restrict__ bbox_reg,
+                                                        const float* __restrict__ bbox_cls, int n_cls1, int img_w,
+                                                        int img_h, float nms_thresh, float min_score,
+                                                        int proposal_number, float* __restrict__ det,
+                                                        int* __restrict__ n_det) {
+  __shared__ unsigned long long skey[POST_MAX];
+  __shared__ float sbox[POST_MAX][4];
+  __shared__ float sscore[POST_MAX];
+  __shared__ int scls[POST_MAX];
+  __shared__ unsigned char alive[POST_MAX];
+  __shared__ int s_cnt;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int R = min(n_roi[0], roi_cap);
+  int P = 1;
+  while (P < R) P <<= 1;
+  // 1. class arg-max (first maximum), score
+  for (int r = tid; r < P; r += blockDim.x) {
+    unsigned long long key = 0ull;
+    if (r < R) {
+      const float* pc = bbox_cls + ((long long)b * roi_cap + r) * n_cls1;
+      float best = pc[0]; int bi = 0;
+      for (int c = 1; c < n_cls1; ++c) { const float v = pc[c]; if (v > best) { best = v; bi = c; } }
+      key = ((unsigned long long)nbm_f2key(best) << 32) | (unsigned int)(~(unsigned int)r);
+      scls[r] = bi;  // temporarily indexed by roi
+    }
+    skey[r] = key;
+  }
+  __syncthreads();
+  // 2. sort by (score desc, roi index asc)
+  for (int k = 2; k <= P; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < P; i += blockDim.x) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long x = skey[i], y = skey[ixj];
+          const bool desc = (i & k) == 0;
+          if (desc ? (x < y) : (x > y)) { skey[i] = y; skey[ixj] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  // 3. decode the arg-max class deltas against the RoI, clip (sorted position s <- roi r)
+  __shared__ int ocls[POST_MAX];
+  for (int s = tid; s < R; s += blockDim.x) {
+    const unsigned long long key = skey[s];
+    const int r = (int)(~(unsigned int)(key & 0xffffffffull));
+    const int c = scls[r];
+    const float* pd = bbox_reg + ((long long)b * roi_cap + r) * (4 * n_cls1) + 4 * c;
+    const float* pr = rois + ((long long)b * roi_cap + r) * 4;
+    float d[4] = {pd[0], pd[1], pd[2], pd[3]}, a[4] = {pr[0], pr[1], pr[2], pr[3]};
+    decode_clip(d, a, img_w, img_h, sbox[s]);
+    sscore[s] = nbm_key2f((uint32_t)(key >> 32));
+    ocls[s] = c;
+    alive[s] = c > 0 ? 1 : 0;                      // background dropped before the first NMS (layers.py:734)
+  }
+  __syncthreads();
+  // 4. class-agnostic greedy NMS in score order (layers.py:742)
+  for (int i = 0; i < R; ++i) {
+    if (alive[i]) {
+      for (int j = i + 1 + tid; j < R; j += blockDim.x)
+        if (alive[j] && iou_incl(sbox[i], sbox[j]) >= nms_thresh) alive[j] = 0;
+    }
+    __syncthreads();
+  }
+  // 5. per-class greedy NMS (layers.py:761).  After step 4 no surviving pair overlaps >= thresh, so this
+  //    only reproduces the per-class truncation to `proposal_number`; kept for faithfulness.
+  for (int i = 0; i < R; ++i) {
+    if (alive[i]) {
+      for (int j = i + 1 + tid; j < R; j += blockDim.x)
+        if (alive[j] && ocls[j] == ocls[i] && iou_incl(sbox[i], sbox[j]) >= nms_thresh) alive[j] = 0;
+    }
+    __syncthreads();
+  }
+  // 6. rank inside class (truncate to proposal_number), min_score filter, emit sorted by (class, score desc)
+  if (tid == 0) s_cnt = 0;
+  __syncthreads();
+  __shared__ unsigned char emit[POST_MAX];
+  for (int s = tid; s < R; s += blockDim.x) {
+    int rank_in_class = 0;
+    if (alive[s])
+      for (int j = 0; j < s; ++j) rank_in_class += (alive[j] && ocls[j] == ocls[s]) ? 1 : 0;
+    emit[s] = (alive[s] && rank_in_class < proposal_number && sscore[s] > min_score) ? 1 : 0;
+  }
+  __syncthreads();
+  for (int s = tid; s < R; s += blockDim.x) {
+    if (!emit[s]) continue;
+    int pos = 0;
+    for (int j = 0; j < R; ++j)
+      if (emit[j] && (ocls[j] < ocls[s] || (ocls[j] == ocls[s] && j < s))) ++pos;
+    float* o = det + ((long long)b * roi_cap + pos) * 6;
+    o[0] = (float)ocls[s]; o[1] = sbox[s][0]; o[2] = sbox[s][1]; o[3] = sbox[s][2]; o[4] = sbox[s][3];
+    o[5] = sscore[s];
+    atomicAdd(&s_cnt, 1);
+  }
+  __syncthreads();
+  if (tid == 0) n_det[b] = s_cnt;
+}
+
+}  // namespace
+
+extern "C" int nbm_rpn_decode(const float* cls, const float* reg, const float* anchors, int B, int KA,
+                                int n_anchor, int img_w, int img_h, int min_size, float* boxes, uint32_t* keys,
+                                int* keep_count, void* stream) {
+  if (!cls || !reg || !anchors || !boxes || !keys || !keep_count || B <= 0 || KA <= 0 || n_anchor <= 0 ||
+      KA % n_anchor)
+    return NBM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(keep_count, 0, sizeof(int) * B, st);
+  if (e != hipSuccess) return (int)e;
+  dim3 grid((KA + 255) / 256, B);
+  hipLaunchKernelGGL(rpn_decode_kernel, grid, dim3(256), 0, st, cls, reg, anchors, KA, n_anchor, img_w, img_h,
+                     (float)min_size, boxes, keys, keep_count);
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_rpn_select(const float* boxes, const uint32_t* keys, const int* keep_count, int B, int KA,
+                              int top_n, int fail_below, int cap, float* sel_boxes, float* sel_scores, int* n_sel,
+                              void* stream) {
+  if (!boxes || !keys || !keep_count || !sel_boxes || !sel_scores || !n_sel || B <= 0 || KA <= 0) return NBM_EINVAL;
+  if (cap < top_n || cap > 4096 || (cap & (cap - 1))) return NBM_EINVAL;
+  const size_t shmem = (size_t)cap * 8 + 256 * 4;
+  hipLaunchKernelGGL(rpn_select_kernel, dim3(B), dim3(SEL_THREADS), shmem, (hipStream_t)stream, boxes, keys,
+                     keep_count, B, KA, top_n, fail_below, cap, sel_boxes, sel_scores, n_sel);
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_nms_batched(const float* boxes, const float* scores, const int* n_in, int B, int cap,
+                               float thresh, int post_n, uint64_t* mask_ws, int* keep_ws, float* rois,
+                               float* roi_scores, int* n_out, void* stream) {
+  if (!boxes || !scores || !n_in || !mask_ws || !keep_ws || !rois || !roi_scores || !n_out || B <= 0) return NBM_EINVAL;
+  if (cap <= 0 || cap > 4096 || (cap & 63) || post_n <= 0 || post_n > cap) return NBM_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int words = cap / 64;
+  int* keep_idx = keep_ws;
+  int* keep_cnt = keep_ws + (size_t)B * cap;
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words, B), dim3(64), 0, st, boxes, n_in, cap, words, thresh,
+                     reinterpret_cast<unsigned long long*>(mask_ws));
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, st, reinterpret_cast<const unsigned long long*>(mask_ws),
+                     n_in, cap, words, keep_idx, keep_cnt);
+  hipLaunchKernelGGL(nms_gather_kernel, dim3(B), dim3(256), 0, st, boxes, scores, keep_idx, keep_cnt, B, cap, post_n,
+                     rois, roi_scores, n_out);
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_roi_pool(const nbm_roi_desc* d, void* stream) {
+  if (!d || !d->rois || !d->n_roi || !d->pool || !d->pe || !d->level || !d->pe_f || !d->pe_t) return NBM_EINVAL;
+  if (d->n_levels < 1 || d->n_levels > 5 || d->C <= 0 || (d->C & 1) || d->B <= 0 || d->roi_cap <= 0) return NBM_EINVAL;
+  RoiParams p;
+  for (int i = 0; i < 5; ++i) {
+    p.fmap[i] = d->fmap[i]; p.fh[i] = d->fh[i]; p.fw[i] = d->fw[i];
+    if (i < d->n_levels && (!d->fmap[i] || d->fh[i] < 2 || d->fw[i] < 2)) return NBM_EINVAL;
+  }
+  p.n_levels = d->n_levels; p.C = d->C; p.rois = d->rois; p.n_roi = d->n_roi; p.B = d->B; p.roi_cap = d->roi_cap;
+  p.pe_f = d->pe_f; p.pe_t = d->pe_t; p.img_h = d->img_h; p.img_w = d->img_w;
+  p.pool = d->pool; p.pe = d->pe; p.level = d->level;
+  hipLaunchKernelGGL(roi_pool_kernel, dim3(d->B * d->roi_cap), dim3(256), 0, (hipStream_t)stream, p);
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_rcnn_post(const float* rois, const int* n_roi, int B, int roi_cap, const float* bbox_reg,
+                             const float* bbox_cls, int n_cls1, int img_w, int img_h, float nms_thresh,
+                             float min_score, int proposal_number, float* det, int* n_det, void* stream) {
+  if (!rois || !n_roi || !bbox_reg || !bbox_cls || !det || !n_det || B <= 0 || roi_cap <= 0 || roi_cap > POST_MAX ||
+      n_cls1 < 2)
+    return NBM_EINVAL;
+  hipLaunchKernelGGL(rcnn_post_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, rois, n_roi, roi_cap, bbox_reg,
+                     bbox_cls, n_cls1, img_w, img_h, nms_thresh, min_score, proposal_number, det, n_det);
+  return nbm_launch_status();
+}

@@ -1,0 +1,311 @@
+// Implicit-GEMM convolution / batched GEMM on the gfx950 fp32 matrix core
+// (v_mfma_f32_32x32x2_f32: exact fp32 fmaf chain, 64 FLOP/clk/SIMD).
+//
+//   C[m][n] = sum_k A[m][k] * W[n][k]
+//
+// A is gathered on the fly from the NHWC activation (im2col never materialised), W is KRSC.
+// Block tile BM x BN x 32; 4 waves (one per SIMD), each owning (WM/32) x (WN/32) accumulator tiles of
+// 32x32.  Operands are staged global -> registers -> LDS ([rows][36] floats: the 4-float pad makes every
+// ds_read_b128 lane group hit 16 distinct 16-byte slots), double buffered with ONE barrier per K-step:
+// the global loads of step k+1 are issued before the MFMAs of step k and written to the other buffer
+// after them.
+//
+// K order inside a 32-wide step is free as long as A and W agree: lane (row i, half h) feeds k = 16h + j
+// to MFMA j, so each lane reads 16 contiguous floats (4 x ds_read_b128) per operand row.
+// For kh*kw > 1 the K loop runs channel-chunk OUTER, filter tap INNER, so the 3x3 halo of a block
+// (3 rows x 130 px x 128 B) is re-read 9x from L2 instead of streaming the whole 384-channel pixel per tap.
+//
+// Workgroup -> tile mapping is XCD-aware (bijective chunking of the grid over the 8 L2s) so the N-tiles
+// of one M-tile, which share the gathered A rows, run on the same XCD.
+#include "nbm_common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int PITCH = 36;  // floats per LDS row (32 + 4 pad)
+
+enum { A_FAST = 0, A_GENERIC = 1 };
+enum { EPI_STD = 0, EPI_STFT = 1 };
+
+struct IgemmParams {
+  const float* x; const float* w; float* y;
+  const float* scale; const float* shift; const float* residual;
+  long long x_gs, w_gs, y_gs, res_gs;
+  int M, N, K;           // K = kh*kw*Cin (valid)
+  int nk;                // number of 32-wide K steps
+  int H, W, Cin, kh, kw, stride, pad, Ho, Wo, HoWo;
+  int x_ld, w_ld, y_ld, res_ld;
+  int m_tiles, n_tiles;
+  float alpha; int act; int shift_per_row;
+  // STFT epilogue
+  int n_bins; float floor_amp; int db_ld; uint32_t* minmax;
+};
+
+template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
+  constexpr int MT = WM / 32, NT = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  constexpr int AR = BM / 32, BR = BN / 32;  // rows per thread in the staging pass
+  static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
+
+  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * PITCH];
+  float* As = lds;                       // [2][BM][PITCH]
+  float* Bs = lds + 2 * BM * PITCH;      // [2][BN][PITCH]
+
+  // ---- XCD-aware tile id (bijective for any grid size)
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tile_m = wg / p.n_tiles, tile_n = wg - tile_m * p.n_tiles;
+  const int bm0 = tile_m * BM, bn0 = tile_n * BN;
+  const int g = blockIdx.z;
+
+  const float* __restrict__ xg = p.x + (long long)g * p.x_gs;
+  const float* __restrict__ wgp = p.w + (long long)g * p.w_gs;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+  const int lrow = lane & 31, lh = lane >> 5;
+
+  // ---- staging assignment: thread -> (row r0 + 32 i, 16-byte chunk c4)
+  const int c4 = tid & 7, r0 = tid >> 3;
+  long long a_base[AR];
+  int a_iy0[AR], a_ix0[AR];
+  bool a_ok[AR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    const int m = bm0 + r0 + 32 * i;
+    a_ok[i] = m < p.M;
+    const int mm = a_ok[i] ? m : 0;
+    const int b = mm / p.HoWo, rem = mm - b * p.HoWo;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    a_iy0[i] = oy * p.stride - p.pad;
+    a_ix0[i] = ox * p.stride - p.pad;
+    a_base[i] = ((long long)(b * p.H + a_iy0[i]) * p.W + a_ix0[i]) * p.x_ld;
+  }
+  const float* b_ptr[BR];
+  bool b_ok[BR];
+#pragma unroll
+  for (int i = 0; i < BR; ++i) {
+    const int n = bn0 + r0 + 32 * i;
+    b_ok[i] = n < p.N;
+    b_ptr[i] = wgp + (long long)(b_ok[i] ? n : 0) * p.w_ld + c4 * 4;
+  }
+
+  f32x4 ra[AR], rb[BR];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+  // K-step cursor (FAST: channel chunk outer, tap inner)
+  int cur_r = 0, cur_s = 0, cur_c0 = 0;
+
+  auto load_tiles = [&](int kt) {
+    if constexpr (AMODE == A_FAST) {
+      const long long tap_off = ((long long)cur_r * p.W + cur_s) * p.x_ld + cur_c0 + c4 * 4;
+      const int koff = (cur_r * p.kw + cur_s) * p.Cin + cur_c0;
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const int iy = a_iy0[i] + cur_r, ix = a_ix0[i] + cur_s;
+        const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        ra[i] = ok ? *reinterpret_cast<const f32x4*>(xg + a_base[i] + tap_off) : zero4;
+      }
+#pragma unroll
+      for (int i = 0; i < BR; ++i)
+        rb[i] = b_ok[i] ? *reinterpret_cast<const f32x4*>(b_ptr[i] + koff) : zero4;
+      // advance cursor
+      if (++cur_s == p.kw) { cur_s = 0; if (++cur_r == p.kh) { cur_r = 0; cur_c0 += BK; } }
+    } else {
+      const int k0 = kt * BK + c4 * 4;
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        f32x4 v = zero4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int k = k0 + e;
+          if (a_ok[i] && k < p.K) {
+            const int tap = k / p.Cin, c = k - tap * p.Cin;
+            const int r = tap / p.kw, s = tap - r * p.kw;
+            const int iy = a_iy0[i] + r, ix = a_ix0[i] + s;
+            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+              v[e] = xg[a_base[i] + ((long long)r * p.W + s) * p.x_ld + c];
+          }
+        }
+        ra[i] = v;
+      }
+#pragma unroll
+      for (int i = 0; i < BR; ++i)
+        rb[i] = b_ok[i] ? *reinterpret_cast<const f32x4*>(b_ptr[i] + kt * BK) : zero4;
+    }
+  };
+  auto store_lds = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AR; ++i)
+      *reinterpret_cast<f32x4*>(As + (buf * BM + r0 + 32 * i) * PITCH + c4 * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BR; ++i)
+      *reinterpret_cast<f32x4*>(Bs + (buf * BN + r0 + 32 * i) * PITCH + c4 * 4) = rb[i];
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  load_tiles(0);
+  store_lds(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < p.nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < p.nk;
+    if (more) load_tiles(kt + 1);
+
+    const float* Ab = As + (cur * BM + wm0 + lrow) * PITCH + lh * 16;
+    const float* Bb = Bs + (cur * BN + wn0 + lrow) * PITCH + lh * 16;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 a[MT], b[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * PITCH + q * 4);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * PITCH + q * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+    }
+
+    if (more) store_lds(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue.  C/D layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+  if constexpr (EPI == EPI_STD) {
+    float* __restrict__ yg = p.y + (long long)g * p.y_gs;
+    const float* __restrict__ rg = p.residual ? p.residual + (long long)g * p.res_gs : nullptr;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = bn0 + wn0 + j * 32 + lrow;
+      if (n >= p.N) continue;
+      const float sc = p.scale ? p.scale[n] : 1.0f;
+      const float sh = (p.shift && !p.shift_per_row) ? p.shift[n] : 0.0f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int m = bm0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          if (m >= p.M) continue;
+          float v = acc[i][j][e] * p.alpha;
+          v = v * sc + sh;
+          if (p.shift_per_row && p.shift) v += p.shift[m];
+          if (rg) v += rg[(long long)m * p.res_ld + n];
+          if (p.act == NBM_ACT_RELU) v = fmaxf(v, 0.0f);
+          else if (p.act == NBM_ACT_SILU) v = v / (1.0f + expf(-v));
+          yg[(long long)m * p.y_ld + n] = v;
+        }
+      }
+    }
+  } else {
+    // STFT: acc[0][j] = Re (cos rows), acc[1][j] = Im (sin rows) of 32 bins x 32 frames.
+    static_assert(EPI == EPI_STD || MT == 2, "STFT epilogue pairs two M tiles");
+    float* __restrict__ yg = p.y + (long long)g * p.y_gs;
+    float vmin = INFINITY, vmax = -INFINITY;
+    const int bin0 = (bm0 + wm0) >> 1;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int t = bn0 + wn0 + j * 32 + lrow;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int bin = bin0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const float re = acc[0][j][e], im = acc[MT - 1][j][e];
+        const float mag = sqrtf(re * re + im * im);
+        const float db = 20.0f * log10f(fmaxf(p.floor_amp, mag));
+        if (bin < p.n_bins && t < p.N) {
+          yg[(long long)bin * p.db_ld + t] = db;
+          vmin = fminf(vmin, db);
+          vmax = fmaxf(vmax, db);
+        }
+      }
+    }
+    vmin = nbm_wave_min(vmin);
+    vmax = nbm_wave_max(vmax);
+    if (lane == 0 && vmin <= vmax) {
+      atomicMin(p.minmax + 2 * g, nbm_f2key(vmin));
+      atomicMax(p.minmax + 2 * g + 1, nbm_f2key(vmax));
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
+int launch(const IgemmParams& p, int groups, hipStream_t st) {
+  dim3 grid(p.m_tiles * p.n_tiles, 1, groups);
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, AMODE, EPI>), grid, dim3(256), 0, st, p);
+  return nbm_launch_status();
+}
+
+}  // namespace
+
+extern "C" int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream) {
+  if (!d || !d->x || !d->w || !d->y) return NBM_EINVAL;
+  if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->N <= 0 || d->kh <= 0 || d->kw <= 0 ||
+      d->stride <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->groups <= 0)
+    return NBM_EINVAL;
+  // host-side shape check: the output geometry must be the one the gather assumes
+  if ((d->H + 2 * d->pad - d->kh) / d->stride + 1 != d->Ho || (d->W + 2 * d->pad - d->kw) / d->stride + 1 != d->Wo)
+    return NBM_EINVAL;
+  if (d->x_ld < d->Cin || d->y_ld < d->N || (d->residual && d->res_ld < d->N)) return NBM_EINVAL;
+  IgemmParams p{};
+  p.x = d->x; p.w = d->w; p.y = d->y; p.scale = d->scale; p.shift = d->shift; p.residual = d->residual;
+  p.x_gs = d->x_gs; p.w_gs = d->w_gs; p.y_gs = d->y_gs; p.res_gs = d->res_gs;
+  p.M = d->B * d->Ho * d->Wo; p.N = d->N; p.K = d->kh * d->kw * d->Cin;
+  p.nk = (p.K + BK - 1) / BK;
+  p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad;
+  p.Ho = d->Ho; p.Wo = d->Wo; p.HoWo = d->Ho * d->Wo;
+  p.x_ld = d->x_ld; p.w_ld = d->w_ld; p.y_ld = d->y_ld; p.res_ld = d->res_ld;
+  p.alpha = d->alpha; p.act = d->act; p.shift_per_row = d->shift_per_row;
+  if (p.w_ld < p.nk * BK) return NBM_EINVAL;  // every W row must hold nk*32 readable floats
+  if ((d->w_ld & 3) || (d->w_gs & 3) || !nbm_aligned16(d->w)) return NBM_EALIGN;
+  const bool fast = (d->Cin % BK) == 0 && (d->x_ld & 3) == 0 && (d->x_gs & 3) == 0 && nbm_aligned16(d->x);
+  hipStream_t st = (hipStream_t)stream;
+  const int BM = 128;
+  p.m_tiles = (p.M + BM - 1) / BM;
+  if (d->N > 64) {
+    p.n_tiles = (d->N + 127) / 128;
+    return fast ? launch<128, 128, 64, 64, A_FAST, EPI_STD>(p, d->groups, st)
+                : launch<128, 128, 64, 64, A_GENERIC, EPI_STD>(p, d->groups, st);
+  } else if (d->N > 32) {
+    p.n_tiles = 1;
+    return fast ? launch<128, 64, 64, 32, A_FAST, EPI_STD>(p, d->groups, st)
+                : launch<128, 64, 64, 32, A_GENERIC, EPI_STD>(p, d->groups, st);
+  } else {
+    p.n_tiles = 1;
+    return fast ? launch<128, 32, 32, 32, A_FAST, EPI_STD>(p, d->groups, st)
+                : launch<128, 32, 32, 32, A_GENERIC, EPI_STD>(p, d->groups, st);
+  }
+}
+
+// db[b][f][t] = 20 log10(max(floor, |DFT|)) -- see nbm_hip.h.  M = basis rows (cos/sin blocks), N = frames.
+extern "C" int nbm_stft_db(const float* wave, int64_t wave_ld, int batch, int n_frames, int hop,
+                           const float* basis, int basis_rows, int basis_ld, int n_bins, float floor_amp,
+                           float* db, int64_t db_bs, int db_ld, uint32_t* minmax, void* stream) {
+  if (!wave || !basis || !db || !minmax || batch <= 0 || n_frames <= 0 || hop <= 0) return NBM_EINVAL;
+  if (basis_rows % 128 || basis_ld % BK || n_bins > basis_rows / 2 || db_ld < n_frames) return NBM_EINVAL;
+  if ((hop & 3) || (wave_ld & 3) || !nbm_aligned16(wave) || !nbm_aligned16(basis)) return NBM_EALIGN;
+  if ((int64_t)(n_frames - 1) * hop + basis_ld > wave_ld) return NBM_EINVAL;  // last frame must stay inside its row
+  IgemmParams p{};
+  p.x = basis; p.w = wave; p.y = db;
+  p.x_gs = 0; p.w_gs = wave_ld; p.y_gs = db_bs;
+  p.M = basis_rows; p.N = n_frames; p.K = basis_ld; p.nk = basis_ld / BK;
+  p.H = basis_rows; p.W = 1; p.Cin = basis_ld; p.kh = 1; p.kw = 1; p.stride = 1; p.pad = 0;
+  p.Ho = basis_rows; p.Wo = 1; p.HoWo = basis_rows;
+  p.x_ld = basis_ld; p.w_ld = hop; p.y_ld = db_ld;
+  p.alpha = 1.f;
+  p.n_bins = n_bins; p.floor_amp = floor_amp; p.db_ld = db_ld; p.minmax = minmax;
+  p.m_tiles = basis_rows / 128; p.n_tiles = (n_frames + 127) / 128;
+  return launch<128, 128, 64, 64, A_FAST, EPI_STFT>(p, batch, (hipStream_t)stream);
+}

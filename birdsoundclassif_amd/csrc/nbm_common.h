@@ -1,0 +1,48 @@
+// Shared device/host helpers for the NBM HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "nbm_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define NBM_WAVE 64
+
+static inline int nbm_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? NBM_OK : (int)e;
+}
+
+static inline bool nbm_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// Order-preserving map float -> uint32 (larger float => larger key); NaN sorts above +inf.
+__device__ __forceinline__ uint32_t nbm_f2key(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float nbm_key2f(uint32_t k) {
+  uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(u);
+}
+
+__device__ __forceinline__ float nbm_silu_f(float v) { return v / (1.0f + __expf(-v)); }
+
+// torch.round / np.rint: round half to even.
+__device__ __forceinline__ float nbm_rint(float v) { return rintf(v); }
+
+__device__ __forceinline__ float nbm_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float nbm_wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float nbm_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}

@@ -1,0 +1,311 @@
+// HBM-bound stages of the NBM hot path: waveform preparation, spectrogram normalise/window, and the
+// point-wise / small-window detector layers.  All NHWC fp32; every kernel is a coalesced grid-stride
+// sweep with the channel (or time) index fastest across lanes.
+#include "nbm_common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+inline int grid_for(long long n, int per_block = TPB, int cap = 256 * 16) {
+  long long g = (n + per_block - 1) / per_block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// ------------------------------------------------------------------ front end
+__global__ void pcm16_to_wave_kernel(const int16_t* __restrict__ pcm, long long pcm_ld, int n, int upsample,
+                                     const int32_t* __restrict__ hq, float* __restrict__ out, long long out_ld,
+                                     int lead) {
+  const int b = blockIdx.y;
+  const int16_t* x = pcm + (long long)b * pcm_ld;
+  float* o = out + (long long)b * out_ld;
+  const int n_out = upsample ? 2 * n : n;
+  for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < out_ld;
+       j += (long long)gridDim.x * blockDim.x) {
+    const long long i = j - lead;
+    float v = 0.f;
+    if (i >= 0 && i < n_out) {
+      if (!upsample) {
+        v = (float)x[i] * (1.0f / 32768.0f);
+      } else if ((i & 1) == 0) {
+        v = (float)x[i >> 1] * (1.0f / 32768.0f);
+      } else {
+        const int n0 = (int)(i >> 1);
+        long long acc = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const int ia = n0 - k, ib = n0 + 1 + k;
+          const int xa = (ia >= 0 && ia < n) ? x[ia] : 0;
+          const int xb = (ib >= 0 && ib < n) ? x[ib] : 0;
+          acc += (long long)hq[k] * (xa + xb);
+        }
+        long long q = (acc + 16384) >> 15;
+        q = q < -32768 ? -32768 : (q > 32767 ? 32767 : q);
+        v = (float)q * (1.0f / 32768.0f);
+      }
+    }
+    o[j] = v;
+  }
+}
+
+__global__ void minmax_init_kernel(uint32_t* mm, int batch) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < batch) { mm[2 * i] = 0xFFFFFFFFu; mm[2 * i + 1] = 0u; }
+}
+
+__global__ void spec_windows_kernel(const float* __restrict__ db, long long db_bs, int db_ld, int n_bins,
+                                    int n_frames, const uint32_t* __restrict__ minmax, float* __restrict__ img,
+                                    int n_img, int w_pix, int hop_img) {
+  const int b = blockIdx.z, k = blockIdx.y;
+  const float lo = nbm_key2f(minmax[2 * b]), hi = nbm_key2f(minmax[2 * b + 1]);
+  const float range = hi - lo;
+  const float* src = db + (long long)b * db_bs;
+  float* dst = img + ((long long)b * n_img + k) * n_bins * w_pix;
+  const int start = k * hop_img;
+  const int avail = n_frames - start;  // columns of this window that exist (>= 1)
+  const long long total = (long long)n_bins * w_pix;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int f = (int)(i / w_pix), c = (int)(i - (long long)f * w_pix);
+    int j = c;
+    if (c >= avail) {  // np.pad(mode='reflect'): periodic extension with period 2 (avail - 1)
+      if (avail <= 1) j = 0;
+      else { const int per = 2 * (avail - 1); j = c % per; if (j >= avail) j = per - j; }
+    }
+    dst[i] = (src[(long long)f * db_ld + start + j] - lo) / range;
+  }
+}
+
+// ------------------------------------------------------------------ detector point-wise stages
+__global__ void init_conv_kernel(const float* __restrict__ x, long long n_pix, const float* __restrict__ w,
+                                 const float* __restrict__ b, int C, float* __restrict__ y) {
+  const long long total = n_pix * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long p = i / C;
+    const int c = (int)(i - p * C);
+    y[i] = x[p] * w[c] + b[c];
+  }
+}
+
+__global__ void maxpool3x3s2_kernel(const float* __restrict__ x, int B, int H, int W, int C4,
+                                    float* __restrict__ y, int Ho, int Wo) {
+  const long long total = (long long)B * Ho * Wo * C4;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  f32x4* y4 = reinterpret_cast<f32x4*>(y);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    long long t = i / C4;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int iy = oy * 2 - 1 + r;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int ix = ox * 2 - 1 + s;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const f32x4 v = x4[((long long)(b * H + iy) * W + ix) * C4 + c];
+        m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+      }
+    }
+    y4[i] = m;
+  }
+}
+
+__global__ void upsample_add_kernel(const float* __restrict__ src, int B, int Hi, int Wi, int C4,
+                                    const float* __restrict__ add, float* __restrict__ y, int Ho, int Wo,
+                                    float sh, float sw) {
+  const long long total = (long long)B * Ho * Wo * C4;
+  const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+  const f32x4* a4 = reinterpret_cast<const f32x4*>(add);
+  f32x4* y4 = reinterpret_cast<f32x4*>(y);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    long long t = i / C4;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    const float fy = sh * oy, fx = sw * ox;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < Hi - 1 ? 1 : 0), x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
+    const float ly = fminf(fmaxf(fy - y0, 0.f), 1.f), lx = fminf(fmaxf(fx - x0, 0.f), 1.f);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const long long rb = (long long)b * Hi;
+    const f32x4 v00 = s4[((rb + y0) * Wi + x0) * C4 + c], v01 = s4[((rb + y0) * Wi + x1) * C4 + c];
+    const f32x4 v10 = s4[((rb + y1) * Wi + x0) * C4 + c], v11 = s4[((rb + y1) * Wi + x1) * C4 + c];
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]);
+    if (add) { const f32x4 a = a4[i]; r[0] += a[0]; r[1] += a[1]; r[2] += a[2]; r[3] += a[3]; }
+    y4[i] = r;
+  }
+}
+
+// one wave per row; 4 rows per 256-thread block
+__global__ void softmax_rows_kernel(float* __restrict__ x, long long rows, int cols, long long ld) {
+  const int lane = threadIdx.x & 63;
+  for (long long row = blockIdx.x * 4ll + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * 4) {
+    float* r = x + row * ld;
+    float m = -INFINITY;
+    for (int c = lane; c < cols; c += 64) m = fmaxf(m, r[c]);
+    m = nbm_wave_max(m);
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) { const float e = expf(r[c] - m); r[c] = e; s += e; }
+    s = nbm_wave_sum(s);
+    for (int c = lane; c < cols; c += 64) r[c] = r[c] / s;
+  }
+}
+
+__global__ void dwconv3x3_kernel(const float* __restrict__ x, int B, int H, int W, int Cin, int mult, int stride,
+                                 const float* __restrict__ w, const float* __restrict__ bias,
+                                 const float* __restrict__ film, long long film_ld, float* __restrict__ y,
+                                 int Ho, int Wo) {
+  const int Cout = Cin * mult;
+  const long long total = (long long)B * Ho * Wo * Cout;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int o = (int)(i % Cout);
+    const long long pix = i / Cout;
+    long long t = pix;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    const int ci = o / mult;
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int iy = oy * stride - 1 + r;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int ix = ox * stride - 1 + s;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        acc += x[((long long)(b * H + iy) * W + ix) * Cin + ci] * w[o * 9 + r * 3 + s];
+      }
+    }
+    if (bias) acc += bias[o];
+    if (film) acc = acc * film[pix * film_ld + o] + film[pix * film_ld + Cout + o];
+    y[i] = acc;
+  }
+}
+
+__global__ void silu_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
+       i += (long long)gridDim.x * blockDim.x) {
+    const float v = x[i];
+    y[i] = v / (1.0f + expf(-v));
+  }
+}
+
+__global__ void pair_softmax_kernel(const float* __restrict__ x, long long n_pix, int n_anchor, int x_ld,
+                                    float* __restrict__ y, int y_ld) {
+  const long long total = n_pix * n_anchor;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const long long p = i / n_anchor;
+    const int a = (int)(i - p * n_anchor);
+    const float v0 = x[p * x_ld + 2 * a], v1 = x[p * x_ld + 2 * a + 1];
+    const float m = fmaxf(v0, v1);
+    const float e0 = expf(v0 - m), e1 = expf(v1 - m);
+    const float s = e0 + e1;
+    y[p * y_ld + 2 * a] = e0 / s;
+    y[p * y_ld + 2 * a + 1] = e1 / s;
+  }
+}
+
+}  // namespace
+
+extern "C" const char* nbm_version(void) { return "nbm_hip 0.1 (gfx950)"; }
+
+extern "C" int nbm_pcm16_to_wave(const int16_t* pcm, int64_t pcm_ld, int batch, int n, int upsample,
+                                 const int32_t* hq, float* out, int64_t out_ld, int lead, void* stream) {
+  if (!pcm || !out || batch <= 0 || n <= 0 || lead < 0 || (upsample && !hq)) return NBM_EINVAL;
+  if ((int64_t)lead + (upsample ? 2 * (int64_t)n : n) > out_ld) return NBM_EINVAL;
+  dim3 grid(grid_for(out_ld, TPB, 1024), batch);
+  hipLaunchKernelGGL(pcm16_to_wave_kernel, grid, dim3(TPB), 0, (hipStream_t)stream, pcm, (long long)pcm_ld, n,
+                     upsample, hq, out, (long long)out_ld, lead);
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_minmax_init(uint32_t* minmax, int batch, void* stream) {
+  if (!minmax || batch <= 0) return NBM_EINVAL;
+  hipLaunchKernelGGL(minmax_init_kernel, dim3((batch + 63) / 64), dim3(64), 0, (hipStream_t)stream, minmax, batch);
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_spec_windows(const float* db, int64_t db_bs, int db_ld, int batch, int n_bins, int n_frames,
+                                const uint32_t* minmax, float* img, int n_img, int w_pix, int hop_img,
+                                void* stream) {
+  if (!db || !minmax || !img || batch <= 0 || n_img <= 0 || n_frames <= 0) return NBM_EINVAL;
+  if ((n_img - 1) * hop_img >= n_frames) return NBM_EINVAL;  // every window must own >= 1 real column
+  if ((n_img - 2) * (long long)hop_img + w_pix > n_frames && n_img > 1) return NBM_EINVAL;  // only the last may be short
+  dim3 grid(grid_for((long long)n_bins * w_pix, TPB, 512), n_img, batch);
+  hipLaunchKernelGGL(spec_windows_kernel, grid, dim3(TPB), 0, (hipStream_t)stream, db, (long long)db_bs, db_ld,
+                     n_bins, n_frames, minmax, img, n_img, w_pix, hop_img);
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_init_conv(const float* x, int64_t n_pix, const float* w, const float* b, int C, float* y,
+                             void* stream) {
+  if (!x || !w || !b || !y || n_pix <= 0 || C <= 0) return NBM_EINVAL;
+  hipLaunchKernelGGL(init_conv_kernel, dim3(grid_for(n_pix * C)), dim3(TPB), 0, (hipStream_t)stream, x,
+                     (long long)n_pix, w, b, C, y);
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_maxpool3x3s2(const float* x, int B, int H, int W, int C, float* y, int Ho, int Wo, void* stream) {
+  if (!x || !y || B <= 0 || C <= 0 || (C & 3)) return NBM_EINVAL;
+  if ((H + 2 - 3) / 2 + 1 != Ho || (W + 2 - 3) / 2 + 1 != Wo) return NBM_EINVAL;
+  if (!nbm_aligned16(x) || !nbm_aligned16(y)) return NBM_EALIGN;
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for((long long)B * Ho * Wo * (C / 4))), dim3(TPB), 0,
+                     (hipStream_t)stream, x, B, H, W, C / 4, y, Ho, Wo);
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_upsample_bilinear_add(const float* src, int B, int Hi, int Wi, int C, const float* add, float* y,
+                                         int Ho, int Wo, void* stream) {
+  if (!src || !y || B <= 0 || C <= 0 || (C & 3) || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return NBM_EINVAL;
+  if (!nbm_aligned16(src) || !nbm_aligned16(y) || (add && !nbm_aligned16(add))) return NBM_EALIGN;
+  const float sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
+  const float sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+  hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_for((long long)B * Ho * Wo * (C / 4))), dim3(TPB), 0,
+                     (hipStream_t)stream, src, B, Hi, Wi, C / 4, add, y, Ho, Wo, sh, sw);
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_softmax_rows(float* x, int64_t rows, int cols, int64_t ld, void* stream) {
+  if (!x || rows <= 0 || cols <= 0 || ld < cols) return NBM_EINVAL;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(grid_for(rows, 4, 256 * 32)), dim3(256), 0, (hipStream_t)stream, x,
+                     (long long)rows, cols, (long long)ld);
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_dwconv3x3(const float* x, int B, int H, int W, int Cin, int mult, int stride, const float* w,
+                             const float* bias, const float* film, int64_t film_ld, float* y, int Ho, int Wo,
+                             void* stream) {
+  if (!x || !w || !y || B <= 0 || Cin <= 0 || mult <= 0 || stride <= 0) return NBM_EINVAL;
+  if ((H + 2 - 3) / stride + 1 != Ho || (W + 2 - 3) / stride + 1 != Wo) return NBM_EINVAL;
+  if (film && film_ld < 2ll * Cin * mult) return NBM_EINVAL;
+  hipLaunchKernelGGL(dwconv3x3_kernel, dim3(grid_for((long long)B * Ho * Wo * Cin * mult)), dim3(TPB), 0,
+                     (hipStream_t)stream, x, B, H, W, Cin, mult, stride, w, bias, film, (long long)film_ld, y, Ho, Wo);
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_silu(const float* x, float* y, int64_t n, void* stream) {
+  if (!x || !y || n <= 0) return NBM_EINVAL;
+  hipLaunchKernelGGL(silu_kernel, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)stream, x, y, (long long)n);
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_pair_softmax(const float* x, int64_t n_pix, int n_anchor, int x_ld, float* y, int y_ld,
+                                void* stream) {
+  if (!x || !y || n_pix <= 0 || n_anchor <= 0 || x_ld < 2 * n_anchor || y_ld < 2 * n_anchor) return NBM_EINVAL;
+  hipLaunchKernelGGL(pair_softmax_kernel, dim3(grid_for(n_pix * n_anchor)), dim3(TPB), 0, (hipStream_t)stream, x,
+                     (long long)n_pix, n_anchor, x_ld, y, y_ld);
+  return nbm_launch_status();
+}

@@ -1,0 +1,60 @@
+"""Weight-layout preparation for the HIP kernels.
+
+Checkpoints keep the reference layout (conv weight [Cout, Cin, kh, kw]); the implicit-GEMM kernel
+wants KRSC rows [Cout, kh*kw*Cin] (k contiguous, padded to a multiple of 32 floats when Cin is not).
+Prepared copies are cached per parameter and invalidated by torch's version counter.
+"""
+import torch
+import torch.nn.functional as F
+
+_cache = {}
+
+
+def _cached(key_t, tag, fn):
+    key = (id(key_t), tag)
+    ver = (key_t.data_ptr(), key_t._version, key_t.device)
+    hit = _cache.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    with torch.no_grad():
+        val = fn()
+    _cache[key] = (ver, val)
+    return val
+
+
+def krsc(weight):
+    """[Cout, Cin, kh, kw] -> contiguous [Cout, K'] with K' = kh*kw*Cin rounded up to 32 when Cin % 32 != 0."""
+    def make():
+        co, ci, kh, kw = weight.shape
+        w = weight.detach().permute(0, 2, 3, 1).reshape(co, kh * kw * ci)
+        if ci % 32:
+            w = F.pad(w, (0, (-w.shape[1]) % 32))
+        return w.contiguous()
+    return _cached(weight, 'krsc', make)
+
+
+def bn_affine(weight, bias, mean, var, eps, conv_bias=None):
+    """Fold (conv bias +) BatchNorm running statistics into per-channel (scale, shift):
+    y = (z + conv_bias - mean) * weight / sqrt(var + eps) + bias  =  z * scale + shift."""
+    def make():
+        scale = weight.detach() * (var + eps).rsqrt()
+        shift = bias.detach() - mean * scale
+        if conv_bias is not None:
+            shift = shift + conv_bias.detach() * scale
+        return scale.contiguous(), shift.contiguous()
+    # any of the five tensors changing must invalidate: fold their versions into the tag
+    tag = ('bn', weight._version, bias._version, mean._version, var._version,
+           None if conv_bias is None else conv_bias._version, mean.data_ptr())
+    return _cached(weight, tag, make)
+
+
+def cat_rows(tag, *tensors):
+    """Concatenate several [Ni, K] weight matrices (or [Ni] biases) along dim 0, cached on the first."""
+    def make():
+        return torch.cat([t.detach().reshape(t.shape[0], -1) if t.dim() > 1 else t.detach() for t in tensors], 0).contiguous()
+    vtag = (tag,) + tuple(t._version for t in tensors)
+    return _cached(tensors[0], vtag, make)
+
+
+def clear():
+    _cache.clear()

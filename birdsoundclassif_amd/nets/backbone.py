@@ -1,0 +1,155 @@
+"""Backbone modules (reference nets/backbone.py), HIP forward.
+
+Same classes / constructor arguments / state_dict keys as the reference: `backbone.0.init_conv.*`,
+`backbone.0.body.<torchvision ResNet-50 names>`.  torchvision is not a dependency: the ResNet-50 v1.5
+definition (public architecture, reference backbone.py:131 `getattr(torchvision.models, name)`) is
+stated here as parameter containers, and the forward is a chain of fp32-MFMA implicit-GEMM launches with
+FrozenBatchNorm affine + ReLU + residual fused into the epilogues.  Activations are NHWC.
+"""
+import torch
+from torch import nn
+
+from .. import ops
+from . import _prep
+from .position_encoding import build_position_encoding
+
+bcbk_channels = {'resnet': {'2': 64, '3': 256, '4': 512, '5': 1024, '6': 2048}}
+_RESNET_LAYERS = {'resnet50': [3, 4, 6, 3], 'resnet101': [3, 4, 23, 3], 'resnet152': [3, 8, 36, 3]}
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """Fixed statistics + affine (reference backbone.py:26-62, eps = 1e-5); never run on its own: its
+    (scale, shift) are folded into the producing convolution's epilogue."""
+
+    def __init__(self, n):
+        super().__init__()
+        self.register_buffer('weight', torch.ones(n))
+        self.register_buffer('bias', torch.zeros(n))
+        self.register_buffer('running_mean', torch.zeros(n))
+        self.register_buffer('running_var', torch.ones(n))
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        state_dict.pop(prefix + 'num_batches_tracked', None)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                      error_msgs)
+
+    def affine(self):
+        return _prep.bn_affine(self.weight, self.bias, self.running_mean, self.running_var, 1e-5)
+
+
+class _Bottleneck(nn.Module):
+    """ResNet v1.5 bottleneck (stride on the 3x3)."""
+
+    def __init__(self, inplanes, planes, stride, downsample, norm_layer):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = norm_layer(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = norm_layer(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = norm_layer(planes * 4)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        s, b = self.bn1.affine()
+        o = ops.conv2d(x, _prep.krsc(self.conv1.weight), scale=s, shift=b, act=ops.ACT_RELU)
+        s, b = self.bn2.affine()
+        o = ops.conv2d(o, _prep.krsc(self.conv2.weight), 3, 3, self.stride, 1, scale=s, shift=b, act=ops.ACT_RELU)
+        if self.downsample is not None:
+            s, b = self.downsample[1].affine()
+            idt = ops.conv2d(x, _prep.krsc(self.downsample[0].weight), stride=self.stride, scale=s, shift=b)
+        else:
+            idt = x
+        s, b = self.bn3.affine()
+        return ops.conv2d(o, _prep.krsc(self.conv3.weight), scale=s, shift=b, residual=idt, act=ops.ACT_RELU)
+
+
+class _ResNetBody(nn.Module):
+    """conv1/bn1/relu/maxpool/layer1..4 with torchvision's names; returns the 5 taps the reference takes
+    with IntermediateLayerGetter (backbone.py:82-85): relu, layer1..layer4."""
+
+    def __init__(self, layers, norm_layer):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = norm_layer(64)
+        inplanes = 64
+        for li, (planes, n, stride) in enumerate(zip((64, 128, 256, 512), layers, (1, 2, 2, 2)), start=1):
+            blocks = []
+            for bi in range(n):
+                st = stride if bi == 0 else 1
+                ds = None
+                if bi == 0 and (st != 1 or inplanes != planes * 4):
+                    ds = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=st, bias=False), norm_layer(planes * 4))
+                blocks.append(_Bottleneck(inplanes, planes, st, ds, norm_layer))
+                inplanes = planes * 4
+            setattr(self, f'layer{li}', nn.Sequential(*blocks))
+
+    def forward(self, x):
+        s, b = self.bn1.affine()
+        x = ops.conv2d(x, _prep.krsc(self.conv1.weight), 7, 7, 2, 3, scale=s, shift=b, act=ops.ACT_RELU)
+        taps = [x]
+        x = ops.maxpool3x3s2(x)
+        for li in range(1, 5):
+            for blk in getattr(self, f'layer{li}'):
+                x = blk(x)
+            taps.append(x)
+        return taps
+
+
+class BackboneBase(nn.Module):
+
+    def __init__(self, backbone, name, in_channels, train_backbone):
+        super().__init__()
+        for _, parameter in backbone.named_parameters():
+            if not train_backbone:
+                parameter.requires_grad_(False)
+        self.body = backbone
+        self.num_channels = list(bcbk_channels['resnet'].values())
+        if in_channels != 3:
+            self.init_conv = nn.Conv2d(in_channels, 3, 1)
+        self.in_channels = in_channels
+        self.strides = [2 ** (i + 1) for i in range(len(self.num_channels))]
+
+    def forward(self, x):
+        """x: NHWC [B,H,W,in_channels] -> list of 5 NHWC maps (reference backbone.py:110-113)."""
+        if hasattr(self, 'init_conv'):
+            if self.in_channels != 1:
+                raise NotImplementedError('init_conv is implemented for 1 input channel (reference default)')
+            x = ops.init_conv(x, self.init_conv.weight.detach(), self.init_conv.bias.detach())
+        return self.body(x)
+
+
+class Backbone(BackboneBase):
+    """ResNet backbone with frozen BatchNorm (reference backbone.py:116-132)."""
+
+    def __init__(self, name, in_channels, train_backbone, dilation, norm_layer_name):
+        if name not in _RESNET_LAYERS:
+            raise ValueError(f'not supported {name}: the accelerated path implements {sorted(_RESNET_LAYERS)}')
+        if dilation:
+            raise NotImplementedError('--dilation (DC5) is outside the hot-path scope')
+        if norm_layer_name != 'frozen_batchnorm':
+            raise NotImplementedError('only --norm_layer_backbone frozen_batchnorm (reference default) is implemented')
+        super().__init__(_ResNetBody(_RESNET_LAYERS[name], FrozenBatchNorm2d), name, in_channels, train_backbone)
+
+
+class Joiner(nn.Sequential):
+    def __init__(self, backbone, position_embedding):
+        super().__init__(backbone, position_embedding)
+
+    def forward(self, x):
+        """-> (list of 5 NHWC feature maps, None).  The per-level sine encodings of the reference
+        (backbone.py:139-148) are unused by the default config and not evaluated."""
+        return self[0](x), None
+
+
+def build_backbone(args):
+    position_embedding = build_position_encoding(args)
+    train_backbone = args.lr_backbone > 0
+    backbone = Backbone(args.backbone, args.inpt_channels, train_backbone, args.dilation, args.norm_layer_backbone)
+    model = Joiner(backbone, position_embedding)
+    model.num_channels = backbone.num_channels
+    model.strides = backbone.strides
+    setattr(args, 'n_layers', len(backbone.num_channels))
+    return model

@@ -1,0 +1,44 @@
+"""Feature pyramid (reference nets/fpn.py:120-146), HIP forward.
+
+state_dict keys: `fpn.pt_wise.{i}` (bottom-up) and `fpn.out_convs.{i}` ('0' applied to the COARSEST
+level, reference fpn.py:137-145 / SURVEY Appendix C-2).  The 3x3 384->256 output convolutions carry 70 %
+of the detector's forward FLOPs; they run on the fp32-MFMA implicit-GEMM kernel.
+"""
+import torch.nn as nn
+
+from .. import ops
+from . import _prep
+from .self_attention import Scaled
+
+
+class FPN(nn.Module):
+
+    def __init__(self, channels, p_cn, out_cn):
+        super().__init__()
+        self.pt_wise = nn.ModuleDict({str(i): nn.Conv2d(cn, p_cn, 1) for i, cn in enumerate(channels)})
+        self.out_convs = nn.ModuleDict({str(i): nn.Conv2d(p_cn, out_cn, 3, padding=1) for i in range(len(channels))})
+
+    def forward(self, x):
+        """x: bottom-up list of NHWC maps (or Scaled(map, factor)) -> bottom-up list of NHWC [B,h,w,out_cn]."""
+        lat = []
+        for i, fm in enumerate(x):
+            t, alpha = (fm.tensor, fm.factor) if isinstance(fm, Scaled) else (fm, 1.0)
+            c = self.pt_wise[str(i)]
+            lat.append(ops.conv2d(t, _prep.krsc(c.weight), shift=c.bias.detach(), alpha=alpha))
+        i = 0
+        out = lat.pop(-1)
+        c = self.out_convs[str(i)]
+        outs = [ops.conv2d(out, _prep.krsc(c.weight), 3, 3, 1, 1, shift=c.bias.detach())]
+        while len(lat) > 0:
+            i += 1
+            p = lat.pop(-1)
+            out = ops.upsample_bilinear_add(out, p.shape[1], p.shape[2], add=p)
+            c = self.out_convs[str(i)]
+            outs.insert(0, ops.conv2d(out, _prep.krsc(c.weight), 3, 3, 1, 1, shift=c.bias.detach()))
+        return outs
+
+
+def build_fpn(args, channels):
+    if args.fpn != 'fpn':
+        raise ValueError(f'not supported {args.fpn}: BiFPN is outside the hot-path scope (SURVEY.md §8f)')
+    return FPN(channels, args.fpn_p_chan, args.out_fpn_chan)

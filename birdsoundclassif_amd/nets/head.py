@@ -1,0 +1,45 @@
+"""Faster-R-CNN head wiring (reference nets/head.py:9-42)."""
+import torch
+import torch.nn as nn
+
+from .layers import RegionProposalNetwork, ProposalLayer, FastRCNN
+
+
+class Faster_RCNN(nn.Module):
+
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.rpn = RegionProposalNetwork(args, args.n_layers, args.top_size)
+        self.prop_layer = ProposalLayer(args, args.n_layers)
+        self.fast_rcnn = FastRCNN(args)
+
+    def forward(self, x, nms_thresh=0.3, min_score=0.5):
+        rois, _, _ = self.forward_first_stage(x)
+        return self.forward_second_stage(x, rois, nms_thresh, min_score)
+
+    def forward_second_stage(self, *args, **kwargs):
+        return self.fast_rcnn(*args, **kwargs)
+
+    def forward_first_stage_device(self, fpn_nhwc):
+        """-> (rois [B,cap,4], roi_scores, n_roi device int, cls NHWC, reg NHWC, raw cls NHWC); no host sync."""
+        cls, reg, cls_raw = self.rpn.forward_nhwc(fpn_nhwc)
+        with torch.no_grad():
+            rois, scores, n_roi = self.prop_layer.forward_device(cls.detach(), reg.detach())
+        return rois, scores, n_roi, cls, reg, cls_raw
+
+    def forward_first_stage(self, fpn_pyramid_out):
+        """fpn_pyramid_out: list of NCHW-shaped maps -> (rois [B,R,4] | empty, cls_scores, bbox_reg) (head.py:32-38)."""
+        fm = [f.permute(0, 2, 3, 1).contiguous() for f in fpn_pyramid_out]
+        rois, _, n_roi, cls, reg, _ = self.forward_first_stage_device(fm)
+        n = int(n_roi.item())
+        if n == 0:
+            print('Not enough possible RoIs, RPN failed')
+            rois = torch.tensor([]).to(cls.device)
+        else:
+            rois = rois[:, :n].contiguous()
+        return rois, cls.permute(0, 3, 1, 2), reg.permute(0, 3, 1, 2)
+
+
+def build_head(args):
+    return Faster_RCNN(args)

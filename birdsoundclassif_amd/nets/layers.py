@@ -1,0 +1,275 @@
+"""Detector head layers (reference nets/layers.py), HIP forward.
+
+Same class names, constructor arguments and state_dict keys as the reference.  Public `forward`s keep the
+reference's NCHW-shaped return values (as permuted views of the NHWC buffers the kernels work on); the
+`*_device` methods are the sync-free internal path (fixed-capacity buffers + device-side counters) used by
+`NbmModel.forward`.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from . import _prep
+from .position_encoding import one_dimension_positional_encoding
+from .util.nets_utils import (weight_init, generate_anchors_frcnn as generate_anchors,
+                              get_anchor_shifts_frcnn as get_anchor_shifts)
+
+
+def _nhwc(t):
+    """NCHW-shaped tensor (any strides) -> contiguous NHWC tensor (no copy for our own permuted views)."""
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def _pow2_cap(n):
+    c = 64
+    while c < n:
+        c <<= 1
+    return c
+
+
+class DepthwiseSepConv2d(nn.Module):
+    """Inverted depthwise-separable block (reference layers.py:13-46): [bilinear x(1/stride)] -> depthwise 3x3
+    (channel multiplier = expansion_fact) -> [FiLM from the positional encoding] -> 1x1 -> BatchNorm -> SiLU."""
+
+    def __init__(self, indim, outdim, kernel=3, stride=1, expansion_fact=4, bias_out=True, pe_channels=None):
+        super().__init__()
+        if kernel != 3:
+            raise NotImplementedError('only 3x3 depthwise kernels are on the hot path')
+        self.stride = stride
+        self.expansion_fact = expansion_fact
+        self.depth_wise = nn.Conv2d(indim, expansion_fact * indim, kernel, stride=int(max(1, stride)), padding=1,
+                                    groups=indim)
+        if pe_channels is not None:
+            self.pe_proj = nn.Conv2d(pe_channels, 2 * expansion_fact * indim, 1)
+        self.pt_wise = nn.Conv2d(expansion_fact * indim, outdim, 1, bias=bias_out)
+        self.norm = nn.BatchNorm2d(outdim)
+        self.act = nn.SiLU()
+
+    def forward(self, x, pe_act=None):
+        """x NHWC; pe_act = SiLU(pe) NHWC (the activation is shared by the blocks of the RCNN) or None."""
+        if self.training:
+            raise NotImplementedError('train-mode (batch-statistics) BatchNorm of the heads: see nets/train_ops.py')
+        if self.stride < 1:
+            size = ((1 / self.stride) * np.array(x.shape[1:3])).astype(np.int64).tolist()
+            x = ops.upsample_bilinear_add(x, size[0], size[1])
+        film = None
+        if pe_act is not None:
+            film = ops.conv2d(pe_act, _prep.krsc(self.pe_proj.weight), shift=self.pe_proj.bias.detach())
+            film = film.view(-1, film.shape[-1])
+        out = ops.dwconv3x3(x, self.depth_wise.weight.detach(), self.depth_wise.bias.detach(), self.expansion_fact,
+                            int(max(1, self.stride)), film=film)
+        s, b = _prep.bn_affine(self.norm.weight, self.norm.bias, self.norm.running_mean, self.norm.running_var,
+                               self.norm.eps, conv_bias=self.pt_wise.bias)
+        return ops.conv2d(out, _prep.krsc(self.pt_wise.weight), scale=s, shift=b, act=ops.ACT_SILU)
+
+
+class RegionProposalNetwork(nn.Module):
+    """reference layers.py:49-99."""
+
+    def __init__(self, args, n_layers, top_layer_size):
+        super().__init__()
+        in_cn = args.out_fpn_chan
+        self.A = args.n_ratios
+        self.n_layers = n_layers
+        self.top_size = tuple(top_layer_size)
+        self.convs = nn.ModuleDict({
+            str(i): DepthwiseSepConv2d(in_cn, in_cn, stride=(args.anchor_stride / (2 ** (i + 1))), expansion_fact=2)
+            for i in range(n_layers)})
+        self.avgpool = nn.AdaptiveAvgPool2d(top_layer_size)          # identity at the reference geometry
+        self.cls_score = nn.ModuleDict({str(i): nn.Conv2d(in_cn, self.A * 2, 1) for i in range(n_layers)})
+        self.bbox_reg = nn.ModuleDict({str(i): nn.Conv2d(in_cn, self.A * 4, 1) for i in range(n_layers)})
+        self.apply(weight_init)
+
+    def forward_nhwc(self, x):
+        """x: list of NHWC FPN maps -> (cls softmaxed [B,h,w,n_layers*A*2], reg [B,h,w,n_layers*A*4], raw cls)."""
+        A, nl = self.A, self.n_layers
+        feats = []
+        for i, fm in enumerate(x):
+            f = self.convs[str(i)](fm)
+            if tuple(f.shape[1:3]) != self.top_size:
+                raise NotImplementedError(f'RPN map {tuple(f.shape[1:3])} != top_size {self.top_size}: adaptive '
+                                          'average pooling to a different size is outside the hot-path scope')
+            feats.append(f)
+        B, h, w, cn = feats[0].shape
+        cls_raw = torch.empty((B, h, w, nl * A * 2), device=feats[0].device, dtype=torch.float32)
+        reg = torch.empty((B, h, w, nl * A * 4), device=feats[0].device, dtype=torch.float32)
+        for i, f in enumerate(feats):
+            c, r = self.cls_score[str(i)], self.bbox_reg[str(i)]
+            ops.gemm_conv(f, _prep.krsc(c.weight), cls_raw[..., i * A * 2:], B=1, H=B * h * w, W=1, Cin=cn,
+                          N=A * 2, y_ld=nl * A * 2, shift=c.bias.detach())
+            ops.gemm_conv(f, _prep.krsc(r.weight), reg[..., i * A * 4:], B=1, H=B * h * w, W=1, Cin=cn,
+                          N=A * 4, y_ld=nl * A * 4, shift=r.bias.detach())
+        return ops.pair_softmax(cls_raw, nl * A), reg, cls_raw
+
+    def forward(self, x):
+        """-> (cls_scores [B, n_layers*A*2, h, w], bbox_reg [B, n_layers*A*4, h, w]) like the reference."""
+        cls, reg, _ = self.forward_nhwc(x)
+        return cls.permute(0, 3, 1, 2), reg.permute(0, 3, 1, 2)
+
+
+class ProposalLayer(nn.Module):
+    """reference layers.py:219-303: decode, clip, size filter, top-N by objectness, greedy NMS 0.7,
+    batch-coupled truncation -- all on device."""
+
+    def __init__(self, config, n_layers):
+        super().__init__()
+        self.n_layers = n_layers
+        self.config = config
+        self._anchors = {}
+
+    def anchors(self, height, width, device):
+        key = (height, width, str(device))
+        if key not in self._anchors:
+            cfg = self.config
+            a = generate_anchors(base_size=cfg.base_size, ratios=cfg.ratios, scales=2 ** np.arange(self.n_layers))
+            s = get_anchor_shifts(width, height, cfg.anchor_stride)
+            self._anchors[key] = torch.from_numpy((a + s).reshape(-1, 4).astype(np.float32)).to(device)
+        return self._anchors[key]
+
+    def forward_device(self, cls_nhwc, reg_nhwc):
+        """-> (rois [B,post_n,4], scores [B,post_n], n_roi int32[1] on device); n_roi = 0 <=> "RPN failed"."""
+        cfg = self.config
+        B, h, w, c2 = cls_nhwc.shape
+        n_anchor = c2 // 2
+        pre, post = (cfg.pre_nms_topN, cfg.post_nms_topN) if self.training else \
+            (cfg.pre_nms_topN_eval, cfg.post_nms_topN_eval)
+        anchors = self.anchors(h, w, cls_nhwc.device)
+        boxes, keys, cnt = ops.rpn_decode(cls_nhwc, reg_nhwc, anchors, n_anchor, cfg.img_width, cfg.img_height,
+                                          cfg.min_threshold)
+        cap = _pow2_cap(pre)
+        sb, ss, n_sel = ops.rpn_select(boxes, keys, cnt, pre, cfg.rcnn_batch_size, cap)
+        return ops.nms_batched(sb, ss, n_sel, cfg.nms_thresh, post)
+
+    def forward(self, labels_pred, bbox_reg):
+        rois, scores, n = self.forward_device(_nhwc(labels_pred), _nhwc(bbox_reg))
+        n = int(n.item())
+        if n == 0:
+            print('Not enough possible RoIs, RPN failed')
+            return torch.tensor([]).to(rois.device), torch.tensor([]).to(rois.device)
+        return rois[:, :n].contiguous(), scores[:, :n].contiguous()
+
+
+class ROIPooling(nn.Module):
+    """reference layers.py:399-497."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self._pe = {}
+
+    def pe_tables(self, device):
+        key = str(device)
+        if key not in self._pe:
+            cfg = self.config
+            self._pe[key] = (one_dimension_positional_encoding(cfg.img_height, cfg.out_fpn_chan // 2).to(device).contiguous(),
+                             one_dimension_positional_encoding(cfg.img_width, cfg.out_fpn_chan // 2).to(device).contiguous())
+        return self._pe[key]
+
+    def forward_device(self, rois, n_roi, fmaps_nhwc):
+        """rois [B,cap,4], n_roi device int32[1] -> pool, pe NHWC [B*cap,2,2,C], level int32 [B,cap]."""
+        cfg = self.config
+        if (cfg.roi_pool_h, cfg.roi_pool_w) != (2, 2):
+            raise NotImplementedError('roi_pool 2x2 (reference default) only')
+        pe_f, pe_t = self.pe_tables(rois.device)
+        return ops.roi_pool(fmaps_nhwc, rois, n_roi, pe_f, pe_t, cfg.img_height, cfg.img_width)
+
+    def forward(self, rois, conv_out):
+        B, R = rois.shape[:2]
+        n = torch.full((1,), R, device=rois.device, dtype=torch.int32)
+        pool, pe, lvl = self.forward_device(rois.contiguous(), n, [_nhwc(f) for f in conv_out])
+        C_ = pool.shape[-1]
+        return (pool.view(B, R, 2, 2, C_).permute(0, 1, 4, 2, 3), pe.view(B, R, 2, 2, C_).permute(0, 1, 4, 2, 3),
+                lvl.cpu().numpy())
+
+
+class RCNN(nn.Module):
+    """reference layers.py:500-586 (the positional-encoding / FiLM variant, the only live branch)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        cn = config.out_fpn_chan
+        hidden_size = cn * config.roi_pool_h * config.roi_pool_w
+        self.pe_proj = nn.Conv2d(cn, cn, 1)
+        self.rcnn = nn.ModuleList([DepthwiseSepConv2d(cn, cn, pe_channels=cn) for _ in range(config.depth_rcnn)])
+        self.bbox_reg_layer = nn.Linear(hidden_size, 4 * (1 + config.num_classes))
+        self.bbox_classif_layer = nn.Linear(hidden_size, 1 + config.num_classes)
+        self.softmax_layer = nn.Softmax(dim=-1)
+        self.apply(weight_init)
+
+    @staticmethod
+    def _hwc_weight(lin, cn):
+        """Linear weight over flatten([C,h,w]) -> the same weight over our (h,w,C) feature order."""
+        def make():
+            o = lin.weight.shape[0]
+            return lin.weight.detach().view(o, cn, -1).permute(0, 2, 1).reshape(o, -1).contiguous()
+        return _prep._cached(lin.weight, 'hwc', make)
+
+    def forward_nhwc(self, pool, pe):
+        """pool, pe: NHWC [N,2,2,C] -> (bbox_reg [N, 4(1+nc)], bbox_classes [N, 1+nc] softmaxed)."""
+        cn = pool.shape[-1]
+        roi_pe = ops.conv2d(pe, _prep.krsc(self.pe_proj.weight), shift=self.pe_proj.bias.detach())
+        pe_act = ops.silu(roi_pe)
+        out = pool
+        for blk in self.rcnn:
+            out = blk(out, pe_act)
+        feat = out.view(out.shape[0], -1)
+        reg = ops.linear(feat, self._hwc_weight(self.bbox_reg_layer, cn), self.bbox_reg_layer.bias.detach())
+        cls = ops.linear(feat, self._hwc_weight(self.bbox_classif_layer, cn), self.bbox_classif_layer.bias.detach())
+        return reg, ops.softmax_rows_(cls)
+
+    def forward(self, roi_pool_out, roi_pe_out):
+        """[B,R,C,2,2] x2 -> (bbox_reg [B*R, 4(1+nc)], bbox_classes [B*R, 1+nc])."""
+        p = roi_pool_out.flatten(end_dim=1).permute(0, 2, 3, 1).contiguous()
+        e = roi_pe_out.flatten(end_dim=1).permute(0, 2, 3, 1).contiguous()
+        return self.forward_nhwc(p, e)
+
+
+class FastRCNN(nn.Module):
+    """reference layers.py:654-778."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.roi_pooling = ROIPooling(config)
+        if config.tf_rcnn:
+            raise NotImplementedError('--tf_rcnn (Transformer_RCNN) is a "next" row of SURVEY.md §8f')
+        self.rcnn = RCNN(config)
+
+    def detect_device(self, fmaps_nhwc, rois, n_roi, nms_thresh=0.3, min_score=0.5):
+        """Sync-free eval path -> (det [B,cap,6] rows {class,x1,y1,x2,y2,score}, n_det int32 [B])."""
+        cfg = self.config
+        pool, pe, _ = self.roi_pooling.forward_device(rois, n_roi, fmaps_nhwc)
+        reg, cls = self.rcnn.forward_nhwc(pool, pe)
+        return ops.rcnn_post(rois, n_roi, reg, cls, cfg.img_width, cfg.img_height, nms_thresh, min_score,
+                             cfg.proposal_number)
+
+    @staticmethod
+    def dets_to_dicts(det, n_det, num_classes):
+        """One D2H copy, then the reference's output structure: list[B] of {'1'..'nc': {'bbox_coord': f32[n,4],
+        'scores': f32[1,n]}} with `torch.Tensor()` for empty classes (layers.py:749-776)."""
+        det, n_det = det.cpu(), n_det.cpu().tolist()
+        out = []
+        for b, n in enumerate(n_det):
+            rows = det[b, :n]
+            cls = rows[:, 0].to(torch.int64)
+            res = {str(c): dict(bbox_coord=torch.Tensor(), scores=torch.Tensor()) for c in range(1, num_classes + 1)}
+            for c in torch.unique(cls).tolist():
+                m = cls == c
+                res[str(c)] = dict(bbox_coord=rows[m, 1:5].clone(), scores=rows[m, 5][None].clone())
+            out.append(res)
+        return out
+
+    def forward(self, conv_out, rois, nms_thresh=0.3, min_score=0.5, training=None):
+        if training is None:
+            training = self.training
+        B, R = rois.shape[:2]
+        fm = [_nhwc(f) for f in conv_out]
+        rois = rois.contiguous()
+        n = torch.full((1,), R, device=rois.device, dtype=torch.int32)
+        if training:
+            pool, pe, _ = self.roi_pooling.forward_device(rois, n, fm)
+            return self.rcnn.forward_nhwc(pool, pe)
+        det, n_det = self.detect_device(fm, rois, n, nms_thresh, min_score)
+        return self.dets_to_dicts(det, n_det, self.config.num_classes)

@@ -1,0 +1,103 @@
+"""NbmModel / SetCriterion / initialize_model / build (reference nets/nbm_model.py), HIP forward.
+
+The module tree, and therefore every `state_dict` key and shape, is the reference's:
+a released `{'checkpoints': state_dict}` file loads unchanged through `initialize_model`.
+"""
+import numpy as np
+import torch
+from torch import nn
+
+from .backbone import build_backbone
+from .fpn import build_fpn
+from .self_attention import build_sa_layers
+from .head import build_head
+
+
+class NbmModel(nn.Module):
+    """reference nbm_model.py:22-80."""
+
+    def __init__(self, args, backbone, attn, fpn, head):
+        super().__init__()
+        if getattr(args, 'fpn_first', False) or getattr(args, 'sandwich_attn', False) or getattr(args, 'add_posenc', False):
+            raise NotImplementedError('only the default ordering fpn(attn(backbone(x))) is on the hot path')
+        self.args = args
+        self.backbone = backbone
+        self.attn = attn
+        self.fpn = fpn
+        self.head = head
+
+    def _fpn_nhwc(self, samples):
+        if samples.dim() != 4 or samples.shape[1] != self.args.inpt_channels:
+            raise ValueError(f'expected [B,{self.args.inpt_channels},H,W], got {tuple(samples.shape)}')
+        x = samples.permute(0, 2, 3, 1).contiguous()
+        features, _ = self.backbone(x)
+        return self.fpn(self.attn(features))
+
+    def forward_first_stage(self, samples):
+        """samples [B,1,H,W] f32 on the GPU -> {'rois','rpn_cls_scores','rpn_bbox_reg','fpn_out'} (nbm_model.py:39-54).
+        Tensors are NCHW-shaped views of NHWC storage."""
+        fpn_out = self._fpn_nhwc(samples)
+        rois, cls, reg = self.head.forward_first_stage([f.permute(0, 3, 1, 2) for f in fpn_out])
+        return {'rois': rois, 'rpn_cls_scores': cls, 'rpn_bbox_reg': reg,
+                'fpn_out': [f.permute(0, 3, 1, 2) for f in fpn_out]}
+
+    def forward_second_stage(self, fpn_pyramid_out, rois, nms_thresh=None, min_score=None, training=None):
+        """nbm_model.py:56-64."""
+        if training is None:
+            training = self.training
+        nms_thresh = 0.3 if nms_thresh is None else nms_thresh
+        min_score = 0.5 if min_score is None else min_score
+        outputs = self.head.forward_second_stage(fpn_pyramid_out, rois, nms_thresh, min_score, training)
+        if training:
+            bbox_reg, bbox_classes = outputs
+            return {'bbox_reg': bbox_reg, 'bbox_classes': bbox_classes}
+        return outputs
+
+    @torch.no_grad()
+    def detect(self, samples, nms_thresh=0.3, min_score=0.5):
+        """Sync-free eval forward: -> (det [B,50,6] rows {class,x1,y1,x2,y2,score} sorted by (class, score desc),
+        n_det int32 [B]), both on the device.  Used by bulk inference; `forward` wraps it."""
+        fpn_out = self._fpn_nhwc(samples)
+        rois, _, n_roi, _, _, _ = self.head.forward_first_stage_device(fpn_out)
+        return self.head.fast_rcnn.detect_device(fpn_out, rois, n_roi, nms_thresh, min_score)
+
+    def forward(self, samples, nms_thresh=0.3, min_score=0.5):
+        """-> list[B] of {'1'..'num_classes': {'bbox_coord','scores'}} (nbm_model.py:66-80).  Eval only."""
+        if self.training:
+            raise RuntimeError('NbmModel.forward is the inference entry point; call .eval() first '
+                               '(training goes through forward_first_stage / forward_second_stage)')
+        det, n_det = self.detect(samples, nms_thresh, min_score)
+        return self.head.fast_rcnn.dets_to_dicts(det, n_det, self.args.num_classes)
+
+
+def initialize_model(model, path=None, train=True):
+    """reference nbm_model.py:325-341 (keeps only checkpoint keys that exist in the model)."""
+    if path is not None:
+        model_dict = model.state_dict()
+        state_dict = torch.load(path, map_location='cpu', weights_only=False)
+        state_dict = {k: v for k, v in state_dict['checkpoints'].items() if k in model_dict}
+        model_dict.update(state_dict)
+        model.load_state_dict(model_dict)
+    if train:
+        model.train()
+    else:
+        model.eval()
+    return model
+
+
+def build(args, train=True):
+    """reference nbm_model.py:344-381 -> (NbmModel, SetCriterion)."""
+    from .criterion import SetCriterion
+    device = torch.device(args.device)
+    backbone = build_backbone(args)
+    attn = build_sa_layers(args, backbone.num_channels)
+    fpn = build_fpn(args, backbone.num_channels)
+    head = build_head(args)
+    model = NbmModel(args, backbone, attn, fpn, head).to(device)
+    model = initialize_model(model, train=train)
+    weight_dict = {'first_class_loss': args.fs_cls_loss_coef, 'first_regression_loss': args.fs_reg_loss_coef,
+                   'sec_class_loss': args.sec_cls_loss_coef, 'sec_regression_loss': args.sec_reg_loss_coef,
+                   'first_neg_class_loss': args.fs_neg_cls_loss_coef, 'sec_neg_class_loss': args.sec_neg_cls_loss_coef}
+    criterion = SetCriterion(args, weight_dict)
+    criterion.to(device)
+    return model, criterion

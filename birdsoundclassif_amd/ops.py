@@ -1,0 +1,282 @@
+"""Host-side operator layer: thin wrappers that hand raw device pointers of torch tensors to the
+C ABI of libnbm_hip.so on torch's current HIP stream.  torch is plumbing here (HBM allocations,
+streams); all arithmetic happens in the hand-written kernels.  Activations are NHWC fp32.
+
+Every function raises if the tensor is not a contiguous float32 CUDA tensor -- there is no CPU path.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc, RoiDesc, check
+
+ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _chk(t, dtype=torch.float32, name='tensor'):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise RuntimeError(f'{name}: the NBM HIP path needs CUDA (ROCm) tensors; no CPU fallback exists')
+    if t.dtype != dtype:
+        raise TypeError(f'{name}: expected {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise ValueError(f'{name}: must be contiguous')
+    return t
+
+
+def lib():
+    return _lib.load()
+
+
+# --------------------------------------------------------------------------- implicit GEMM
+def gemm_conv(x, w, y, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, Ho=None, Wo=None,
+              x_ld=None, w_ld=None, y_ld=None, scale=None, shift=None, residual=None, res_ld=None,
+              groups=1, x_gs=0, w_gs=0, y_gs=0, res_gs=0, alpha=1.0, act=ACT_NONE, shift_per_row=False):
+    """Raw call of nbm_gemm_conv (see include/nbm_hip.h for the exact semantics)."""
+    Ho = (H + 2 * pad - kh) // stride + 1 if Ho is None else Ho
+    Wo = (W + 2 * pad - kw) // stride + 1 if Wo is None else Wo
+    d = GemmDesc()
+    d.x, d.w, d.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
+    d.scale = scale.data_ptr() if scale is not None else None
+    d.shift = shift.data_ptr() if shift is not None else None
+    d.residual = residual.data_ptr() if residual is not None else None
+    d.x_gs, d.w_gs, d.y_gs, d.res_gs = x_gs, w_gs, y_gs, res_gs
+    d.groups = groups
+    d.B, d.H, d.W, d.Cin, d.N = B, H, W, Cin, N
+    d.kh, d.kw, d.stride, d.pad, d.Ho, d.Wo = kh, kw, stride, pad, Ho, Wo
+    d.x_ld = Cin if x_ld is None else x_ld
+    d.w_ld = kh * kw * Cin if w_ld is None else w_ld
+    d.y_ld = N if y_ld is None else y_ld
+    d.res_ld = (N if res_ld is None else res_ld) if residual is not None else 0
+    d.alpha, d.act, d.shift_per_row = float(alpha), int(act), int(bool(shift_per_row))
+    check(lib().nbm_gemm_conv(C.byref(d), _stream()), 'nbm_gemm_conv')
+    return y
+
+
+def conv2d(x, w, kh=1, kw=1, stride=1, pad=0, scale=None, shift=None, residual=None, act=ACT_NONE,
+           alpha=1.0, out=None, w_ld=None):
+    """x [B,H,W,Cin] NHWC, w [N, w_ld>=kh*kw*Cin] (KRSC rows) -> [B,Ho,Wo,N]."""
+    _chk(x, name='x'), _chk(w, name='w')
+    B, H, W, Cin = x.shape
+    N = w.shape[0]
+    Ho = (H + 2 * pad - kh) // stride + 1
+    Wo = (W + 2 * pad - kw) // stride + 1
+    y = out if out is not None else torch.empty((B, Ho, Wo, N), device=x.device, dtype=torch.float32)
+    if residual is not None:
+        _chk(residual, name='residual')
+        assert residual.shape == y.shape
+    gemm_conv(x, w, y, B=B, H=H, W=W, Cin=Cin, N=N, kh=kh, kw=kw, stride=stride, pad=pad, Ho=Ho, Wo=Wo,
+              w_ld=w.shape[1] if w_ld is None else w_ld, scale=scale, shift=shift, residual=residual,
+              alpha=alpha, act=act)
+    return y
+
+
+def linear(x2d, w, bias=None, act=ACT_NONE, out=None, alpha=1.0, residual=None, y_ld=None):
+    """x2d [M,K], w [N,K] -> [M,N] (= x @ w.T + bias)."""
+    _chk(x2d, name='x'), _chk(w, name='w')
+    M, K = x2d.shape
+    N = w.shape[0]
+    y = out if out is not None else torch.empty((M, N), device=x2d.device, dtype=torch.float32)
+    gemm_conv(x2d, w, y, B=1, H=M, W=1, Cin=K, N=N, w_ld=w.shape[1], shift=bias, act=act, alpha=alpha,
+              residual=residual, y_ld=y_ld)
+    return y
+
+
+def bgemm_nt(a, b, out=None, alpha=1.0, shift=None, shift_per_row=False, residual=None, act=ACT_NONE):
+    """a [G,M,K] (or [M,K] shared by all groups), b [G,N,K] -> [G,M,N] = alpha * a @ b^T (+shift)(+residual)."""
+    _chk(a, name='a'), _chk(b, name='b')
+    G, N, K = b.shape
+    M = a.shape[-2]
+    assert a.shape[-1] == K
+    a_gs = M * K if a.dim() == 3 else 0
+    y = out if out is not None else torch.empty((G, M, N), device=b.device, dtype=torch.float32)
+    gemm_conv(a, b, y, B=1, H=M, W=1, Cin=K, N=N, w_ld=K, groups=G, x_gs=a_gs, w_gs=N * K, y_gs=M * N,
+              alpha=alpha, shift=shift, shift_per_row=shift_per_row, residual=residual,
+              res_gs=M * N if residual is not None else 0, act=act)
+    return y
+
+
+# --------------------------------------------------------------------------- front end
+def pcm16_to_wave(pcm, out_ld, lead, upsample, hq=None):
+    """pcm int16 [batch, n] -> f32 [batch, out_ld] zero-padded (lead zeros in front)."""
+    _chk(pcm, torch.int16, 'pcm')
+    batch, n = pcm.shape
+    out = torch.empty((batch, out_ld), device=pcm.device, dtype=torch.float32)
+    if upsample:
+        _chk(hq, torch.int32, 'hq')
+    check(lib().nbm_pcm16_to_wave(_ptr(pcm), n, batch, n, int(bool(upsample)), _ptr(hq), _ptr(out), out_ld, lead,
+                                  _stream()), 'nbm_pcm16_to_wave')
+    return out
+
+
+def stft_db(wave, n_frames, hop, basis, n_bins, floor_amp, db_ld=None):
+    """wave f32 [batch, wave_ld] (already centre-padded) -> (db [batch, n_bins, db_ld], minmax u32 [batch,2])."""
+    _chk(wave, name='wave'), _chk(basis, name='basis')
+    batch, wave_ld = wave.shape
+    db_ld = n_frames if db_ld is None else db_ld
+    db = torch.empty((batch, n_bins, db_ld), device=wave.device, dtype=torch.float32)
+    mm = torch.empty((batch, 2), device=wave.device, dtype=torch.int32)
+    check(lib().nbm_minmax_init(_ptr(mm), batch, _stream()), 'nbm_minmax_init')
+    check(lib().nbm_stft_db(_ptr(wave), wave_ld, batch, n_frames, hop, _ptr(basis), basis.shape[0], basis.shape[1],
+                            n_bins, float(floor_amp), _ptr(db), n_bins * db_ld, db_ld, _ptr(mm), _stream()),
+          'nbm_stft_db')
+    return db, mm
+
+
+def spec_windows(db, minmax, n_frames, n_img, w_pix, hop_img):
+    """db [batch, n_bins, db_ld] + min/max -> img [batch, n_img, n_bins, w_pix] normalised to [0,1]."""
+    _chk(db, name='db')
+    batch, n_bins, db_ld = db.shape
+    img = torch.empty((batch, n_img, n_bins, w_pix), device=db.device, dtype=torch.float32)
+    check(lib().nbm_spec_windows(_ptr(db), n_bins * db_ld, db_ld, batch, n_bins, n_frames, _ptr(minmax), _ptr(img),
+                                 n_img, w_pix, hop_img, _stream()), 'nbm_spec_windows')
+    return img
+
+
+# --------------------------------------------------------------------------- point-wise stages
+def init_conv(x, w, b):
+    """x [B,H,W,1] -> [B,H,W,C]."""
+    _chk(x, name='x')
+    C_ = w.numel()
+    y = torch.empty(x.shape[:3] + (C_,), device=x.device, dtype=torch.float32)
+    check(lib().nbm_init_conv(_ptr(x), x.numel(), _ptr(_chk(w.reshape(-1))), _ptr(_chk(b)), C_, _ptr(y), _stream()),
+          'nbm_init_conv')
+    return y
+
+
+def maxpool3x3s2(x):
+    _chk(x, name='x')
+    B, H, W, C_ = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((B, Ho, Wo, C_), device=x.device, dtype=torch.float32)
+    check(lib().nbm_maxpool3x3s2(_ptr(x), B, H, W, C_, _ptr(y), Ho, Wo, _stream()), 'nbm_maxpool3x3s2')
+    return y
+
+
+def upsample_bilinear_add(src, Ho, Wo, add=None):
+    _chk(src, name='src')
+    B, Hi, Wi, C_ = src.shape
+    if add is not None:
+        _chk(add, name='add')
+        assert tuple(add.shape) == (B, Ho, Wo, C_)
+    y = torch.empty((B, Ho, Wo, C_), device=src.device, dtype=torch.float32)
+    check(lib().nbm_upsample_bilinear_add(_ptr(src), B, Hi, Wi, C_, _ptr(add), _ptr(y), Ho, Wo, _stream()),
+          'nbm_upsample_bilinear_add')
+    return y
+
+
+def softmax_rows_(x2d):
+    _chk(x2d, name='x')
+    rows, cols = x2d.shape
+    check(lib().nbm_softmax_rows(_ptr(x2d), rows, cols, cols, _stream()), 'nbm_softmax_rows')
+    return x2d
+
+
+def dwconv3x3(x, w, bias, mult, stride=1, film=None):
+    """x [B,H,W,Cin], w [Cin*mult,1,3,3] (reference layout) -> [B,Ho,Wo,Cin*mult]; film [B*Ho*Wo, 2*Cout]."""
+    _chk(x, name='x'), _chk(w, name='w')
+    B, H, W, Cin = x.shape
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.empty((B, Ho, Wo, Cin * mult), device=x.device, dtype=torch.float32)
+    film_ld = 0
+    if film is not None:
+        _chk(film, name='film')
+        film_ld = film.shape[-1]
+    check(lib().nbm_dwconv3x3(_ptr(x), B, H, W, Cin, mult, stride, _ptr(w), _ptr(bias), _ptr(film), film_ld, _ptr(y),
+                              Ho, Wo, _stream()), 'nbm_dwconv3x3')
+    return y
+
+
+def silu(x):
+    _chk(x, name='x')
+    y = torch.empty_like(x)
+    check(lib().nbm_silu(_ptr(x), _ptr(y), x.numel(), _stream()), 'nbm_silu')
+    return y
+
+
+def pair_softmax(x, n_anchor):
+    """x [..., 2*n_anchor] -> softmax over each (bg, fg) pair."""
+    _chk(x, name='x')
+    ld = x.shape[-1]
+    y = torch.empty_like(x)
+    check(lib().nbm_pair_softmax(_ptr(x), x.numel() // ld, n_anchor, ld, _ptr(y), ld, _stream()), 'nbm_pair_softmax')
+    return y
+
+
+# --------------------------------------------------------------------------- proposal / RoI / detection
+def rpn_decode(cls, reg, anchors, n_anchor, img_w, img_h, min_size):
+    """cls [B,K,2A] softmaxed, reg [B,K,4A], anchors [K*A,4] -> boxes [B,KA,4], keys u32 [B,KA], keep_count [B]."""
+    _chk(cls, name='cls'), _chk(reg, name='reg'), _chk(anchors, name='anchors')
+    B = cls.shape[0]
+    KA = anchors.shape[0]
+    boxes = torch.empty((B, KA, 4), device=cls.device, dtype=torch.float32)
+    keys = torch.empty((B, KA), device=cls.device, dtype=torch.int32)
+    cnt = torch.empty((B,), device=cls.device, dtype=torch.int32)
+    check(lib().nbm_rpn_decode(_ptr(cls), _ptr(reg), _ptr(anchors), B, KA, n_anchor, img_w, img_h, int(min_size),
+                               _ptr(boxes), _ptr(keys), _ptr(cnt), _stream()), 'nbm_rpn_decode')
+    return boxes, keys, cnt
+
+
+def rpn_select(boxes, keys, keep_count, top_n, fail_below, cap):
+    B, KA = keys.shape
+    sel_boxes = torch.empty((B, cap, 4), device=boxes.device, dtype=torch.float32)
+    sel_scores = torch.empty((B, cap), device=boxes.device, dtype=torch.float32)
+    n_sel = torch.empty((1,), device=boxes.device, dtype=torch.int32)
+    check(lib().nbm_rpn_select(_ptr(boxes), _ptr(keys), _ptr(keep_count), B, KA, top_n, fail_below, cap,
+                               _ptr(sel_boxes), _ptr(sel_scores), _ptr(n_sel), _stream()), 'nbm_rpn_select')
+    return sel_boxes, sel_scores, n_sel
+
+
+def nms_batched(boxes, scores, n_in, thresh, post_n):
+    """boxes [B,cap,4] in walk order, n_in device int -> rois [B,post_n,4], scores [B,post_n], n_out device int."""
+    _chk(boxes, name='boxes'), _chk(scores, name='scores')
+    B, cap = scores.shape
+    words = cap // 64
+    mask_ws = torch.empty((B * cap * words,), device=boxes.device, dtype=torch.int64)
+    keep_ws = torch.empty((B * (cap + 1),), device=boxes.device, dtype=torch.int32)
+    rois = torch.empty((B, post_n, 4), device=boxes.device, dtype=torch.float32)
+    rs = torch.empty((B, post_n), device=boxes.device, dtype=torch.float32)
+    n_out = torch.empty((1,), device=boxes.device, dtype=torch.int32)
+    check(lib().nbm_nms_batched(_ptr(boxes), _ptr(scores), _ptr(n_in), B, cap, float(thresh), post_n, _ptr(mask_ws),
+                                _ptr(keep_ws), _ptr(rois), _ptr(rs), _ptr(n_out), _stream()), 'nbm_nms_batched')
+    return rois, rs, n_out
+
+
+def roi_pool(fmaps, rois, n_roi, pe_f, pe_t, img_h, img_w):
+    """fmaps: list of NHWC [B,h,w,C]; rois [B,cap,4]; n_roi device int32[1] -> pool, pe [B*cap,2,2,C], level [B,cap]."""
+    B, cap = rois.shape[:2]
+    C_ = fmaps[0].shape[-1]
+    d = RoiDesc()
+    for i, f in enumerate(fmaps):
+        _chk(f, name=f'fmap{i}')
+        d.fmap[i] = f.data_ptr()
+        d.fh[i], d.fw[i] = f.shape[1], f.shape[2]
+    d.n_levels, d.C = len(fmaps), C_
+    d.rois, d.n_roi, d.B, d.roi_cap = _chk(rois).data_ptr(), n_roi.data_ptr(), B, cap
+    d.pe_f, d.pe_t, d.img_h, d.img_w = _chk(pe_f).data_ptr(), _chk(pe_t).data_ptr(), img_h, img_w
+    pool = torch.zeros((B * cap, 2, 2, C_), device=rois.device, dtype=torch.float32)
+    pe = torch.zeros((B * cap, 2, 2, C_), device=rois.device, dtype=torch.float32)
+    level = torch.zeros((B, cap), device=rois.device, dtype=torch.int32)
+    d.pool, d.pe, d.level = pool.data_ptr(), pe.data_ptr(), level.data_ptr()
+    check(lib().nbm_roi_pool(C.byref(d), _stream()), 'nbm_roi_pool')
+    return pool, pe, level
+
+
+def rcnn_post(rois, n_roi, bbox_reg, bbox_cls, img_w, img_h, nms_thresh, min_score, proposal_number):
+    """-> det [B,cap,6] rows {class,x1,y1,x2,y2,score} sorted by (class, score desc), n_det [B]."""
+    B, cap = rois.shape[:2]
+    n_cls1 = bbox_cls.shape[-1]
+    det = torch.zeros((B, cap, 6), device=rois.device, dtype=torch.float32)
+    n_det = torch.zeros((B,), device=rois.device, dtype=torch.int32)
+    check(lib().nbm_rcnn_post(_ptr(_chk(rois)), _ptr(n_roi), B, cap, _ptr(_chk(bbox_reg)), _ptr(_chk(bbox_cls)),
+                              n_cls1, img_w, img_h, float(nms_thresh), float(min_score), int(proposal_number),
+                              _ptr(det), _ptr(n_det), _stream()), 'nbm_rcnn_post')
+    return det, n_det

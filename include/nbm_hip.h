@@ -1,0 +1,185 @@
+/* nbm_hip.h — C ABI of the MI355X-native NBM hot path (libnbm_hip.so).
+ *
+ * The reference (LouisBearing/BirdSoundClassif) is 100 % Python: it has no FFI layer, its "native"
+ * boundary is torch's own CPU/CUDA operators.  Every entry point below replaces the torch / numpy /
+ * librosa operator call(s) named in its comment (reference file:line, relative to /root/reference).
+ * The host side (birdsoundclassif_amd/ops.py) binds them with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless the name ends in _host; no ownership transfer,
+ *     the caller allocates outputs and workspaces;
+ *   - activations are NHWC fp32 ("pixel pitch" = *_ld floats between consecutive pixels);
+ *   - `stream` is a hipStream_t passed as void*; all functions are asynchronous on it, re-entrant,
+ *     and keep no global state;
+ *   - return value: 0 = success, otherwise a negative NBM_E* code (bad argument) or a positive
+ *     hipError_t from the launch.
+ */
+#ifndef NBM_HIP_H
+#define NBM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NBM_OK 0
+#define NBM_EINVAL (-1)
+#define NBM_EALIGN (-2)
+#define NBM_EUNSUPPORTED (-3)
+
+#define NBM_ACT_NONE 0
+#define NBM_ACT_RELU 1
+#define NBM_ACT_SILU 2
+
+const char* nbm_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution / batched GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ *
+ *   y[g][m][n] = act( alpha * sum_k A[g][m][k] * W[g][n][k] * scale[n] + shift[n|m] + residual[g][m][n] )
+ *
+ *   A is the im2col view of x (NHWC): m = (b, oy, ox), k = (r, s, c) -> x[b][oy*stride-pad+r][ox*stride-pad+s][c]
+ *   (zero outside the image).  W is [N][w_ld] with k contiguous (KRSC weights).  A plain GEMM is the
+ *   case H = M, W = 1, kh = kw = 1.  `groups` (blockIdx.z) strides x / w / y / residual by *_gs floats
+ *   (attention: one GEMM per clip; 0 = operand shared by all groups).
+ *
+ * Replaces: F.conv2d / nn.Linear / torch.matmul call sites of the detector forward
+ *   backbone.py:104-113 (+ torchvision ResNet-50 convs), self_attention.py:43-49, fpn.py:132-146,
+ *   layers.py:25-46,79-99,574-579; FrozenBatchNorm2d affine (backbone.py:52-62), bias, ReLU/SiLU and
+ *   the residual add are fused in the epilogue.
+ */
+typedef struct nbm_gemm_desc {
+  const float* x;        /* A source, NHWC [B][H][W][Cin] with pixel pitch x_ld            */
+  const float* w;        /* [N][w_ld], K = kh*kw*Cin valid columns (rest must be finite)   */
+  float* y;              /* [M][y_ld] (NHWC output, N valid channels)                      */
+  const float* scale;    /* [N] or NULL                                                    */
+  const float* shift;    /* [N] (or [M] when shift_per_row) or NULL                        */
+  const float* residual; /* [M][res_ld] or NULL                                            */
+  int64_t x_gs, w_gs, y_gs, res_gs; /* per-group strides in floats                        */
+  int groups;
+  int B, H, W, Cin;      /* input geometry                                                 */
+  int N;                 /* output channels                                                */
+  int kh, kw, stride, pad;
+  int Ho, Wo;            /* output geometry; M = B*Ho*Wo                                   */
+  int x_ld, w_ld, y_ld, res_ld;
+  float alpha;
+  int act;               /* NBM_ACT_*                                                      */
+  int shift_per_row;     /* 1: shift is indexed by m (row) instead of n                    */
+} nbm_gemm_desc;
+
+int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Spectrogram front end.  Replaces File_Processor.load/spectrogram/split_power_spec
+ * (nbm_model/nbm_datasets/prepare_dataset.py:160-184, 228-252, 255-294) incl. librosa.stft and the
+ * ffmpeg 2x resample (third-party).
+ */
+
+/* PCM16 -> zero-padded fp32 waveform rows: out[b][lead + i] = pcm/32768 (upsample=0) or the 2x
+ * half-band integer interpolation (upsample=1, output length 2n); everything else in the row
+ * [0, out_ld) is written as 0.  hq = 16 Q15 odd-phase taps (oracle/frontend_ref.py:upsample2x_coeffs). */
+int nbm_pcm16_to_wave(const int16_t* pcm, int64_t pcm_ld, int batch, int n, int upsample,
+                      const int32_t* hq, float* out, int64_t out_ld, int lead, void* stream);
+
+/* STFT magnitude in dB for bins [low_bin, low_bin+n_bins) as a DFT-GEMM on the fp32 MFMA:
+ *   db[b][f][t] = 20 log10(max(floor, | sum_n basis[f][n] * wave[b][t*hop + n] |))
+ * basis: [ceil(n_bins/32)*64][basis_ld] rows in blocks of 64 = 32 cos rows then 32 sin rows (window
+ * folded in, zero beyond n_fft and beyond n_bins).  minmax[b] = {min, max} over the clip as
+ * order-preserving uint32 keys; must be initialised with nbm_minmax_init.  */
+int nbm_minmax_init(uint32_t* minmax, int batch, void* stream);
+int nbm_stft_db(const float* wave, int64_t wave_ld, int batch, int n_frames, int hop,
+                const float* basis, int basis_rows, int basis_ld, int n_bins, float floor_amp,
+                float* db, int64_t db_bs, int db_ld, uint32_t* minmax, void* stream);
+
+/* (x - min)/(max - min) + window split (hop_img) + reflect padding of the last window:
+ * img[b][k][f][c], k < n_img, c < w_pix.  minmax_group: clips [g*minmax_group, (g+1)*minmax_group)
+ * share one min/max (a long file cut in chunks); 1 = per clip. */
+int nbm_spec_windows(const float* db, int64_t db_bs, int db_ld, int batch, int n_bins, int n_frames,
+                     const uint32_t* minmax, float* img, int n_img, int w_pix, int hop_img, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Point-wise / small-window detector stages (NHWC fp32).
+ */
+
+/* y[p][c] = x[p]*w[c] + b[c]  -- BackboneBase.init_conv (backbone.py:104-105,110-113), 1 -> C. */
+int nbm_init_conv(const float* x, int64_t n_pix, const float* w, const float* b, int C, float* y, void* stream);
+
+/* 3x3 / stride 2 / pad 1 max pooling -- torchvision ResNet `maxpool` (backbone.py:131). */
+int nbm_maxpool3x3s2(const float* x, int B, int H, int W, int C, float* y, int Ho, int Wo, void* stream);
+
+/* y = bilinear_align_corners(src -> Ho x Wo) [+ add]  -- fpn.py:143-144, layers.py:35-37. */
+int nbm_upsample_bilinear_add(const float* src, int B, int Hi, int Wi, int C, const float* add,
+                              float* y, int Ho, int Wo, void* stream);
+
+/* in-place row softmax of [rows][cols] with pitch ld -- self_attention.py:47, layers.py:579. */
+int nbm_softmax_rows(float* x, int64_t rows, int cols, int64_t ld, void* stream);
+
+/* depthwise 3x3, pad 1, channel multiplier `mult` (out channel o reads in channel o/mult), + bias;
+ * optional FiLM: y = y*gamma + beta with film[p][0:Cout]=gamma, film[p][Cout:2Cout]=beta
+ * -- DepthwiseSepConv2d.depth_wise / FiLM (layers.py:25-26,38-42). */
+int nbm_dwconv3x3(const float* x, int B, int H, int W, int Cin, int mult, int stride,
+                  const float* w /*[Cin*mult][9]*/, const float* bias, const float* film, int64_t film_ld,
+                  float* y, int Ho, int Wo, void* stream);
+
+/* y = x * sigmoid(x) -- nn.SiLU (layers.py:31,41). */
+int nbm_silu(const float* x, float* y, int64_t n, void* stream);
+
+/* softmax over the (bg, fg) pair of every anchor: x[p][2a], x[p][2a+1] (pitch ld) -> y (pitch y_ld)
+ * -- layers.py:90. */
+int nbm_pair_softmax(const float* x, int64_t n_pix, int n_anchor, int x_ld, float* y, int y_ld, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Proposal / RoI / detection stages (integer + sort work; bit-exact vs the oracle).
+ */
+
+/* ProposalLayer decode (layers.py:266-285, nets_utils.py:169-186): per image and anchor (K-major):
+ * boxes[b][i][4] (rounded, clipped), keys[b][i] = order-preserving uint32 of the fg score or 0 when the
+ * box is smaller than min_size; keep_count[b] = #kept. cls: [B][K][2A] softmaxed, reg: [B][K][4A]. */
+int nbm_rpn_decode(const float* cls, const float* reg, const float* anchors /*[K*A][4]*/, int B, int KA,
+                   int n_anchor /*A: anchors per location*/, int img_w, int img_h, int min_size, float* boxes,
+                   uint32_t* keys, int* keep_count, void* stream);
+
+/* Top-N selection by (score desc, index asc) among kept anchors, N = min(top_n, min_b keep_count[b]);
+ * writes sel_boxes[b][cap][4], sel_scores[b][cap], n_sel[0] = N (0 if N < fail_below: "RPN failed"
+ * layers.py:287-290).  -- layers.py:292-297.  cap >= top_n, cap power of two <= 4096. */
+int nbm_rpn_select(const float* boxes, const uint32_t* keys, const int* keep_count, int B, int KA,
+                   int top_n, int fail_below, int cap, float* sel_boxes, float* sel_scores, int* n_sel,
+                   void* stream);
+
+/* Greedy NMS in the given order (suppress IoU >= thresh, +1 pixel convention) then the batch-coupled
+ * truncation R = min(post_n, min_b #keep_b) -- nets_utils.py:189-245.  n_in[0] boxes per image.
+ * Workspaces: mask_ws B*cap*(cap/64) uint64, keep_ws B*(cap+1) int32.  Writes rois[b][post_n][4],
+ * roi_scores[b][post_n], n_out[0] = R.  cap: multiple of 64, <= 4096. */
+int nbm_nms_batched(const float* boxes, const float* scores, const int* n_in, int B, int cap, float thresh,
+                    int post_n, uint64_t* mask_ws, int* keep_ws, float* rois, float* roi_scores, int* n_out,
+                    void* stream);
+
+/* ROIPooling (layers.py:406-497): level assignment, window, 2x2 adaptive average of the FPN map and of
+ * the separable positional encoding.  fmaps: 5 device pointers (NHWC, C channels); pe_f [img_h][C/2],
+ * pe_t [img_w][C/2].  n_roi[0] RoIs per image out of roi_cap slots.  Outputs NHWC [B*roi_cap][2][2][C]. */
+typedef struct nbm_roi_desc {
+  const float* fmap[5];
+  int fh[5], fw[5];
+  int n_levels, C;
+  const float* rois;     /* [B][roi_cap][4] */
+  const int* n_roi;      /* device scalar   */
+  int B, roi_cap;
+  const float* pe_f; const float* pe_t; int img_h, img_w;
+  float* pool; float* pe; int* level;
+} nbm_roi_desc;
+int nbm_roi_pool(const nbm_roi_desc* d, void* stream);
+
+/* FastRCNN eval post-processing (layers.py:688-776) for B images, n_roi[0] RoIs each:
+ * class arg-max, per-class delta gather, decode+clip, sort by score, drop background, class-agnostic
+ * NMS, per-class NMS (top proposal_number) and score > min_score.  Output rows sorted by (class asc,
+ * score desc): det[b][cap][6] = {class, x1, y1, x2, y2, score}, n_det[b]. */
+int nbm_rcnn_post(const float* rois, const int* n_roi, int B, int roi_cap, const float* bbox_reg,
+                  const float* bbox_cls, int n_cls1 /*1+num_classes*/, int img_w, int img_h,
+                  float nms_thresh, float min_score, int proposal_number, float* det, int* n_det,
+                  void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

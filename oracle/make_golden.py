@@ -31,7 +31,7 @@ def sample_idx(name, numel):
 
 def pack(store, name, t, full_limit=200_000):
     t = t.detach().float().contiguous()
-    flat = t.flatten().numpy()
+    flat = t.flatten().numpy().copy()          # copy: live buffers keep changing after this call
     store[name + '.shape'] = np.array(t.shape, dtype=np.int64)
     if flat.size <= full_limit:
         store[name + '.full'] = flat

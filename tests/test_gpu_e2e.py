@@ -1,0 +1,141 @@
+"""GPU parity tests, path level: front end and detector forward through the reference-shaped API
+(File_Processor / NbmModel) against the oracle and the golden fixtures generated from the real reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from birdsoundclassif_amd import synth                                     # noqa: E402
+from helpers import check_packed, dets_to_rows, filler_state_dict, load_golden   # noqa: E402
+from oracle import frontend_ref as FR, nets_ref as O                       # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def model():
+    from birdsoundclassif_amd.nets import build_model
+    from birdsoundclassif_amd.train import default_args
+    m, _ = build_model(default_args(device='cuda'))
+    m.load_state_dict(filler_state_dict())
+    return m.cuda().eval()
+
+
+# --------------------------------------------------------------------------- front end
+def test_upsample_bit_exact_and_image_parity(tmp_path):
+    from birdsoundclassif_amd.nbm_datasets.prepare_dataset import SpectrogramFrontEnd, File_Processor
+    from birdsoundclassif_amd import ops
+    fe = SpectrogramFrontEnd('cuda')
+    pcm = synth.clip_batch_pcm16(0, 3)
+    # integer stage: bit exact
+    lead = 662
+    wave = ops.pcm16_to_wave(torch.from_numpy(pcm).cuda(), 2 * pcm.shape[1] + 2 * lead + 20, lead, True, fe.hq).cpu().numpy()
+    for b in range(3):
+        ref = FR.upsample2x_pcm16(pcm[b]).astype(np.float32) / np.float32(32768)
+        assert np.array_equal(wave[b, lead:lead + len(ref)], ref)
+        assert not wave[b, :lead].any() and not wave[b, lead + len(ref):].any()
+    # whole front end: fp32 DFT-GEMM vs float64 FFT oracle; tolerance 5e-5 on the [0,1] image
+    imgs, L = fe(torch.from_numpy(pcm).cuda(), 22050)
+    assert L == 1003 and tuple(imgs.shape) == (3, 1, 375, 1024)
+    for b in range(3):
+        ref_imgs, c = FR.process_waveform(FR.upsample2x_pcm16(pcm[b]).astype(np.float32) / np.float32(32768))
+        assert len(ref_imgs) == 1 and c['spectrogram_length'] == L
+        err = np.abs(imgs[b, 0].cpu().numpy() - ref_imgs[0])
+        assert err.max() < 5e-5, err.max()
+        assert imgs[b, 0].min() == 0.0 and imgs[b, 0].max() == 1.0
+    # File_Processor interface on a wav file, 44.1 kHz multi-window file
+    p = str(tmp_path / 'long.wav')
+    long_pcm = np.concatenate([FR.upsample2x_pcm16(synth.clip_pcm16(10 + i)) for i in range(3)])
+    synth.write_wav(p, long_pcm, 44100)
+    fp = File_Processor(p)
+    got, _ = fp.process_file()
+    ref_imgs, c = FR.process_file(p)
+    assert len(got) == len(ref_imgs) == 4 and fp.spectrogram_length == c['spectrogram_length']
+    assert fp.W_PIX == 1024 and fp.HOP_SPECTRO == 819
+    for a, b in zip(got, ref_imgs):
+        assert np.abs(a - b).max() < 5e-5
+
+
+def test_silent_file_is_nan_like_reference():
+    from birdsoundclassif_amd.nbm_datasets.prepare_dataset import SpectrogramFrontEnd
+    fe = SpectrogramFrontEnd('cuda')
+    imgs, _ = fe(torch.zeros((1, 66150), dtype=torch.int16).cuda(), 22050)
+    assert torch.isnan(imgs).all()          # (x - min)/(max - min) with max == min, Appendix C-8
+
+
+# --------------------------------------------------------------------------- detector forward vs golden (real reference)
+def test_forward_matches_reference_golden(model):
+    g = load_golden('eval_b2.npz')
+    x = torch.from_numpy(synth.image_batch(0, 2))[:, None].cuda()
+    with torch.no_grad():
+        o = model.forward_first_stage(x)
+    # logits-level tensors: 1e-4 absolute (BASELINE.json north_star tolerance) on O(1) activations
+    for i, f in enumerate(o['fpn_out']):
+        check_packed(g, f'fpn{i}', f, atol=1e-4, rtol=1e-4)
+    check_packed(g, 'rpn_cls_scores', o['rpn_cls_scores'], atol=1e-4)
+    check_packed(g, 'rpn_bbox_reg', o['rpn_bbox_reg'], atol=1e-4)
+    # discrete outputs: bit exact box assignments
+    ref_rois = g['rois.full'].reshape(g['rois.shape'])
+    assert tuple(o['rois'].shape) == tuple(ref_rois.shape)
+    n_bad = int((o['rois'].cpu().numpy() != ref_rois).any(-1).sum())
+    assert n_bad == 0, f'{n_bad} RoIs differ from the reference'
+    with torch.no_grad():
+        s = model.forward_second_stage(o['fpn_out'], o['rois'], training=True)
+    check_packed(g, 'bbox_reg', s['bbox_reg'], atol=1e-4)
+    check_packed(g, 'bbox_classes', s['bbox_classes'], atol=1e-4)
+    for ms in (0.05, 0.2, 0.5):
+        with torch.no_grad():
+            dets = model(x, min_score=ms)
+        rows, ref = dets_to_rows(dets), g[f'dets_min{ms}']
+        assert rows.shape == ref.shape, (ms, rows.shape, ref.shape)
+        assert np.array_equal(rows[:, :6], ref[:, :6]), f'class / box assignment differs at min_score={ms}'
+        assert np.abs(rows[:, 6] - ref[:, 6]).max() < 1e-4
+
+
+def test_intermediate_taps_vs_golden(model):
+    g = load_golden('eval_b2.npz')
+    x = torch.from_numpy(synth.image_batch(0, 2)).cuda()[..., None].contiguous()      # NHWC
+    with torch.no_grad():
+        taps, _ = model.backbone(x)
+        for i, t in enumerate(taps):
+            check_packed(g, f'tap{i}', t.permute(0, 3, 1, 2), atol=5e-5, rtol=5e-5)
+        att = model.attn(taps)
+        for i in (3, 4):
+            check_packed(g, f'attn{i}', att[i].permute(0, 3, 1, 2), atol=1e-4, rtol=1e-4)
+
+
+def test_forward_matches_oracle_other_seed(model):
+    """Same comparison against the oracle restatement on inputs the golden file does not cover (B=3)."""
+    sd = filler_state_dict()
+    cfg = O.make_cfg()
+    x = torch.from_numpy(synth.image_batch(40, 3))[:, None]
+    with torch.no_grad():
+        ref = O.forward_first_stage(sd, cfg, x)
+        got = model.forward_first_stage(x.cuda())
+    for a, b in zip(got['fpn_out'], ref['fpn_out']):
+        assert (a.cpu() - b).abs().max() < 1e-4
+    assert (got['rpn_cls_scores'].cpu() - ref['rpn_cls_scores']).abs().max() < 1e-4
+    assert tuple(got['rois'].shape) == tuple(ref['rois'].shape)
+    assert torch.equal(got['rois'].cpu(), ref['rois'])
+    with torch.no_grad():
+        ref_d = O.forward_second_stage(sd, cfg, ref['fpn_out'], ref['rois'], 0.3, 0.1)
+        got_d = model(x.cuda(), min_score=0.1)
+    r, q = dets_to_rows(ref_d), dets_to_rows(got_d)
+    assert r.shape == q.shape and np.array_equal(r[:, :6], q[:, :6])
+
+
+def test_checkpoint_layout_roundtrip(model, tmp_path):
+    """{'checkpoints': state_dict} written like reference train.py:171-187 loads through initialize_model."""
+    from birdsoundclassif_amd.nets.nbm_model import initialize_model
+    from birdsoundclassif_amd.nets import build_model
+    from birdsoundclassif_amd.train import default_args
+    p = str(tmp_path / 'model_chkpt.pt')
+    torch.save({'checkpoints': {k: v.cpu() for k, v in model.state_dict().items()}, 'steps': 1, 'epoch': 0,
+                'best_val_cls_loss': 99}, p)
+    m2, _ = build_model(default_args(device='cuda'))
+    m2 = initialize_model(m2, p, train=False)
+    x = torch.from_numpy(synth.image_batch(0, 1))[:, None].cuda()
+    with torch.no_grad():
+        a, b = model.detect(x, min_score=0.05), m2.cuda().detect(x, min_score=0.05)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
