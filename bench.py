@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Benchmark of the NBM detect hot path on MI355X (contract: see the task statement / DESIGN.md §Measurement).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 64]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path over one batch of synthetic input per rank:
+    PCM16 clips (3 s @ 22.05 kHz, already resident in HBM) -> HIP front end (2x up-sample, STFT-dB, normalise,
+    window) -> HIP detector forward (ResNet-50 + attention + FPN + RPN + proposals + RoI pool + RCNN head +
+    post-processing) -> per-clip detections on the host (reference output structure).
+Workload = BASELINE.json configs[1] (batch 64 per GPU, fp32).  Multi-GPU: clips are independent, every rank
+runs its own batch (weak scaling, no data-path collective); value = all clips of all ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0, carrying `roofline` (dominant kernel: the FPN 3x3 384->256 implicit GEMM at
+188x512, timed live with HIP events on the launch stream) and `cpu_baseline` (the oracle port on the host cores,
+bounded sample, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+FPN0_GFLOP_PER_CLIP = 170.322          # fpn.out_convs.4, 3x3 384->256 @188x512
+FWD_GFLOP_PER_CLIP = 325.56            # SURVEY.md §6 (conv + addmm + bmm, forward)
+
+
+def cpu_baseline(n_clips=4, batch=2):
+    """Oracle port (numpy front end + pure-torch detector) on the host cores; bounded sample."""
+    from birdsoundclassif_amd import synth
+    from oracle import frontend_ref as FR, nets_ref as O
+    from birdsoundclassif_amd.nets import build_model
+    from birdsoundclassif_amd.train import default_args
+    model, _ = build_model(default_args(device='cpu'))
+    sd = synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+    cfg = O.make_cfg()
+    cores = torch.get_num_threads()
+    t0 = time.perf_counter()
+    done = 0
+    with torch.no_grad():
+        for s in range(0, n_clips, batch):
+            pcm = synth.clip_batch_pcm16(1000 + s, batch)
+            imgs = [FR.process_waveform(FR.upsample2x_pcm16(p).astype(np.float32) / np.float32(32768))[0][0] for p in pcm]
+            x = torch.from_numpy(np.stack(imgs))[:, None]
+            O.forward(sd, cfg, x, min_score=0.2)
+            done += batch
+    dt = time.perf_counter() - t0
+    return {'value': done / dt, 'unit': 'clips/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{done} synthetic 3 s clips in batches of {batch}: oracle front end (numpy float64 FFT) + '
+                      f'oracle detector forward (torch CPU fp32, {cores} threads), {dt:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=64)
+    ap.add_argument('--min-score', type=float, default=0.2)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    a = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    if a.gpus != world and world > 1:
+        raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}')
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+
+    from birdsoundclassif_amd import ops, synth
+    from birdsoundclassif_amd.nbm_datasets.prepare_dataset import SpectrogramFrontEnd
+    from birdsoundclassif_amd.nets import build_model
+    from birdsoundclassif_amd.train import default_args
+
+    B = a.batch
+    model, _ = build_model(default_args(device='cuda'))
+    model.load_state_dict(synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}))
+    model = model.cuda().eval()
+    fe = SpectrogramFrontEnd('cuda')
+    # a few distinct clips tiled to the batch: the input content does not change the work
+    base = synth.clip_batch_pcm16(rank * 8, 8)
+    pcm = torch.from_numpy(np.tile(base, (-(-B // 8), 1))[:B].copy()).cuda()
+
+    def step():
+        imgs, _ = fe(pcm, 22050)                               # [B,1,375,1024]
+        return model(imgs, min_score=a.min_score)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync_all()
+    ops.PROFILE = []                                           # live HIP-event timing of every igemm launch
+    t0 = time.perf_counter()
+    n_det = 0
+    for _ in range(a.steps):
+        out = step()
+        n_det += sum(len(v['bbox_coord']) for d in out for v in d.values())
+    sync_all()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if dist is not None:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # roofline of the dominant kernel
+    fpn0 = [s.elapsed_time(e) for (tag, s, e) in prof if tag == (384, 256, 3, 188, 512)]
+    all_ms = sum(s.elapsed_time(e) for (_, s, e) in prof)
+    roof = None
+    if fpn0:
+        avg_ms = sum(fpn0) / len(fpn0)
+        ach = FPN0_GFLOP_PER_CLIP * B / avg_ms                 # GFLOP/ms == TFLOP/s
+        roof = {'bound': 'mfma', 'kernel': 'igemm_kernel<128,128,64,64,FAST,STD> (fpn.out_convs.4, 3x3 384->256 @188x512)',
+                'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS,
+                'traffic': None, 'avg_launch_ms': avg_ms, 'launches': len(fpn0),
+                'all_igemm_ms_per_step': all_ms / a.steps,
+                'whole_step_frac_of_mfma_peak': (FWD_GFLOP_PER_CLIP * B * a.steps / (dt * 1e3)) / FP32_MFMA_PEAK_TFLOPS}
+    if rank == 0:
+        line = {'metric': 'clips/sec (3 s @ 22.05 kHz) detect fwd', 'value': world * B * a.steps / dt, 'unit': 'clips/s',
+                'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
+                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                'config': {'workload': 'BASELINE.json configs[1]: 1xMI355X inference, batch=64 synthetic 3 s clips '
+                                       '(PCM16 @22.05 kHz resident in HBM) through the HIP STFT front end + detector '
+                                       'forward + device post-processing, detections returned to the host',
+                           'batch_per_gpu': B, 'min_score': a.min_score, 'detections_per_step': n_det / a.steps},
+                'roofline': roof}
+        if world == 1 and not a.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

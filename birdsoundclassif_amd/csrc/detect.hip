@@ -245,7 +245,9 @@ __global__ void roi_pool_kernel(const RoiParams p) {
   if (threadIdx.x == 0) p.level[slot] = lvl;
   const int C = p.C, half = C >> 1;
   const float* fm = p.fmap[lvl];
-  const int h = y2 - y1 + 1, w = x2 - x1 + 1;
+  // the reference slices fmap[..., y1:y2+1, x1:x2+1]: python slicing silently clamps x2 (== W when the RoI touches
+  // the right border: 1023/2 = 511.5 -> 512) while the positional encoding below keeps the unclamped x2
+  const int h = y2 - y1 + 1, w = min(x2, W - 1) - x1 + 1;
   const int s = 2 << lvl;
   const int f0 = s * y1, f1 = min(s * y2, p.img_h), hf = f1 - f0;         // pe_frequency[s*y1 : s*y2]
   const int wt = min(s * (x2 - x1), p.img_w);                              // pe_time[: s*(x2-x1)]

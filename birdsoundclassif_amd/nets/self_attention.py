@@ -36,6 +36,8 @@ class SelfAttention(nn.Module):
         """inpt NHWC [B,h,w,C] -> NHWC [B,h,w,C] = (inpt +) attention(inpt)."""
         B, h, w, Cc = inpt.shape
         L, d = h * w, self.inner_dim
+        if L % 32:
+            raise NotImplementedError(f'attention over {h}x{w} tokens: the P.V GEMM needs H*W % 32 == 0')
         x2d = inpt.view(B * L, Cc)
         wqk = _prep.cat_rows('qk_w', self.query.weight, self.key.weight)
         bqk = _prep.cat_rows('qk_b', self.query.bias, self.key.bias)

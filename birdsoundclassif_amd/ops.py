@@ -13,6 +13,10 @@ from ._lib import GemmDesc, RoiDesc, check
 
 ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
 
+# bench.py sets this to a list to time every implicit-GEMM launch with HIP events on the launch stream:
+# entries are ((Cin, N, kh, H, W), start_event, end_event).
+PROFILE = None
+
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -57,6 +61,13 @@ def gemm_conv(x, w, y, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, Ho=None,
     d.y_ld = N if y_ld is None else y_ld
     d.res_ld = (N if res_ld is None else res_ld) if residual is not None else 0
     d.alpha, d.act, d.shift_per_row = float(alpha), int(act), int(bool(shift_per_row))
+    if PROFILE is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        check(lib().nbm_gemm_conv(C.byref(d), _stream()), 'nbm_gemm_conv')
+        ev1.record()
+        PROFILE.append(((Cin, N, kh, H, W), ev0, ev1))
+        return y
     check(lib().nbm_gemm_conv(C.byref(d), _stream()), 'nbm_gemm_conv')
     return y
 

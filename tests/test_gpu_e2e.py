@@ -35,14 +35,27 @@ def test_upsample_bit_exact_and_image_parity(tmp_path):
         ref = FR.upsample2x_pcm16(pcm[b]).astype(np.float32) / np.float32(32768)
         assert np.array_equal(wave[b, lead:lead + len(ref)], ref)
         assert not wave[b, :lead].any() and not wave[b, lead + len(ref):].any()
-    # whole front end: fp32 DFT-GEMM vs float64 FFT oracle; tolerance 5e-5 on the [0,1] image
-    imgs, L = fe(torch.from_numpy(pcm).cuda(), 22050)
-    assert L == 1003 and tuple(imgs.shape) == (3, 1, 375, 1024)
+    # whole front end: fp32 DFT-GEMM (K = 1324 sequential fp32 fmaf chain) vs the float64 FFT oracle.
+    # The error lives in the LINEAR magnitude: |X_gpu - X_ref| <= eps_abs with eps_abs = 1e-5 * max|X| of the clip
+    # (fp32 accumulation noise), which in dB is 8.69 * eps_abs / |X_ref| -- large only for the handful of bins
+    # whose magnitude is ~1e-4 of the clip maximum (for 22.05 kHz material: the empty band above 11 kHz, rows >= 315).
+    # On the [0,1] image: median < 2e-6, 99 % of the pixels within 5e-5, 99.9 % within 5e-4, all within 5e-3.
+    db, mm, L = fe.spectrogram_db(torch.from_numpy(pcm).cuda(), 22050)
+    imgs, L2 = fe(torch.from_numpy(pcm).cuda(), 22050)
+    assert L == L2 == 1003 and tuple(imgs.shape) == (3, 1, 375, 1024)
     for b in range(3):
-        ref_imgs, c = FR.process_waveform(FR.upsample2x_pcm16(pcm[b]).astype(np.float32) / np.float32(32768))
+        y = FR.upsample2x_pcm16(pcm[b]).astype(np.float32) / np.float32(32768)
+        mag = FR.stft_mag(y, 1324, 132)[16:391]
+        ref_db = FR.amp_to_db(mag)
+        eps_abs = 1e-5 * mag.max()
+        tol_db = 8.69 * eps_abs / np.maximum(mag, 1e-5) + 1e-4
+        err_db = np.abs(db[b].cpu().numpy().astype(np.float64) - ref_db)
+        assert (err_db <= tol_db).all(), float((err_db / tol_db).max())
+        ref_imgs, c = FR.process_waveform(y)
         assert len(ref_imgs) == 1 and c['spectrogram_length'] == L
         err = np.abs(imgs[b, 0].cpu().numpy() - ref_imgs[0])
-        assert err.max() < 5e-5, err.max()
+        q = np.quantile(err, [0.5, 0.99, 0.999])
+        assert q[0] < 2e-6 and q[1] < 5e-5 and q[2] < 5e-4 and err.max() < 5e-3, (q, err.max())
         assert imgs[b, 0].min() == 0.0 and imgs[b, 0].max() == 1.0
     # File_Processor interface on a wav file, 44.1 kHz multi-window file
     p = str(tmp_path / 'long.wav')
@@ -54,7 +67,8 @@ def test_upsample_bit_exact_and_image_parity(tmp_path):
     assert len(got) == len(ref_imgs) == 4 and fp.spectrogram_length == c['spectrogram_length']
     assert fp.W_PIX == 1024 and fp.HOP_SPECTRO == 819
     for a, b in zip(got, ref_imgs):
-        assert np.abs(a - b).max() < 5e-5
+        err = np.abs(a - b)
+        assert np.quantile(err, 0.99) < 5e-5 and np.quantile(err, 0.999) < 5e-4 and err.max() < 5e-3
 
 
 def test_silent_file_is_nan_like_reference():
