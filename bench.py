@@ -124,12 +124,20 @@ def main():
     fpn0 = [s.elapsed_time(e) for (tag, s, e) in prof if tag == (384, 256, 3, 188, 512)]
     all_ms = sum(s.elapsed_time(e) for (_, s, e) in prof)
     roof = None
+    traffic = None                      # HBM bytes per launch of the dominant kernel: PMC counters cannot be read live;
+    try:                                # the value comes from the committed rocprofv3 --pmc passes of this same command
+        pj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_fpn0.json')))
+        if B == 64:
+            traffic = pj['traffic_bytes_per_launch']
+    except Exception:
+        traffic = None
     if fpn0:
         avg_ms = sum(fpn0) / len(fpn0)
         ach = FPN0_GFLOP_PER_CLIP * B / avg_ms                 # GFLOP/ms == TFLOP/s
         roof = {'bound': 'mfma', 'kernel': 'igemm_kernel<128,128,64,64,FAST,STD> (fpn.out_convs.4, 3x3 384->256 @188x512)',
                 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS,
-                'traffic': None, 'avg_launch_ms': avg_ms, 'launches': len(fpn0),
+                'traffic': traffic, 'traffic_unit': 'bytes/launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_fpn0.json; '
+                                                         'algorithmic 15.77e9)', 'avg_launch_ms': avg_ms, 'launches': len(fpn0),
                 'all_igemm_ms_per_step': all_ms / a.steps,
                 'whole_step_frac_of_mfma_peak': (FWD_GFLOP_PER_CLIP * B * a.steps / (dt * 1e3)) / FP32_MFMA_PEAK_TFLOPS}
     if rank == 0:
