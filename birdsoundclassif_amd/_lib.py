@@ -37,6 +37,18 @@ class RoiDesc(C.Structure):
                 ('pool', C.c_void_p), ('pe', C.c_void_p), ('level', C.c_void_p)]
 
 
+class BwdDesc(C.Structure):
+    """struct nbm_bwd_desc (include/nbm_hip.h)."""
+    _fields_ = [('g', C.c_void_p), ('w', C.c_void_p), ('x', C.c_void_p), ('out', C.c_void_p),
+                ('a_scale', C.c_void_p), ('row_scale', C.c_void_p), ('residual', C.c_void_p), ('mask', C.c_void_p),
+                ('g_gs', C.c_int64), ('w_gs', C.c_int64), ('x_gs', C.c_int64), ('out_gs', C.c_int64), ('res_gs', C.c_int64),
+                ('groups', C.c_int),
+                ('B', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cin', C.c_int), ('N', C.c_int),
+                ('kh', C.c_int), ('kw', C.c_int), ('stride', C.c_int), ('pad', C.c_int), ('Ho', C.c_int), ('Wo', C.c_int),
+                ('g_ld', C.c_int), ('w_ld', C.c_int), ('x_ld', C.c_int), ('out_ld', C.c_int), ('res_ld', C.c_int),
+                ('mask_ld', C.c_int), ('alpha', C.c_float)]
+
+
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
 # name -> argtypes (restype is int unless noted); must list every symbol of include/nbm_hip.h
@@ -58,6 +70,25 @@ SIGNATURES = {
     'nbm_nms_batched': [_P, _P, _P, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P],
     'nbm_roi_pool': [C.POINTER(RoiDesc), _P],
     'nbm_rcnn_post': [_P, _P, _I, _I, _P, _P, _I, _I, _I, _F, _F, _I, _P, _P, _P],
+    # ---- training path
+    'nbm_conv_dgrad': [C.POINTER(BwdDesc), _P],
+    'nbm_conv_wgrad': [C.POINTER(BwdDesc), _P],
+    'nbm_relu_bwd': [_P, _P, _P, _L, _P],
+    'nbm_silu_bwd': [_P, _P, _P, _L, _P],
+    'nbm_axpby': [_P, _P, _P, _F, _F, _L, _P],
+    'nbm_colsum': [_P, _L, _I, _I, _P, _P],
+    'nbm_maxpool3x3s2_bwd': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    'nbm_upsample_bilinear_bwd': [_P, _I, _I, _I, _I, _P, _I, _I, _P],
+    'nbm_softmax_rows_bwd': [_P, _P, _P, _L, _I, _F, _P],
+    'nbm_pair_softmax_bwd': [_P, _P, _P, _L, _P],
+    'nbm_dwconv3x3_bwd': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P],
+    'nbm_film_fwd': [_P, _P, _P, _L, _I, _P],
+    'nbm_film_bwd': [_P, _P, _P, _P, _P, _L, _I, _P],
+    'nbm_bn_train_fwd': [_P, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P],
+    'nbm_bn_train_bwd': [_P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _P, _P],
+    'nbm_roi_pool_bwd': [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.POINTER(C.c_int), _I, _I, _P, _P, _I, _I, _P, _P],
+    'nbm_sqnorm_accum': [_P, _L, _P, _P],
+    'nbm_adamw_step': [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P, _F, _P],
 }
 
 

@@ -1,0 +1,408 @@
+// Backward implicit GEMMs on the gfx950 fp32 matrix core (v_mfma_f32_32x32x2_f32).
+//
+//   NN  (data gradient):   dX[m][c] = sum_{r,s,n} G[pix(m,r,s)][n] * a_scale[n] * W[n][r][s][c]
+//        m enumerates the INPUT pixels of the forward convolution; a forward stride > 1 is handled as a dilated gather
+//        of G (only taps with (iy+pad-r) % stride == 0 contribute).  A operand: gathered G rows, n contiguous;
+//        B operand "K-major": the KRSC weight rows W[n][r][s][:] are already contiguous along c, no transposed copy
+//        of the weights is ever made.  Also serves plain C = A * B ("NN") GEMMs (attention dQ, P.V, dX of linears).
+//   TN  (weight gradient): dW[n][r][s][c] += row_scale[n] * sum_m G[m][n] * X[pix(m,r,s)][c]
+//        reduction over the output pixels, split over gridDim.y chunks, fp32 atomics into a zeroed dW (KRSC).  Both
+//        operands are K-major (pixel-major, exactly as they lie in HBM), so neither is transposed: the MFMA fragments
+//        are read from LDS with 16 ds_read_b32 (conflict-free: 32 consecutive floats per half-wave).
+//
+// Tile / wave geometry, LDS double buffering and the XCD-aware tile map are those of igemm.hip.
+#include "nbm_common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int PITCH = 36;     // row-major-K tile: [rows][32 + 4]
+constexpr int KPITCH = 132;   // K-major tile:     [32][128 + 4]
+
+struct BwdParams {
+  const float* g; const float* w; const float* x; float* out;
+  const float* a_scale;      // NN: per-n multiplier of G (FrozenBN scale) or null
+  const float* row_scale;    // TN: per-n multiplier of dW rows or null
+  const float* residual;     // NN: added to dX (gradient accumulation) or null
+  const float* mask;         // NN: forward output of the producer; dX is zeroed where mask <= 0 (ReLU) or null
+  long long g_gs, w_gs, x_gs, out_gs, res_gs;
+  int B, H, W, Cin, N, kh, kw, stride, pad, Ho, Wo;
+  int g_ld, w_ld, x_ld, out_ld, res_ld, mask_ld;
+  int M;                     // NN: B*H*W input pixels; TN: B*Ho*Wo output pixels
+  int m_tiles, n_tiles;
+  int k_chunk;               // TN: pixels per split
+  float alpha;
+  int b_generic;             // TN: gather the X tile element-wise (Cin % 4 != 0)
+  int w_row;                 // NN: floats between W[n] and W[n+1] (= taps*Cin, or the padded pitch)
+};
+
+__device__ __forceinline__ int xcd_tile(int nwg, int bid) {
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+}
+
+// ---------------------------------------------------------------------------------------------------- NN
+template <int BN>
+__global__ __launch_bounds__(256, 2) void igemm_nn_kernel(const BwdParams p) {
+  constexpr int BM = 128, WM = 64, WN = BN / 2, MT = 2, NT = WN / 32;
+  constexpr int BP = BN + 4;                                   // K-major B tile pitch
+  __shared__ __attribute__((aligned(16))) float lds[2 * BM * PITCH + 2 * BK * BP];
+  float* As = lds;
+  float* Bs = lds + 2 * BM * PITCH;
+
+  const int wg = xcd_tile(gridDim.x, blockIdx.x);
+  const int tile_m = wg / p.n_tiles, tile_n = wg - tile_m * p.n_tiles;
+  const int bm0 = tile_m * BM, bn0 = tile_n * BN;
+  const int grp = blockIdx.z;
+  const float* __restrict__ gg = p.g + (long long)grp * p.g_gs;
+  const float* __restrict__ wg_ = p.w + (long long)grp * p.w_gs;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int lrow = lane & 31, lh = lane >> 5;
+
+  // A staging: 128 rows x 8 chunks of 16 B
+  const int c4 = tid & 7, r0 = tid >> 3;
+  int a_iy[4], a_ix[4], a_b[4];
+  bool a_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = bm0 + r0 + 32 * i;
+    a_ok[i] = m < p.M;
+    const int mm = a_ok[i] ? m : 0;
+    const int hw = p.H * p.W;
+    a_b[i] = mm / hw;
+    const int rem = mm - a_b[i] * hw;
+    a_iy[i] = rem / p.W;
+    a_ix[i] = rem - a_iy[i] * p.W;
+  }
+  // B staging (K-major): 32 rows x BN/4 chunks; thread -> rows rk0 + (256/(BN/4)) * i
+  constexpr int BCH = BN / 4;                 // 16-byte chunks per row
+  constexpr int BROWS = 256 / BCH;            // rows covered per pass
+  constexpr int BPASS = BK / BROWS;
+  const int bc = tid % BCH, rk0 = tid / BCH;
+
+  f32x4 ra[4], rb[BPASS];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  int cur_r = 0, cur_s = 0, cur_n0 = 0;
+  const int taps = p.kh * p.kw;
+
+  auto load_tiles = [&]() {
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f};
+    if (p.a_scale) sc = *reinterpret_cast<const f32x4*>(p.a_scale + cur_n0 + c4 * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ty = a_iy[i] + p.pad - cur_r, tx = a_ix[i] + p.pad - cur_s;
+      bool ok = a_ok[i] && ty >= 0 && tx >= 0;
+      int oy = ty, ox = tx;
+      if (p.stride > 1) {
+        ok = ok && (ty % p.stride == 0) && (tx % p.stride == 0);
+        oy = ty / p.stride; ox = tx / p.stride;
+      }
+      ok = ok && oy < p.Ho && ox < p.Wo;
+      f32x4 v = zero4;
+      if (ok) {
+        v = *reinterpret_cast<const f32x4*>(gg + ((long long)(a_b[i] * p.Ho + oy) * p.Wo + ox) * p.g_ld + cur_n0 + c4 * 4);
+        v[0] *= sc[0]; v[1] *= sc[1]; v[2] *= sc[2]; v[3] *= sc[3];
+      }
+      ra[i] = v;
+    }
+    const int tap = cur_r * p.kw + cur_s;
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+      const int kk = rk0 + BROWS * i;
+      const int n = cur_n0 + kk, c = bn0 + bc * 4;
+      rb[i] = (n < p.N && c < p.Cin)
+                  ? *reinterpret_cast<const f32x4*>(wg_ + (long long)n * p.w_row + (long long)tap * p.Cin + c)
+                  : zero4;
+    }
+    if (++cur_s == p.kw) { cur_s = 0; if (++cur_r == p.kh) { cur_r = 0; cur_n0 += BK; } }
+  };
+  auto store_lds = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<f32x4*>(As + (buf * BM + r0 + 32 * i) * PITCH + c4 * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i)
+      *reinterpret_cast<f32x4*>(Bs + (buf * BK + rk0 + BROWS * i) * BP + bc * 4) = rb[i];
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = ((p.N + BK - 1) / BK) * taps;
+  load_tiles();
+  store_lds(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nk;
+    if (more) load_tiles();
+    const float* Ab = As + (cur * BM + wm0 + lrow) * PITCH + lh * 16;
+    const float* Bb = Bs + (cur * BK + lh * 16) * BP + wn0 + lrow;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 a[MT];
+      float b[NT][4];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * PITCH + q * 4);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[j][e] = Bb[(q * 4 + e) * BP + j * 32];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_lds(cur ^ 1);
+    __syncthreads();
+  }
+
+  float* __restrict__ og = p.out + (long long)grp * p.out_gs;
+  const float* __restrict__ rg = p.residual ? p.residual + (long long)grp * p.res_gs : nullptr;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int c = bn0 + wn0 + j * 32 + lrow;
+    if (c >= p.Cin) continue;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = bm0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (m >= p.M) continue;
+        float v = acc[i][j][e] * p.alpha;
+        if (rg) v += rg[(long long)m * p.res_ld + c];
+        if (p.mask && !(p.mask[(long long)m * p.mask_ld + c] > 0.f)) v = 0.f;
+        og[(long long)m * p.out_ld + c] = v;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------- TN
+template <int BN>
+__global__ __launch_bounds__(256, 2) void igemm_tn_kernel(const BwdParams p) {
+  constexpr int BM = 128, WM = 64, WN = BN / 2, MT = 2, NT = WN / 32;
+  constexpr int AP = BM + 4, BP = BN + 4;
+  __shared__ __attribute__((aligned(16))) float lds[2 * BK * AP + 2 * BK * BP];
+  float* As = lds;                    // [2][32][AP]   G tile:  pixel-major, n contiguous
+  float* Bs = lds + 2 * BK * AP;      // [2][32][BP]   X tile:  pixel-major, c contiguous
+
+  const int wg = xcd_tile(gridDim.x, blockIdx.x);
+  const int tile_m = wg / p.n_tiles, tile_n = wg - tile_m * p.n_tiles;
+  const int bm0 = tile_m * BM;                      // n0
+  const int grp = blockIdx.z;
+  const int taps = p.kh * p.kw;
+  // N-tile -> (tap, c0)  [fast]   or   j0 over (tap, c) flattened  [generic]
+  const int ctiles = p.b_generic ? 1 : (p.Cin + BN - 1) / BN;
+  const int tap = p.b_generic ? 0 : tile_n / ctiles;
+  const int c0 = p.b_generic ? 0 : (tile_n - tap * ctiles) * BN;
+  const int j0 = tile_n * BN;                       // generic only
+  const int tr = tap / p.kw, ts = tap - tr * p.kw;
+
+  const float* __restrict__ gg = p.g + (long long)grp * p.g_gs;
+  const float* __restrict__ xg = p.x + (long long)grp * p.x_gs;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int lrow = lane & 31, lh = lane >> 5;
+
+  constexpr int ACH = BM / 4, AROWS = 256 / ACH, APASS = BK / AROWS;   // 32 chunks, 8 rows/pass, 4 passes
+  constexpr int BCH = BN / 4, BROWS = 256 / BCH, BPASS = BK / BROWS;
+  const int ac = tid % ACH, ar0 = tid / ACH;
+  const int bc = tid % BCH, br0 = tid / BCH;
+
+  const int m_begin = blockIdx.y * p.k_chunk;
+  const int m_end = min(p.M, m_begin + p.k_chunk);
+  const int nk = (m_end - m_begin + BK - 1) / BK;
+  if (nk <= 0) return;
+
+  f32x4 ra[APASS], rb[BPASS];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const int HoWo = p.Ho * p.Wo;
+
+  auto load_tiles = [&](int kt) {
+    const int mbase = m_begin + kt * BK;
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      const int m = mbase + ar0 + AROWS * i, n = bm0 + ac * 4;
+      ra[i] = (m < m_end && n < p.N) ? *reinterpret_cast<const f32x4*>(gg + (long long)m * p.g_ld + n) : zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+      const int m = mbase + br0 + BROWS * i;
+      f32x4 v = zero4;
+      if (m < m_end) {
+        const int b = m / HoWo, rem = m - b * HoWo;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        if (!p.b_generic) {
+          const int iy = oy * p.stride - p.pad + tr, ix = ox * p.stride - p.pad + ts;
+          const int c = c0 + bc * 4;
+          if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c < p.Cin)
+            v = *reinterpret_cast<const f32x4*>(xg + ((long long)(b * p.H + iy) * p.W + ix) * p.x_ld + c);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int j = j0 + bc * 4 + e;
+            if (j < taps * p.Cin) {
+              const int t = j / p.Cin, c = j - t * p.Cin;
+              const int r = t / p.kw, s = t - r * p.kw;
+              const int iy = oy * p.stride - p.pad + r, ix = ox * p.stride - p.pad + s;
+              if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                v[e] = xg[((long long)(b * p.H + iy) * p.W + ix) * p.x_ld + c];
+            }
+          }
+        }
+      }
+      rb[i] = v;
+    }
+  };
+  auto store_lds = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < APASS; ++i)
+      *reinterpret_cast<f32x4*>(As + (buf * BK + ar0 + AROWS * i) * AP + ac * 4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i)
+      *reinterpret_cast<f32x4*>(Bs + (buf * BK + br0 + BROWS * i) * BP + bc * 4) = rb[i];
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  load_tiles(0);
+  store_lds(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = kt + 1 < nk;
+    if (more) load_tiles(kt + 1);
+    const float* Ab = As + (cur * BK + lh * 16) * AP + wm0 + lrow;
+    const float* Bb = Bs + (cur * BK + lh * 16) * BP + wn0 + lrow;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float a[MT][4], b[NT][4];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[i][e] = Ab[(q * 4 + e) * AP + i * 32];
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b[j][e] = Bb[(q * 4 + e) * BP + j * 32];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_lds(cur ^ 1);
+    __syncthreads();
+  }
+
+  float* __restrict__ og = p.out + (long long)grp * p.out_gs;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int jj = wn0 + j * 32 + lrow;
+    int col;
+    if (!p.b_generic) { const int c = c0 + jj; if (c >= p.Cin) continue; col = tap * p.Cin + c; }
+    else { col = j0 + jj; if (col >= taps * p.Cin) continue; }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int n = bm0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (n >= p.N) continue;
+        float v = acc[i][j][e] * p.alpha;
+        if (p.row_scale) v *= p.row_scale[n];
+        atomicAdd(og + (long long)n * p.out_ld + col, v);
+      }
+  }
+}
+
+}  // namespace
+
+static int fill_common(const nbm_bwd_desc* d, BwdParams& p) {
+  if (!d || !d->g || !d->out) return NBM_EINVAL;
+  if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->N <= 0 || d->kh <= 0 || d->kw <= 0 || d->stride <= 0 ||
+      d->groups <= 0)
+    return NBM_EINVAL;
+  if ((d->H + 2 * d->pad - d->kh) / d->stride + 1 != d->Ho || (d->W + 2 * d->pad - d->kw) / d->stride + 1 != d->Wo)
+    return NBM_EINVAL;
+  p.g = d->g; p.w = d->w; p.x = d->x; p.out = d->out;
+  p.a_scale = d->a_scale; p.row_scale = d->row_scale; p.residual = d->residual; p.mask = d->mask;
+  p.g_gs = d->g_gs; p.w_gs = d->w_gs; p.x_gs = d->x_gs; p.out_gs = d->out_gs; p.res_gs = d->res_gs;
+  p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.N = d->N; p.kh = d->kh; p.kw = d->kw;
+  p.stride = d->stride; p.pad = d->pad; p.Ho = d->Ho; p.Wo = d->Wo;
+  p.g_ld = d->g_ld; p.w_ld = d->w_ld; p.x_ld = d->x_ld; p.out_ld = d->out_ld; p.res_ld = d->res_ld; p.mask_ld = d->mask_ld;
+  p.alpha = d->alpha;
+  return NBM_OK;
+}
+
+extern "C" int nbm_conv_dgrad(const nbm_bwd_desc* d, void* stream) {
+  BwdParams p{};
+  int rc = fill_common(d, p);
+  if (rc) return rc;
+  if (!d->w) return NBM_EINVAL;
+  // G rows must hold ceil(N/32)*32 readable floats (zero padded), 16-byte aligned; W rows are read along c
+  if ((d->g_ld & 3) || d->g_ld < ((d->N + 31) / 32) * 32 || (d->Cin & 3) || (d->w_ld & 3) || (d->g_gs & 3) || (d->w_gs & 3) ||
+      !nbm_aligned16(d->g) || !nbm_aligned16(d->w) || (d->a_scale && !nbm_aligned16(d->a_scale)))
+    return NBM_EALIGN;
+  if (d->out_ld < d->Cin || (d->residual && d->res_ld < d->Cin) || (d->mask && d->mask_ld < d->Cin)) return NBM_EINVAL;
+  if (d->a_scale && (d->N & 31)) return NBM_EINVAL;
+  p.M = d->B * d->H * d->W;
+  p.w_row = d->w_ld;
+  p.m_tiles = (p.M + 127) / 128;
+  hipStream_t st = (hipStream_t)stream;
+  if (d->Cin > 64) {
+    p.n_tiles = (d->Cin + 127) / 128;
+    hipLaunchKernelGGL(igemm_nn_kernel<128>, dim3(p.m_tiles * p.n_tiles, 1, d->groups), dim3(256), 0, st, p);
+  } else {
+    p.n_tiles = 1;
+    hipLaunchKernelGGL(igemm_nn_kernel<64>, dim3(p.m_tiles, 1, d->groups), dim3(256), 0, st, p);
+  }
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_conv_wgrad(const nbm_bwd_desc* d, void* stream) {
+  BwdParams p{};
+  int rc = fill_common(d, p);
+  if (rc) return rc;
+  if (!d->x) return NBM_EINVAL;
+  if ((d->g_ld & 3) || (d->g_gs & 3) || !nbm_aligned16(d->g) || d->g_ld < ((d->N + 3) / 4) * 4) return NBM_EALIGN;
+  p.b_generic = ((d->Cin & 3) || (d->x_ld & 3) || (d->x_gs & 3) || !nbm_aligned16(d->x)) ? 1 : 0;
+  const int taps = d->kh * d->kw;
+  if (d->out_ld < taps * d->Cin) return NBM_EINVAL;
+  p.M = d->B * d->Ho * d->Wo;
+  p.m_tiles = (d->N + 127) / 128;
+  hipStream_t st = (hipStream_t)stream;
+  const bool wide = !p.b_generic && d->Cin > 64;
+  const int BN = wide ? 128 : 64;
+  p.n_tiles = p.b_generic ? (taps * d->Cin + BN - 1) / BN : taps * ((d->Cin + BN - 1) / BN);
+  // split the pixel reduction so that the grid fills the chip (>= ~2048 workgroups) with >= 8 K-steps per split
+  const int tiles = p.m_tiles * p.n_tiles * d->groups;
+  int splits = (2048 + tiles - 1) / tiles;
+  const int max_splits = (p.M + 8 * BK - 1) / (8 * BK);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  p.k_chunk = (((p.M + splits - 1) / splits) + BK - 1) / BK * BK;
+  splits = (p.M + p.k_chunk - 1) / p.k_chunk;
+  dim3 grid(p.m_tiles * p.n_tiles, splits, d->groups);
+  if (wide) hipLaunchKernelGGL(igemm_tn_kernel<128>, grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(igemm_tn_kernel<64>, grid, dim3(256), 0, st, p);
+  return nbm_launch_status();
+}

@@ -1,0 +1,530 @@
+// Backward / training-only point-wise kernels of the NBM detector (NHWC fp32): activation and pooling
+// gradients, bilinear top-down gradient, softmax gradients, depthwise-conv gradients, train-mode BatchNorm,
+// RoI-pool gradient, and the fused clip-norm + AdamW step over flat parameter buffers.
+// All gather-form (deterministic) except where noted (weight-gradient and RoI reductions use fp32 atomics).
+#include "nbm_common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+inline int grid_for(long long n, int per_block = TPB, int cap = 256 * 16) {
+  long long g = (n + per_block - 1) / per_block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+#define GRID_STRIDE(i, n) \
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
+
+__global__ void relu_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y, float* __restrict__ out,
+                                long long n) {
+  GRID_STRIDE(i, n) out[i] = y[i] > 0.f ? gy[i] : 0.f;
+}
+
+__global__ void silu_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x, float* __restrict__ out,
+                                long long n) {
+  GRID_STRIDE(i, n) {
+    const float v = x[i], s = 1.0f / (1.0f + expf(-v));
+    out[i] = gy[i] * (s * (1.0f + v * (1.0f - s)));
+  }
+}
+
+__global__ void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                             float alpha, float beta, long long n) {
+  GRID_STRIDE(i, n) out[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
+}
+
+// out[n] += sum_m g[m][n]   (block partial sums in double, one atomic per column per block)
+__global__ void colsum_kernel(const float* __restrict__ g, long long M, int N, int ld, float* __restrict__ out) {
+  const int n = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int sub = threadIdx.x >> 6;                      // 4 row lanes
+  __shared__ double part[4][64];
+  double acc = 0.0;
+  if (n < N)
+    for (long long m = blockIdx.x * 4ll + sub; m < M; m += (long long)gridDim.x * 4) acc += (double)g[m * ld + n];
+  part[sub][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (sub == 0 && n < N) atomicAdd(out + n, (float)(part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]));
+}
+
+// gradient of 3x3/s2/p1 max pooling, gather form; ties resolved like torch CPU (first maximum in (r, s) scan order)
+__global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ gx,
+                                   int B, int H, int W, int C, int Ho, int Wo) {
+  const long long total = (long long)B * H * W * C;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C);
+    long long t = i / C;
+    const int ix = (int)(t % W); t /= W;
+    const int iy = (int)(t % H);
+    const int b = (int)(t / H);
+    float acc = 0.f;
+    // windows containing (iy, ix): oy with oy*2-1 <= iy <= oy*2+1
+    for (int oy = (iy >> 1); oy <= ((iy + 1) >> 1); ++oy) {
+      if (oy >= Ho) continue;
+      for (int ox = (ix >> 1); ox <= ((ix + 1) >> 1); ++ox) {
+        if (ox >= Wo) continue;
+        float best = -INFINITY; int by = -1, bx = -1;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const int yy = oy * 2 - 1 + r;
+          if ((unsigned)yy >= (unsigned)H) continue;
+#pragma unroll
+          for (int s = 0; s < 3; ++s) {
+            const int xx = ox * 2 - 1 + s;
+            if ((unsigned)xx >= (unsigned)W) continue;
+            const float v = x[((long long)(b * H + yy) * W + xx) * C + c];
+            if (v > best || v != v) { best = v; by = yy; bx = xx; }
+          }
+        }
+        if (by == iy && bx == ix) acc += gy[((long long)(b * Ho + oy) * Wo + ox) * C + c];
+      }
+    }
+    gx[i] = acc;
+  }
+}
+
+// gradient of bilinear(align_corners) up-sampling wrt the coarse map, gather form
+__global__ void upsample_bwd_kernel(const float* __restrict__ gy, int B, int Hi, int Wi, int C4, float* __restrict__ gsrc,
+                                    int Ho, int Wo, float sh, float sw) {
+  const long long total = (long long)B * Hi * Wi * C4;
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(gy);
+  f32x4* o4 = reinterpret_cast<f32x4*>(gsrc);
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C4);
+    long long t = i / C4;
+    const int X = (int)(t % Wi); t /= Wi;
+    const int Y = (int)(t % Hi);
+    const int b = (int)(t / Hi);
+    // candidate fine rows: floor(sh*oy) in {Y-1, Y}
+    int oy_lo = sh > 0.f ? (int)floorf((Y - 1) / sh) - 1 : 0, oy_hi = sh > 0.f ? (int)ceilf((Y + 1) / sh) + 1 : Ho - 1;
+    int ox_lo = sw > 0.f ? (int)floorf((X - 1) / sw) - 1 : 0, ox_hi = sw > 0.f ? (int)ceilf((X + 1) / sw) + 1 : Wo - 1;
+    oy_lo = max(oy_lo, 0); oy_hi = min(oy_hi, Ho - 1); ox_lo = max(ox_lo, 0); ox_hi = min(ox_hi, Wo - 1);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      const float fy = sh * oy;
+      const int y0 = (int)fy, y1 = y0 + (y0 < Hi - 1 ? 1 : 0);
+      const float ly = fminf(fmaxf(fy - y0, 0.f), 1.f);
+      float wy = 0.f;
+      if (y0 == Y) wy += 1.f - ly;
+      if (y1 == Y) wy += ly;
+      if (wy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        const float fx = sw * ox;
+        const int x0 = (int)fx, x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
+        const float lx = fminf(fmaxf(fx - x0, 0.f), 1.f);
+        float wx = 0.f;
+        if (x0 == X) wx += 1.f - lx;
+        if (x1 == X) wx += lx;
+        if (wx == 0.f) continue;
+        const f32x4 g = g4[((long long)(b * Ho + oy) * Wo + ox) * C4 + c];
+        const float w = wy * wx;
+        acc[0] += w * g[0]; acc[1] += w * g[1]; acc[2] += w * g[2]; acc[3] += w * g[3];
+      }
+    }
+    o4[i] = acc;
+  }
+}
+
+// dS = P * (dP - sum(P*dP)) * alpha, one wave per row
+__global__ void softmax_bwd_kernel(const float* __restrict__ p, const float* __restrict__ gp, float* __restrict__ out,
+                                   long long rows, int cols, float alpha) {
+  const int lane = threadIdx.x & 63;
+  for (long long row = blockIdx.x * 4ll + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * 4) {
+    const float* pr = p + row * cols;
+    const float* gr = gp + row * cols;
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) s += pr[c] * gr[c];
+    s = nbm_wave_sum(s);
+    float* o = out + row * cols;
+    for (int c = lane; c < cols; c += 64) o[c] = pr[c] * (gr[c] - s) * alpha;
+  }
+}
+
+__global__ void pair_softmax_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gy,
+                                        float* __restrict__ gx, long long n_pairs) {
+  GRID_STRIDE(i, n_pairs) {
+    const float p0 = y[2 * i], p1 = y[2 * i + 1], g0 = gy[2 * i], g1 = gy[2 * i + 1];
+    const float s = p0 * g0 + p1 * g1;
+    gx[2 * i] = p0 * (g0 - s);
+    gx[2 * i + 1] = p1 * (g1 - s);
+  }
+}
+
+// depthwise 3x3 (pad 1, multiplier mult, stride st): data gradient, gather form
+__global__ void dwconv_bwd_data_kernel(const float* __restrict__ g, int B, int H, int W, int Cin, int mult, int stride,
+                                       const float* __restrict__ w, float* __restrict__ gx, int Ho, int Wo) {
+  const int Cout = Cin * mult;
+  const long long total = (long long)B * H * W * Cin;
+  GRID_STRIDE(i, total) {
+    const int ci = (int)(i % Cin);
+    long long t = i / Cin;
+    const int ix = (int)(t % W); t /= W;
+    const int iy = (int)(t % H);
+    const int b = (int)(t / H);
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int ty = iy + 1 - r;
+      if (ty < 0 || ty % stride) continue;
+      const int oy = ty / stride;
+      if (oy >= Ho) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int tx = ix + 1 - s;
+        if (tx < 0 || tx % stride) continue;
+        const int ox = tx / stride;
+        if (ox >= Wo) continue;
+        const float* gp = g + ((long long)(b * Ho + oy) * Wo + ox) * Cout + ci * mult;
+        for (int e = 0; e < mult; ++e) acc += gp[e] * w[(ci * mult + e) * 9 + r * 3 + s];
+      }
+    }
+    gx[i] = acc;
+  }
+}
+
+// depthwise 3x3 weight (+bias) gradient: one block column per output channel group, atomics on 9(+1) scalars
+__global__ void dwconv_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ g, int B, int H, int W,
+                                         int Cin, int mult, int stride, float* __restrict__ gw, float* __restrict__ gb,
+                                         int Ho, int Wo) {
+  const int Cout = Cin * mult;
+  const int o = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int sub = threadIdx.x >> 6;
+  __shared__ float part[4][64][10];
+  float acc[10];
+#pragma unroll
+  for (int e = 0; e < 10; ++e) acc[e] = 0.f;
+  if (o < Cout) {
+    const int ci = o / mult;
+    const long long npix = (long long)B * Ho * Wo;
+    for (long long pix = blockIdx.x * 4ll + sub; pix < npix; pix += (long long)gridDim.x * 4) {
+      long long t = pix;
+      const int ox = (int)(t % Wo); t /= Wo;
+      const int oy = (int)(t % Ho);
+      const int b = (int)(t / Ho);
+      const float gv = g[pix * Cout + o];
+      acc[9] += gv;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int iy = oy * stride - 1 + r;
+        if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const int ix = ox * stride - 1 + s;
+          if ((unsigned)ix >= (unsigned)W) continue;
+          acc[r * 3 + s] += gv * x[((long long)(b * H + iy) * W + ix) * Cin + ci];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 10; ++e) part[sub][threadIdx.x & 63][e] = acc[e];
+  __syncthreads();
+  if (sub == 0 && o < Cout) {
+#pragma unroll
+    for (int e = 0; e < 9; ++e)
+      atomicAdd(gw + o * 9 + e, part[0][threadIdx.x][e] + part[1][threadIdx.x][e] + part[2][threadIdx.x][e] + part[3][threadIdx.x][e]);
+    if (gb) atomicAdd(gb + o, part[0][threadIdx.x][9] + part[1][threadIdx.x][9] + part[2][threadIdx.x][9] + part[3][threadIdx.x][9]);
+  }
+}
+
+// FiLM: y = z*gamma + beta with film[p][0:C] = gamma, film[p][C:2C] = beta
+__global__ void film_fwd_kernel(const float* __restrict__ z, const float* __restrict__ film, float* __restrict__ y,
+                                long long n_pix, int C) {
+  const long long total = n_pix * C;
+  GRID_STRIDE(i, total) {
+    const long long p = i / C;
+    const int c = (int)(i - p * C);
+    y[i] = z[i] * film[p * 2 * C + c] + film[p * 2 * C + C + c];
+  }
+}
+__global__ void film_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ z, const float* __restrict__ film,
+                                float* __restrict__ gz, float* __restrict__ gfilm, long long n_pix, int C) {
+  const long long total = n_pix * C;
+  GRID_STRIDE(i, total) {
+    const long long p = i / C;
+    const int c = (int)(i - p * C);
+    const float g = gy[i];
+    gz[i] = g * film[p * 2 * C + c];
+    gfilm[p * 2 * C + c] = g * z[i];
+    gfilm[p * 2 * C + C + c] = g;
+  }
+}
+
+// ---- train-mode BatchNorm over [M][C] (per-channel statistics over the M rows)
+// pass 1: sums in double -> stats[c] = {sum, sumsq}
+__global__ void bn_stats_kernel(const float* __restrict__ x, long long M, int C, double* __restrict__ stats) {
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int sub = threadIdx.x >> 6;
+  __shared__ double ps[4][64], pq[4][64];
+  double s = 0.0, q = 0.0;
+  if (c < C)
+    for (long long m = blockIdx.x * 4ll + sub; m < M; m += (long long)gridDim.x * 4) {
+      const double v = (double)x[m * C + c];
+      s += v; q += v * v;
+    }
+  ps[sub][threadIdx.x & 63] = s; pq[sub][threadIdx.x & 63] = q;
+  __syncthreads();
+  if (sub == 0 && c < C) {
+    atomicAdd(stats + 2 * c, ps[0][threadIdx.x] + ps[1][threadIdx.x] + ps[2][threadIdx.x] + ps[3][threadIdx.x]);
+    atomicAdd(stats + 2 * c + 1, pq[0][threadIdx.x] + pq[1][threadIdx.x] + pq[2][threadIdx.x] + pq[3][threadIdx.x]);
+  }
+}
+// finalize: mean, invstd; running stats update (momentum, unbiased variance) -- nn.BatchNorm2d semantics
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, long long M, int C, float eps, float momentum,
+                                   float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ run_mean,
+                                   float* __restrict__ run_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mu = stats[2 * c] / (double)M;
+  double var = stats[2 * c + 1] / (double)M - mu * mu;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)mu;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (run_mean) {
+    const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mu;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unb;
+  }
+}
+__global__ void bn_apply_kernel(const float* __restrict__ x, long long M, int C, const float* __restrict__ mean,
+                                const float* __restrict__ invstd, const float* __restrict__ w, const float* __restrict__ b,
+                                float* __restrict__ y) {
+  const long long total = M * C;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C);
+    y[i] = (x[i] - mean[c]) * invstd[c] * w[c] + b[c];
+  }
+}
+// backward pass 1: red[c] = {sum g, sum g*xhat}
+__global__ void bn_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ x, long long M, int C,
+                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                     double* __restrict__ red) {
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int sub = threadIdx.x >> 6;
+  __shared__ double ps[4][64], pq[4][64];
+  double s = 0.0, q = 0.0;
+  if (c < C) {
+    const float mu = mean[c], is = invstd[c];
+    for (long long m = blockIdx.x * 4ll + sub; m < M; m += (long long)gridDim.x * 4) {
+      const double gv = (double)g[m * C + c];
+      s += gv; q += gv * (double)((x[m * C + c] - mu) * is);
+    }
+  }
+  ps[sub][threadIdx.x & 63] = s; pq[sub][threadIdx.x & 63] = q;
+  __syncthreads();
+  if (sub == 0 && c < C) {
+    atomicAdd(red + 2 * c, ps[0][threadIdx.x] + ps[1][threadIdx.x] + ps[2][threadIdx.x] + ps[3][threadIdx.x]);
+    atomicAdd(red + 2 * c + 1, pq[0][threadIdx.x] + pq[1][threadIdx.x] + pq[2][threadIdx.x] + pq[3][threadIdx.x]);
+  }
+}
+// backward pass 2: gx = w*invstd*(g - sum_g/M - xhat*sum_gxhat/M); gw = sum_gxhat, gb = sum_g
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ x, long long M, int C,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ w, const double* __restrict__ red, float* __restrict__ gx,
+                                    float* __restrict__ gw, float* __restrict__ gb) {
+  const long long total = M * C;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C);
+    const float xh = (x[i] - mean[c]) * invstd[c];
+    const float sg = (float)(red[2 * c] / (double)M), sgx = (float)(red[2 * c + 1] / (double)M);
+    gx[i] = w[c] * invstd[c] * (g[i] - sg - xh * sgx);
+    if (i < C) { gw[i] = (float)red[2 * i + 1]; gb[i] = (float)red[2 * i]; }
+  }
+}
+
+// ---- RoI pooling gradient (scatter with atomics; RoI windows overlap)
+struct RoiBwdParams {
+  float* gfmap[5]; int fh[5], fw[5]; int C; const float* rois; const int* level; int B, n_roi; const float* gpool;
+};
+__global__ void roi_pool_bwd_kernel(const RoiBwdParams p) {
+  const int slot = blockIdx.x;
+  const int b = slot / p.n_roi;
+  const float* roi = p.rois + (long long)slot * 4;
+  const int lvl = p.level[slot];
+  const float stride = (float)(2 << lvl);
+  int x1 = (int)rintf(roi[0] / stride), y1 = (int)rintf(roi[1] / stride);
+  int x2 = (int)rintf(roi[2] / stride), y2 = (int)rintf(roi[3] / stride);
+  const int H = p.fh[lvl], W = p.fw[lvl];
+  y2 = min(y2, H - 1);
+  while (y2 - y1 + 1 < 2) { y1 = max(0, y1 - 1); y2 = min(H - 1, y2 + 1); }
+  while (x2 - x1 + 1 < 2) { x1 = max(0, x1 - 1); x2 = min(W - 1, x2 + 1); }
+  const int h = y2 - y1 + 1, w = min(x2, W - 1) - x1 + 1;
+  float* gf = p.gfmap[lvl];
+  const int C = p.C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ya = (i * h) / 2, yb = ((i + 1) * h + 1) / 2;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int xa = (j * w) / 2, xb = ((j + 1) * w + 1) / 2;
+        const float gv = p.gpool[((long long)slot * 4 + i * 2 + j) * C + c] / (float)((yb - ya) * (xb - xa));
+        for (int yy = ya; yy < yb; ++yy)
+          for (int xx = xa; xx < xb; ++xx)
+            atomicAdd(gf + (((long long)b * H + y1 + yy) * W + x1 + xx) * C + c, gv);
+      }
+    }
+  }
+}
+
+// ---- optimiser: squared gradient norm, then clip + AdamW (torch.optim.AdamW semantics, decoupled decay)
+__global__ void sqnorm_kernel(const float* __restrict__ g, long long n, double* __restrict__ out) {
+  double acc = 0.0;
+  GRID_STRIDE(i, n) { const double v = (double)g[i]; acc += v * v; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  __shared__ double part[TPB / 64];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) { double s = 0.0; for (int i = 0; i < TPB / 64; ++i) s += part[i]; atomicAdd(out, s); }
+}
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, long long n, float lr, float beta1, float beta2, float eps, float wd,
+                             float bc1, float bc2_sqrt, const double* __restrict__ sqnorm, float max_norm) {
+  float coef = 1.f;
+  if (sqnorm && max_norm > 0.f) {                                  // torch.nn.utils.clip_grad_norm_
+    const float total = (float)sqrt(*sqnorm);
+    coef = fminf(max_norm / (total + 1e-6f), 1.0f);
+  }
+  GRID_STRIDE(i, n) {
+    const float gi = g[i] * coef;
+    float pi = p[i];
+    pi *= 1.f - lr * wd;
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+  }
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int nbm_relu_bwd(const float* gy, const float* y, float* out, int64_t n, void* stream) {
+  if (!gy || !y || !out || n <= 0) return NBM_EINVAL;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n)), dim3(TPB), 0, ST, gy, y, out, (long long)n);
+  return nbm_launch_status();
+}
+extern "C" int nbm_silu_bwd(const float* gy, const float* x, float* out, int64_t n, void* stream) {
+  if (!gy || !x || !out || n <= 0) return NBM_EINVAL;
+  hipLaunchKernelGGL(silu_bwd_kernel, dim3(grid_for(n)), dim3(TPB), 0, ST, gy, x, out, (long long)n);
+  return nbm_launch_status();
+}
+extern "C" int nbm_axpby(const float* a, const float* b, float* out, float alpha, float beta, int64_t n, void* stream) {
+  if (!a || !out || n <= 0) return NBM_EINVAL;
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(TPB), 0, ST, a, b, out, alpha, beta, (long long)n);
+  return nbm_launch_status();
+}
+extern "C" int nbm_colsum(const float* g, int64_t M, int N, int ld, float* out, void* stream) {
+  if (!g || !out || M <= 0 || N <= 0 || ld < N) return NBM_EINVAL;
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * N, ST);
+  if (e != hipSuccess) return (int)e;
+  dim3 grid(grid_for(M, 4, 1024), (N + 63) / 64);
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, ST, g, (long long)M, N, ld, out);
+  return nbm_launch_status();
+}
+extern "C" int nbm_maxpool3x3s2_bwd(const float* x, const float* gy, float* gx, int B, int H, int W, int C, int Ho,
+                                    int Wo, void* stream) {
+  if (!x || !gy || !gx || B <= 0 || C <= 0) return NBM_EINVAL;
+  if ((H + 2 - 3) / 2 + 1 != Ho || (W + 2 - 3) / 2 + 1 != Wo) return NBM_EINVAL;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((long long)B * H * W * C)), dim3(TPB), 0, ST, x, gy, gx, B, H, W, C,
+                     Ho, Wo);
+  return nbm_launch_status();
+}
+extern "C" int nbm_upsample_bilinear_bwd(const float* gy, int B, int Hi, int Wi, int C, float* gsrc, int Ho, int Wo,
+                                         void* stream) {
+  if (!gy || !gsrc || B <= 0 || C <= 0 || (C & 3) || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return NBM_EINVAL;
+  if (!nbm_aligned16(gy) || !nbm_aligned16(gsrc)) return NBM_EALIGN;
+  const float sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
+  const float sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for((long long)B * Hi * Wi * (C / 4))), dim3(TPB), 0, ST, gy, B, Hi,
+                     Wi, C / 4, gsrc, Ho, Wo, sh, sw);
+  return nbm_launch_status();
+}
+extern "C" int nbm_softmax_rows_bwd(const float* p, const float* gp, float* out, int64_t rows, int cols, float alpha,
+                                    void* stream) {
+  if (!p || !gp || !out || rows <= 0 || cols <= 0) return NBM_EINVAL;
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3(grid_for(rows, 4, 256 * 32)), dim3(256), 0, ST, p, gp, out, (long long)rows,
+                     cols, alpha);
+  return nbm_launch_status();
+}
+extern "C" int nbm_pair_softmax_bwd(const float* y, const float* gy, float* gx, int64_t n_pairs, void* stream) {
+  if (!y || !gy || !gx || n_pairs <= 0) return NBM_EINVAL;
+  hipLaunchKernelGGL(pair_softmax_bwd_kernel, dim3(grid_for(n_pairs)), dim3(TPB), 0, ST, y, gy, gx, (long long)n_pairs);
+  return nbm_launch_status();
+}
+extern "C" int nbm_dwconv3x3_bwd(const float* x, const float* g, const float* w, int B, int H, int W, int Cin, int mult,
+                                 int stride, float* gx, float* gw, float* gb, int Ho, int Wo, void* stream) {
+  if (!x || !g || !w || B <= 0 || Cin <= 0 || mult <= 0 || stride <= 0) return NBM_EINVAL;
+  if ((H + 2 - 3) / stride + 1 != Ho || (W + 2 - 3) / stride + 1 != Wo) return NBM_EINVAL;
+  const int Cout = Cin * mult;
+  if (gx)
+    hipLaunchKernelGGL(dwconv_bwd_data_kernel, dim3(grid_for((long long)B * H * W * Cin)), dim3(TPB), 0, ST, g, B, H, W,
+                       Cin, mult, stride, w, gx, Ho, Wo);
+  if (gw) {
+    hipError_t e = hipMemsetAsync(gw, 0, sizeof(float) * Cout * 9, ST);
+    if (e == hipSuccess && gb) e = hipMemsetAsync(gb, 0, sizeof(float) * Cout, ST);
+    if (e != hipSuccess) return (int)e;
+    dim3 grid(grid_for((long long)B * Ho * Wo, 4, 512), (Cout + 63) / 64);
+    hipLaunchKernelGGL(dwconv_bwd_weight_kernel, grid, dim3(256), 0, ST, x, g, B, H, W, Cin, mult, stride, gw, gb, Ho, Wo);
+  }
+  return nbm_launch_status();
+}
+extern "C" int nbm_film_fwd(const float* z, const float* film, float* y, int64_t n_pix, int C, void* stream) {
+  if (!z || !film || !y || n_pix <= 0 || C <= 0) return NBM_EINVAL;
+  hipLaunchKernelGGL(film_fwd_kernel, dim3(grid_for(n_pix * C)), dim3(TPB), 0, ST, z, film, y, (long long)n_pix, C);
+  return nbm_launch_status();
+}
+extern "C" int nbm_film_bwd(const float* gy, const float* z, const float* film, float* gz, float* gfilm, int64_t n_pix,
+                            int C, void* stream) {
+  if (!gy || !z || !film || !gz || !gfilm || n_pix <= 0 || C <= 0) return NBM_EINVAL;
+  hipLaunchKernelGGL(film_bwd_kernel, dim3(grid_for(n_pix * C)), dim3(TPB), 0, ST, gy, z, film, gz, gfilm, (long long)n_pix, C);
+  return nbm_launch_status();
+}
+extern "C" int nbm_bn_train_fwd(const float* x, int64_t M, int C, const float* w, const float* b, float eps,
+                                float momentum, float* run_mean, float* run_var, double* stats_ws, float* mean,
+                                float* invstd, float* y, void* stream) {
+  if (!x || !w || !b || !stats_ws || !mean || !invstd || !y || M <= 0 || C <= 0) return NBM_EINVAL;
+  hipError_t e = hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * C, ST);
+  if (e != hipSuccess) return (int)e;
+  dim3 grid(grid_for(M, 4, 1024), (C + 63) / 64);
+  hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), 0, ST, x, (long long)M, C, stats_ws);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, ST, stats_ws, (long long)M, C, eps, momentum,
+                     mean, invstd, run_mean, run_var);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(M * C)), dim3(TPB), 0, ST, x, (long long)M, C, mean, invstd, w, b, y);
+  return nbm_launch_status();
+}
+extern "C" int nbm_bn_train_bwd(const float* g, const float* x, int64_t M, int C, const float* mean, const float* invstd,
+                                const float* w, double* red_ws, float* gx, float* gw, float* gb, void* stream) {
+  if (!g || !x || !mean || !invstd || !w || !red_ws || !gx || !gw || !gb || M <= 0 || C <= 0 || M * (int64_t)C < C) return NBM_EINVAL;
+  hipError_t e = hipMemsetAsync(red_ws, 0, sizeof(double) * 2 * C, ST);
+  if (e != hipSuccess) return (int)e;
+  dim3 grid(grid_for(M, 4, 1024), (C + 63) / 64);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, ST, g, x, (long long)M, C, mean, invstd, red_ws);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(M * C)), dim3(TPB), 0, ST, g, x, (long long)M, C, mean, invstd, w,
+                     red_ws, gx, gw, gb);
+  return nbm_launch_status();
+}
+extern "C" int nbm_roi_pool_bwd(float* const* gfmap, const int* fh, const int* fw, int n_levels, int C, const float* rois,
+                                const int* level, int B, int n_roi, const float* gpool, void* stream) {
+  if (!gfmap || !fh || !fw || !rois || !level || !gpool || n_levels < 1 || n_levels > 5 || B <= 0 || n_roi <= 0) return NBM_EINVAL;
+  RoiBwdParams p;
+  for (int i = 0; i < 5; ++i) { p.gfmap[i] = i < n_levels ? gfmap[i] : nullptr; p.fh[i] = i < n_levels ? fh[i] : 0; p.fw[i] = i < n_levels ? fw[i] : 0; }
+  p.C = C; p.rois = rois; p.level = level; p.B = B; p.n_roi = n_roi; p.gpool = gpool;
+  hipLaunchKernelGGL(roi_pool_bwd_kernel, dim3(B * n_roi), dim3(256), 0, ST, p);
+  return nbm_launch_status();
+}
+extern "C" int nbm_sqnorm_accum(const float* g, int64_t n, double* out, void* stream) {
+  if (!g || !out || n <= 0) return NBM_EINVAL;
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(grid_for(n, TPB, 2048)), dim3(TPB), 0, ST, g, (long long)n, out);
+  return nbm_launch_status();
+}
+extern "C" int nbm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                              float eps, float weight_decay, int step, const double* sqnorm, float max_norm, void* stream) {
+  if (!p || !g || !m || !v || n <= 0 || step < 1) return NBM_EINVAL;
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(TPB), 0, ST, p, g, m, v, (long long)n, lr, beta1, beta2, eps,
+                     weight_decay, bc1, bc2s, sqnorm, max_norm);
+  return nbm_launch_status();
+}

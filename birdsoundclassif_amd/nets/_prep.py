@@ -8,11 +8,19 @@ import torch
 import torch.nn.functional as F
 
 _cache = {}
+_epoch = 0          # bumped whenever a kernel rewrote parameters / buffers through raw pointers
+
+
+def bump():
+    """Invalidate every prepared copy: the fused optimiser and the train-mode BatchNorm kernels update tensors in
+    place through raw pointers, which torch's version counters cannot see."""
+    global _epoch
+    _epoch += 1
 
 
 def _cached(key_t, tag, fn):
     key = (id(key_t), tag)
-    ver = (key_t.data_ptr(), key_t._version, key_t.device)
+    ver = (key_t.data_ptr(), key_t._version, key_t.device, _epoch)
     hit = _cache.get(key)
     if hit is not None and hit[0] == ver:
         return hit[1]

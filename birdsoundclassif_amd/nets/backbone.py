@@ -10,7 +10,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from . import _prep
+from . import _prep, functional as Fn
 from .position_encoding import build_position_encoding
 
 bcbk_channels = {'resnet': {'2': 64, '3': 256, '4': 512, '5': 1024, '6': 2048}}
@@ -54,16 +54,16 @@ class _Bottleneck(nn.Module):
 
     def forward(self, x):
         s, b = self.bn1.affine()
-        o = ops.conv2d(x, _prep.krsc(self.conv1.weight), scale=s, shift=b, act=ops.ACT_RELU)
+        o = Fn.conv(x, self.conv1.weight, scale=s, shift=b, act=ops.ACT_RELU)
         s, b = self.bn2.affine()
-        o = ops.conv2d(o, _prep.krsc(self.conv2.weight), 3, 3, self.stride, 1, scale=s, shift=b, act=ops.ACT_RELU)
+        o = Fn.conv(o, self.conv2.weight, scale=s, shift=b, kh=3, kw=3, stride=self.stride, pad=1, act=ops.ACT_RELU)
         if self.downsample is not None:
             s, b = self.downsample[1].affine()
-            idt = ops.conv2d(x, _prep.krsc(self.downsample[0].weight), stride=self.stride, scale=s, shift=b)
+            idt = Fn.conv(x, self.downsample[0].weight, scale=s, shift=b, stride=self.stride)
         else:
             idt = x
         s, b = self.bn3.affine()
-        return ops.conv2d(o, _prep.krsc(self.conv3.weight), scale=s, shift=b, residual=idt, act=ops.ACT_RELU)
+        return Fn.conv(o, self.conv3.weight, scale=s, shift=b, residual=idt, act=ops.ACT_RELU)
 
 
 class _ResNetBody(nn.Module):
@@ -86,11 +86,15 @@ class _ResNetBody(nn.Module):
                 inplanes = planes * 4
             setattr(self, f'layer{li}', nn.Sequential(*blocks))
 
-    def forward(self, x):
+    def forward(self, x, init_conv=None):
+        """x: NHWC image; with `init_conv` (1 -> 3 channels) the stem is ONE differentiable op (Fn.Stem)."""
         s, b = self.bn1.affine()
-        x = ops.conv2d(x, _prep.krsc(self.conv1.weight), 7, 7, 2, 3, scale=s, shift=b, act=ops.ACT_RELU)
+        if init_conv is not None:
+            x = Fn.Stem.apply(x, init_conv.weight, init_conv.bias, self.conv1.weight, s, b)
+        else:
+            x = Fn.conv(x, self.conv1.weight, scale=s, shift=b, kh=7, kw=7, stride=2, pad=3, act=ops.ACT_RELU)
         taps = [x]
-        x = ops.maxpool3x3s2(x)
+        x = Fn.MaxPool.apply(x)
         for li in range(1, 5):
             for blk in getattr(self, f'layer{li}'):
                 x = blk(x)
@@ -117,7 +121,7 @@ class BackboneBase(nn.Module):
         if hasattr(self, 'init_conv'):
             if self.in_channels != 1:
                 raise NotImplementedError('init_conv is implemented for 1 input channel (reference default)')
-            x = ops.init_conv(x, self.init_conv.weight.detach(), self.init_conv.bias.detach())
+            return self.body(x, self.init_conv)
         return self.body(x)
 
 

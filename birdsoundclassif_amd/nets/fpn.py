@@ -7,7 +7,7 @@ of the detector's forward FLOPs; they run on the fp32-MFMA implicit-GEMM kernel.
 import torch.nn as nn
 
 from .. import ops
-from . import _prep
+from . import functional as Fn
 from .self_attention import Scaled
 
 
@@ -24,17 +24,17 @@ class FPN(nn.Module):
         for i, fm in enumerate(x):
             t, alpha = (fm.tensor, fm.factor) if isinstance(fm, Scaled) else (fm, 1.0)
             c = self.pt_wise[str(i)]
-            lat.append(ops.conv2d(t, _prep.krsc(c.weight), shift=c.bias.detach(), alpha=alpha))
+            lat.append(Fn.conv(t, c.weight, bias=c.bias, alpha=alpha))
         i = 0
         out = lat.pop(-1)
         c = self.out_convs[str(i)]
-        outs = [ops.conv2d(out, _prep.krsc(c.weight), 3, 3, 1, 1, shift=c.bias.detach())]
+        outs = [Fn.conv(out, c.weight, bias=c.bias, kh=3, kw=3, pad=1)]
         while len(lat) > 0:
             i += 1
             p = lat.pop(-1)
-            out = ops.upsample_bilinear_add(out, p.shape[1], p.shape[2], add=p)
+            out = Fn.UpsampleAdd.apply(out, p, p.shape[1], p.shape[2])
             c = self.out_convs[str(i)]
-            outs.insert(0, ops.conv2d(out, _prep.krsc(c.weight), 3, 3, 1, 1, shift=c.bias.detach()))
+            outs.insert(0, Fn.conv(out, c.weight, bias=c.bias, kh=3, kw=3, pad=1))
         return outs
 
 

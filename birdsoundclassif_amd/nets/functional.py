@@ -1,0 +1,317 @@
+"""Differentiable operator layer of the training path.
+
+torch.autograd is used as the tape (plumbing: it sequences the backward calls and owns the buffers); every
+forward AND backward computation below is a HIP kernel of libnbm_hip.so.  Replaces what autograd derives for the
+reference's `losses.backward()` (reference train.py:212).  Activations NHWC fp32; weights arrive in the checkpoint
+layout and their gradients are returned in the same layout.
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import ops
+from . import _prep
+
+ACT_NONE, ACT_RELU = ops.ACT_NONE, ops.ACT_RELU
+
+
+def _pad32_rows(g2d, n):
+    """[M, n] -> zero-padded contiguous [M, ceil32(n)] (the dgrad kernel reads whole 32-float K steps)."""
+    n32 = (n + 31) // 32 * 32
+    if n32 == n:
+        return g2d
+    out = torch.zeros((g2d.shape[0], n32), device=g2d.device, dtype=torch.float32)
+    out[:, :n] = g2d
+    return out
+
+
+def _w_to_ref_layout(gw, weight):
+    """KRSC gradient rows [N, >=K] -> the parameter's own layout."""
+    if weight.dim() == 2:
+        return gw[:, :weight.shape[1]]
+    n, c, kh, kw = weight.shape
+    return gw[:, :kh * kw * c].view(n, kh, kw, c).permute(0, 3, 1, 2)
+
+
+class Conv(Function):
+    """y = act(alpha * conv(x, W) * scale + (bias | shift) + residual); also nn.Linear (x [1,M,1,K])."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, scale, shift, residual, kh, kw, stride, pad, act, alpha):
+        wk = _prep.krsc(weight) if weight.dim() == 4 else weight.detach()
+        sh = bias.detach() if bias is not None else shift
+        y = ops.conv2d(x, wk, kh, kw, stride, pad, scale=scale, shift=sh, residual=residual, act=act, alpha=alpha)
+        ctx.geom = (kh, kw, stride, pad, act, alpha)
+        ctx.has_bias, ctx.has_res = bias is not None, residual is not None
+        ctx.save_for_backward(x, weight, scale, y if act == ACT_RELU else None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, weight, scale, y = ctx.saved_tensors
+        kh, kw, stride, pad, act, alpha = ctx.geom
+        gy = gy.contiguous()
+        g = ops.relu_bwd(gy, y) if act == ACT_RELU else gy
+        B, H, W, Cin = x.shape
+        N = weight.shape[0]
+        wk = _prep.krsc(weight) if weight.dim() == 4 else weight.detach()
+        gp = _pad32_rows(g.view(-1, N), N)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            ops.conv_dgrad(gp, wk, gx, B=B, H=H, W=W, Cin=Cin, N=N, kh=kh, kw=kw, stride=stride, pad=pad,
+                           g_ld=gp.shape[1], w_ld=wk.shape[1], a_scale=scale, alpha=alpha)
+        if ctx.needs_input_grad[1]:
+            gwk = torch.zeros_like(wk)
+            ops.conv_wgrad(gp, x, gwk, B=B, H=H, W=W, Cin=Cin, N=N, kh=kh, kw=kw, stride=stride, pad=pad,
+                           g_ld=gp.shape[1], out_ld=wk.shape[1], row_scale=scale, alpha=alpha)
+            gw = _w_to_ref_layout(gwk, weight)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = ops.colsum(gp, N)
+        gres = g if (ctx.has_res and ctx.needs_input_grad[5]) else None
+        return gx, gw, gb, None, None, gres, None, None, None, None, None, None
+
+
+def conv(x, weight, bias=None, scale=None, shift=None, residual=None, kh=1, kw=1, stride=1, pad=0, act=ACT_NONE, alpha=1.0):
+    return Conv.apply(x, weight, bias, scale, shift, residual, kh, kw, stride, pad, act, alpha)
+
+
+def linear(x2d, weight, bias=None):
+    M, K = x2d.shape
+    return Conv.apply(x2d.view(1, M, 1, K), weight, bias, None, None, None, 1, 1, 1, 0, ACT_NONE, 1.0).view(M, -1)
+
+
+class Stem(Function):
+    """init_conv (1 -> 3, 1x1 + bias) followed by conv1 7x7/s2 + FrozenBN + ReLU (reference backbone.py:104-113 and
+    torchvision's stem).  Backward never forms the 3-channel data gradient: with U[n,t] = sum_m g[m,n] x[pix(m)+t] and
+    V[n,t] = sum_m g[m,n] [pix(m)+t inside], dW1[n,c,t] = w_c U + b_c V, dw_c = sum W1[n,c,t] U, db_c = sum W1[n,c,t] V;
+    U and V are ONE weight-gradient launch over the 2-channel image (x, 1)."""
+
+    @staticmethod
+    def forward(ctx, x, w_init, b_init, w1, scale, shift):
+        y0 = ops.init_conv(x, w_init.detach(), b_init.detach())
+        y = ops.conv2d(y0, _prep.krsc(w1), 7, 7, 2, 3, scale=scale, shift=shift, act=ACT_RELU)
+        ctx.save_for_backward(x, w_init, b_init, w1, scale, y)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, w_init, b_init, w1, scale, y = ctx.saved_tensors
+        g = ops.relu_bwd(gy.contiguous(), y)
+        B, H, W, _ = x.shape
+        x2 = torch.ones((B, H, W, 2), device=x.device, dtype=torch.float32)
+        x2[..., 0] = x[..., 0]
+        uv = torch.zeros((64, 7 * 7 * 2), device=x.device, dtype=torch.float32)
+        ops.conv_wgrad(g.view(-1, 64), x2, uv, B=B, H=H, W=W, Cin=2, N=64, kh=7, kw=7, stride=2, pad=3, row_scale=scale)
+        uv = uv.view(64, 7, 7, 2)
+        U, V = uv[..., 0], uv[..., 1]                                     # [64,7,7]
+        wi, bi = w_init.detach().view(3), b_init.detach().view(3)
+        gw1 = wi.view(1, 3, 1, 1) * U[:, None] + bi.view(1, 3, 1, 1) * V[:, None]
+        w1d = w1.detach()
+        gwi = (w1d * U[:, None]).sum(dim=(0, 2, 3)).view_as(w_init)
+        gbi = (w1d * V[:, None]).sum(dim=(0, 2, 3))
+        return None, gwi, gbi, gw1, None, None
+
+
+class MaxPool(Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = ops.maxpool3x3s2(x)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        return ops.maxpool3x3s2_bwd(x, gy.contiguous())
+
+
+class UpsampleAdd(Function):
+    @staticmethod
+    def forward(ctx, src, add, Ho, Wo):
+        ctx.hw = src.shape[1:3]
+        ctx.has_add = add is not None
+        return ops.upsample_bilinear_add(src, Ho, Wo, add=add)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        gy = gy.contiguous()
+        gs = ops.upsample_bilinear_bwd(gy, ctx.hw[0], ctx.hw[1]) if ctx.needs_input_grad[0] else None
+        return gs, (gy if ctx.has_add and ctx.needs_input_grad[1] else None), None, None
+
+
+class DwConv(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, mult, stride):
+        y = ops.dwconv3x3(x, weight.detach(), bias.detach() if bias is not None else None, mult, stride)
+        ctx.cfg = (mult, stride, bias is not None)
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        mult, stride, has_bias = ctx.cfg
+        gx, gw, gb = ops.dwconv3x3_bwd(x, gy.contiguous(), weight.detach(), mult, stride,
+                                       need_gx=ctx.needs_input_grad[0], need_gw=True, has_bias=has_bias)
+        return gx, gw, gb, None, None
+
+
+class Film(Function):
+    """y = z * gamma + beta with film[..., :C] = gamma, film[..., C:] = beta (reference layers.py:42)."""
+
+    @staticmethod
+    def forward(ctx, z, film):
+        ctx.save_for_backward(z, film)
+        return ops.film_fwd(z, film)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        z, film = ctx.saved_tensors
+        return ops.film_bwd(gy.contiguous(), z, film)
+
+
+class Silu(Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.silu(x)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        return ops.silu_bwd(gy.contiguous(), x)
+
+
+class BatchNormTrain(Function):
+    """nn.BatchNorm2d in training mode over NHWC rows; running statistics updated in place."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, run_mean, run_var, eps, momentum):
+        C_ = x.shape[-1]
+        y, mean, invstd = ops.bn_train_fwd(x.view(-1, C_), weight.detach(), bias.detach(), eps, momentum, run_mean, run_var)
+        _prep.bump()                       # running statistics changed behind torch's back
+        ctx.save_for_backward(x, weight, mean, invstd)
+        return y.view(x.shape)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, weight, mean, invstd = ctx.saved_tensors
+        C_ = x.shape[-1]
+        gx, gw, gb = ops.bn_train_bwd(gy.contiguous().view(-1, C_), x.view(-1, C_), mean, invstd, weight.detach())
+        return gx.view(x.shape), gw, gb, None, None, None, None
+
+
+class PairSoftmax(Function):
+    @staticmethod
+    def forward(ctx, x, n_anchor):
+        y = ops.pair_softmax(x, n_anchor)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        return ops.pair_softmax_bwd(y, gy.contiguous()), None
+
+
+class SoftmaxRows(Function):
+    @staticmethod
+    def forward(ctx, x2d):
+        y = ops.softmax_rows_(x2d.clone())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        return ops.softmax_rows_bwd(y, gy.contiguous())
+
+
+class RoiPool(Function):
+    """ROIPooling (reference layers.py:406-497): gradient flows to the five FPN maps only."""
+
+    @staticmethod
+    def forward(ctx, rois, n_roi, pe_f, pe_t, img_h, img_w, *fmaps):
+        pool, pe, level = ops.roi_pool(list(fmaps), rois, n_roi, pe_f, pe_t, img_h, img_w)
+        ctx.shapes = [tuple(f.shape) for f in fmaps]
+        ctx.save_for_backward(rois, level)
+        ctx.mark_non_differentiable(pe, level)
+        return pool, pe, level
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gpool, _gpe, _glvl):
+        rois, level = ctx.saved_tensors
+        gf = ops.roi_pool_bwd(gpool.contiguous(), rois, level, ctx.shapes)
+        return (None, None, None, None, None, None, *gf)
+
+
+class Attention(Function):
+    """fm + SelfAttention(fm) (reference self_attention.py:24-56,76) with a hand-written backward: 5 forward and
+    9 backward fp32-MFMA GEMM launches (NT / NN / TN forms), row softmax and its gradient."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, wo, bo, inv):
+        B, L, Cc = x.shape
+        d = wq.shape[0]
+        x2d = x.view(B * L, Cc)
+        wqkv = torch.cat([wq.detach(), wk.detach(), wv.detach()], 0)
+        bqkv = torch.cat([bq.detach(), bk.detach(), bv.detach()], 0)
+        qkv = ops.linear(x2d, wqkv, bqkv)                                             # [B*L, 3d]
+        p = torch.empty((B, L, L), device=x.device, dtype=torch.float32)
+        ops.gemm_conv(qkv, qkv[:, d:], p, B=1, H=L, W=1, Cin=d, N=L, x_ld=3 * d, w_ld=3 * d, groups=B,
+                      x_gs=L * 3 * d, w_gs=L * 3 * d, y_gs=L * L, alpha=inv)
+        ops.softmax_rows_(p.view(B * L, L))
+        cx = torch.empty((B * L, d), device=x.device, dtype=torch.float32)
+        ops.conv_dgrad(p, qkv[:, 2 * d:], cx, B=1, H=L, W=1, Cin=d, N=L, g_ld=L, w_ld=3 * d, out_ld=d, groups=B,
+                       g_gs=L * L, w_gs=L * 3 * d, out_gs=L * d)                       # ctx = P @ V
+        out = ops.linear(cx, wo.detach(), bo.detach(), residual=x2d)
+        ctx.save_for_backward(x, qkv, p, cx, wqkv, wo)
+        ctx.inv = inv
+        return out.view(B, L, Cc)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        x, qkv, p, cx, wqkv, wo = ctx.saved_tensors
+        inv = ctx.inv
+        B, L, Cc = x.shape
+        d = wo.shape[1]
+        M = B * L
+        go = gout.contiguous().view(M, Cc)
+        x2d = x.view(M, Cc)
+        dev = x.device
+        gbo = ops.colsum(go)
+        gwo = torch.zeros((Cc, d), device=dev, dtype=torch.float32)
+        ops.conv_wgrad(go, cx, gwo, B=1, H=M, W=1, Cin=d, N=Cc)                        # dWo = go^T cx
+        gcx = torch.empty((M, d), device=dev, dtype=torch.float32)
+        ops.conv_dgrad(go, wo, gcx, B=1, H=M, W=1, Cin=d, N=Cc)                        # dctx = go Wo
+        gp = torch.empty((B, L, L), device=dev, dtype=torch.float32)
+        ops.gemm_conv(gcx, qkv[:, 2 * d:], gp, B=1, H=L, W=1, Cin=d, N=L, x_ld=d, w_ld=3 * d, groups=B,
+                      x_gs=L * d, w_gs=L * 3 * d, y_gs=L * L)                          # dP = dctx V^T
+        gqkv = torch.zeros((M, 3 * d), device=dev, dtype=torch.float32)
+        ops.conv_wgrad(p, gcx, gqkv[:, 2 * d:], B=1, H=L, W=1, Cin=d, N=L, g_ld=L, x_ld=d, out_ld=3 * d, groups=B,
+                       g_gs=L * L, x_gs=L * d, out_gs=L * 3 * d)                        # dV = P^T dctx
+        gs = ops.softmax_rows_bwd(p.view(M, L), gp.view(M, L), alpha=inv)              # dS (incl. 1/denominator)
+        ops.conv_dgrad(gs, qkv[:, d:], gqkv, B=1, H=L, W=1, Cin=d, N=L, g_ld=L, w_ld=3 * d, out_ld=3 * d, groups=B,
+                       g_gs=L * L, w_gs=L * 3 * d, out_gs=L * 3 * d)                    # dQ = dS K
+        ops.conv_wgrad(gs, qkv, gqkv[:, d:], B=1, H=L, W=1, Cin=d, N=L, g_ld=L, x_ld=3 * d, out_ld=3 * d, groups=B,
+                       g_gs=L * L, x_gs=L * 3 * d, out_gs=L * 3 * d)                    # dK = dS^T Q
+        gbqkv = ops.colsum(gqkv)
+        gwqkv = torch.zeros((3 * d, Cc), device=dev, dtype=torch.float32)
+        ops.conv_wgrad(gqkv, x2d, gwqkv, B=1, H=M, W=1, Cin=Cc, N=3 * d)
+        gx = torch.empty((M, Cc), device=dev, dtype=torch.float32)
+        ops.conv_dgrad(gqkv, wqkv, gx, B=1, H=M, W=1, Cin=Cc, N=3 * d, residual=go)    # + residual branch
+        return (gx.view(B, L, Cc), gwqkv[:d], gbqkv[:d], gwqkv[d:2 * d], gbqkv[d:2 * d], gwqkv[2 * d:], gbqkv[2 * d:],
+                gwo, gbo, None)

@@ -10,8 +10,9 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from . import _prep
+from . import _prep, functional as Fn
 from .position_encoding import one_dimension_positional_encoding
+from .targets import AnchorTargetLayer, ProposalTargetLayer   # noqa: F401  (reference exports them from layers.py)
 from .util.nets_utils import (weight_init, generate_anchors_frcnn as generate_anchors,
                               get_anchor_shifts_frcnn as get_anchor_shifts)
 
@@ -47,9 +48,23 @@ class DepthwiseSepConv2d(nn.Module):
         self.act = nn.SiLU()
 
     def forward(self, x, pe_act=None):
-        """x NHWC; pe_act = SiLU(pe) NHWC (the activation is shared by the blocks of the RCNN) or None."""
+        """x NHWC; pe_act = SiLU(pe) NHWC (the activation is shared by the blocks of the RCNN) or None.
+        eval: BatchNorm (running statistics) + SiLU are folded into the 1x1 GEMM's epilogue;
+        train: batch statistics (nn.BatchNorm2d semantics) through the differentiable ops."""
+        st = int(max(1, self.stride))
         if self.training:
-            raise NotImplementedError('train-mode (batch-statistics) BatchNorm of the heads: see nets/train_ops.py')
+            if self.stride < 1:
+                size = ((1 / self.stride) * np.array(x.shape[1:3])).astype(np.int64).tolist()
+                x = Fn.UpsampleAdd.apply(x, None, size[0], size[1])
+            out = Fn.DwConv.apply(x, self.depth_wise.weight, self.depth_wise.bias, self.expansion_fact, st)
+            if pe_act is not None:
+                film = Fn.conv(pe_act, self.pe_proj.weight, bias=self.pe_proj.bias)
+                out = Fn.Film.apply(out, film)
+            out = Fn.conv(out, self.pt_wise.weight, bias=self.pt_wise.bias)
+            self.norm.num_batches_tracked += 1
+            out = Fn.BatchNormTrain.apply(out, self.norm.weight, self.norm.bias, self.norm.running_mean,
+                                          self.norm.running_var, self.norm.eps, self.norm.momentum)
+            return Fn.Silu.apply(out)
         if self.stride < 1:
             size = ((1 / self.stride) * np.array(x.shape[1:3])).astype(np.int64).tolist()
             x = ops.upsample_bilinear_add(x, size[0], size[1])
@@ -58,7 +73,7 @@ class DepthwiseSepConv2d(nn.Module):
             film = ops.conv2d(pe_act, _prep.krsc(self.pe_proj.weight), shift=self.pe_proj.bias.detach())
             film = film.view(-1, film.shape[-1])
         out = ops.dwconv3x3(x, self.depth_wise.weight.detach(), self.depth_wise.bias.detach(), self.expansion_fact,
-                            int(max(1, self.stride)), film=film)
+                            st, film=film)
         s, b = _prep.bn_affine(self.norm.weight, self.norm.bias, self.norm.running_mean, self.norm.running_var,
                                self.norm.eps, conv_bias=self.pt_wise.bias)
         return ops.conv2d(out, _prep.krsc(self.pt_wise.weight), scale=s, shift=b, act=ops.ACT_SILU)
@@ -92,6 +107,15 @@ class RegionProposalNetwork(nn.Module):
                                           'average pooling to a different size is outside the hot-path scope')
             feats.append(f)
         B, h, w, cn = feats[0].shape
+        if torch.is_grad_enabled() and any(f.requires_grad for f in feats):
+            cls_l, reg_l = [], []
+            for i, f in enumerate(feats):
+                c, r = self.cls_score[str(i)], self.bbox_reg[str(i)]
+                cls_l.append(Fn.conv(f, c.weight, bias=c.bias))
+                reg_l.append(Fn.conv(f, r.weight, bias=r.bias))
+            cls_raw = torch.cat(cls_l, -1)
+            reg = torch.cat(reg_l, -1)
+            return Fn.PairSoftmax.apply(cls_raw, nl * A), reg, cls_raw
         cls_raw = torch.empty((B, h, w, nl * A * 2), device=feats[0].device, dtype=torch.float32)
         reg = torch.empty((B, h, w, nl * A * 4), device=feats[0].device, dtype=torch.float32)
         for i, f in enumerate(feats):
@@ -172,7 +196,7 @@ class ROIPooling(nn.Module):
         if (cfg.roi_pool_h, cfg.roi_pool_w) != (2, 2):
             raise NotImplementedError('roi_pool 2x2 (reference default) only')
         pe_f, pe_t = self.pe_tables(rois.device)
-        return ops.roi_pool(fmaps_nhwc, rois, n_roi, pe_f, pe_t, cfg.img_height, cfg.img_width)
+        return Fn.RoiPool.apply(rois, n_roi, pe_f, pe_t, cfg.img_height, cfg.img_width, *fmaps_nhwc)
 
     def forward(self, rois, conv_out):
         B, R = rois.shape[:2]
@@ -209,6 +233,20 @@ class RCNN(nn.Module):
     def forward_nhwc(self, pool, pe):
         """pool, pe: NHWC [N,2,2,C] -> (bbox_reg [N, 4(1+nc)], bbox_classes [N, 1+nc] softmaxed)."""
         cn = pool.shape[-1]
+        if torch.is_grad_enabled() and (self.training or pool.requires_grad):
+            if not self.training:
+                raise NotImplementedError('gradients through the eval-mode (running-statistics) head are not implemented')
+            roi_pe = Fn.conv(pe, self.pe_proj.weight, bias=self.pe_proj.bias)
+            pe_act = Fn.Silu.apply(roi_pe)
+            out = pool
+            for blk in self.rcnn:
+                out = blk(out, pe_act)
+            feat = out.reshape(out.shape[0], -1)
+            wr = self.bbox_reg_layer.weight.view(-1, cn, 4).permute(0, 2, 1).reshape(-1, 4 * cn)
+            wc = self.bbox_classif_layer.weight.view(-1, cn, 4).permute(0, 2, 1).reshape(-1, 4 * cn)
+            reg = Fn.linear(feat, wr, self.bbox_reg_layer.bias)
+            cls = Fn.linear(feat, wc, self.bbox_classif_layer.bias)
+            return reg, Fn.SoftmaxRows.apply(cls)
         roi_pe = ops.conv2d(pe, _prep.krsc(self.pe_proj.weight), shift=self.pe_proj.bias.detach())
         pe_act = ops.silu(roi_pe)
         out = pool

@@ -2,8 +2,9 @@
 
 state_dict keys: `attn.attention_modules.{i}.{query,key,value,final_projection}.{weight,bias}` for the
 top-n levels; the lower levels hold nn.Identity.  One level = five fp32-MFMA GEMM launches + one row
-softmax: [Q|K] projection (one GEMM, N = 2d), V^T projection (bias per row), S = QK^T * (1/denom),
-softmax rows, ctx = P V, final projection with the residual `fm + attn(fm)` fused in its epilogue.
+softmax: [Q|K|V] projection (one GEMM, N = 3d), S = QK^T * (1/denom) (NT), softmax rows, ctx = P V (NN),
+final projection with the residual `fm + attn(fm)` fused in its epilogue; the backward is hand-written
+(nets/functional.py:Attention).
 """
 from collections import namedtuple
 
@@ -12,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from . import _prep
+from . import _prep, functional as Fn
 
 # A level that the reference passes through nn.Identity comes out as fm + fm (self_attention.py:69,76,
 # SURVEY Appendix C-1).  Instead of materialising 2*fm the pyramid hands (fm, 2.0) to the FPN, whose
@@ -38,20 +39,12 @@ class SelfAttention(nn.Module):
         L, d = h * w, self.inner_dim
         if L % 32:
             raise NotImplementedError(f'attention over {h}x{w} tokens: the P.V GEMM needs H*W % 32 == 0')
-        x2d = inpt.view(B * L, Cc)
-        wqk = _prep.cat_rows('qk_w', self.query.weight, self.key.weight)
-        bqk = _prep.cat_rows('qk_b', self.query.bias, self.key.bias)
-        qk = ops.linear(x2d, wqk, bqk)                                              # [B*L, 2d]
-        vt = ops.bgemm_nt(self.value.weight.detach(), inpt.view(B, L, Cc), shift=self.value.bias.detach(),
-                          shift_per_row=True)                                          # [B, d, L]
+        if not residual:
+            raise NotImplementedError('SelfAttention without the SAPyramid residual is not on the hot path')
         inv = float(np.float32(1.0) / np.float32(np.round(np.sqrt(d), 2)))            # self_attention.py:47
-        s = torch.empty((B, L, L), device=inpt.device, dtype=torch.float32)
-        ops.gemm_conv(qk, qk[:, d:], s, B=1, H=L, W=1, Cin=d, N=L, x_ld=2 * d, w_ld=2 * d, groups=B,
-                      x_gs=L * 2 * d, w_gs=L * 2 * d, y_gs=L * L, alpha=inv)
-        ops.softmax_rows_(s.view(B * L, L))
-        ctx = ops.bgemm_nt(s, vt)                                                       # [B, L, d]
-        out = ops.linear(ctx.view(B * L, d), self.final_projection.weight.detach(),
-                         self.final_projection.bias.detach(), residual=x2d if residual else None)
+        out = Fn.Attention.apply(inpt.view(B, L, Cc), self.query.weight, self.query.bias, self.key.weight, self.key.bias,
+                                 self.value.weight, self.value.bias, self.final_projection.weight,
+                                 self.final_projection.bias, inv)
         return out.view(B, h, w, Cc)
 
 

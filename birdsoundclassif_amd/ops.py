@@ -291,3 +291,184 @@ def rcnn_post(rois, n_roi, bbox_reg, bbox_cls, img_w, img_h, nms_thresh, min_sco
                               n_cls1, img_w, img_h, float(nms_thresh), float(min_score), int(proposal_number),
                               _ptr(det), _ptr(n_det), _stream()), 'nbm_rcnn_post')
     return det, n_det
+
+
+# =========================================================================== training path
+from ._lib import BwdDesc  # noqa: E402
+
+
+def _bwd_desc(g, *, B, H, W, Cin, N, kh, kw, stride, pad, g_ld, groups=1, alpha=1.0):
+    d = BwdDesc()
+    d.g = g.data_ptr()
+    d.groups = groups
+    d.B, d.H, d.W, d.Cin, d.N = B, H, W, Cin, N
+    d.kh, d.kw, d.stride, d.pad = kh, kw, stride, pad
+    d.Ho = (H + 2 * pad - kh) // stride + 1
+    d.Wo = (W + 2 * pad - kw) // stride + 1
+    d.g_ld = g_ld
+    d.alpha = float(alpha)
+    return d
+
+
+def conv_dgrad(g, w, out, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, g_ld=None, w_ld=None, out_ld=None,
+               a_scale=None, residual=None, mask=None, alpha=1.0, groups=1, g_gs=0, w_gs=0, out_gs=0, res_gs=0):
+    """Raw nbm_conv_dgrad: out[B*H*W][Cin] = gather(g)[..][N] x W (see include/nbm_hip.h)."""
+    d = _bwd_desc(g, B=B, H=H, W=W, Cin=Cin, N=N, kh=kh, kw=kw, stride=stride, pad=pad,
+                  g_ld=N if g_ld is None else g_ld, groups=groups, alpha=alpha)
+    d.w, d.out = w.data_ptr(), out.data_ptr()
+    d.w_ld = kh * kw * Cin if w_ld is None else w_ld
+    d.out_ld = Cin if out_ld is None else out_ld
+    d.a_scale = a_scale.data_ptr() if a_scale is not None else None
+    d.residual = residual.data_ptr() if residual is not None else None
+    d.res_ld = Cin if residual is not None else 0
+    d.mask = mask.data_ptr() if mask is not None else None
+    d.mask_ld = Cin if mask is not None else 0
+    d.g_gs, d.w_gs, d.out_gs, d.res_gs = g_gs, w_gs, out_gs, res_gs
+    check(lib().nbm_conv_dgrad(C.byref(d), _stream()), 'nbm_conv_dgrad')
+    return out
+
+
+def conv_wgrad(g, x, out, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, g_ld=None, x_ld=None, out_ld=None,
+               row_scale=None, alpha=1.0, groups=1, g_gs=0, x_gs=0, out_gs=0):
+    """Raw nbm_conv_wgrad: out[N][kh*kw*Cin] += g^T x im2col(x); `out` must be zeroed (or hold a partial sum)."""
+    d = _bwd_desc(g, B=B, H=H, W=W, Cin=Cin, N=N, kh=kh, kw=kw, stride=stride, pad=pad,
+                  g_ld=N if g_ld is None else g_ld, groups=groups, alpha=alpha)
+    d.x, d.out = x.data_ptr(), out.data_ptr()
+    d.x_ld = Cin if x_ld is None else x_ld
+    d.out_ld = kh * kw * Cin if out_ld is None else out_ld
+    d.row_scale = row_scale.data_ptr() if row_scale is not None else None
+    d.g_gs, d.x_gs, d.out_gs = g_gs, x_gs, out_gs
+    check(lib().nbm_conv_wgrad(C.byref(d), _stream()), 'nbm_conv_wgrad')
+    return out
+
+
+def relu_bwd(gy, y):
+    out = torch.empty_like(gy)
+    check(lib().nbm_relu_bwd(_ptr(_chk(gy)), _ptr(_chk(y)), _ptr(out), gy.numel(), _stream()), 'nbm_relu_bwd')
+    return out
+
+
+def silu_bwd(gy, x):
+    out = torch.empty_like(gy)
+    check(lib().nbm_silu_bwd(_ptr(_chk(gy)), _ptr(_chk(x)), _ptr(out), gy.numel(), _stream()), 'nbm_silu_bwd')
+    return out
+
+
+def axpby(a, b=None, alpha=1.0, beta=1.0):
+    out = torch.empty_like(a)
+    check(lib().nbm_axpby(_ptr(_chk(a)), _ptr(b), _ptr(out), float(alpha), float(beta), a.numel(), _stream()), 'nbm_axpby')
+    return out
+
+
+def colsum(g2d, n=None):
+    """g2d [M, ld] -> [n] column sums (n defaults to ld)."""
+    _chk(g2d, name='g')
+    M, ld = g2d.shape
+    n = ld if n is None else n
+    out = torch.empty((n,), device=g2d.device, dtype=torch.float32)
+    check(lib().nbm_colsum(_ptr(g2d), M, n, ld, _ptr(out), _stream()), 'nbm_colsum')
+    return out
+
+
+def maxpool3x3s2_bwd(x, gy):
+    B, H, W, C_ = x.shape
+    gx = torch.empty_like(x)
+    check(lib().nbm_maxpool3x3s2_bwd(_ptr(_chk(x)), _ptr(_chk(gy)), _ptr(gx), B, H, W, C_, gy.shape[1], gy.shape[2],
+                                     _stream()), 'nbm_maxpool3x3s2_bwd')
+    return gx
+
+
+def upsample_bilinear_bwd(gy, Hi, Wi):
+    B, Ho, Wo, C_ = gy.shape
+    gs = torch.empty((B, Hi, Wi, C_), device=gy.device, dtype=torch.float32)
+    check(lib().nbm_upsample_bilinear_bwd(_ptr(_chk(gy)), B, Hi, Wi, C_, _ptr(gs), Ho, Wo, _stream()),
+          'nbm_upsample_bilinear_bwd')
+    return gs
+
+
+def softmax_rows_bwd(p2d, gp2d, alpha=1.0):
+    rows, cols = p2d.shape
+    out = torch.empty_like(p2d)
+    check(lib().nbm_softmax_rows_bwd(_ptr(_chk(p2d)), _ptr(_chk(gp2d)), _ptr(out), rows, cols, float(alpha), _stream()),
+          'nbm_softmax_rows_bwd')
+    return out
+
+
+def pair_softmax_bwd(y, gy):
+    gx = torch.empty_like(y)
+    check(lib().nbm_pair_softmax_bwd(_ptr(_chk(y)), _ptr(_chk(gy)), _ptr(gx), y.numel() // 2, _stream()),
+          'nbm_pair_softmax_bwd')
+    return gx
+
+
+def dwconv3x3_bwd(x, g, w, mult, stride, need_gx=True, need_gw=True, has_bias=True):
+    B, H, W, Cin = x.shape
+    Ho, Wo = g.shape[1], g.shape[2]
+    gx = torch.empty_like(x) if need_gx else None
+    gw = torch.empty((Cin * mult, 1, 3, 3), device=x.device, dtype=torch.float32) if need_gw else None
+    gb = torch.empty((Cin * mult,), device=x.device, dtype=torch.float32) if (need_gw and has_bias) else None
+    check(lib().nbm_dwconv3x3_bwd(_ptr(_chk(x)), _ptr(_chk(g)), _ptr(_chk(w)), B, H, W, Cin, mult, stride, _ptr(gx),
+                                  _ptr(gw), _ptr(gb), Ho, Wo, _stream()), 'nbm_dwconv3x3_bwd')
+    return gx, gw, gb
+
+
+def film_fwd(z, film):
+    y = torch.empty_like(z)
+    C_ = z.shape[-1]
+    check(lib().nbm_film_fwd(_ptr(_chk(z)), _ptr(_chk(film)), _ptr(y), z.numel() // C_, C_, _stream()), 'nbm_film_fwd')
+    return y
+
+
+def film_bwd(gy, z, film):
+    gz, gf = torch.empty_like(z), torch.empty_like(film)
+    C_ = z.shape[-1]
+    check(lib().nbm_film_bwd(_ptr(_chk(gy)), _ptr(_chk(z)), _ptr(_chk(film)), _ptr(gz), _ptr(gf), z.numel() // C_, C_,
+                             _stream()), 'nbm_film_bwd')
+    return gz, gf
+
+
+def bn_train_fwd(x2d, w, b, eps, momentum, run_mean, run_var):
+    """x2d [M,C] -> (y, mean, invstd); running stats updated in place."""
+    M, C_ = x2d.shape
+    ws = torch.empty((2 * C_,), device=x2d.device, dtype=torch.float64)
+    mean = torch.empty((C_,), device=x2d.device, dtype=torch.float32)
+    invstd = torch.empty_like(mean)
+    y = torch.empty_like(x2d)
+    check(lib().nbm_bn_train_fwd(_ptr(_chk(x2d)), M, C_, _ptr(_chk(w)), _ptr(_chk(b)), float(eps), float(momentum),
+                                 _ptr(run_mean), _ptr(run_var), _ptr(ws), _ptr(mean), _ptr(invstd), _ptr(y), _stream()),
+          'nbm_bn_train_fwd')
+    return y, mean, invstd
+
+
+def bn_train_bwd(g2d, x2d, mean, invstd, w):
+    M, C_ = x2d.shape
+    ws = torch.empty((2 * C_,), device=x2d.device, dtype=torch.float64)
+    gx = torch.empty_like(x2d)
+    gw = torch.empty((C_,), device=x2d.device, dtype=torch.float32)
+    gb = torch.empty_like(gw)
+    check(lib().nbm_bn_train_bwd(_ptr(_chk(g2d)), _ptr(_chk(x2d)), M, C_, _ptr(mean), _ptr(invstd), _ptr(_chk(w)), _ptr(ws),
+                                 _ptr(gx), _ptr(gw), _ptr(gb), _stream()), 'nbm_bn_train_bwd')
+    return gx, gw, gb
+
+
+def roi_pool_bwd(gpool, rois, level, fmap_shapes):
+    """gpool [B*R,2,2,C] -> list of zero-initialised-then-accumulated gradient maps (NHWC) for the FPN levels."""
+    B, R = rois.shape[:2]
+    C_ = gpool.shape[-1]
+    gf = [torch.zeros(s, device=gpool.device, dtype=torch.float32) for s in fmap_shapes]
+    n = len(gf)
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in gf])
+    fh = (C.c_int * n)(*[s[1] for s in fmap_shapes])
+    fw = (C.c_int * n)(*[s[2] for s in fmap_shapes])
+    check(lib().nbm_roi_pool_bwd(ptrs, fh, fw, n, C_, _ptr(_chk(rois)), _ptr(level), B, R, _ptr(_chk(gpool)), _stream()),
+          'nbm_roi_pool_bwd')
+    return gf
+
+
+def sqnorm_accum(g, out):
+    check(lib().nbm_sqnorm_accum(_ptr(g), g.numel(), _ptr(out), _stream()), 'nbm_sqnorm_accum')
+
+
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, sqnorm=None, max_norm=0.0):
+    check(lib().nbm_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), float(lr), float(beta1), float(beta2),
+                               float(eps), float(wd), int(step), _ptr(sqnorm), float(max_norm), _stream()), 'nbm_adamw_step')

@@ -179,6 +179,68 @@ int nbm_rcnn_post(const float* rois, const int* n_roi, int B, int roi_cap, const
                   float nms_thresh, float min_score, int proposal_number, float* det, int* n_det,
                   void* stream);
 
+/* ================================================================================================
+ * Training path: backward implicit GEMMs, point-wise gradients, train-mode BatchNorm, optimiser.
+ * Replaces what torch.autograd derives for the reference's train step (train.py:205-217):
+ * conv/linear/matmul backward, ReLU/SiLU/max-pool/bilinear/softmax/BatchNorm backward,
+ * torch.nn.utils.clip_grad_norm_ (train.py:213-214) and torch.optim.AdamW.step (train.py:215,302-303).
+ */
+typedef struct nbm_bwd_desc {
+  const float* g;        /* upstream gradient, NHWC [B][Ho][Wo][N] rows (pitch g_ld)                         */
+  const float* w;        /* dgrad: KRSC weights [N][w_ld]                                                    */
+  const float* x;        /* wgrad: forward input NHWC [B][H][W][Cin] (pitch x_ld)                            */
+  float* out;            /* dgrad: dX [B*H*W][out_ld];  wgrad: dW [N][out_ld] (KRSC, += with fp32 atomics)   */
+  const float* a_scale;  /* dgrad: per-n multiplier of g (needs N % 32 == 0) or NULL                         */
+  const float* row_scale;/* wgrad: per-n multiplier of the dW rows or NULL                                   */
+  const float* residual; /* dgrad: added to dX (gradient accumulation) or NULL                               */
+  const float* mask;     /* dgrad: dX := 0 where mask <= 0 (ReLU of the producing layer) or NULL             */
+  int64_t g_gs, w_gs, x_gs, out_gs, res_gs;
+  int groups;
+  int B, H, W, Cin, N, kh, kw, stride, pad, Ho, Wo;   /* geometry of the FORWARD convolution                */
+  int g_ld, w_ld, x_ld, out_ld, res_ld, mask_ld;
+  float alpha;
+} nbm_bwd_desc;
+
+/* dX[b][iy][ix][c] = alpha * sum_{r,s,n} g[b][(iy+pad-r)/stride][(ix+pad-s)/stride][n] * a_scale[n] * W[n][r][s][c]
+ * (+ residual, ReLU mask).  g rows must be readable (zero padded) up to ceil(N/32)*32 floats.  Also the plain
+ * C[M][Cin] = A[M][N] * B[N][Cin] ("NN") GEMM with H = M, W = 1, 1x1. */
+int nbm_conv_dgrad(const nbm_bwd_desc* d, void* stream);
+/* dW[n][(r,s,c)] += alpha * row_scale[n] * sum_m g[m][n] * x[pix(m)+(r,s)][c]; dW must be zeroed by the caller.
+ * Also the plain C[N][Cin] += A[M][N]^T * B[M][Cin] ("TN") GEMM. */
+int nbm_conv_wgrad(const nbm_bwd_desc* d, void* stream);
+
+int nbm_relu_bwd(const float* gy, const float* y, float* out, int64_t n, void* stream);
+int nbm_silu_bwd(const float* gy, const float* x, float* out, int64_t n, void* stream);
+/* out = alpha*a + beta*b (b may be NULL): explicit gradient accumulation */
+int nbm_axpby(const float* a, const float* b, float* out, float alpha, float beta, int64_t n, void* stream);
+/* out[n] = sum_m g[m][n] (bias gradients) */
+int nbm_colsum(const float* g, int64_t M, int N, int ld, float* out, void* stream);
+int nbm_maxpool3x3s2_bwd(const float* x, const float* gy, float* gx, int B, int H, int W, int C, int Ho, int Wo,
+                         void* stream);
+int nbm_upsample_bilinear_bwd(const float* gy, int B, int Hi, int Wi, int C, float* gsrc, int Ho, int Wo, void* stream);
+int nbm_softmax_rows_bwd(const float* p, const float* gp, float* out, int64_t rows, int cols, float alpha, void* stream);
+int nbm_pair_softmax_bwd(const float* y, const float* gy, float* gx, int64_t n_pairs, void* stream);
+/* depthwise 3x3 gradients: gx (may be NULL), gw [Cout][9] and gb [Cout] (gw NULL = skip both) */
+int nbm_dwconv3x3_bwd(const float* x, const float* g, const float* w, int B, int H, int W, int Cin, int mult, int stride,
+                      float* gx, float* gw, float* gb, int Ho, int Wo, void* stream);
+int nbm_film_fwd(const float* z, const float* film, float* y, int64_t n_pix, int C, void* stream);
+int nbm_film_bwd(const float* gy, const float* z, const float* film, float* gz, float* gfilm, int64_t n_pix, int C,
+                 void* stream);
+/* nn.BatchNorm2d in training mode over rows [M][C]: batch statistics (biased variance for the output, unbiased for the
+ * running estimate), running stats updated in place with `momentum`.  stats_ws / red_ws: 2*C doubles. */
+int nbm_bn_train_fwd(const float* x, int64_t M, int C, const float* w, const float* b, float eps, float momentum,
+                     float* run_mean, float* run_var, double* stats_ws, float* mean, float* invstd, float* y, void* stream);
+int nbm_bn_train_bwd(const float* g, const float* x, int64_t M, int C, const float* mean, const float* invstd,
+                     const float* w, double* red_ws, float* gx, float* gw, float* gb, void* stream);
+/* ROIPooling backward: scatter-add of gpool [B*n_roi][2][2][C] into the (zeroed) FPN gradient maps */
+int nbm_roi_pool_bwd(float* const* gfmap_host, const int* fh_host, const int* fw_host, int n_levels, int C,
+                     const float* rois, const int* level, int B, int n_roi, const float* gpool, void* stream);
+/* out[0] += sum g^2 (double); then AdamW on a flat range with the clip coefficient min(1, max_norm/(sqrt(*sqnorm)+1e-6))
+ * evaluated on device (sqnorm NULL or max_norm <= 0: no clipping). */
+int nbm_sqnorm_accum(const float* g, int64_t n, double* out, void* stream);
+int nbm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int step, const double* sqnorm, float max_norm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,299 @@
+"""GPU parity tests of the training path: every backward kernel against torch autograd of the same op on the CPU
+(fp32), then the whole optimisation step against the golden fixtures generated from the REAL reference
+(two steps of reference train.py:205-217: one positive, one negative)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from birdsoundclassif_amd import ops, synth                     # noqa: E402
+from birdsoundclassif_amd.nets import functional as Fn          # noqa: E402
+from helpers import check_packed, filler_state_dict, load_golden  # noqa: E402
+from oracle import nets_ref as O                                # noqa: E402
+
+
+def rnd(key, *shape, scale=1.0):
+    return torch.from_numpy((synth.normal(key, int(np.prod(shape))) * scale).astype(np.float32).reshape(shape))
+
+
+def nhwc(t):
+    return t.detach().permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(t):
+    return t.detach().cpu().permute(0, 3, 1, 2)
+
+
+def close(got, ref, tol, name):
+    got, ref = got.detach().cpu().float(), ref.detach().cpu().float()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    scale = float(ref.abs().max()) + 1e-12
+    err = float((got - ref).abs().max())
+    assert err <= tol * scale, f'{name}: max err {err:.3e} vs scale {scale:.3e}'
+
+
+@pytest.mark.parametrize('cfg', [
+    # B, H, W, Cin, Cout, k, stride, pad, relu, residual, alpha, bias
+    (2, 12, 14, 64, 64, 1, 1, 0, True, True, 1.0, False),
+    (1, 14, 18, 128, 128, 3, 1, 1, True, False, 1.0, False),
+    (2, 15, 17, 128, 128, 3, 2, 1, True, False, 1.0, False),
+    (2, 12, 14, 256, 512, 1, 2, 0, False, False, 1.0, False),
+    (1, 11, 13, 384, 256, 3, 1, 1, False, False, 1.0, True),
+    (2, 9, 10, 64, 384, 1, 1, 0, False, False, 2.0, True),
+    (1, 9, 8, 256, 6, 1, 1, 0, False, False, 1.0, True),
+    (1, 9, 8, 256, 12, 1, 1, 0, False, False, 1.0, True),
+])
+def test_conv_backward(cfg):
+    B, H, W, Ci, Co, k, st, pad, relu, res, alpha, bias = cfg
+    x = rnd(('x', cfg), B, Ci, H, W).requires_grad_(True)
+    w = rnd(('w', cfg), Co, Ci, k, k, scale=(2.0 / (Ci * k * k)) ** 0.5).requires_grad_(True)
+    b = rnd(('b', cfg), Co, scale=0.1).requires_grad_(True) if bias else None
+    scale = None if bias else (1 + 0.1 * rnd(('s', cfg), Co))
+    shift = None if bias else 0.1 * rnd(('sh', cfg), Co)
+    y = F.conv2d(alpha * x, w, stride=st, padding=pad)
+    y = y + b.view(1, -1, 1, 1) if bias else y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    r = rnd(('r', cfg), *y.shape).requires_grad_(True) if res else None
+    if res:
+        y = y + r
+    if relu:
+        y = F.relu(y)
+    gy = rnd(('g', cfg), *y.shape)
+    y.backward(gy)
+
+    xd = nhwc(x).requires_grad_(True)
+    wd = w.detach().cuda().requires_grad_(True)
+    bd = b.detach().cuda().requires_grad_(True) if bias else None
+    rd = nhwc(r).requires_grad_(True) if res else None
+    yd = Fn.conv(xd, wd, bias=bd, scale=None if bias else scale.cuda(), shift=None if bias else shift.cuda(), residual=rd,
+                 kh=k, kw=k, stride=st, pad=pad, act=ops.ACT_RELU if relu else ops.ACT_NONE, alpha=alpha)
+    close(nchw(yd), y, 3e-5, f'fwd {cfg}')
+    yd.backward(nhwc(gy))
+    close(nchw(xd.grad), x.grad, 5e-5, f'dgrad {cfg}')
+    close(wd.grad, w.grad, 5e-5, f'wgrad {cfg}')
+    if bias:
+        close(bd.grad, b.grad, 5e-5, f'bias grad {cfg}')
+    if res:
+        close(nchw(rd.grad), r.grad, 1e-6, f'residual grad {cfg}')
+
+
+def test_linear_backward_odd_sizes():
+    x = rnd('lx', 70, 1024).requires_grad_(True)
+    w = rnd('lw', 151, 1024, scale=0.05).requires_grad_(True)
+    b = rnd('lb', 151).requires_grad_(True)
+    y = F.linear(x, w, b)
+    gy = rnd('lg', 70, 151)
+    y.backward(gy)
+    xd, wd, bd = (t.detach().cuda().requires_grad_(True) for t in (x, w, b))
+    yd = Fn.linear(xd, wd, bd)
+    close(yd, y, 3e-5, 'linear fwd')
+    yd.backward(gy.cuda())
+    close(xd.grad, x.grad, 5e-5, 'linear dx')
+    close(wd.grad, w.grad, 5e-5, 'linear dw')
+    close(bd.grad, b.grad, 5e-5, 'linear db')
+
+
+def test_stem_backward():
+    x = rnd('stx', 2, 1, 37, 41)
+    wi = (1 + 0.2 * rnd('stwi', 3, 1, 1, 1)).requires_grad_(True)
+    bi = rnd('stbi', 3, scale=0.1).requires_grad_(True)
+    w1 = rnd('stw1', 64, 3, 7, 7, scale=0.1).requires_grad_(True)
+    scale, shift = 1 + 0.1 * rnd('sts', 64), 0.1 * rnd('stsh', 64)
+    y = F.relu(F.conv2d(F.conv2d(x, wi, bi), w1, stride=2, padding=3) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    gy = rnd('stg', *y.shape)
+    y.backward(gy)
+    wid, bid, w1d = (t.detach().cuda().requires_grad_(True) for t in (wi, bi, w1))
+    yd = Fn.Stem.apply(nhwc(x), wid, bid, w1d, scale.cuda(), shift.cuda())
+    close(nchw(yd), y, 3e-5, 'stem fwd')
+    yd.backward(nhwc(gy))
+    close(w1d.grad, w1.grad, 5e-5, 'stem dW1')
+    close(wid.grad, wi.grad, 5e-5, 'stem dw_init')
+    close(bid.grad, bi.grad, 5e-5, 'stem db_init')
+
+
+def test_attention_backward():
+    from birdsoundclassif_amd.nets.self_attention import SelfAttention
+    torch.manual_seed(1)
+    m = SelfAttention(128, 64)
+    sd = {'a.' + k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    x = rnd('attx', 2, 128, 8, 12).requires_grad_(True)
+    y = x + O.self_attention(sd, 'a', x)
+    gy = rnd('attg', *y.shape)
+    y.backward(gy)
+    m = m.cuda()
+    xd = nhwc(x).requires_grad_(True)
+    yd = m(xd)
+    close(nchw(yd), y, 3e-5, 'attention fwd')
+    yd.backward(nhwc(gy))
+    close(nchw(xd.grad), x.grad, 1e-4, 'attention dx')
+    for k, p in m.named_parameters():
+        if 'key.bias' in k:
+            continue                      # mathematically zero (softmax is shift invariant): rounding noise only
+        close(p.grad, sd['a.' + k].grad, 1e-4, f'attention d{k}')
+
+
+def test_pointwise_backward():
+    # max pool (post-ReLU input: many exact ties at 0)
+    x = F.relu(rnd('mpx', 2, 64, 19, 23)).requires_grad_(True)
+    y = F.max_pool2d(x, 3, 2, 1)
+    gy = rnd('mpg', *y.shape)
+    y.backward(gy)
+    xd = nhwc(x).requires_grad_(True)
+    Fn.MaxPool.apply(xd).backward(nhwc(gy))
+    close(nchw(xd.grad), x.grad, 1e-6, 'maxpool bwd')
+    # bilinear up-sampling + add
+    for (hi, wi, ho, wo) in ((6, 8, 12, 15), (12, 32, 24, 64), (5, 7, 10, 14)):
+        s = rnd(('uss', hi), 2, 32, hi, wi).requires_grad_(True)
+        a = rnd(('usa', hi), 2, 32, ho, wo).requires_grad_(True)
+        y = F.interpolate(s, size=(ho, wo), mode='bilinear', align_corners=True) + a
+        gy = rnd(('usg', hi), *y.shape)
+        y.backward(gy)
+        sd_, ad = nhwc(s).requires_grad_(True), nhwc(a).requires_grad_(True)
+        Fn.UpsampleAdd.apply(sd_, ad, ho, wo).backward(nhwc(gy))
+        close(nchw(sd_.grad), s.grad, 5e-6, f'upsample bwd {hi}x{wi}')
+        close(nchw(ad.grad), a.grad, 0, 'upsample add grad')
+    # silu, softmax rows, pair softmax
+    v = rnd('siv', 3000, scale=3.0).requires_grad_(True)
+    gv = rnd('sig', 3000)
+    F.silu(v).backward(gv)
+    vd = v.detach().cuda().requires_grad_(True)
+    Fn.Silu.apply(vd).backward(gv.cuda())
+    close(vd.grad, v.grad, 2e-6, 'silu bwd')
+    s = rnd('smx', 37, 151, scale=3.0).requires_grad_(True)
+    gs = rnd('smg', 37, 151)
+    s.softmax(-1).backward(gs)
+    sd_ = s.detach().cuda().requires_grad_(True)
+    Fn.SoftmaxRows.apply(sd_).backward(gs.cuda())
+    close(sd_.grad, s.grad, 5e-6, 'softmax bwd')
+    p = rnd('psx', 5, 7, 30, scale=2.0).requires_grad_(True)
+    gp = rnd('psg', 5, 7, 30)
+    p.view(5, 7, 15, 2).softmax(-1).view(5, 7, 30).backward(gp)
+    pd = p.detach().cuda().requires_grad_(True)
+    Fn.PairSoftmax.apply(pd, 15).backward(gp.cuda())
+    close(pd.grad, p.grad, 5e-6, 'pair softmax bwd')
+
+
+@pytest.mark.parametrize('cfg', [(2, 16, 20, 64, 2, 1), (2, 33, 41, 32, 2, 4), (1, 24, 32, 32, 2, 8), (3, 2, 2, 64, 4, 1)])
+def test_dwconv_film_backward(cfg):
+    B, H, W, C, mult, st = cfg
+    x = rnd(('dx', cfg), B, C, H, W).requires_grad_(True)
+    w = rnd(('dw', cfg), C * mult, 1, 3, 3, scale=0.3).requires_grad_(True)
+    b = rnd(('db', cfg), C * mult, scale=0.1).requires_grad_(True)
+    z = F.conv2d(x, w, b, stride=st, padding=1, groups=C)
+    film = rnd(('df', cfg), B, 2 * C * mult, *z.shape[-2:]).requires_grad_(True)
+    y = z * film[:, :C * mult] + film[:, C * mult:]
+    gy = rnd(('dg', cfg), *y.shape)
+    y.backward(gy)
+    xd, fd = nhwc(x).requires_grad_(True), nhwc(film).requires_grad_(True)
+    wd, bd = w.detach().cuda().requires_grad_(True), b.detach().cuda().requires_grad_(True)
+    yd = Fn.Film.apply(Fn.DwConv.apply(xd, wd, bd, mult, st), fd)
+    close(nchw(yd), y, 5e-6, f'dw+film fwd {cfg}')
+    yd.backward(nhwc(gy))
+    close(nchw(xd.grad), x.grad, 1e-5, f'dw dx {cfg}')
+    close(wd.grad, w.grad, 2e-5, f'dw dw {cfg}')
+    close(bd.grad, b.grad, 2e-5, f'dw db {cfg}')
+    close(nchw(fd.grad), film.grad, 1e-5, f'film grad {cfg}')
+
+
+def test_batchnorm_train():
+    x = rnd('bnx', 3, 256, 6, 10, scale=2.0).requires_grad_(True)
+    w = (1 + 0.1 * rnd('bnw', 256)).requires_grad_(True)
+    b = (0.1 * rnd('bnb', 256)).requires_grad_(True)
+    rm, rv = 0.05 * rnd('bnrm', 256), 1 + 0.1 * rnd('bnrv', 256).abs()
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y = F.batch_norm(x, rm_ref, rv_ref, w, b, True, 0.1, 1e-5)
+    gy = rnd('bng', *y.shape)
+    y.backward(gy)
+    xd = nhwc(x).requires_grad_(True)
+    wd, bd = w.detach().cuda().requires_grad_(True), b.detach().cuda().requires_grad_(True)
+    rmd, rvd = rm.cuda(), rv.cuda()
+    yd = Fn.BatchNormTrain.apply(xd, wd, bd, rmd, rvd, 1e-5, 0.1)
+    close(nchw(yd), y, 1e-5, 'bn fwd')
+    close(rmd, rm_ref, 1e-6, 'running mean')
+    close(rvd, rv_ref, 1e-6, 'running var')
+    yd.backward(nhwc(gy))
+    close(nchw(xd.grad), x.grad, 2e-5, 'bn dx')
+    close(wd.grad, w.grad, 2e-5, 'bn dw')
+    close(bd.grad, b.grad, 2e-5, 'bn db')
+
+
+def test_roi_pool_backward():
+    cfg = O.make_cfg()
+    B = 2
+    fm = [rnd(('rfm', i), B, 256, h, w).requires_grad_(True) for i, (h, w) in
+          enumerate([(188, 512), (94, 256), (47, 128), (24, 64), (12, 32)])]
+    u = synth.uniform('rb_rois', B * 16 * 4).reshape(B, 16, 4)
+    x1, y1 = np.floor(u[..., 0] * 1000), np.floor(u[..., 1] * 360)
+    w, h = np.floor(2 + u[..., 2] ** 3 * 1000), np.floor(2 + u[..., 3] ** 3 * 370)
+    rois = torch.tensor(np.stack([x1, y1, np.minimum(x1 + w, 1023), np.minimum(y1 + h, 374)], -1), dtype=torch.float32)
+    pool, _, _ = O.roi_pooling(cfg, rois, fm)
+    gp = rnd('rb_g', *pool.shape)
+    pool.backward(gp)
+    from birdsoundclassif_amd.nets.layers import ROIPooling
+    from birdsoundclassif_amd.train import default_args
+    rp = ROIPooling(default_args())
+    fmd = [nhwc(f).requires_grad_(True) for f in fm]
+    n = torch.tensor([16], dtype=torch.int32).cuda()
+    pd, _, _ = rp.forward_device(rois.cuda(), n, fmd)
+    close(pd.view(B, 16, 2, 2, 256).permute(0, 1, 4, 2, 3), pool, 5e-6, 'roi pool fwd')
+    pd.backward(gp.permute(0, 1, 3, 4, 2).reshape(B * 16, 2, 2, 256).contiguous().cuda())
+    for i in range(5):
+        if fm[i].grad is None:
+            assert float(fmd[i].grad.abs().max()) == 0
+        else:
+            close(nchw(fmd[i].grad), fm[i].grad, 1e-5, f'roi pool grad level {i}')
+
+
+def test_fused_adamw_matches_torch():
+    from birdsoundclassif_amd.train import FusedAdamW
+    ps = [rnd(('p', i), *s) for i, s in enumerate([(64, 32, 3, 3), (100,), (7, 13)])]
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    got = [p.clone().cuda().requires_grad_(True) for p in ps]
+    o_ref = torch.optim.AdamW([{'params': ref[:2]}, {'params': ref[2:], 'lr': 1e-2}], lr=1e-3, weight_decay=1e-2)
+    o_got = FusedAdamW([{'params': got[:2]}, {'params': got[2:], 'lr': 1e-2}], lr=1e-3, weight_decay=1e-2)
+    for it in range(3):
+        for i, (r, g) in enumerate(zip(ref, got)):
+            gr = rnd(('g', it, i), *r.shape, scale=3.0)
+            r.grad, g.grad = gr.clone(), gr.clone().cuda()
+        gn = torch.nn.utils.clip_grad_norm_(ref, 0.5)
+        o_ref.step()
+        o_got.step(max_norm=0.5)
+        assert abs(o_got.grad_norm() - float(gn)) < 1e-4 * float(gn)
+        for r, g in zip(ref, got):
+            close(g, r, 2e-6, f'adamw step {it}')
+
+
+# --------------------------------------------------------------------------- whole optimisation steps vs the real reference
+def test_two_train_steps_vs_reference_golden():
+    from birdsoundclassif_amd.nets import build_model
+    from birdsoundclassif_amd.train import default_args, build_optimizer, train_one_step
+    g = load_golden('train_b2.npz')
+    args = default_args(device='cuda')
+    model, crit = build_model(args)
+    model.load_state_dict(filler_state_dict())
+    model = model.cuda().train()
+    crit.train()
+    opt, _ = build_optimizer(model, args)
+    img = torch.from_numpy(synth.image_batch(0, 2))
+    neg_img = torch.from_numpy(synth.image_batch(100, 2))
+    bb, ids, lengths = synth.label_batch(0, 2)
+    batch = [img, neg_img, bb, ids, lengths]
+    params = dict(model.named_parameters())
+    np.random.seed(1234)
+    for si, neg in enumerate((False, True)):
+        loss = train_one_step(model, crit, opt, batch, args.clip_max_norm, 'cuda', negative_sample=neg)
+        for k, v in loss.items():
+            ref = float(g[f's{si}.loss.{k}'])
+            assert abs(float(v) - ref) <= 2e-4 * max(1.0, abs(ref)), (si, k, float(v), ref)
+        gn_ref = float(g[f's{si}.grad_norm'])
+        assert abs(opt.grad_norm() - gn_ref) <= 2e-3 * gn_ref, (si, opt.grad_norm(), gn_ref)
+        coef = min(1.0, args.clip_max_norm / (gn_ref + 1e-6))
+        for name in [k[len(f's{si}.grad.'):-len('.shape')] for k in g if k.startswith(f's{si}.grad.') and k.endswith('.shape')]:
+            # stored unclipped; ours are unclipped too (the clip coefficient is applied inside the AdamW kernel)
+            check_packed(g, f's{si}.grad.{name}', params[name].grad, atol=2e-4 * gn_ref / 50, rtol=2e-3)
+        for name in [k[len(f's{si}.param.'):-len('.shape')] for k in g if k.startswith(f's{si}.param.') and k.endswith('.shape')]:
+            check_packed(g, f's{si}.param.{name}', params[name], atol=2e-6, rtol=1e-5)
+        msd = model.state_dict()
+        for name in [k[len(f's{si}.buffer.'):-len('.shape')] for k in g if k.startswith(f's{si}.buffer.') and k.endswith('.shape')]:
+            check_packed(g, f's{si}.buffer.{name}', msd[name], atol=2e-5, rtol=2e-5)
