@@ -27,6 +27,13 @@ class SetCriterion(nn.Module):
         self.weight_dict = weight_dict
         self.anchor_target_layer = AnchorTargetLayer(args)
         self.proposal_target_layer = ProposalTargetLayer(args)
+        self._pre = None
+
+    def precompute_first_stage_targets(self, gt_bbox, lengths):
+        """Run the AnchorTargetLayer (host, NumPy RNG) ahead of the forward pass so that it overlaps with the GPU work
+        still queued from the previous step; `first_stage_loss` consumes the result.  Same RNG call order as computing
+        it inside the loss (anchor targets are always drawn before proposal targets)."""
+        self._pre = self.anchor_target_layer(gt_bbox, lengths, device='cpu')
 
     def first_stage_loss(self, labels_pred, bbox_reg, gt_bbox=None, lengths=None, neg_sample=False):
         """labels_pred [B,2A',h,w] softmaxed, bbox_reg [B,4A',h,w] (reference nbm_model.py:102-164)."""
@@ -40,17 +47,24 @@ class SetCriterion(nn.Module):
             top_p = p[torch.arange(B, device=p.device), top]
             return {'first_neg_class_loss': (-torch.log(top_p)).mean()}
         assert gt_bbox is not None and lengths is not None
-        labels, reg_targets = self.anchor_target_layer(gt_bbox, lengths, device=labels_pred.device)
-        p = labels_pred.permute(0, 2, 3, 1).reshape(-1, 2)
-        lab = labels.permute(0, 2, 3, 1).flatten()
-        keep = torch.nonzero(lab != -1)[:, 0]
-        p, lab = p[keep], lab[keep]
-        class_loss = (-torch.log(p[torch.arange(len(p), device=p.device), lab])).sum() * (1 / len(p))
+        dev = labels_pred.device
+        if self._pre is not None:
+            (labels, reg_targets), self._pre = self._pre, None
+        else:
+            labels, reg_targets = self.anchor_target_layer(gt_bbox, lengths, device='cpu')   # host (NumPy RNG)
+        lab_np = labels.permute(0, 2, 3, 1).reshape(-1).numpy()
+        keep_np = np.nonzero(lab_np != -1)[0]
+        lab_k = lab_np[keep_np]
+        n_keep, n_pos = len(keep_np), int((lab_k > 0).sum())
+        keep = torch.from_numpy(keep_np).to(dev)
+        lab = torch.from_numpy(lab_k).to(dev)
+        t = reg_targets.permute(0, 2, 3, 1).reshape(-1, 4)[torch.from_numpy(keep_np)].to(dev)
+        p = labels_pred.permute(0, 2, 3, 1).reshape(-1, 2)[keep]
+        class_loss = (-torch.log(p.gather(1, lab[:, None])[:, 0])).sum() * (1 / n_keep)
         r = bbox_reg.permute(0, 2, 3, 1).reshape(-1, 4)[keep]
-        t = reg_targets.permute(0, 2, 3, 1).reshape(-1, 4)[keep]
         regression_loss = (smooth_l1(r, t) * (lab == 1).float()[:, None]).sum()
-        if regression_loss > 0:
-            regression_loss = regression_loss * (4 / (lab > 0).sum())
+        if n_pos > 0:            # reference: `if regression_loss > 0` -- equivalent without a device sync
+            regression_loss = regression_loss * (4 / n_pos)
         return {'first_class_loss': class_loss, 'first_regression_loss': regression_loss}
 
     @torch.no_grad()
@@ -66,21 +80,21 @@ class SetCriterion(nn.Module):
             return {'sec_neg_class_loss': (-torch.log(bbox_classes[:, 0])).mean()}
         assert bbox_targets is not None and labels is not None
         B, nb, nc = len(bbox_targets), cfg.rcnn_batch_size, cfg.num_classes
+        dev = bbox_reg.device
         t = bbox_targets.view(B * nb, 4 * (nc + 1))
-        lab = labels.flatten().long()
-        ar = torch.arange(len(lab), device=lab.device)
-        pg = bbox_classes[ar, lab]
+        lab_np = labels.detach().flatten().cpu().numpy().astype(np.int64)        # 16 labels per image
+        n_fg = int((lab_np > 0).sum())
+        lab = torch.from_numpy(lab_np).to(dev)
+        pg = bbox_classes.gather(1, lab[:, None])[:, 0]
         if cfg.focal_loss:
             class_loss = (-(1 - pg).pow(1.5) * torch.log(pg)).mean()
         else:
             class_loss = (-torch.log(pg)).sum() * (1 / (B * nb))
-        mask = torch.zeros_like(bbox_reg)
-        for i in range(4):
-            mask[ar, i + lab * 4] = 1
-        mask[:, 0:4] = 0
-        regression_loss = (mask * smooth_l1(bbox_reg, t)).sum()
-        if regression_loss > 0:
-            regression_loss = regression_loss * (4 / (lab > 0).sum())
+        cols = torch.from_numpy((lab_np[:, None] * 4 + np.arange(4)[None, :])).to(dev)   # the 4 slots of the GT class
+        fg = torch.from_numpy((lab_np > 0).astype(np.float32)).to(dev)[:, None]          # no objective for background
+        regression_loss = (smooth_l1(bbox_reg.gather(1, cols), t.gather(1, cols)) * fg).sum()
+        if n_fg > 0:
+            regression_loss = regression_loss * (4 / n_fg)
         return {'sec_class_loss': class_loss, 'sec_regression_loss': regression_loss}
 
     @torch.no_grad()

@@ -69,44 +69,104 @@ import torch  # noqa: E402
 
 class FusedAdamW(torch.optim.Optimizer):
     """torch.optim.AdamW semantics (reference train.py:302-303) on the HIP kernels `nbm_sqnorm_accum` +
-    `nbm_adamw_step`; gradient clipping (torch.nn.utils.clip_grad_norm_, train.py:213-214) is folded into the step:
-    the clip coefficient is evaluated on the device from the accumulated squared norm, no host sync."""
+    `nbm_adamw_step`, over FLAT buffers: at construction every parameter of a group is re-homed into one contiguous
+    fp32 buffer (values preserved; `p.data`, `p.grad`, `exp_avg`, `exp_avg_sq` become views), so that
+
+      * `zero_grad` is one memset per group, the squared gradient norm one reduction launch per group, the update one
+        launch per contiguous run of parameters that received a gradient (torch skips parameters whose grad is None:
+        e.g. `bbox_reg_layer` in a negative step -- tracked with post-accumulate hooks),
+      * gradient clipping (torch.nn.utils.clip_grad_norm_, train.py:213-214) is folded into the update: the clip
+        coefficient is evaluated on the device from the accumulated squared norm, no host sync,
+      * the data-parallel exchange is ONE all-reduce per group on the flat gradient buffer (`allreduce_grads`).
+    """
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._sq = None
-        self.last_grad_norm = None
+        self._flat = []          # per group: dict(p, g, m, v, spans=[(param, offset, numel)], step)
+        self._touched = set()
+        for group in self.param_groups:
+            ps = [p for p in group['params']]
+            if not ps:
+                self._flat.append(None)
+                continue
+            dev = ps[0].device
+            if dev.type != 'cuda':
+                raise RuntimeError('FusedAdamW needs the parameters on the GPU (no CPU fallback)')
+            al = lambda k: (k + 63) // 64 * 64          # every view starts 256-byte aligned (kernels need 16 B)
+            n = sum(al(p.numel()) for p in ps)
+            fp = torch.zeros(n, device=dev, dtype=torch.float32)
+            fg = torch.zeros(n, device=dev, dtype=torch.float32)
+            fm = torch.zeros(n, device=dev, dtype=torch.float32)
+            fv = torch.zeros(n, device=dev, dtype=torch.float32)
+            spans, off = [], 0
+            for p in ps:
+                k = p.numel()
+                with torch.no_grad():
+                    fp[off:off + k].copy_(p.data.reshape(-1))
+                p.data = fp[off:off + k].view(p.shape)
+                p.grad = fg[off:off + k].view(p.shape)
+                self.state[p] = {'step': 0, 'exp_avg': fm[off:off + k].view(p.shape),
+                                 'exp_avg_sq': fv[off:off + k].view(p.shape)}
+                p.register_post_accumulate_grad_hook(self._mark)
+                spans.append((p, off, al(k)))       # the zero padding rides along (stays exactly zero)
+                off += al(k)
+            self._flat.append(dict(p=fp, g=fg, m=fm, v=fv, spans=spans))
+        from .nets import _prep
+        _prep.bump()
+
+    def _mark(self, p):
+        self._touched.add(id(p))
+
+    def mark_all(self):
+        """Treat every parameter as having received a gradient (for gradients written into `p.grad` by hand)."""
+        for f in self._flat:
+            if f is not None:
+                self._touched.update(id(p) for (p, _, _) in f['spans'])
+
+    def zero_grad(self, set_to_none=True):
+        """Gradients live in the flat buffers: zero them in place (never set to None)."""
+        for f in self._flat:
+            if f is not None:
+                f['g'].zero_()
+        self._touched.clear()
+
+    def flat_grads(self):
+        return [f['g'] for f in self._flat if f is not None]
 
     @torch.no_grad()
     def step(self, max_norm=0.0):
         from . import ops
         from .nets import _prep
-        items = []
-        for group in self.param_groups:
-            for p in group['params']:
-                if p.grad is None:
-                    continue
-                if not p.grad.is_contiguous():
-                    p.grad = p.grad.contiguous()
-                st = self.state[p]
-                if len(st) == 0:
-                    st['step'] = 0
-                    st['exp_avg'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                st['step'] = int(st['step']) + 1
-                items.append((p, st, group))
-        if not items:
-            return
         sq = None
         if max_norm and max_norm > 0:
-            sq = torch.zeros((1,), device=items[0][0].device, dtype=torch.float64)
-            for p, _, _ in items:
-                ops.sqnorm_accum(p.grad, sq)
+            sq = torch.zeros((1,), device=self._flat[0]['g'].device, dtype=torch.float64)
+            for f in self._flat:
+                if f is not None:
+                    ops.sqnorm_accum(f['g'], sq)      # untouched parameters hold zeros
             self._sq = sq
-        for p, st, group in items:
+        for group, f in zip(self.param_groups, self._flat):
+            if f is None:
+                continue
             b1, b2 = group['betas']
-            ops.adamw_step(p.data, p.grad, st['exp_avg'], st['exp_avg_sq'], group['lr'], b1, b2, group['eps'],
-                           group['weight_decay'], st['step'], sqnorm=sq, max_norm=max_norm or 0.0)
+            # contiguous runs of parameters that received a gradient in this backward and share the step count
+            runs, cur = [], None
+            for (p, off, k) in f['spans']:
+                if id(p) not in self._touched:
+                    cur = None
+                    continue
+                st = self.state[p]
+                st['step'] = int(st['step']) + 1
+                step = st['step']
+                if cur is not None and cur[2] == step and cur[0] + cur[1] == off:
+                    cur[1] += k
+                else:
+                    cur = [off, k, step]
+                    runs.append(cur)
+            for off, k, step in runs:
+                ops.adamw_step(f['p'][off:off + k], f['g'][off:off + k], f['m'][off:off + k], f['v'][off:off + k],
+                               group['lr'], b1, b2, group['eps'], group['weight_decay'], step, sqnorm=sq,
+                               max_norm=max_norm or 0.0)
         _prep.bump()
 
     def grad_norm(self):
@@ -131,6 +191,8 @@ def step(model, criterion, batch, device, negative_sample):
     img, neg_img, bb_coord, bird_ids = img.to(device), neg_img.to(device), bb_coord.to(device), bird_ids.to(device)
     loss = {}
     inpt = (neg_img if negative_sample else img)[:, None]
+    if not negative_sample and hasattr(criterion, 'precompute_first_stage_targets'):
+        criterion.precompute_first_stage_targets(bb_coord, lengths)      # host work, hidden behind queued GPU work
     out_first_stage = model.forward_first_stage(inpt)
     loss.update(criterion.first_stage_loss(out_first_stage['rpn_cls_scores'], out_first_stage['rpn_bbox_reg'],
                                            bb_coord, lengths, negative_sample))
@@ -150,21 +212,32 @@ def step(model, criterion, batch, device, negative_sample):
     return loss
 
 
-def allreduce_grads(model, world_size=None):
-    """Data-parallel exchange step (NEW capability): average the fp32 gradients of all ranks with ONE
-    collective over a flat buffer (RCCL all-reduce over xGMI when the backend is nccl; gloo in the CPU tests)."""
+def allreduce_grads(optimizer_or_model):
+    """Data-parallel exchange step (NEW capability): average the fp32 gradients of all ranks -- one
+    collective per flat gradient buffer (RCCL all-reduce over xGMI when the backend is nccl; gloo in the CPU tests).
+    No-op when torch.distributed is not initialised or world_size == 1."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return
-    grads = [p.grad for p in model.parameters() if p.grad is not None]
-    flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    flat.div_(dist.get_world_size())
-    off = 0
-    for g in grads:
-        n = g.numel()
-        g.copy_(flat[off:off + n].view_as(g))
-        off += n
+    world = dist.get_world_size()
+    if hasattr(optimizer_or_model, 'flat_grads'):
+        bufs = optimizer_or_model.flat_grads()
+    else:                                             # plain module: flatten once (used by the gloo CPU tests)
+        grads = [p.grad for p in optimizer_or_model.parameters() if p.grad is not None]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(world)
+        off = 0
+        for g in grads:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+        return
+    for b in bufs:
+        if dist.get_backend() == 'nccl':
+            dist.all_reduce(b, op=dist.ReduceOp.AVG)          # RCCL averages in the collective itself
+        else:
+            dist.all_reduce(b, op=dist.ReduceOp.SUM)
+            b.div_(world)
 
 
 def train_one_step(model, criterion, optimizer, batch, max_norm, device, negative_sample):
@@ -174,7 +247,7 @@ def train_one_step(model, criterion, optimizer, batch, max_norm, device, negativ
     losses = sum(loss_dict[k] * weight_dict[k] for k in loss_dict.keys() if k in weight_dict)
     optimizer.zero_grad()
     losses.backward()
-    allreduce_grads(model)
+    allreduce_grads(optimizer if isinstance(optimizer, FusedAdamW) else model)
     if isinstance(optimizer, FusedAdamW):
         optimizer.step(max_norm=max_norm)
     else:

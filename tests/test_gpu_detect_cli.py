@@ -1,0 +1,91 @@
+"""GPU: the per-file driver (reference run_detection.py / nbm_detect.py): merge_images against the golden fixture from
+the real reference, and BASELINE.json configs[0] -- nbm_detect on 8 synthetic 3 s 22.05 kHz wav files with a checkpoint
+directory in the reference layout -- against the oracle pipeline."""
+import ast
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from birdsoundclassif_amd import synth                                       # noqa: E402
+from helpers import filler_state_dict, load_golden                            # noqa: E402
+from oracle import frontend_ref as FR, nets_ref as O                          # noqa: E402
+
+
+def _merge_windows():
+    wins = []
+    for i in range(4):                              # same synthetic windows as oracle/make_golden.py
+        u = synth.uniform(('merge', i), 64)
+        d = {str(c): dict(bbox_coord=torch.Tensor(), scores=torch.Tensor()) for c in range(1, 151)}
+        for j in range(6):
+            c = 1 + int(u[8 * j] * 5)
+            x1 = float(np.floor(u[8 * j + 1] * 1000)); w = float(np.floor(10 + u[8 * j + 2] * 300))
+            y1 = float(np.floor(u[8 * j + 3] * 300)); h = float(np.floor(10 + u[8 * j + 4] * 60))
+            if j == 0:
+                x1 = 0.0
+            if j == 1:
+                x1 = 1023.0 - w
+            box = torch.tensor([[x1, y1, min(x1 + w, 1023.0), min(y1 + h, 374.0)]])
+            sc = torch.tensor([[float(u[8 * j + 5])]])
+            e = d[str(c)]
+            d[str(c)] = dict(bbox_coord=box, scores=sc) if len(e['bbox_coord']) == 0 else \
+                dict(bbox_coord=torch.cat([e['bbox_coord'], box]), scores=torch.cat([e['scores'], sc], 1))
+        wins.append(d)
+    return wins
+
+
+def test_merge_images_vs_reference_golden():
+    from birdsoundclassif_amd.run_detection import merge_images
+    g = load_golden('merge.npz')
+    wins = _merge_windows()
+    fp = type('FP', (), dict(W_PIX=1024, HOP_SPECTRO=819, spectrogram_length=819 * 3 + 700))()
+    merged = merge_images(fp, [wins[:2], wins[2:]], 150)
+    rows = []
+    for k, v in merged.items():
+        for i in range(len(v['bbox_coord'])):
+            rows.append([int(k), *v['bbox_coord'][i].tolist(), float(v['scores'][i])])
+    rows = np.array(rows).reshape(-1, 6)
+    assert rows.shape == g['merged'].shape and np.allclose(rows, g['merged'], atol=1e-7)
+
+
+def test_nbm_detect_cli_on_8_wavs(tmp_path):
+    from birdsoundclassif_amd import nbm_detect
+    from birdsoundclassif_amd.train import default_args
+    ck = tmp_path / 'model_weights'
+    ck.mkdir()
+    args = default_args(device='cuda')
+    cfg = {k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in vars(args).items() if k not in ('scales',)}
+    (ck / 'args').write_text(json.dumps(cfg))
+    sd = filler_state_dict()
+    torch.save({'checkpoints': sd, 'steps': 0, 'epoch': 0, 'best_val_cls_loss': 99}, str(ck / 'model_chkpt.pt'))
+    names = {f'Species {i}': i for i in range(1, 151)}
+    (tmp_path / 'bird_dict.json').write_text(json.dumps(names))
+    audio = tmp_path / 'audio'
+    audio.mkdir()
+    for i in range(8):
+        synth.write_wav(str(audio / f'clip{i}.wav'), synth.clip_pcm16(200 + i), 22050)
+    nbm_detect.main(['--ckpt', str(ck), '--audio_dir', str(audio), '--min_score', '0.05', '--batch', '4',
+                     '--bird_dict', str(tmp_path / 'bird_dict.json')])
+    outs = sorted(audio.glob('*.txt'))
+    assert len(outs) == 8
+    ocfg = O.make_cfg()
+    n_total = 0
+    for i in range(8):
+        got = ast.literal_eval((audio / f'clip{i}.txt').read_text())
+        n_total += sum(len(v['scores']) for v in got.values())
+        if i >= 2:
+            continue                                                   # oracle check on the first two files (CPU time)
+        imgs, meta = FR.process_file(str(audio / f'clip{i}.wav'))
+        with torch.no_grad():
+            dets = O.forward(sd, ocfg, torch.from_numpy(np.stack(imgs))[:, None], min_score=0.05)
+        ref = O.merge_images(meta['W_PIX'], meta['HOP_SPECTRO'], meta['spectrogram_length'], dets, 150)
+        ref = {f'Species {j}': v for j, v in ((int(k), v) for k, v in ref.items()) if len(v['bbox_coord']) > 0}
+        assert set(got) == set(ref), (i, sorted(got), sorted(ref))
+        for k in ref:
+            assert np.array_equal(np.array(got[k]['bbox_coord']), ref[k]['bbox_coord'].numpy()), (i, k)
+            assert np.allclose(np.array(got[k]['scores']), ref[k]['scores'].numpy(), atol=2e-4)
+    assert n_total > 0
