@@ -30,6 +30,57 @@ import torch         # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 FPN0_GFLOP_PER_CLIP = 170.322          # fpn.out_convs.4, 3x3 384->256 @188x512
 FWD_GFLOP_PER_CLIP = 325.56            # SURVEY.md §6 (conv + addmm + bmm, forward)
+TRAIN_GFLOP_PER_CLIP = 993.45          # SURVEY.md §6 (fwd + bwd, positive step)
+
+
+def train_bench(rank, world, dist, batch, steps, warmup):
+    """BASELINE.json configs[2]/[3]: data-parallel training step, `batch` synthetic clips + random boxes/labels per GPU,
+    HIP fwd/bwd + fused clip/AdamW, one RCCL all-reduce of the flat fp32 gradients per step when world > 1."""
+    from birdsoundclassif_amd import synth
+    from birdsoundclassif_amd.nets import build_model
+    from birdsoundclassif_amd.train import default_args, build_optimizer, train_one_step
+    args = default_args(device='cuda')
+    model, crit = build_model(args)
+    model.load_state_dict(synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}))
+    model = model.cuda().train()
+    crit.train()
+    opt, _ = build_optimizer(model, args)
+    base = synth.image_batch(rank * 8, 8)
+    img = torch.from_numpy(np.tile(base, (-(-batch // 8), 1, 1))[:batch].copy()).cuda()
+    bbs, idss, lens = [], [], []
+    for i in range(batch):
+        bb, ids, ln = synth.label_batch(rank * 8 + i % 8, 1)
+        bbs.append(bb), idss.append(ids)
+        lens += ln
+    data = [img, img, torch.cat(bbs).cuda(), torch.cat(idss).cuda(), lens]
+    np.random.seed(1000 + rank)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        train_one_step(model, crit, opt, data, args.clip_max_norm, 'cuda', negative_sample=False)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = train_one_step(model, crit, opt, data, args.clip_max_norm, 'cuda', negative_sample=False)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    del model, opt
+    torch.cuda.empty_cache()
+    v = world * batch * steps / dt
+    return {'value': v, 'unit': 'clips/s', 'batch_per_gpu': batch, 'global_batch': world * batch, 'steps': steps,
+            'ms_per_step': dt / steps * 1e3, 'parallelism': f'dp{world}',
+            'frac_of_mfma_peak': v / world * TRAIN_GFLOP_PER_CLIP / 1e3 / FP32_MFMA_PEAK_TFLOPS,
+            'final_loss': {k: float(x) for k, x in loss.items()},
+            'workload': 'BASELINE.json configs[2]/[3]: positive training step (fwd + bwd + clip + AdamW), fp32'}
 
 
 def cpu_baseline(n_clips=4, batch=2):
@@ -65,6 +116,9 @@ def main():
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--min-score', type=float, default=0.2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--train-batch', type=int, default=128)
+    ap.add_argument('--train-steps', type=int, default=3)
+    ap.add_argument('--no-train', action='store_true')
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -140,6 +194,11 @@ def main():
                                                          'algorithmic 15.77e9)', 'avg_launch_ms': avg_ms, 'launches': len(fpn0),
                 'all_igemm_ms_per_step': all_ms / a.steps,
                 'whole_step_frac_of_mfma_peak': (FWD_GFLOP_PER_CLIP * B * a.steps / (dt * 1e3)) / FP32_MFMA_PEAK_TFLOPS}
+    train = None
+    if not a.no_train:
+        del model
+        torch.cuda.empty_cache()
+        train = train_bench(rank, world, dist, a.train_batch, a.train_steps, 1)
     if rank == 0:
         line = {'metric': 'clips/sec (3 s @ 22.05 kHz) detect fwd', 'value': world * B * a.steps / dt, 'unit': 'clips/s',
                 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
@@ -148,7 +207,7 @@ def main():
                                        '(PCM16 @22.05 kHz resident in HBM) through the HIP STFT front end + detector '
                                        'forward + device post-processing, detections returned to the host',
                            'batch_per_gpu': B, 'min_score': a.min_score, 'detections_per_step': n_det / a.steps},
-                'roofline': roof}
+                'roofline': roof, 'train_step': train}
         if world == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -37,6 +37,7 @@ struct IgemmParams {
   int x_ld, w_ld, y_ld, res_ld;
   int m_tiles, n_tiles;
   float alpha; int act; int shift_per_row;
+  int vec_epi;           // epilogue may use 16-byte accesses (N % 4 == 0, pitches % 4 == 0, 16-byte aligned bases)
   // STFT epilogue
   int n_bins; float floor_amp; int db_ld; uint32_t* minmax;
 };
@@ -188,6 +189,52 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   if constexpr (EPI == EPI_STD) {
     float* __restrict__ yg = p.y + (long long)g * p.y_gs;
     const float* __restrict__ rg = p.residual ? p.residual + (long long)g * p.res_gs : nullptr;
+    if (p.vec_epi) {
+      // Stage the accumulator tile through LDS (the operand buffers are free after the last barrier) so that every
+      // lane finishes 4 consecutive channels: 16-byte residual / scale / shift loads and 16-byte stores instead of
+      // 64 dword stores per lane (store-issue bound on the short-K 1x1 layers).
+      constexpr int CP = BN + 4;
+      static_assert(BM * CP <= 2 * (BM + BN) * PITCH, "epilogue tile must fit the operand buffers");
+      float* Cs = lds;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            Cs[(wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * CP + wn0 + j * 32 + lrow] = acc[i][j][e];
+      __syncthreads();
+      constexpr int CH = BN / 4;                 // 16-byte chunks per tile row
+      constexpr int RPP = 256 / CH;              // rows per pass
+      const int cc = tid % CH, rr = tid / CH;
+      const int n = bn0 + cc * 4;
+      if (n < p.N) {
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+        if (p.shift && !p.shift_per_row) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+#pragma unroll 4
+        for (int r = rr; r < BM; r += RPP) {
+          const int m = bm0 + r;
+          if (m >= p.M) break;
+          f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CP + cc * 4);
+          const float rs = (p.shift_per_row && p.shift) ? p.shift[m] : 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (v[e] * p.alpha) * sc[e] + sh[e] + rs;
+          if (rg) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(rg + (long long)m * p.res_ld + n);
+            v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3];
+          }
+          if (p.act == NBM_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+          } else if (p.act == NBM_ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + expf(-v[e]));
+          }
+          *reinterpret_cast<f32x4*>(yg + (long long)m * p.y_ld + n) = v;
+        }
+      }
+    } else {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int n = bn0 + wn0 + j * 32 + lrow;
@@ -209,6 +256,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
           yg[(long long)m * p.y_ld + n] = v;
         }
       }
+    }
     }
   } else {
     // STFT: acc[0][j] = Re (cos rows), acc[1][j] = Im (sin rows) of 32 bins x 32 frames.
@@ -269,6 +317,10 @@ extern "C" int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream) {
   p.x_ld = d->x_ld; p.w_ld = d->w_ld; p.y_ld = d->y_ld; p.res_ld = d->res_ld;
   p.alpha = d->alpha; p.act = d->act; p.shift_per_row = d->shift_per_row;
   if (p.w_ld < p.nk * BK) return NBM_EINVAL;  // every W row must hold nk*32 readable floats
+  p.vec_epi = ((d->N & 3) == 0 && (d->y_ld & 3) == 0 && (d->y_gs & 3) == 0 && nbm_aligned16(d->y) &&
+               (!d->residual || ((d->res_ld & 3) == 0 && (d->res_gs & 3) == 0 && nbm_aligned16(d->residual))) &&
+               (!d->scale || nbm_aligned16(d->scale)) && (!d->shift || d->shift_per_row || nbm_aligned16(d->shift)))
+                  ? 1 : 0;
   if ((d->w_ld & 3) || (d->w_gs & 3) || !nbm_aligned16(d->w)) return NBM_EALIGN;
   const bool fast = (d->Cin % BK) == 0 && (d->x_ld & 3) == 0 && (d->x_gs & 3) == 0 && nbm_aligned16(d->x);
   hipStream_t st = (hipStream_t)stream;

@@ -17,7 +17,6 @@ namespace {
 
 constexpr int BK = 32;
 constexpr int PITCH = 36;     // row-major-K tile: [rows][32 + 4]
-constexpr int KPITCH = 132;   // K-major tile:     [32][128 + 4]
 
 struct BwdParams {
   const float* g; const float* w; const float* x; float* out;
@@ -34,6 +33,7 @@ struct BwdParams {
   float alpha;
   int b_generic;             // TN: gather the X tile element-wise (Cin % 4 != 0)
   int w_row;                 // NN: floats between W[n] and W[n+1] (= taps*Cin, or the padded pitch)
+  int vec_epi;               // NN: 16-byte epilogue accesses are legal
 };
 
 __device__ __forceinline__ int xcd_tile(int nwg, int bid) {
@@ -169,6 +169,44 @@ __global__ __launch_bounds__(256, 2) void igemm_nn_kernel(const BwdParams p) {
 
   float* __restrict__ og = p.out + (long long)grp * p.out_gs;
   const float* __restrict__ rg = p.residual ? p.residual + (long long)grp * p.res_gs : nullptr;
+  if (p.vec_epi) {
+    // accumulator tile -> LDS -> 16-byte residual / mask loads and stores (see igemm.hip)
+    constexpr int CP = BN + 4;
+    static_assert(BM * CP <= 2 * BM * PITCH + 2 * BK * BP, "epilogue tile must fit the operand buffers");
+    float* Cs = lds;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          Cs[(wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * CP + wn0 + j * 32 + lrow] = acc[i][j][e];
+    __syncthreads();
+    constexpr int CH = BN / 4, RPP = 256 / CH;
+    const int cc = tid % CH, rr = tid / CH;
+    const int c = bn0 + cc * 4;
+    if (c < p.Cin) {
+#pragma unroll 4
+      for (int r = rr; r < BM; r += RPP) {
+        const int m = bm0 + r;
+        if (m >= p.M) break;
+        f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CP + cc * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+        if (rg) {
+          const f32x4 q = *reinterpret_cast<const f32x4*>(rg + (long long)m * p.res_ld + c);
+          v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3];
+        }
+        if (p.mask) {
+          const f32x4 q = *reinterpret_cast<const f32x4*>(p.mask + (long long)m * p.mask_ld + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (!(q[e] > 0.f)) v[e] = 0.f;
+        }
+        *reinterpret_cast<f32x4*>(og + (long long)m * p.out_ld + c) = v;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int c = bn0 + wn0 + j * 32 + lrow;
@@ -366,6 +404,9 @@ extern "C" int nbm_conv_dgrad(const nbm_bwd_desc* d, void* stream) {
   if (d->a_scale && (d->N & 31)) return NBM_EINVAL;
   p.M = d->B * d->H * d->W;
   p.w_row = d->w_ld;
+  p.vec_epi = ((d->out_ld & 3) == 0 && (d->out_gs & 3) == 0 && nbm_aligned16(d->out) &&
+               (!d->residual || ((d->res_ld & 3) == 0 && (d->res_gs & 3) == 0 && nbm_aligned16(d->residual))) &&
+               (!d->mask || ((d->mask_ld & 3) == 0 && nbm_aligned16(d->mask)))) ? 1 : 0;
   p.m_tiles = (p.M + 127) / 128;
   hipStream_t st = (hipStream_t)stream;
   if (d->Cin > 64) {

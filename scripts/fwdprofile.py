@@ -1,0 +1,28 @@
+import sys, os, time, torch, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from birdsoundclassif_amd import ops, synth
+from birdsoundclassif_amd.nets import build_model
+from birdsoundclassif_amd.train import default_args
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+model, _ = build_model(default_args(device='cuda'))
+model.load_state_dict(synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}))
+model = model.cuda().eval()
+x = torch.from_numpy(np.tile(synth.image_batch(0, 8), (B // 8, 1, 1))).cuda()[:, None]
+with torch.no_grad():
+    model.detect(x); torch.cuda.synchronize()
+    ops.PROFILE = []
+    model.detect(x); torch.cuda.synchronize()
+prof, ops.PROFILE = ops.PROFILE, None
+agg = {}
+for (tag, s, e) in prof:
+    agg.setdefault(tag, []).append(s.elapsed_time(e))
+rows = []
+for (Cin, N, k, H, W), ts in agg.items():
+    # stride unknown from the tag: FLOPs from output size is not recoverable; report time only + upper bound at stride 1
+    rows.append((sum(ts), len(ts), Cin, N, k, H, W))
+rows.sort(reverse=True)
+tot = sum(r[0] for r in rows)
+print(f'total igemm {tot:.1f} ms')
+for t, n, Cin, N, k, H, W in rows[:40]:
+    fl = 2.0 * (B if H * W < 10**6 else 1) * H * W * N * Cin * k * k * n / 1e9   # GFLOP at stride 1
+    print(f'{t:8.2f} ms x{n:2d}  Cin={Cin:4d} N={N:4d} k={k} HxW={H}x{W}  <= {fl / t:7.1f} TF/s (stride-1 bound)')
