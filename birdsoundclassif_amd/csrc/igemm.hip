@@ -18,6 +18,7 @@
 // Workgroup -> tile mapping is XCD-aware (bijective chunking of the grid over the 8 L2s) so the N-tiles
 // of one M-tile, which share the gathered A rows, run on the same XCD.
 #include "nbm_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -50,6 +51,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
 
   __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * PITCH];
+  nbm_stagger_priority();
   float* As = lds;                       // [2][BM][PITCH]
   float* Bs = lds + 2 * BM * PITCH;      // [2][BN][PITCH]
 
@@ -73,6 +75,18 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   long long a_base[AR];
   int a_iy0[AR], a_ix0[AR];
   bool a_ok[AR];
+  // FAST path: per-row 32-bit offsets relative to a block-uniform (scalar) base, and one bit per filter tap that says
+  // whether the tap lands inside the image -- the K loop then needs one add and one bit test per row instead of
+  // re-deriving coordinates (the address/validity VALU work sat in front of every MFMA burst: 15 % of the kernel).
+  unsigned a_rel[AR];
+  unsigned long long a_taps[AR];
+  long long blk_base = 0;
+  {
+    const int m0 = bm0 < p.M ? bm0 : 0;
+    const int b = m0 / p.HoWo, rem = m0 - b * p.HoWo;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    blk_base = ((long long)(b * p.H + oy * p.stride - p.pad) * p.W + (ox * p.stride - p.pad)) * p.x_ld;
+  }
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
     const int m = bm0 + r0 + 32 * i;
@@ -83,15 +97,30 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     a_iy0[i] = oy * p.stride - p.pad;
     a_ix0[i] = ox * p.stride - p.pad;
     a_base[i] = ((long long)(b * p.H + a_iy0[i]) * p.W + a_ix0[i]) * p.x_ld;
+    a_rel[i] = ((unsigned)(a_base[i] - blk_base) + c4 * 4) * 4u;   // bytes; rows ascend with m: never negative
+    unsigned long long mk = 0ull;
+    if constexpr (AMODE == A_FAST) {
+      if (a_ok[i])
+        for (int r = 0; r < p.kh; ++r)
+          for (int s2 = 0; s2 < p.kw; ++s2)
+            if ((unsigned)(a_iy0[i] + r) < (unsigned)p.H && (unsigned)(a_ix0[i] + s2) < (unsigned)p.W)
+              mk |= 1ull << (r * p.kw + s2);
+    }
+    a_taps[i] = mk;
   }
   const float* b_ptr[BR];
   bool b_ok[BR];
+  unsigned b_rel[BR];
 #pragma unroll
   for (int i = 0; i < BR; ++i) {
     const int n = bn0 + r0 + 32 * i;
     b_ok[i] = n < p.N;
     b_ptr[i] = wgp + (long long)(b_ok[i] ? n : 0) * p.w_ld + c4 * 4;
+    b_rel[i] = b_ok[i] ? (unsigned)(n * p.w_ld + c4 * 4) * 4u : 0x80000000u;   // bytes, or out of range
   }
+  // raw buffer resources (stride 0, 2 GB window): base = block-uniform pointer, range check gives the zero padding
+  const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xg + blk_base), 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wgp), 0, 0x7ffffff0, 0x00020000);
 
   f32x4 ra[AR], rb[BR];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -101,17 +130,19 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 
   auto load_tiles = [&](int kt) {
     if constexpr (AMODE == A_FAST) {
-      const long long tap_off = ((long long)cur_r * p.W + cur_s) * p.x_ld + cur_c0 + c4 * 4;
-      const int koff = (cur_r * p.kw + cur_s) * p.Cin + cur_c0;
+      const int tap = cur_r * p.kw + cur_s;
+      // buffer loads: block-uniform resource + scalar tap offset + per-lane 32-bit offset; a tap outside the image (or
+      // a row beyond M / N) gets an out-of-range offset and the hardware range check returns zeros -- no branches.
+      const unsigned a_soff = (unsigned)((((long long)cur_r * p.W + cur_s) * p.x_ld + cur_c0) * 4);
+      const unsigned b_soff = (unsigned)((tap * p.Cin + cur_c0) * 4);
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
-        const int iy = a_iy0[i] + cur_r, ix = a_ix0[i] + cur_s;
-        const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        ra[i] = ok ? *reinterpret_cast<const f32x4*>(xg + a_base[i] + tap_off) : zero4;
+        const unsigned vo = ((a_taps[i] >> tap) & 1ull) ? a_rel[i] : 0x80000000u;
+        ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, vo, a_soff, 0));
       }
 #pragma unroll
       for (int i = 0; i < BR; ++i)
-        rb[i] = b_ok[i] ? *reinterpret_cast<const f32x4*>(b_ptr[i] + koff) : zero4;
+        rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_rel[i], b_soff, 0));
       // advance cursor
       if (++cur_s == p.kw) { cur_s = 0; if (++cur_r == p.kh) { cur_r = 0; cur_c0 += BK; } }
     } else {
@@ -154,36 +185,74 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  // Software pipeline (ONE barrier per K-step, loads two tiles ahead):
+  //   iteration kt:  barrier | MFMA group 0 + LDS writes of tile kt+1 (from registers, into the buffer nobody reads)
+  //                          | MFMA group 1 + global loads of tile kt+2 (into the registers just freed)
+  //                          | MFMA groups 2, 3
+  // so the global-load / address / ds_write instructions issue BETWEEN this wave's own MFMAs instead of in a separate
+  // window in front of them (that window cost 15 % of the kernel: both waves of a SIMD hit it together).
   load_tiles(0);
   store_lds(0);
-  __syncthreads();
+  if (p.nk > 1) load_tiles(1);
 
-  for (int kt = 0; kt < p.nk; ++kt) {
+  auto mfma_group = [&](const float* Ab, const float* Bb, int q) {
+    f32x4 a[MT], b[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * PITCH + q * 4);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * PITCH + q * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+  };
+
+  // One K-step.  STORE / LOAD are compile-time so that the steady-state body is ONE basic block: the scheduler is then
+  // told (sched_group_barrier) to place one LDS write, resp. one buffer load, after every second MFMA.
+  auto k_step = [&](int kt, auto store_c, auto load_c) {
+    constexpr bool STORE = decltype(store_c)::value, LOAD = decltype(load_c)::value;
     const int cur = kt & 1;
-    const bool more = kt + 1 < p.nk;
-    if (more) load_tiles(kt + 1);
-
+    __syncthreads();
     const float* Ab = As + (cur * BM + wm0 + lrow) * PITCH + lh * 16;
     const float* Bb = Bs + (cur * BN + wn0 + lrow) * PITCH + lh * 16;
+    mfma_group(Ab, Bb, 0);
+    if constexpr (STORE) {
+      store_lds(cur ^ 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 a[MT], b[NT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * PITCH + q * 4);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * PITCH + q * 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+      for (int z = 0; z < AR + BR; ++z) {
+        __builtin_amdgcn_sched_group_barrier(0x008, (4 * MT * NT) / (AR + BR) > 0 ? (4 * MT * NT) / (AR + BR) : 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
     }
-
-    if (more) store_lds(cur ^ 1);
-    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(Ab, Bb, 1);
+    if constexpr (LOAD) {
+      load_tiles(kt + 2);
+      __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
+#pragma unroll
+      for (int z = 0; z < AR + BR; ++z) {
+        __builtin_amdgcn_sched_group_barrier(0x008, (4 * MT * NT) / (AR + BR) > 0 ? (4 * MT * NT) / (AR + BR) : 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(Ab, Bb, 2);
+    mfma_group(Ab, Bb, 3);
+  };
+  {
+    using T = std::true_type;
+    using F = std::false_type;
+    int kt = 0;
+    for (; kt + 2 < p.nk; ++kt) k_step(kt, T{}, T{});
+    if (p.nk >= 2) { k_step(kt, T{}, F{}); ++kt; }
+    k_step(kt, F{}, F{});
   }
+  __syncthreads();
 
   // ---- epilogue.  C/D layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
   if constexpr (EPI == EPI_STD) {

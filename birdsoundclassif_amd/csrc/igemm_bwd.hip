@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256, 2) void igemm_nn_kernel(const BwdParams p) {
   __shared__ __attribute__((aligned(16))) float lds[2 * BM * PITCH + 2 * BK * BP];
   float* As = lds;
   float* Bs = lds + 2 * BM * PITCH;
+  nbm_stagger_priority();
 
   const int wg = xcd_tile(gridDim.x, blockIdx.x);
   const int tile_m = wg / p.n_tiles, tile_n = wg - tile_m * p.n_tiles;
@@ -231,6 +232,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(const BwdParams p) {
   constexpr int BM = 128, WM = 64, WN = BN / 2, MT = 2, NT = WN / 32;
   constexpr int AP = BM + 4, BP = BN + 4;
   __shared__ __attribute__((aligned(16))) float lds[2 * BK * AP + 2 * BK * BP];
+  nbm_stagger_priority();
   float* As = lds;                    // [2][32][AP]   G tile:  pixel-major, n contiguous
   float* Bs = lds + 2 * BK * AP;      // [2][32][BP]   X tile:  pixel-major, c contiguous
 

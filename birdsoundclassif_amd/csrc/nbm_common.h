@@ -46,3 +46,13 @@ __device__ __forceinline__ float nbm_wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+
+// Two workgroups share a CU (one wave each per SIMD).  Started together they stay in lockstep: both waves of a SIMD
+// reach their load / LDS-write window at the same time and the matrix pipe idles (80 % MFMA busy measured; 92 % with
+// the loads ablated).  Pairs that run in lockstep also finish together, so their successors start together again.
+// Break the symmetry once per workgroup: half of the workgroups (chosen so that both the first generation, ids b and
+// b + 256, and later same-XCD neighbours, ids b and b + 8, differ) start half a K-step late.
+__device__ __forceinline__ void nbm_stagger_priority() {
+  const unsigned b = blockIdx.x;
+  if (((b >> 3) ^ (b >> 8)) & 1u) __builtin_amdgcn_s_sleep(36);      // 36 x 64 cycles ~ half a K-step of 64 MFMAs
+}
