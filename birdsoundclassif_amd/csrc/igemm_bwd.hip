@@ -10,13 +10,17 @@
 //        operands are K-major (pixel-major, exactly as they lie in HBM), so neither is transposed: the MFMA fragments
 //        are read from LDS with 16 ds_read_b32 (conflict-free: 32 consecutive floats per half-wave).
 //
-// Tile / wave geometry, LDS double buffering and the XCD-aware tile map are those of igemm.hip.
+// Same structure as igemm.hip: 128 x BN x 32 tiles, 4 waves, double-buffered LDS with one barrier per K-step, operands
+// fetched with branch-free raw buffer loads (invalid taps / rows get an out-of-range offset and read zeros), global
+// loads issued two tiles ahead and, like the LDS writes, scheduled between the MFMAs of the running K-step.
 #include "nbm_common.h"
+#include <type_traits>
 
 namespace {
 
 constexpr int BK = 32;
 constexpr int PITCH = 36;     // row-major-K tile: [rows][32 + 4]
+constexpr unsigned OOB = 0x80000000u;
 
 struct BwdParams {
   const float* g; const float* w; const float* x; float* out;
@@ -41,6 +45,13 @@ __device__ __forceinline__ int xcd_tile(int nwg, int bid) {
   return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
 }
 
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, bytes, 0x00020000);
+}
+
 // ---------------------------------------------------------------------------------------------------- NN
 template <int BN>
 __global__ __launch_bounds__(256, 2) void igemm_nn_kernel(const BwdParams p) {
@@ -61,68 +72,81 @@ __global__ __launch_bounds__(256, 2) void igemm_nn_kernel(const BwdParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
   const int lrow = lane & 31, lh = lane >> 5;
+  const int st = p.stride, taps = p.kh * p.kw;
+  const int frm = (p.kh - 1) / st, fsm = (p.kw - 1) / st;      // largest tap shift in G rows / columns
 
-  // A staging: 128 rows x 8 chunks of 16 B
+  // A staging: 128 rows x 8 chunks of 16 B.  Row i gathers G at (b, fy - r/st, fx - s/st) for the taps whose parity
+  // matches; offsets are relative to a block-uniform base shifted by the largest tap so that they stay non-negative.
   const int c4 = tid & 7, r0 = tid >> 3;
-  int a_iy[4], a_ix[4], a_b[4];
-  bool a_ok[4];
+  unsigned a_rel[4];
+  unsigned long long a_taps[4];
+  long long blk_base;
+  {
+    const int m0 = bm0 < p.M ? bm0 : 0;
+    const int hw = p.H * p.W;
+    const int b = m0 / hw, rem = m0 - b * hw;
+    const int iy = rem / p.W, ix = rem - iy * p.W;
+    // column 0 of the first row's G row: with stride > 1 two consecutive input rows can map to the SAME G row, so the
+    // first pixel of the tile is not necessarily the smallest address (offsets must stay non-negative)
+    (void)ix;
+    blk_base = ((long long)(b * p.Ho + (iy + p.pad) / st) * p.Wo) * p.g_ld;
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = bm0 + r0 + 32 * i;
-    a_ok[i] = m < p.M;
-    const int mm = a_ok[i] ? m : 0;
+    const bool ok = m < p.M;
+    const int mm = ok ? m : 0;
     const int hw = p.H * p.W;
-    a_b[i] = mm / hw;
-    const int rem = mm - a_b[i] * hw;
-    a_iy[i] = rem / p.W;
-    a_ix[i] = rem - a_iy[i] * p.W;
+    const int b = mm / hw, rem = mm - b * hw;
+    const int iy = rem / p.W, ix = rem - iy * p.W;
+    const int fy = (iy + p.pad) / st, fx = (ix + p.pad) / st;
+    const int py = (iy + p.pad) - fy * st, px = (ix + p.pad) - fx * st;
+    const long long base = ((long long)(b * p.Ho + fy) * p.Wo + fx) * p.g_ld;
+    a_rel[i] = ((unsigned)(base - blk_base) + c4 * 4) * 4u;
+    unsigned long long mk = 0ull;
+    if (ok)
+      for (int r = 0; r < p.kh; ++r)
+        for (int s = 0; s < p.kw; ++s) {
+          const int oy = fy - r / st, ox = fx - s / st;
+          if (r % st == py && s % st == px && oy >= 0 && oy < p.Ho && ox >= 0 && ox < p.Wo) mk |= 1ull << (r * p.kw + s);
+        }
+    a_taps[i] = mk;
   }
-  // B staging (K-major): 32 rows x BN/4 chunks; thread -> rows rk0 + (256/(BN/4)) * i
-  constexpr int BCH = BN / 4;                 // 16-byte chunks per row
-  constexpr int BROWS = 256 / BCH;            // rows covered per pass
-  constexpr int BPASS = BK / BROWS;
-  const int bc = tid % BCH, rk0 = tid / BCH;
+  const long long maxoff = ((long long)frm * p.Wo + fsm) * p.g_ld;
+  const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(gg + blk_base - maxoff, 0x7ffffff0u);
 
-  f32x4 ra[4], rb[BPASS];
-  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  // B staging (K-major): 32 rows x BN/4 chunks; thread -> rows rk0 + (256/(BN/4)) * i
+  constexpr int BCH = BN / 4, BROWS = 256 / BCH, BPASS = BK / BROWS;
+  const int bc = tid % BCH, rk0 = tid / BCH;
+  unsigned b_rel[BPASS];
+#pragma unroll
+  for (int i = 0; i < BPASS; ++i)
+    b_rel[i] = (bn0 + bc * 4 < p.Cin) ? (unsigned)((rk0 + BROWS * i) * p.w_row + bn0 + bc * 4) * 4u : OOB;
+  // rows n >= N fall outside the resource and read zeros
+  const long long wbytes = (long long)p.N * p.w_row * 4;
+  const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(wg_, (unsigned)(wbytes < 0x7ffffff0ll ? wbytes : 0x7ffffff0ll));
+
+  f32x4 ra[4], rb[BPASS], rsc = {1.f, 1.f, 1.f, 1.f};
   int cur_r = 0, cur_s = 0, cur_n0 = 0;
-  const int taps = p.kh * p.kw;
 
   auto load_tiles = [&]() {
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f};
-    if (p.a_scale) sc = *reinterpret_cast<const f32x4*>(p.a_scale + cur_n0 + c4 * 4);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ty = a_iy[i] + p.pad - cur_r, tx = a_ix[i] + p.pad - cur_s;
-      bool ok = a_ok[i] && ty >= 0 && tx >= 0;
-      int oy = ty, ox = tx;
-      if (p.stride > 1) {
-        ok = ok && (ty % p.stride == 0) && (tx % p.stride == 0);
-        oy = ty / p.stride; ox = tx / p.stride;
-      }
-      ok = ok && oy < p.Ho && ox < p.Wo;
-      f32x4 v = zero4;
-      if (ok) {
-        v = *reinterpret_cast<const f32x4*>(gg + ((long long)(a_b[i] * p.Ho + oy) * p.Wo + ox) * p.g_ld + cur_n0 + c4 * 4);
-        v[0] *= sc[0]; v[1] *= sc[1]; v[2] *= sc[2]; v[3] *= sc[3];
-      }
-      ra[i] = v;
-    }
     const int tap = cur_r * p.kw + cur_s;
+    const unsigned a_soff = (unsigned)((maxoff - ((long long)(cur_r / st) * p.Wo + cur_s / st) * p.g_ld + cur_n0) * 4);
+    const unsigned b_soff = (unsigned)(((long long)cur_n0 * p.w_row + (long long)tap * p.Cin) * 4);
 #pragma unroll
-    for (int i = 0; i < BPASS; ++i) {
-      const int kk = rk0 + BROWS * i;
-      const int n = cur_n0 + kk, c = bn0 + bc * 4;
-      rb[i] = (n < p.N && c < p.Cin)
-                  ? *reinterpret_cast<const f32x4*>(wg_ + (long long)n * p.w_row + (long long)tap * p.Cin + c)
-                  : zero4;
-    }
+    for (int i = 0; i < 4; ++i) ra[i] = buf_load4(rsrc_a, ((a_taps[i] >> tap) & 1ull) ? a_rel[i] : OOB, a_soff);
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) rb[i] = buf_load4(rsrc_b, b_rel[i], b_soff);
+    if (p.a_scale) rsc = *reinterpret_cast<const f32x4*>(p.a_scale + cur_n0 + c4 * 4);
     if (++cur_s == p.kw) { cur_s = 0; if (++cur_r == p.kh) { cur_r = 0; cur_n0 += BK; } }
   };
   auto store_lds = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<f32x4*>(As + (buf * BM + r0 + 32 * i) * PITCH + c4 * 4) = ra[i];
+    for (int i = 0; i < 4; ++i) {
+      f32x4 v = ra[i];
+      v[0] *= rsc[0]; v[1] *= rsc[1]; v[2] *= rsc[2]; v[3] *= rsc[3];
+      *reinterpret_cast<f32x4*>(As + (buf * BM + r0 + 32 * i) * PITCH + c4 * 4) = v;
+    }
 #pragma unroll
     for (int i = 0; i < BPASS; ++i)
       *reinterpret_cast<f32x4*>(Bs + (buf * BK + rk0 + BROWS * i) * BP + bc * 4) = rb[i];
@@ -136,37 +160,71 @@ __global__ __launch_bounds__(256, 2) void igemm_nn_kernel(const BwdParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  auto mfma_group = [&](const float* Ab, const float* Bb, int q) {
+    f32x4 a[MT];
+    float b[NT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * PITCH + q * 4);
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) b[j][e] = Bb[(q * 4 + e) * BP + j * 32];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+  };
+
   const int nk = ((p.N + BK - 1) / BK) * taps;
   load_tiles();
   store_lds(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
+  if (nk > 1) load_tiles();
+
+  auto k_step = [&](int kt, auto store_c, auto load_c) {
+    constexpr bool STORE = decltype(store_c)::value, LOAD = decltype(load_c)::value;
     const int cur = kt & 1;
-    const bool more = kt + 1 < nk;
-    if (more) load_tiles();
+    __syncthreads();
     const float* Ab = As + (cur * BM + wm0 + lrow) * PITCH + lh * 16;
     const float* Bb = Bs + (cur * BK + lh * 16) * BP + wn0 + lrow;
+    mfma_group(Ab, Bb, 0);
+    if constexpr (STORE) {
+      store_lds(cur ^ 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, MT + 4 * NT, 0);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      f32x4 a[MT];
-      float b[NT][4];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * PITCH + q * 4);
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) b[j][e] = Bb[(q * 4 + e) * BP + j * 32];
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+      for (int z = 0; z < 4 + BPASS; ++z) {
+        __builtin_amdgcn_sched_group_barrier(0x008, (4 * MT * NT) / (4 + BPASS), 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
     }
-    if (more) store_lds(cur ^ 1);
-    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(Ab, Bb, 1);
+    if constexpr (LOAD) {
+      load_tiles();
+      __builtin_amdgcn_sched_group_barrier(0x100, MT + 4 * NT, 0);
+#pragma unroll
+      for (int z = 0; z < 4 + BPASS; ++z) {
+        __builtin_amdgcn_sched_group_barrier(0x008, (4 * MT * NT) / (4 + BPASS), 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(Ab, Bb, 2);
+    mfma_group(Ab, Bb, 3);
+  };
+  {
+    using T = std::true_type;
+    using F = std::false_type;
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) k_step(kt, T{}, T{});
+    if (nk >= 2) { k_step(kt, T{}, F{}); ++kt; }
+    k_step(kt, F{}, F{});
   }
+  __syncthreads();
 
   float* __restrict__ og = p.out + (long long)grp * p.out_gs;
   const float* __restrict__ rg = p.residual ? p.residual + (long long)grp * p.res_gs : nullptr;
@@ -269,26 +327,59 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(const BwdParams p) {
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   const int HoWo = p.Ho * p.Wo;
 
-  auto load_tiles = [&](int kt) {
-    const int mbase = m_begin + kt * BK;
+  // A rows: pixel-major G; rows beyond m_end fall outside the per-step resource and read zeros
+  unsigned a_rel[APASS];
 #pragma unroll
-    for (int i = 0; i < APASS; ++i) {
-      const int m = mbase + ar0 + AROWS * i, n = bm0 + ac * 4;
-      ra[i] = (m < m_end && n < p.N) ? *reinterpret_cast<const f32x4*>(gg + (long long)m * p.g_ld + n) : zero4;
-    }
+  for (int i = 0; i < APASS; ++i)
+    a_rel[i] = (bm0 + ac * 4 < p.N) ? (unsigned)((ar0 + AROWS * i) * p.g_ld + bm0 + ac * 4) * 4u : OOB;
+  // B rows (fast path): output pixel -> input pixel, tracked incrementally (+32 pixels per K-step)
+  int b_b[BPASS], b_oy[BPASS], b_ox[BPASS];
+  const bool c_ok = c0 + bc * 4 < p.Cin;
 #pragma unroll
-    for (int i = 0; i < BPASS; ++i) {
-      const int m = mbase + br0 + BROWS * i;
-      f32x4 v = zero4;
-      if (m < m_end) {
-        const int b = m / HoWo, rem = m - b * HoWo;
-        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        if (!p.b_generic) {
-          const int iy = oy * p.stride - p.pad + tr, ix = ox * p.stride - p.pad + ts;
-          const int c = c0 + bc * 4;
-          if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c < p.Cin)
-            v = *reinterpret_cast<const f32x4*>(xg + ((long long)(b * p.H + iy) * p.W + ix) * p.x_ld + c);
+  for (int i = 0; i < BPASS; ++i) {
+    const int m = m_begin + br0 + BROWS * i;
+    b_b[i] = m / HoWo;
+    const int rem = m - b_b[i] * HoWo;
+    b_oy[i] = rem / p.Wo;
+    b_ox[i] = rem - b_oy[i] * p.Wo;
+  }
+  int kt_load = 0;
+
+  auto load_tiles = [&]() {
+    const int mbase = m_begin + kt_load * BK;
+    const int rows = min(BK, m_end - mbase);
+    const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(gg + (long long)mbase * p.g_ld, (unsigned)(rows * p.g_ld * 4));
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) ra[i] = buf_load4(rsrc_a, a_rel[i], 0);
+    if (!p.b_generic) {
+#pragma unroll
+      for (int i = 0; i < BPASS; ++i) {
+        const int m = mbase + br0 + BROWS * i;
+        const int iy = b_oy[i] * p.stride - p.pad + tr, ix = b_ox[i] * p.stride - p.pad + ts;
+        const bool ok = c_ok && m < m_end && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const float* src = xg + ((long long)(b_b[i] * p.H + (ok ? iy : 0)) * p.W + (ok ? ix : 0)) * p.x_ld + c0 + bc * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(ok ? src : xg);
+        rb[i] = ok ? v : zero4;
+        // advance this row by 32 output pixels
+        if (p.Wo >= BK) {
+          b_ox[i] += BK;
+          if (b_ox[i] >= p.Wo) { b_ox[i] -= p.Wo; if (++b_oy[i] == p.Ho) { b_oy[i] = 0; ++b_b[i]; } }
         } else {
+          const int mn = m + BK;
+          b_b[i] = mn / HoWo;
+          const int rem = mn - b_b[i] * HoWo;
+          b_oy[i] = rem / p.Wo;
+          b_ox[i] = rem - b_oy[i] * p.Wo;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < BPASS; ++i) {
+        const int m = mbase + br0 + BROWS * i;
+        f32x4 v = zero4;
+        if (m < m_end) {
+          const int b = m / HoWo, rem = m - b * HoWo;
+          const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int j = j0 + bc * 4 + e;
@@ -301,9 +392,10 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(const BwdParams p) {
             }
           }
         }
+        rb[i] = v;
       }
-      rb[i] = v;
     }
+    ++kt_load;
   };
   auto store_lds = [&](int buf) {
 #pragma unroll
@@ -322,36 +414,59 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(const BwdParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  load_tiles(0);
-  store_lds(0);
-  __syncthreads();
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    const bool more = kt + 1 < nk;
-    if (more) load_tiles(kt + 1);
-    const float* Ab = As + (cur * BK + lh * 16) * AP + wm0 + lrow;
-    const float* Bb = Bs + (cur * BK + lh * 16) * BP + wn0 + lrow;
+  auto mfma_group = [&](const float* Ab, const float* Bb, int q) {
+    float a[MT][4], b[NT][4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float a[MT][4], b[NT][4];
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[i][e] = Ab[(q * 4 + e) * AP + i * 32];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) b[j][e] = Bb[(q * 4 + e) * BP + j * 32];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) a[i][e] = Ab[(q * 4 + e) * AP + i * 32];
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) b[j][e] = Bb[(q * 4 + e) * BP + j * 32];
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
-    }
-    if (more) store_lds(cur ^ 1);
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+  };
+
+  load_tiles();
+  store_lds(0);
+  if (nk > 1) load_tiles();
+
+  auto k_step = [&](int kt, auto store_c, auto load_c) {
+    constexpr bool STORE = decltype(store_c)::value, LOAD = decltype(load_c)::value;
+    const int cur = kt & 1;
     __syncthreads();
+    const float* Ab = As + (cur * BK + lh * 16) * AP + wm0 + lrow;
+    const float* Bb = Bs + (cur * BK + lh * 16) * BP + wn0 + lrow;
+    mfma_group(Ab, Bb, 0);
+    if constexpr (STORE) {
+      store_lds(cur ^ 1);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4 * (MT + NT), 0);
+#pragma unroll
+      for (int z = 0; z < APASS + BPASS; ++z) {
+        __builtin_amdgcn_sched_group_barrier(0x008, (4 * MT * NT) / (APASS + BPASS) > 0 ? (4 * MT * NT) / (APASS + BPASS) : 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(Ab, Bb, 1);
+    if constexpr (LOAD) load_tiles();
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(Ab, Bb, 2);
+    mfma_group(Ab, Bb, 3);
+  };
+  {
+    using T = std::true_type;
+    using F = std::false_type;
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) k_step(kt, T{}, T{});
+    if (nk >= 2) { k_step(kt, T{}, F{}); ++kt; }
+    k_step(kt, F{}, F{});
   }
 
   float* __restrict__ og = p.out + (long long)grp * p.out_gs;
@@ -379,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(const BwdParams p) {
 static int fill_common(const nbm_bwd_desc* d, BwdParams& p) {
   if (!d || !d->g || !d->out) return NBM_EINVAL;
   if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->N <= 0 || d->kh <= 0 || d->kw <= 0 || d->stride <= 0 ||
-      d->groups <= 0)
+      d->groups <= 0 || d->kh * d->kw > 64)
     return NBM_EINVAL;
   if ((d->H + 2 * d->pad - d->kh) / d->stride + 1 != d->Ho || (d->W + 2 * d->pad - d->kw) / d->stride + 1 != d->Wo)
     return NBM_EINVAL;
@@ -404,6 +519,13 @@ extern "C" int nbm_conv_dgrad(const nbm_bwd_desc* d, void* stream) {
     return NBM_EALIGN;
   if (d->out_ld < d->Cin || (d->residual && d->res_ld < d->Cin) || (d->mask && d->mask_ld < d->Cin)) return NBM_EINVAL;
   if (d->a_scale && (d->N & 31)) return NBM_EINVAL;
+  // the gather window of one 128-row tile (+ one image boundary) must stay inside the 2 GB buffer resource
+  {
+    const long long row = (long long)d->Wo * d->g_ld * 4;                  // bytes per G image row
+    const long long span = (d->W == 1 && d->kh == 1) ? 130ll * d->g_ld * 4   // plain GEMM: 128 consecutive rows
+                                                      : (d->kh + 130) * row + (long long)d->Ho * row;
+    if (span > 0x70000000ll) return NBM_EUNSUPPORTED;
+  }
   p.M = d->B * d->H * d->W;
   p.w_row = d->w_ld;
   p.vec_epi = ((d->out_ld & 3) == 0 && (d->out_gs & 3) == 0 && nbm_aligned16(d->out) &&
