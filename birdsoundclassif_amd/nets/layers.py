@@ -283,19 +283,29 @@ class FastRCNN(nn.Module):
         return ops.rcnn_post(rois, n_roi, reg, cls, cfg.img_width, cfg.img_height, nms_thresh, min_score,
                              cfg.proposal_number)
 
+    _EMPTY = {}
+
     @staticmethod
     def dets_to_dicts(det, n_det, num_classes):
-        """One D2H copy, then the reference's output structure: list[B] of {'1'..'nc': {'bbox_coord': f32[n,4],
-        'scores': f32[1,n]}} with `torch.Tensor()` for empty classes (layers.py:749-776)."""
-        det, n_det = det.cpu(), n_det.cpu().tolist()
+        """One D2H copy (if the rows are still on the device), then the reference's output structure: list[B] of
+        {'1'..'nc': {'bbox_coord': f32[n,4], 'scores': f32[1,n]}} with `torch.Tensor()` for empty classes
+        (layers.py:749-776).  Rows arrive sorted by (class, score desc), so every class is one contiguous slice."""
+        det = det.cpu() if det.is_cuda else det
+        n_det = (n_det.cpu() if n_det.is_cuda else n_det).tolist()
+        tmpl = FastRCNN._EMPTY.get(num_classes)
+        if tmpl is None:
+            empty = dict(bbox_coord=torch.Tensor(), scores=torch.Tensor())
+            tmpl = FastRCNN._EMPTY[num_classes] = {str(c): empty for c in range(1, num_classes + 1)}
+        cls_all = det[..., 0].to(torch.int64).numpy()
         out = []
         for b, n in enumerate(n_det):
-            rows = det[b, :n]
-            cls = rows[:, 0].to(torch.int64)
-            res = {str(c): dict(bbox_coord=torch.Tensor(), scores=torch.Tensor()) for c in range(1, num_classes + 1)}
-            for c in torch.unique(cls).tolist():
-                m = cls == c
-                res[str(c)] = dict(bbox_coord=rows[m, 1:5].clone(), scores=rows[m, 5][None].clone())
+            res = dict(tmpl)
+            if n:
+                rows, cls = det[b, :n], cls_all[b, :n]
+                starts = np.flatnonzero(np.r_[True, cls[1:] != cls[:-1]])
+                ends = np.r_[starts[1:], n]
+                for s0, e0 in zip(starts.tolist(), ends.tolist()):
+                    res[str(int(cls[s0]))] = dict(bbox_coord=rows[s0:e0, 1:5].clone(), scores=rows[s0:e0, 5][None].clone())
             out.append(res)
         return out
 
