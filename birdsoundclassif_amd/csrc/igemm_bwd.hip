@@ -455,7 +455,16 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(const BwdParams p) {
     }
     __builtin_amdgcn_sched_barrier(0);
     mfma_group(Ab, Bb, 1);
-    if constexpr (LOAD) load_tiles();
+    if constexpr (LOAD) {
+      load_tiles();
+      __builtin_amdgcn_sched_group_barrier(0x100, 4 * (MT + NT), 0);
+#pragma unroll
+      for (int z = 0; z < 4 * MT * NT; ++z) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+        if (z < APASS + BPASS) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
     mfma_group(Ab, Bb, 2);
     mfma_group(Ab, Bb, 3);
