@@ -133,12 +133,18 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', 0))
     if a.gpus != world and world > 1:
         raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}')
-    torch.cuda.set_device(local)
+    # NBM_BENCH_SHARE_GPU=1 (functional rehearsal of the multi-rank path on a one-GPU box): every rank uses cuda:0 and
+    # the collectives go through gloo, because RCCL refuses two ranks on one device.  Never set for measurements.
+    share = os.environ.get('NBM_BENCH_SHARE_GPU') == '1'
+    torch.cuda.set_device(0 if share else local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if share:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
 
     from birdsoundclassif_amd import ops, synth
     from birdsoundclassif_amd.nbm_datasets.prepare_dataset import SpectrogramFrontEnd

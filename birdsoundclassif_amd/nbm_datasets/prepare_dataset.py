@@ -77,27 +77,52 @@ class SpectrogramFrontEnd:
     def n_images(self, n_frames):
         return max(1, int(1 + np.ceil((n_frames - self.W_PIX) / self.HOP_SPECTRO)))  # :267
 
-    def spectrogram_db(self, pcm, sr):
-        """pcm int16 [batch, n] on the device -> (db [batch,375,L], minmax, L)."""
-        if pcm.dtype != torch.int16 or pcm.dim() != 2:
-            raise TypeError('pcm must be int16 [batch, n]')
+    MAX_CHUNK = int(5e7)           # STFT chunk length in 44.1 kHz samples (reference prepare_dataset.py:234)
+    MAX_FILE = int(15e7)           # beyond this the reference goes through process_long_file (:187-225)
+
+    def _rate(self, sr):
         if sr == self.FREQ:
-            up = False
-        elif sr * 2 == self.FREQ:
-            up = True
-        else:
-            raise NotImplementedError(f'sample rate {sr}: only 44100 and 22050 Hz inputs are supported')
+            return False
+        if sr * 2 == self.FREQ:
+            return True
+        raise NotImplementedError(f'sample rate {sr}: only 44100 and 22050 Hz inputs are supported')
+
+    def _stft_chunk(self, pcm, up, out=None, col0=0):
         n44 = pcm.shape[1] * (2 if up else 1)
-        if n44 > int(5e7):
-            raise NotImplementedError('files longer than 5e7 samples (chunked STFT, prepare_dataset.py:234-237) '
-                                      'are not implemented yet')
         L = self.n_frames(n44)
         lead = self.WIN_LENGTH // 2
         ld = max(lead + n44 + lead, (L - 1) * self.HOP_LENGTH + self.basis.shape[1])
         ld = -(-ld // 4) * 4
         wave_f = ops.pcm16_to_wave(pcm.contiguous(), ld, lead, up, self.hq)
-        db, mm = ops.stft_db(wave_f, L, self.HOP_LENGTH, self.basis, self.H_PIX, self.floor_amp)
+        db, mm = ops.stft_db(wave_f, L, self.HOP_LENGTH, self.basis, self.H_PIX, self.floor_amp, out=out, col0=col0)
         return db, mm, L
+
+    def spectrogram_db(self, pcm, sr):
+        """pcm int16 [batch, n] on the device -> (db [batch,375,L], minmax, L).  Rows longer than 5e7 samples (19 min)
+        are transformed chunk by chunk like the reference (every chunk is centre-padded on its own, the min/max runs
+        over the whole row)."""
+        if pcm.dtype != torch.int16 or pcm.dim() != 2:
+            raise TypeError('pcm must be int16 [batch, n]')
+        up = self._rate(sr)
+        n44 = pcm.shape[1] * (2 if up else 1)
+        if n44 > self.MAX_FILE - self.MAX_FILE % self.FREQ:
+            raise NotImplementedError('files longer than 1.5e8 samples: the reference re-enters process_file per 56-minute '
+                                      'split and returns nested lists that its own run_detection cannot batch '
+                                      '(prepare_dataset.py:187-225); split such recordings before detection')
+        if n44 <= self.MAX_CHUNK:
+            return self._stft_chunk(pcm, up)
+        step_in = self.MAX_CHUNK // (2 if up else 1)
+        pieces = [pcm[:, k * step_in:(k + 1) * step_in] for k in range(int(n44 / self.MAX_CHUNK) + 1)]
+        pieces = [p for p in pieces if p.shape[1] > 0]
+        Ls = [self.n_frames(p.shape[1] * (2 if up else 1)) for p in pieces]
+        db = torch.empty((pcm.shape[0], self.H_PIX, sum(Ls)), device=pcm.device, dtype=torch.float32)
+        mm = torch.empty((pcm.shape[0], 2), device=pcm.device, dtype=torch.int32)
+        ops.check(ops.lib().nbm_minmax_init(ops._ptr(mm), pcm.shape[0], ops._stream()), 'nbm_minmax_init')
+        col = 0
+        for p, L in zip(pieces, Ls):
+            self._stft_chunk(p, up, out=(db, mm), col0=col)
+            col += L
+        return db, mm, sum(Ls)
 
     def __call__(self, pcm, sr):
         """pcm int16 [batch, n] (device) -> images f32 [batch, n_img, 375, w_pix] in [0,1], spectrogram length."""
@@ -113,7 +138,7 @@ def read_wav_pcm16(path):
         x = np.frombuffer(f.readframes(n), dtype='<i2').reshape(-1, nch)
     if nch > 1:
         x = np.round(x.astype(np.float64).mean(1)).astype(np.int16)[:, None]
-    return np.ascontiguousarray(x[:, 0]), sr
+    return np.array(x[:, 0], dtype=np.int16), sr          # own, writable copy
 
 
 _FE = {}

@@ -128,17 +128,24 @@ def pcm16_to_wave(pcm, out_ld, lead, upsample, hq=None):
     return out
 
 
-def stft_db(wave, n_frames, hop, basis, n_bins, floor_amp, db_ld=None):
-    """wave f32 [batch, wave_ld] (already centre-padded) -> (db [batch, n_bins, db_ld], minmax u32 [batch,2])."""
+def stft_db(wave, n_frames, hop, basis, n_bins, floor_amp, db_ld=None, out=None, col0=0):
+    """wave f32 [batch, wave_ld] (already centre-padded) -> (db [batch, n_bins, db_ld], minmax u32 [batch,2]).
+    `out=(db, minmax)` + `col0`: write the frames at column offset col0 of an existing spectrogram and keep accumulating
+    its min/max (chunked STFT of a long file, reference prepare_dataset.py:234-237)."""
     _chk(wave, name='wave'), _chk(basis, name='basis')
     batch, wave_ld = wave.shape
-    db_ld = n_frames if db_ld is None else db_ld
-    db = torch.empty((batch, n_bins, db_ld), device=wave.device, dtype=torch.float32)
-    mm = torch.empty((batch, 2), device=wave.device, dtype=torch.int32)
-    check(lib().nbm_minmax_init(_ptr(mm), batch, _stream()), 'nbm_minmax_init')
+    if out is None:
+        db_ld = n_frames if db_ld is None else db_ld
+        db = torch.empty((batch, n_bins, db_ld), device=wave.device, dtype=torch.float32)
+        mm = torch.empty((batch, 2), device=wave.device, dtype=torch.int32)
+        check(lib().nbm_minmax_init(_ptr(mm), batch, _stream()), 'nbm_minmax_init')
+    else:
+        db, mm = out
+        db_ld = db.shape[-1]
+        assert col0 + n_frames <= db_ld and db.shape[0] == batch
     check(lib().nbm_stft_db(_ptr(wave), wave_ld, batch, n_frames, hop, _ptr(basis), basis.shape[0], basis.shape[1],
-                            n_bins, float(floor_amp), _ptr(db), n_bins * db_ld, db_ld, _ptr(mm), _stream()),
-          'nbm_stft_db')
+                            n_bins, float(floor_amp), C.c_void_p(db.data_ptr() + 4 * col0), n_bins * db_ld, db_ld, _ptr(mm),
+                            _stream()), 'nbm_stft_db')
     return db, mm
 
 

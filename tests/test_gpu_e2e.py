@@ -153,3 +153,22 @@ def test_checkpoint_layout_roundtrip(model, tmp_path):
     with torch.no_grad():
         a, b = model.detect(x, min_score=0.05), m2.cuda().detect(x, min_score=0.05)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_chunked_stft_of_a_long_row(monkeypatch):
+    """Rows longer than the STFT chunk (5e7 samples in the reference) are transformed chunk by chunk, every chunk centre
+    padded on its own, min/max over the whole row -- checked with the chunk size scaled down on both sides."""
+    from birdsoundclassif_amd.nbm_datasets.prepare_dataset import SpectrogramFrontEnd
+    fe = SpectrogramFrontEnd('cuda')
+    monkeypatch.setattr(SpectrogramFrontEnd, 'MAX_CHUNK', 100000)
+    pcm44 = np.concatenate([FR.upsample2x_pcm16(synth.clip_pcm16(20 + i)) for i in range(2)])[:250000]
+    imgs, L = fe(torch.from_numpy(pcm44)[None].cuda(), 44100)
+    y = pcm44.astype(np.float32) / np.float32(32768)
+    c = FR.constants()
+    parts = [FR.amp_to_db(FR.stft_mag(y[k * 100000:(k + 1) * 100000], 1324, 132))[16:391] for k in range(3)]
+    lo, hi = min(p.min() for p in parts), max(p.max() for p in parts)
+    ref = FR.split_power_spec([(p - lo) / (hi - lo) for p in parts], c)
+    assert L == sum(p.shape[1] for p in parts) and imgs.shape[1] == len(ref)
+    for k, r in enumerate(ref):
+        err = np.abs(imgs[0, k].cpu().numpy() - r.astype(np.float32))
+        assert np.quantile(err, 0.99) < 5e-5 and err.max() < 5e-3
