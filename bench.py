@@ -238,6 +238,19 @@ def main():
                                                          'algorithmic 15.77e9)', 'avg_launch_ms': avg_ms, 'launches': len(fpn0),
                 'all_igemm_ms_per_step': all_ms / a.steps,
                 'whole_step_frac_of_mfma_peak': (FWD_GFLOP_PER_CLIP * B * a.steps / (dt * 1e3)) / FP32_MFMA_PEAK_TFLOPS}
+    # front end alone (HBM-bound stage of the path): live HIP events around K replays
+    fe_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+    for s0, e0 in fe_ev:
+        s0.record()
+        fe(pcm, 22050)
+        e0.record()
+    torch.cuda.synchronize()
+    fe_ms = sorted(s0.elapsed_time(e0) for s0, e0 in fe_ev)[len(fe_ev) // 2]
+    frontend = {'ms_per_batch': fe_ms, 'clips_per_s': B / fe_ms * 1e3,
+                'hbm_algorithmic_GBps': B * 1.668e6 / (fe_ms * 1e-3) / 1e9, 'hbm_peak_GBps': 8000.0,
+                'dft_gemm_TFLOPs': B * 2 * 768 * 1344 * 1003 / (fe_ms * 1e-3) / 1e12, 'mfma_f32_peak_TFLOPs': FP32_MFMA_PEAK_TFLOPS,
+                'note': 'PCM16 -> 2x up-sample -> STFT-dB (DFT as fp32-MFMA GEMM) -> normalise/window; algorithmic bytes '
+                        '1.668 MB/clip (SURVEY 8d); the stage is bound by the DFT-GEMM, not by HBM'}
     train = None
     if not a.no_train:
         del model
@@ -251,7 +264,7 @@ def main():
                                        '(PCM16 @22.05 kHz resident in HBM) through the HIP STFT front end + detector '
                                        'forward + device post-processing, detections returned to the host',
                            'batch_per_gpu': B, 'min_score': a.min_score, 'detections_per_step': n_det / a.steps},
-                'roofline': roof, 'train_step': train}
+                'roofline': roof, 'frontend': frontend, 'train_step': train}
         if world == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)
