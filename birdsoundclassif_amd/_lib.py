@@ -64,6 +64,8 @@ SIGNATURES = {
     'nbm_softmax_rows': [_P, _L, _I, _L, _P],
     'nbm_dwconv3x3': [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _L, _P, _I, _I, _P],
     'nbm_silu': [_P, _P, _L, _P],
+    'nbm_layernorm': [_P, _L, _I, _P, _P, _F, _P, _P],
+    'nbm_mha_small': [_P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _L, _L, _P, _F, _P],
     'nbm_pair_softmax': [_P, _L, _I, _I, _P, _I, _P],
     'nbm_rpn_decode': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
     'nbm_rpn_select': [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P],

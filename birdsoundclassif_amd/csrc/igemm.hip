@@ -299,6 +299,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
           } else if (p.act == NBM_ACT_SILU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + expf(-v[e]));
+          } else if (p.act == NBM_ACT_LEAKY) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
           }
           *reinterpret_cast<f32x4*>(yg + (long long)m * p.y_ld + n) = v;
         }
@@ -322,6 +325,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
           if (rg) v += rg[(long long)m * p.res_ld + n];
           if (p.act == NBM_ACT_RELU) v = fmaxf(v, 0.0f);
           else if (p.act == NBM_ACT_SILU) v = v / (1.0f + expf(-v));
+          else if (p.act == NBM_ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
           yg[(long long)m * p.y_ld + n] = v;
         }
       }

@@ -194,6 +194,83 @@ __global__ void dwconv3x3_kernel(const float* __restrict__ x, int B, int H, int 
   }
 }
 
+// one wave per row
+__global__ void layernorm_kernel(const float* __restrict__ x, long long rows, int E, const float* __restrict__ w,
+                                 const float* __restrict__ b, float eps, float* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  for (long long row = blockIdx.x * 4ll + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * 4) {
+    const float* r = x + row * E;
+    float s = 0.f;
+    for (int c = lane; c < E; c += 64) s += r[c];
+    const float mean = nbm_wave_sum(s) / (float)E;
+    float q = 0.f;
+    for (int c = lane; c < E; c += 64) { const float d = r[c] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(nbm_wave_sum(q) / (float)E + eps);
+    float* o = y + row * E;
+    for (int c = lane; c < E; c += 64) o[c] = (r[c] - mean) * rstd * w[c] + b[c];
+  }
+}
+
+// Multi-head attention over SHORT sequences (Transformer_RCNN: S = images per batch or RoIs per image, <= 128; head
+// dim <= 64).  One workgroup per (batch entry n, head); K and V of the group live in LDS, each wave owns query rows.
+// Token (s, n) is row s * seq_stride + n * batch_stride of q/k/v/out; keys >= *n_valid (device counter) are masked.
+#define MHA_SMAX 128
+__global__ __launch_bounds__(256) void mha_small_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                        const float* __restrict__ v, int q_ld, int k_ld, int v_ld,
+                                                        float* __restrict__ out, int out_ld, int S, int nhead, int hd,
+                                                        long long seq_stride, long long batch_stride,
+                                                        const int* __restrict__ n_valid, float scale) {
+  __shared__ float Ks[MHA_SMAX][65];
+  __shared__ float Vs[MHA_SMAX][64];
+  __shared__ float qs[4][64];
+  __shared__ float ps[4][MHA_SMAX];
+  const int n = blockIdx.x / nhead, h = blockIdx.x - n * nhead;
+  const int nv = n_valid ? min(*n_valid, S) : S;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < nv * hd; i += 256) {
+    const int j = i / hd, d = i - j * hd;
+    const long long row = j * seq_stride + n * batch_stride;
+    Ks[j][d] = k[row * k_ld + h * hd + d];
+    Vs[j][d] = v[row * v_ld + h * hd + d];
+  }
+  __syncthreads();
+  for (int r = wave; r < nv; r += 4) {
+    const long long row = r * seq_stride + n * batch_stride;
+    if (lane < hd) qs[wave][lane] = q[row * q_ld + h * hd + lane] * scale;
+    __builtin_amdgcn_wave_barrier();
+    float sc[MHA_SMAX / 64];
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < MHA_SMAX / 64; ++t) {
+      const int j = lane + 64 * t;
+      float a = -INFINITY;
+      if (j < nv) {
+        a = 0.f;
+        for (int d = 0; d < hd; ++d) a += qs[wave][d] * Ks[j][d];
+      }
+      sc[t] = a;
+      m = fmaxf(m, a);
+    }
+    m = nbm_wave_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < MHA_SMAX / 64; ++t) {
+      const int j = lane + 64 * t;
+      const float e = j < nv ? expf(sc[t] - m) : 0.f;
+      if (j < nv) ps[wave][j] = e;
+      sum += e;
+    }
+    sum = nbm_wave_sum(sum);
+    __builtin_amdgcn_wave_barrier();
+    if (lane < hd) {
+      float o = 0.f;
+      for (int j = 0; j < nv; ++j) o += ps[wave][j] * Vs[j][lane];
+      out[row * out_ld + h * hd + lane] = o / sum;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 __global__ void silu_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
        i += (long long)gridDim.x * blockDim.x) {
@@ -293,6 +370,24 @@ extern "C" int nbm_dwconv3x3(const float* x, int B, int H, int W, int Cin, int m
   if (film && film_ld < 2ll * Cin * mult) return NBM_EINVAL;
   hipLaunchKernelGGL(dwconv3x3_kernel, dim3(grid_for((long long)B * Ho * Wo * Cin * mult)), dim3(TPB), 0,
                      (hipStream_t)stream, x, B, H, W, Cin, mult, stride, w, bias, film, (long long)film_ld, y, Ho, Wo);
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_layernorm(const float* x, int64_t rows, int E, const float* w, const float* b, float eps, float* y,
+                             void* stream) {
+  if (!x || !w || !b || !y || rows <= 0 || E <= 0) return NBM_EINVAL;
+  hipLaunchKernelGGL(layernorm_kernel, dim3(grid_for(rows, 4, 256 * 32)), dim3(256), 0, (hipStream_t)stream, x,
+                     (long long)rows, E, w, b, eps, y);
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_mha_small(const float* q, const float* k, const float* v, int q_ld, int k_ld, int v_ld, float* out,
+                             int out_ld, int S, int N, int nhead, int hd, int64_t seq_stride, int64_t batch_stride,
+                             const int32_t* n_valid, float scale, void* stream) {
+  if (!q || !k || !v || !out || S <= 0 || S > MHA_SMAX || N <= 0 || nhead <= 0 || hd <= 0 || hd > 64) return NBM_EINVAL;
+  if (q_ld < nhead * hd || k_ld < nhead * hd || v_ld < nhead * hd || out_ld < nhead * hd) return NBM_EINVAL;
+  hipLaunchKernelGGL(mha_small_kernel, dim3(N * nhead), dim3(256), 0, (hipStream_t)stream, q, k, v, q_ld, k_ld, v_ld, out,
+                     out_ld, S, nhead, hd, (long long)seq_stride, (long long)batch_stride, n_valid, scale);
   return nbm_launch_status();
 }
 

@@ -264,6 +264,94 @@ class RCNN(nn.Module):
         return self.forward_nhwc(p, e)
 
 
+class _EncoderLayer(nn.Module):
+    """Parameter container with the state_dict keys of both encoder flavours the reference can build: torch's
+    nn.TransformerEncoderLayer (layers.py:618-621) and its DETR-style layer (self_attention.py:110-139)."""
+
+    def __init__(self, d_model, nhead, dim_feedforward):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d_model, nhead)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+
+
+class _Encoder(nn.Module):
+    def __init__(self, d_model, nhead, dim_feedforward, num_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([_EncoderLayer(d_model, nhead, dim_feedforward) for _ in range(num_layers)])
+
+
+class Transformer_RCNN(nn.Module):
+    """reference layers.py:589-651 (`--tf_rcnn`), inference only.  Default flavour: post-norm ReLU encoder fed
+    rois_embed + pos_embed with batch_first=False, i.e. the reference attends ACROSS THE IMAGES OF THE BATCH for each RoI
+    slot (sequence axis = bs, <= 128 here); `tf_pe_qk`: DETR flavour, attention across the RoIs of one image with
+    q = k = src + pos and LeakyReLU.  Dropout is inactive in both (eval)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        in_dim = config.out_fpn_chan * config.roi_pool_h * config.roi_pool_w
+        E = config.tf_model_dim
+        self.tf_pe_qk = config.tf_pe_qk
+        if not self.tf_pe_qk and E != 512:
+            raise ValueError('the reference hard-codes d_model=512 for the non-pe_qk encoder (layers.py:619)')
+        self.nhead = config.tf_nhead
+        if E % self.nhead or E // self.nhead > 64:
+            raise NotImplementedError('Transformer_RCNN: head dim must divide tf_model_dim and be <= 64')
+        self.pos_embedding = nn.Sequential(nn.Linear(in_dim, E), nn.LeakyReLU())
+        self.rois_embedding = nn.Sequential(nn.Linear(in_dim, E), nn.LeakyReLU())
+        self.encoder = _Encoder(E, self.nhead, config.tf_dim_feedforward, config.tf_num_encoder_layers)
+        self.bbox_reg_layer = nn.Linear(E, 4 * (1 + config.num_classes))
+        self.bbox_classif_layer = nn.Linear(E, 1 + config.num_classes)
+        self.softmax_layer = nn.Softmax(dim=-1)
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward_nhwc(self, pool, pe, B, R, n_valid=None):
+        """pool, pe: NHWC [B*R,2,2,C]; n_valid: device int32[1] RoIs per image that are real (pe_qk masks the rest)
+        -> (bbox_reg [B*R, 4(1+nc)], bbox_classes [B*R, 1+nc] softmaxed)."""
+        if torch.is_grad_enabled() and (self.training or pool.requires_grad):
+            raise NotImplementedError('training through Transformer_RCNN is not implemented (SURVEY.md 8f "next" row)')
+        cn, M = pool.shape[-1], B * R
+        lin = lambda m: (m.weight.detach(), m.bias.detach())
+        pos = ops.linear(pe.view(M, -1), RCNN._hwc_weight(self.pos_embedding[0], cn), self.pos_embedding[0].bias.detach(),
+                         act=ops.ACT_LEAKY)
+        x = ops.linear(pool.view(M, -1), RCNN._hwc_weight(self.rois_embedding[0], cn),
+                       self.rois_embedding[0].bias.detach(), act=ops.ACT_LEAKY)
+        E = x.shape[1]
+        if self.tf_pe_qk:
+            geom = dict(S=R, N=B, seq_stride=1, batch_stride=R, n_valid=n_valid)
+            ff_act = ops.ACT_LEAKY
+        else:
+            x = ops.axpby(x, pos)
+            geom = dict(S=B, N=R, seq_stride=R, batch_stride=1)
+            ff_act = ops.ACT_RELU
+        for l in self.encoder.layers:
+            w, b = l.self_attn.in_proj_weight.detach(), l.self_attn.in_proj_bias.detach()
+            if self.tf_pe_qk:
+                qk = ops.linear(ops.axpby(x, pos), w[:2 * E], b[:2 * E])
+                q, k, v = qk[:, :E], qk[:, E:], ops.linear(x, w[2 * E:], b[2 * E:])
+            else:
+                qkv = ops.linear(x, w, b)
+                q, k, v = qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:]
+            a = ops.mha_small(q, k, v, nhead=self.nhead, **geom)
+            x = ops.layernorm(ops.linear(a, *lin(l.self_attn.out_proj), residual=x), *lin(l.norm1), eps=l.norm1.eps)
+            h = ops.linear(x, *lin(l.linear1), act=ff_act)
+            x = ops.layernorm(ops.linear(h, *lin(l.linear2), residual=x), *lin(l.norm2), eps=l.norm2.eps)
+        reg = ops.linear(x, *lin(self.bbox_reg_layer))
+        return reg, ops.softmax_rows_(ops.linear(x, *lin(self.bbox_classif_layer)))
+
+    def forward(self, rois, pos):
+        """[B,R,C,2,2] x2 -> (bbox_reg [B*R, 4(1+nc)], bbox_classes [B*R, 1+nc])."""
+        B, R = rois.shape[:2]
+        p = rois.flatten(end_dim=1).permute(0, 2, 3, 1).contiguous()
+        e = pos.flatten(end_dim=1).permute(0, 2, 3, 1).contiguous()
+        return self.forward_nhwc(p, e, B, R)
+
+
 class FastRCNN(nn.Module):
     """reference layers.py:654-778."""
 
@@ -271,15 +359,18 @@ class FastRCNN(nn.Module):
         super().__init__()
         self.config = config
         self.roi_pooling = ROIPooling(config)
-        if config.tf_rcnn:
-            raise NotImplementedError('--tf_rcnn (Transformer_RCNN) is a "next" row of SURVEY.md §8f')
-        self.rcnn = RCNN(config)
+        self.rcnn = Transformer_RCNN(config) if config.tf_rcnn else RCNN(config)
+
+    def _head(self, pool, pe, rois, n_roi):
+        if self.config.tf_rcnn:
+            return self.rcnn.forward_nhwc(pool, pe, rois.shape[0], rois.shape[1], n_roi)
+        return self.rcnn.forward_nhwc(pool, pe)
 
     def detect_device(self, fmaps_nhwc, rois, n_roi, nms_thresh=0.3, min_score=0.5):
         """Sync-free eval path -> (det [B,cap,6] rows {class,x1,y1,x2,y2,score}, n_det int32 [B])."""
         cfg = self.config
         pool, pe, _ = self.roi_pooling.forward_device(rois, n_roi, fmaps_nhwc)
-        reg, cls = self.rcnn.forward_nhwc(pool, pe)
+        reg, cls = self._head(pool, pe, rois, n_roi)
         return ops.rcnn_post(rois, n_roi, reg, cls, cfg.img_width, cfg.img_height, nms_thresh, min_score,
                              cfg.proposal_number)
 
@@ -318,6 +409,6 @@ class FastRCNN(nn.Module):
         n = torch.full((1,), R, device=rois.device, dtype=torch.int32)
         if training:
             pool, pe, _ = self.roi_pooling.forward_device(rois, n, fm)
-            return self.rcnn.forward_nhwc(pool, pe)
+            return self._head(pool, pe, rois, n)
         det, n_det = self.detect_device(fm, rois, n, nms_thresh, min_score)
         return self.dets_to_dicts(det, n_det, self.config.num_classes)

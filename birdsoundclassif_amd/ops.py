@@ -5,13 +5,14 @@ streams); all arithmetic happens in the hand-written kernels.  Activations are N
 Every function raises if the tensor is not a contiguous float32 CUDA tensor -- there is no CPU path.
 """
 import ctypes as C
+import math
 
 import torch
 
 from . import _lib
 from ._lib import GemmDesc, RoiDesc, check
 
-ACT_NONE, ACT_RELU, ACT_SILU = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_SILU, ACT_LEAKY = 0, 1, 2, 3
 
 # bench.py sets this to a list to time every implicit-GEMM launch with HIP events on the launch stream:
 # entries are ((Cin, N, kh, H, W), start_event, end_event).
@@ -218,6 +219,26 @@ def silu(x):
     y = torch.empty_like(x)
     check(lib().nbm_silu(_ptr(x), _ptr(y), x.numel(), _stream()), 'nbm_silu')
     return y
+
+
+def layernorm(x2d, w, b, eps=1e-5):
+    _chk(x2d, name='x')
+    rows, E = x2d.shape
+    y = torch.empty_like(x2d)
+    check(lib().nbm_layernorm(_ptr(x2d), rows, E, _ptr(_chk(w)), _ptr(_chk(b)), float(eps), _ptr(y), _stream()), 'nbm_layernorm')
+    return y
+
+
+def mha_small(q, k, v, S, N, nhead, seq_stride, batch_stride, n_valid=None):
+    """q, k, v: 2-D row views [S*N, >= E] (column slices of a fused projection are fine) -> out [S*N, E]."""
+    E = q.shape[1]
+    hd = E // nhead
+    for t in (q, k, v):
+        assert t.dim() == 2 and t.stride(1) == 1 and t.is_cuda and t.dtype == torch.float32
+    out = torch.zeros((q.shape[0], E), device=q.device, dtype=torch.float32)
+    check(lib().nbm_mha_small(_ptr(q), _ptr(k), _ptr(v), q.stride(0), k.stride(0), v.stride(0), _ptr(out), E, S, N, nhead,
+                              hd, seq_stride, batch_stride, _ptr(n_valid), 1.0 / math.sqrt(hd), _stream()), 'nbm_mha_small')
+    return out
 
 
 def pair_softmax(x, n_anchor):

@@ -31,6 +31,7 @@ extern "C" {
 #define NBM_ACT_NONE 0
 #define NBM_ACT_RELU 1
 #define NBM_ACT_SILU 2
+#define NBM_ACT_LEAKY 3 /* LeakyReLU, negative slope 0.01 (nn.LeakyReLU default) */
 
 const char* nbm_version(void);
 
@@ -124,6 +125,18 @@ int nbm_dwconv3x3(const float* x, int B, int H, int W, int Cin, int mult, int st
 
 /* y = x * sigmoid(x) -- nn.SiLU (layers.py:31,41). */
 int nbm_silu(const float* x, float* y, int64_t n, void* stream);
+
+/* y[r][:] = (x[r][:] - mean_r) / sqrt(var_r + eps) * w + b over rows of E floats (biased variance) -- nn.LayerNorm of the
+ * Transformer_RCNN head (reference layers.py:589-651, self_attention.py:110-131). */
+int nbm_layernorm(const float* x, int64_t rows, int E, const float* w, const float* b, float eps, float* y, void* stream);
+
+/* out = softmax(scale * Q K^T) V per (batch entry, head) for short sequences (S <= 128, hd <= 64): token (s, n) is row
+ * s*seq_stride + n*batch_stride of q/k/v/out (row pitches *_ld floats, head h at columns [h*hd, (h+1)*hd)); keys with
+ * s >= *n_valid (device counter, may be NULL) are masked -- nn.MultiheadAttention inside the Transformer_RCNN encoder
+ * (reference layers.py:613-621,645-646; self_attention.py:110-126). */
+int nbm_mha_small(const float* q, const float* k, const float* v, int q_ld, int k_ld, int v_ld, float* out, int out_ld,
+                  int S, int N, int nhead, int hd, int64_t seq_stride, int64_t batch_stride, const int32_t* n_valid,
+                  float scale, void* stream);
 
 /* softmax over the (bg, fg) pair of every anchor: x[p][2a], x[p][2a+1] (pitch ld) -> y (pitch y_ld)
  * -- layers.py:90. */

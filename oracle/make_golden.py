@@ -13,6 +13,7 @@ from `synth` on any machine.  Stored per tensor: full values for small tensors,
 otherwise 4096 seeded sample positions + (sum, abs-sum, min, max).
 """
 import os
+import sys
 import warnings
 
 import numpy as np
@@ -55,10 +56,36 @@ def pack_dets(store, name, dets):
     store[name] = np.array(rows, dtype=np.float64).reshape(-1, 7)
 
 
+def tf_rcnn_golden():
+    """`--tf_rcnn` head (reference layers.py:589-651), both encoder flavours, B=3 so that the default flavour's
+    attention across the batch axis is exercised: head outputs on the reference's own RoIs + final detections."""
+    g = {}
+    for tag, pe_qk in (('std', False), ('peqk', True)):
+        args = ref_import.default_args(tf_rcnn=True, tf_pe_qk=pe_qk)
+        model, _ = ref_import.build_reference_model(args, train=False)
+        sd = synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+        model.load_state_dict(sd)
+        model.eval()
+        x = torch.from_numpy(synth.image_batch(0, 3))[:, None]
+        with torch.no_grad():
+            o = model.forward_first_stage(x)
+            pack(g, f'{tag}.rois', o['rois'])
+            s = model.forward_second_stage(o['fpn_out'], o['rois'], training=True)
+            pack(g, f'{tag}.bbox_reg', s['bbox_reg'])
+            pack(g, f'{tag}.bbox_classes', s['bbox_classes'])
+            for ms in (0.05, 0.2):
+                pack_dets(g, f'{tag}.dets_min{ms}', model(x, min_score=ms))
+        print('tf_rcnn', tag, 'rois', tuple(o['rois'].shape), 'dets@0.05', len(g[f'{tag}.dets_min0.05']))
+    np.savez_compressed(os.path.join(OUT, 'tf_rcnn_b3.npz'), **g)
+
+
 def main():
     warnings.filterwarnings('ignore')
     torch.manual_seed(0)
     os.makedirs(OUT, exist_ok=True)
+    if '--tf-only' in sys.argv:
+        return tf_rcnn_golden()
+    tf_rcnn_golden()
     args = ref_import.default_args()
     model, crit = ref_import.build_reference_model(args, train=False)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}

@@ -107,6 +107,53 @@ def test_forward_matches_reference_golden(model):
         assert np.abs(rows[:, 6] - ref[:, 6]).max() < 1e-4
 
 
+@pytest.mark.parametrize('tag,pe_qk', [('std', False), ('peqk', True)])
+def test_transformer_rcnn_head_vs_reference_golden(tag, pe_qk):
+    """`--tf_rcnn` (reference layers.py:589-651), both encoder flavours, against the real reference's outputs."""
+    from birdsoundclassif_amd.nets import build_model
+    from birdsoundclassif_amd.train import default_args
+    g = load_golden('tf_rcnn_b3.npz')
+    m, _ = build_model(default_args(device='cuda', tf_rcnn=True, tf_pe_qk=pe_qk))
+    m.load_state_dict(filler_state_dict(tf_rcnn=True, tf_pe_qk=pe_qk))
+    m = m.cuda().eval()
+    x = torch.from_numpy(synth.image_batch(0, 3))[:, None].cuda()
+    with torch.no_grad():
+        o = m.forward_first_stage(x)
+        ref_rois = g[f'{tag}.rois.full'].reshape(g[f'{tag}.rois.shape'])
+        assert np.array_equal(o['rois'].cpu().numpy(), ref_rois)
+        s = m.forward_second_stage(o['fpn_out'], o['rois'], training=True)
+        check_packed(g, f'{tag}.bbox_reg', s['bbox_reg'], atol=1e-4)
+        check_packed(g, f'{tag}.bbox_classes', s['bbox_classes'], atol=1e-4)
+        for ms in (0.05, 0.2):
+            rows, ref = dets_to_rows(m(x, min_score=ms)), g[f'{tag}.dets_min{ms}']
+            assert rows.shape == ref.shape, (ms, rows.shape, ref.shape)
+            assert np.array_equal(rows[:, :6], ref[:, :6])
+            assert np.abs(rows[:, 6] - ref[:, 6]).max() < 1e-4
+        # sync-free path (device counters, padded RoI slots masked inside the attention)
+        det, n_det = m.detect(x, 0.3, 0.2)
+        from birdsoundclassif_amd.nets.layers import FastRCNN
+        rows2 = dets_to_rows(FastRCNN.dets_to_dicts(det, n_det, 150))
+        assert np.array_equal(rows2[:, :6], g[f'{tag}.dets_min0.2'][:, :6])
+
+
+def test_mha_small_masks_padded_keys():
+    """nbm_mha_small against torch on both token layouts, with a device-side valid-length counter."""
+    from birdsoundclassif_amd import ops
+    S, N, nh, E = 50, 5, 8, 512
+    for seq_major in (True, False):
+        qkv = torch.from_numpy(synth.normal(('mha', seq_major), S * N * 3 * E).astype(np.float32).reshape(S * N, 3 * E)).cuda()
+        nv = 37
+        cnt = torch.tensor([nv], dtype=torch.int32, device='cuda')
+        ss, bs = (N, 1) if seq_major else (1, S)
+        out = ops.mha_small(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], S, N, nh, ss, bs, cnt)
+        t = qkv.view(S, N, 3 * E) if seq_major else qkv.view(N, S, 3 * E).transpose(0, 1)
+        q, k, v = (t[..., i * E:(i + 1) * E].reshape(S, N * nh, E // nh).transpose(0, 1).double() for i in range(3))
+        att = torch.softmax((q @ k[:, :nv].transpose(1, 2)) / (E // nh) ** 0.5, -1) @ v[:, :nv]
+        ref = att.transpose(0, 1).reshape(S, N, E)
+        got = out.view(S, N, E) if seq_major else out.view(N, S, E).transpose(0, 1)
+        assert (got[:nv].double() - ref[:nv]).abs().max() < 2e-6
+
+
 def test_intermediate_taps_vs_golden(model):
     g = load_golden('eval_b2.npz')
     x = torch.from_numpy(synth.image_batch(0, 2)).cuda()[..., None].contiguous()      # NHWC

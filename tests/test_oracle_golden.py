@@ -1,6 +1,7 @@
 """CPU: the oracle restatement (oracle/nets_ref.py) against the golden fixtures that
 oracle/make_golden.py generated from the REAL reference (imported with the torchvision stand-in)."""
 import numpy as np
+import pytest
 import torch
 
 from birdsoundclassif_amd import synth
@@ -49,6 +50,27 @@ def test_eval_forward_vs_golden():
         assert tuple(tr.shape) == ref_tr.shape
         assert (tr.numpy() != ref_tr).any(-1).mean() <= 5e-3
         check_packed(g, 'train_roi_scores', ts, atol=2e-5)
+
+
+@pytest.mark.parametrize('tag,pe_qk', [('std', False), ('peqk', True)])
+def test_transformer_rcnn_vs_golden(tag, pe_qk):
+    """`--tf_rcnn` head, both encoder flavours of reference layers.py:613-621 (B=3: the default flavour attends across
+    the batch axis)."""
+    g = load_golden('tf_rcnn_b3.npz')
+    sd = filler_state_dict(tf_rcnn=True, tf_pe_qk=pe_qk)
+    cfg = O.make_cfg(tf_rcnn=True, tf_pe_qk=pe_qk)
+    x = torch.from_numpy(synth.image_batch(0, 3))[:, None]
+    with torch.no_grad():
+        o = O.forward_first_stage(sd, cfg, x)
+        check_packed(g, f'{tag}.rois', o['rois'], atol=0)
+        s = O.forward_second_stage(sd, cfg, o['fpn_out'], o['rois'], training=True)
+        check_packed(g, f'{tag}.bbox_reg', s['bbox_reg'], atol=5e-5)
+        check_packed(g, f'{tag}.bbox_classes', s['bbox_classes'], atol=5e-5)
+        for ms in (0.05, 0.2):
+            rows, ref = dets_to_rows(O.forward(sd, cfg, x, min_score=ms)), g[f'{tag}.dets_min{ms}']
+            assert rows.shape == ref.shape
+            assert np.array_equal(rows[:, :6], ref[:, :6])
+            assert np.abs(rows[:, 6] - ref[:, 6]).max() < 2e-5
 
 
 def test_train_losses_vs_golden():
