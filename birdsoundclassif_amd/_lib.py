@@ -37,6 +37,13 @@ class RoiDesc(C.Structure):
                 ('pool', C.c_void_p), ('pe', C.c_void_p), ('level', C.c_void_p)]
 
 
+class AugmentParams(C.Structure):
+    """struct nbm_augment_params (include/nbm_hip.h)."""
+    _fields_ = [('gain', C.c_float), ('coef', C.c_float), ('denom', C.c_float), ('neg_coef', C.c_float),
+                ('neg_denom', C.c_float), ('flags', C.c_int32), ('hard_index', C.c_int32), ('pad', C.c_int32),
+                ('noise_seed', C.c_uint64)]
+
+
 class BwdDesc(C.Structure):
     """struct nbm_bwd_desc (include/nbm_hip.h)."""
     _fields_ = [('g', C.c_void_p), ('w', C.c_void_p), ('x', C.c_void_p), ('out', C.c_void_p),
@@ -49,7 +56,7 @@ class BwdDesc(C.Structure):
                 ('mask_ld', C.c_int), ('alpha', C.c_float)]
 
 
-_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_P, _I, _L, _F, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 
 # name -> argtypes (restype is int unless noted); must list every symbol of include/nbm_hip.h
 SIGNATURES = {
@@ -81,6 +88,11 @@ SIGNATURES = {
     'nbm_colsum': [_P, _L, _I, _I, _P, _P],
     'nbm_maxpool3x3s2_bwd': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'nbm_upsample_bilinear_bwd': [_P, _I, _I, _I, _I, _P, _I, _I, _P],
+    'nbm_png_unfilter_gray8': [_P, _L, _I, _I, _I, _P, _L, _P, _P],
+    'nbm_image_half_std_u8': [_P, _L, _I, _L, _P, _P],
+    'nbm_randn_fill': [_U64, _L, _P, _P],
+    'nbm_augment_batch': [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
+    'nbm_u8_to_unit': [_P, _L, _P, _P],
     'nbm_softmax_rows_bwd': [_P, _P, _P, _L, _I, _F, _P],
     'nbm_pair_softmax_bwd': [_P, _P, _P, _L, _P],
     'nbm_dwconv3x3_bwd': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P],

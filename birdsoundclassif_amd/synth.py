@@ -108,6 +108,37 @@ def label_batch(start, count, num_classes=150, img_w=1024, img_h=375):
     return (torch.tensor(boxes, dtype=torch.float32), torch.tensor(ids, dtype=torch.float32), lengths)
 
 
+def write_image_dataset(root, encode_png, h=375, w=1024):
+    """Synthetic `Img_dataset` directory (reference image_dataset.py:15-29 layout): two positive recordings (2 + 1
+    windows, a class-0 label among them), ONE negative and ONE hard-negative image (so `np.random.choice` cannot depend
+    on directory listing order).  `encode_png(uint8 [h,w]) -> bytes` is injected (the tests pass the oracle's encoder).
+    Returns the list of positive file names."""
+    import os
+    def u8(i):
+        return np.round(image_batch(i, 1, h, w)[0] * 255.0).astype(np.uint8)
+    names = []
+    plan = {'recA': [(0, [[40, 50, 160, 110], [500, 200, 620, 260], [800, 30, 860, 90]], [7, 0, 113]),
+                     (1, [[300, 120, 420, 190]], [42])],
+            'rec__B': [(0, [[100, 20, 230, 80], [640, 240, 700, 300]], [150, 3])]}
+    for k, (rec, rows) in enumerate(plan.items()):
+        d = os.path.join(root, 'positive_files', rec)
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, 'annotations.csv'), 'w') as f:
+            f.write('index;coord;bird_id\n')
+            for idx, boxes, ids in rows:
+                f.write(f'{idx};{boxes};{ids}\n')
+                name = f'{rec}__{idx}.png'
+                with open(os.path.join(d, name), 'wb') as g:
+                    g.write(encode_png(u8(500 + 10 * k + idx)))
+                names.append(name)
+    for sub, rec, i in (('negative_files', 'negA', 600), ('hard_neg', 'hardA', 700)):
+        d = os.path.join(root, sub, rec)
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, f'{rec}__0.png'), 'wb') as g:
+            g.write(encode_png(u8(i)))
+    return sorted(names)
+
+
 # --------------------------------------------------------------------------- filler weights
 def fill_state_dict(shapes, seed=0):
     """Deterministic filler for a {name: shape} mapping (SURVEY Appendix B layout): conv/linear

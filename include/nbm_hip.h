@@ -254,6 +254,36 @@ int nbm_sqnorm_accum(const float* g, int64_t n, double* out, void* stream);
 int nbm_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                    float weight_decay, int step, const double* sqnorm, float max_norm, void* stream);
 
+/* ---- training-input stage: Img_dataset (reference nbm_datasets/image_dataset.py:36-96) ------------------------- */
+/* per-image augmentation draws, filled by the host in the reference's RNG call order (image_dataset.py:59,68,71-81,90) */
+struct nbm_augment_params {
+  float gain;                 /* np.random.uniform(-0.1, 0.35)                                   :68 */
+  float coef, denom;          /* hard-negative weight c and 1 + c for the positive image         :79-80 */
+  float neg_coef, neg_denom;  /* same for the negative image                                      :82-83 */
+  int32_t flags;              /* bit 0: bool_transform[0] (hard-negative mix), bit 1: [1] (low-pass) :71 */
+  int32_t hard_index;         /* image of `hard` to mix in */
+  int32_t pad;
+  uint64_t noise_seed;        /* stream of the device counter RNG when noise_unit == NULL */
+};
+
+/* PNG scanline reconstruction (filter types 0-4, PNG spec 9.2) of `batch` inflated 8-bit greyscale images:
+ * raw[b] = H lines of (1 filter byte + W bytes) -> out[b] = H*W pixels; *status != 0 afterwards <=> bad filter byte.
+ * Replaces the pixel half of `imageio.imread` (image_dataset.py:44,62,77); the zlib inflate stays on the host. */
+int nbm_png_unfilter_gray8(const uint8_t* raw, int64_t raw_bs, int batch, int H, int W, uint8_t* out, int64_t out_bs,
+                           int32_t* status, void* stream);
+/* half_std[b] = std(float32(img_b / 255), unbiased) / 2 -- the noise scale of image_dataset.py:66 */
+int nbm_image_half_std_u8(const uint8_t* img, int64_t bs, int batch, int64_t n, float* half_std, void* stream);
+/* out[i] = i-th N(0,1) draw of counter stream `seed` (splitmix64 + Box-Muller) -- device stand-in for torch.randn :66 */
+int nbm_randn_fill(uint64_t seed, int64_t n, float* out, void* stream);
+/* the whole `if self.transform:` block (:65-94) for a batch: img = u8/255 (+gain, +clamp(noise*half_std, +-0.5),
+ * hard-negative mix, low-pass curve[b][row]); neg = u8/255 (hard-negative mix).  noise_unit (N(0,1) field, may be
+ * NULL => device counter RNG), curve [batch][H]. */
+int nbm_augment_batch(const uint8_t* pos, const uint8_t* neg, const uint8_t* hard, int batch, int H, int W,
+                      const struct nbm_augment_params* params, const float* half_std, const float* noise_unit,
+                      const float* curve, float* img_out, float* neg_out, void* stream);
+/* out = float32(in / 255) -- `torch.Tensor(img / 255)` :45,63 (transform=False path) */
+int nbm_u8_to_unit(const uint8_t* in, int64_t n, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,13 +79,50 @@ def tf_rcnn_golden():
     np.savez_compressed(os.path.join(OUT, 'tf_rcnn_b3.npz'), **g)
 
 
+def img_dataset_golden():
+    """`Img_dataset.__getitem__` (reference image_dataset.py:36-96) run for real on a synthetic dataset directory:
+    imageio is absent here, so an `imageio.v2` stand-in whose `imread` is the oracle's PNG decoder is registered (the
+    container format is third-party; the augmentation arithmetic and RNG call order are the reference's own code)."""
+    import tempfile
+    import types
+    from . import png_ref
+    io_mod, v2 = types.ModuleType('imageio'), types.ModuleType('imageio.v2')
+    v2.imread = lambda path: png_ref.decode_png_gray8(open(path, 'rb').read())
+    io_mod.v2 = v2
+    sys.modules['imageio'], sys.modules['imageio.v2'] = io_mod, v2
+    import matplotlib
+    matplotlib.use('Agg')
+    ref_import.import_nets()
+    from nbm_model.nbm_datasets.image_dataset import Img_dataset
+    g = {}
+    with tempfile.TemporaryDirectory() as root:
+        names = synth.write_image_dataset(root, png_ref.encode_png_gray8)
+        for transform in (False, True):
+            ds = Img_dataset(root, transform=transform)
+            for seed in range(4 if transform else 1):
+                np.random.seed(100 + seed)
+                torch.manual_seed(100 + seed)
+                for name in names:                               # fixed visiting order = fixed RNG consumption
+                    img, neg, bb, ids = ds[ds.positive_files.index(name)]
+                    key = f't{int(transform)}.s{seed}.{name}'
+                    pack(g, key + '.img', img, full_limit=0)
+                    pack(g, key + '.neg', neg, full_limit=0)
+                    g[key + '.bboxes'] = bb.numpy().astype(np.float32)
+                    g[key + '.bird_ids'] = ids.numpy().astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, 'img_dataset.npz'), **g)
+    print('img_dataset: %d arrays' % len(g))
+
+
 def main():
     warnings.filterwarnings('ignore')
     torch.manual_seed(0)
     os.makedirs(OUT, exist_ok=True)
     if '--tf-only' in sys.argv:
         return tf_rcnn_golden()
+    if '--dataset-only' in sys.argv:
+        return img_dataset_golden()
     tf_rcnn_golden()
+    img_dataset_golden()
     args = ref_import.default_args()
     model, crit = ref_import.build_reference_model(args, train=False)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
