@@ -139,6 +139,65 @@ def write_image_dataset(root, encode_png, h=375, w=1024):
     return sorted(names)
 
 
+def metrics_cases(n_cases=12):
+    """Deterministic (detections, ground truth) file lists for the AP metrics: jittered copies of the GT boxes (hits and
+    near misses), spurious boxes, species missing on either side, unique scores.  -> list of `outputs` arguments of
+    `compute_AP_scores` (reference nets_utils.py:454)."""
+    cases = []
+    for c in range(n_cases):
+        n_files = 1 + c % 4
+        outputs = []
+        for f in range(n_files):
+            u = uniform(('met', c, f), 400)
+            k = 0
+            det, gt = {}, {}
+            for s in range(6):
+                name = f'sp{s}'
+                n_gt = int(u[k] * 4); k += 1
+                boxes = []
+                for _ in range(n_gt):
+                    x1, y1 = np.floor(900 * u[k]), np.floor(300 * u[k + 1])
+                    boxes.append([x1, y1, x1 + np.floor(20 + 100 * u[k + 2]), y1 + np.floor(15 + 50 * u[k + 3])])
+                    k += 4
+                if n_gt and u[k] < 0.85:
+                    gt[name] = boxes
+                k += 1
+                preds, sc = [], []
+                if u[k] < 0.75:
+                    for b in boxes:
+                        if u[k + 1] < 0.8:
+                            j = (u[k + 2:k + 6] - 0.5) * (60 if u[k + 6] < 0.4 else 12)
+                            preds.append([float(np.float32(b[i] + np.floor(j[i]))) for i in range(4)])
+                            sc.append(float(np.float32(0.2 + 0.8 * u[k + 7])))
+                        k += 8
+                    for _ in range(int(u[k] * 3)):
+                        x1, y1 = np.floor(900 * u[k + 1]), np.floor(300 * u[k + 2])
+                        preds.append([float(x1), float(y1), float(x1 + 40), float(y1 + 30)])
+                        sc.append(float(np.float32(0.2 + 0.8 * u[k + 3])))
+                        k += 4
+                k += 1
+                if preds:
+                    det[name] = {'bbox_coord': preds, 'scores': sc}
+            outputs.append((det, gt))
+        cases.append(outputs)
+    cases.append([({}, {})])                                                  # nothing at all
+    cases.append([({'sp0': {'bbox_coord': [[1., 2., 30., 40.]], 'scores': [0.9]}}, {})])       # only a false positive
+    cases.append([({}, {'sp1': [[1., 2., 30., 40.], [5., 5., 9., 9.]]})])                      # only misses
+    return cases
+
+
+def annotation_text(seed=0, n=7):
+    """An Audacity spectral-label file like the reference's test annotations (`t0\\tt1\\tspecies` / `\\\\\\tf0\\tf1`)."""
+    u = uniform(('annot', seed), 5 * n)
+    lines = []
+    for i in range(n):
+        t0 = 170.0 * u[5 * i]
+        f0 = 300.0 + 9000.0 * u[5 * i + 2]
+        lines.append(f'{t0:.6f}\t{t0 + 0.05 + 2.0 * u[5 * i + 1]:.6f}\tsp{int(u[5 * i + 4] * 3)}\n')
+        lines.append(f'\\\t{f0:.6f}\t{f0 + 200.0 + 6000.0 * u[5 * i + 3]:.6f}\n')
+    return ''.join(lines)
+
+
 # --------------------------------------------------------------------------- filler weights
 def fill_state_dict(shapes, seed=0):
     """Deterministic filler for a {name: shape} mapping (SURVEY Appendix B layout): conv/linear

@@ -113,16 +113,42 @@ def img_dataset_golden():
     print('img_dataset: %d arrays' % len(g))
 
 
+def metrics_golden():
+    """`compute_AP_scores` / `format_txt_annots` of the reference (nets_utils.py:419-534) on synth.metrics_cases()."""
+    import json
+    import tempfile
+    ref_import.import_nets()
+    from nbm_model.nets.util.nets_utils import compute_AP_scores, format_txt_annots
+    out = {'cases': [], 'filtered': [], 'annots': []}
+    for outputs in synth.metrics_cases():
+        r = compute_AP_scores(outputs)
+        out['cases'].append({k: float(v) for k, v in r.items()})
+        r = compute_AP_scores(outputs, filter_sp=['sp1', 'sp4'])
+        out['filtered'].append({k: float(v) for k, v in r.items()})
+    with tempfile.TemporaryDirectory() as d:
+        for seed in range(3):
+            p = os.path.join(d, 'a.txt')
+            with open(p, 'w') as f:
+                f.write(synth.annotation_text(seed))
+            out['annots'].append({k: [[float(z) for z in b] for b in v] for k, v in format_txt_annots(p).items()})
+    with open(os.path.join(OUT, 'metrics.json'), 'w') as f:
+        json.dump(out, f, indent=0)
+    print('metrics:', out['cases'][:3])
+
+
 def main():
     warnings.filterwarnings('ignore')
     torch.manual_seed(0)
     os.makedirs(OUT, exist_ok=True)
     if '--tf-only' in sys.argv:
         return tf_rcnn_golden()
+    if '--metrics-only' in sys.argv:
+        return metrics_golden()
     if '--dataset-only' in sys.argv:
         return img_dataset_golden()
     tf_rcnn_golden()
     img_dataset_golden()
+    metrics_golden()
     args = ref_import.default_args()
     model, crit = ref_import.build_reference_model(args, train=False)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
