@@ -295,3 +295,156 @@ def resume_training(out_dir, model, optim, scheduler, lr_drop):
     scheduler.load_state_dict(sd)
     return (model, optim, scheduler, save_dict.get('train_indices'), save_dict.get('val_indices'), save_dict['epoch'],
             save_dict['steps'], save_dict['best_val_cls_loss'])
+
+
+# =========================================================================== training driver (caller of the hot path)
+class ScalarLog:
+    """Stand-in for `SummaryWriter.add_scalar` (tensorboard is not part of this build): one JSON object per line in
+    `<save_dir>/scalars.jsonl`, written by rank 0 only."""
+
+    def __init__(self, save_dir, enabled=True):
+        self.f = open(os.path.join(save_dir, 'scalars.jsonl'), 'a') if enabled else None
+
+    def add_scalar(self, tag, value, global_step):
+        if self.f is not None:
+            import json
+            self.f.write(json.dumps({'tag': tag, 'value': float(value), 'step': int(global_step)}) + '\n')
+            self.f.flush()
+
+
+class _RawItems(torch.utils.data.Dataset):
+    """DataLoader view of `Img_dataset` whose workers do the host half only (inflate, labels, RNG draws)."""
+
+    def __init__(self, dataset):
+        self.dataset = dataset
+
+    def __len__(self):
+        return len(self.dataset)
+
+    def __getitem__(self, idx):
+        return self.dataset.raw_item(idx)
+
+
+def evaluate_test_files(model, args, wav_paths, bird_dicts_path='bird_dict.json', min_score=0.02):
+    """reference train.py:389-394: run_detection on every annotated test recording -> AP / mAP / Rec / mRec."""
+    from .nets.util.nets_utils import compute_AP_scores, format_txt_annots
+    from .run_detection import run_detection
+    outputs = [(run_detection(model, args, w, bird_dicts_path, min_score=min_score), format_txt_annots(w.replace('.wav', '.txt')))
+               for w in wav_paths]
+    return compute_AP_scores(outputs)
+
+
+def main(args):
+    """Training loop of reference train.py:273-404 around `train_one_step`: same checkpoint / resume protocol, loss
+    bookkeeping, StepLR stepped every 1000 iterations, validation (eval-mode `step`) and test-set AP every `val_freq`
+    (500) iterations.  Differences: images are decoded and augmented on the device (`Img_dataset` + `DeviceCollate`),
+    scalars go to `scalars.jsonl`, and under torchrun every rank trains on its own slice of the training indices with
+    the gradient all-reduce of `train_one_step` (rank 0 validates, tests and saves)."""
+    import glob
+    import json
+    import torch.distributed as dist
+    from torch.utils.data import DataLoader, SubsetRandomSampler
+    from .nbm_datasets.image_dataset import Img_dataset
+    from .nets import build_model
+    from .nets.util.nets_utils import train_test_split
+
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+    device = torch.device(args.device)
+    seed_everything(args.seed)                      # the train / validation split must be the same on every rank
+    save_dir = os.path.join(args.save_dir, args.model_name)
+    os.makedirs(save_dir, exist_ok=True)
+    resume = os.path.isfile(os.path.join(save_dir, 'model_chkpt_last.pt'))
+    if rank == 0:
+        with open(os.path.join(save_dir, 'args'), 'w') as f:
+            json.dump({k: v for k, v in args.__dict__.items() if isinstance(v, (int, float, str, bool, type(None)))}, f)
+    setattr_others(args)
+    val_freq, log_freq = getattr(args, 'val_freq', 500), getattr(args, 'log_freq', 50)
+
+    model, criterion = build_model(args)
+    model.to(device)
+    optimizer, lr_scheduler = build_optimizer(model, args)
+    dataset = Img_dataset(args.data_path, transform=True, device=args.device, host_noise=getattr(args, 'host_noise', False))
+    if resume:
+        model, optimizer, lr_scheduler, train_indices, val_indices, epoch, steps, best_val_cls_loss = \
+            resume_training(save_dir, model, optimizer, lr_scheduler, args.lr_drop)
+        print('Resuming training~~~~')
+    else:
+        train_indices, val_indices = train_test_split(len(dataset), val_prop=args.validation_prop)
+        epoch, steps, best_val_cls_loss = 0, 0, 99
+    if world > 1:
+        seed_everything(args.seed + rank)           # per-rank sampling / augmentation streams (SURVEY 8e)
+    raw = _RawItems(dataset)
+    loader = lambda idx, bs, drop: DataLoader(raw, batch_size=bs, sampler=SubsetRandomSampler(idx), collate_fn=list,
+                                              num_workers=args.num_workers, drop_last=drop)
+    train_loader = loader(list(train_indices)[rank::world], args.batch_size, False)
+    validation_loader = loader(val_indices, 2 * args.batch_size, True) if len(val_indices) > 0 else None
+    writer = ScalarLog(save_dir, rank == 0)
+    loss_keys = ['first_class_loss', 'first_regression_loss', 'sec_class_loss', 'sec_regression_loss',
+                 'first_neg_class_loss', 'sec_neg_class_loss', 'cardinality_error']
+    train_losses = {k: 0 for k in loss_keys}
+    save_steps = [180e3, 190e3, 200e3]
+    as_float = lambda k, v: float(v) if k == 'cardinality_error' else v.item()
+    model.train(), criterion.train()
+    print('Start training')
+    while steps < args.max_steps:
+        for raw_batch in train_loader:
+            batch = dataset.collate(raw_batch)
+            negative = (steps % args.neg_step_freq == 0) and (steps > args.first_neg_step)
+            losses = train_one_step(model, criterion, optimizer, batch, args.clip_max_norm, device, negative_sample=negative)
+            for k, v in losses.items():
+                train_losses[k] += as_float(k, v)
+            if steps % log_freq == 0:
+                for k in loss_keys:
+                    freq = log_freq / args.neg_step_freq if 'neg' in k else log_freq
+                    writer.add_scalar(f'Training_Loss/{k}', train_losses[k] / freq, steps)
+                    train_losses[k] = 0
+            if steps in save_steps and rank == 0:
+                save(save_dir, model, epoch, steps, best_val_cls_loss, str(steps), optimizer, lr_scheduler, train_indices, val_indices)
+            steps += 1
+            if steps % 1000 == 0:
+                lr_scheduler.step()
+                writer.add_scalar('Lr', lr_scheduler.get_last_lr()[0], steps)
+            if steps % val_freq == 0 and rank == 0:
+                model.eval(), criterion.eval()
+                if validation_loader is not None and len(validation_loader) > 0:
+                    val_losses = {k: 0 for k in loss_keys}
+                    n_val = 0
+                    for raw_val in validation_loader:
+                        valid_batch = dataset.collate(raw_val)
+                        with torch.no_grad():
+                            loss_dict = step(model, criterion, valid_batch, device, negative_sample=False)
+                        for k, v in loss_dict.items():
+                            val_losses[k] += as_float(k, v)
+                        n_val += 1
+                    for k in loss_keys:
+                        val_losses[k] /= max(1, n_val)
+                    with torch.no_grad():
+                        loss_dict = step(model, criterion, valid_batch, device, negative_sample=True)
+                    for k, v in loss_dict.items():
+                        val_losses[k] += as_float(k, v)
+                    for k in loss_keys:
+                        writer.add_scalar(f'Val_Loss/{k}', val_losses[k], steps)
+                    if (steps / 1000 > args.lr_drop) and (val_losses['sec_class_loss'] < best_val_cls_loss):
+                        best_val_cls_loss = val_losses['sec_class_loss']
+                        save(save_dir, model, epoch, steps, best_val_cls_loss, 'best')
+                wavs = sorted(glob.glob(os.path.join(args.data_path, 'test_files', 'XC_annots') + '/*.wav'))
+                if wavs:
+                    for k, v in evaluate_test_files(model, args, wavs).items():
+                        writer.add_scalar(f'Test_metrics/{k}', v, steps)
+                model.train(), criterion.train()
+            if steps >= args.max_steps:
+                break
+        if (epoch > 0) and (epoch % 10 == 0) and rank == 0:
+            save(save_dir, model, epoch, steps, best_val_cls_loss, 'last', optimizer, lr_scheduler, train_indices, val_indices)
+        epoch += 1
+    return steps
+
+
+if __name__ == '__main__':
+    _p = argparse.ArgumentParser('NbmModel training and evaluation script', parents=[get_args_parser()])
+    _args = _p.parse_args()
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+        import torch.distributed as _dist
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        _dist.init_process_group('nccl')
+    main(_args)
