@@ -52,7 +52,7 @@ def train_bench(rank, world, dist, batch, steps, warmup):
         bb, ids, ln = synth.label_batch(rank * 8 + i % 8, 1)
         bbs.append(bb), idss.append(ids)
         lens += ln
-    data = [img, img, torch.cat(bbs).cuda(), torch.cat(idss).cuda(), lens]
+    data = [img, img, torch.cat(bbs), torch.cat(idss), lens]      # labels stay on the host, as a DataLoader delivers them
     np.random.seed(1000 + rank)
 
     def sync_all():

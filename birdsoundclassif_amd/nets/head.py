@@ -28,10 +28,12 @@ class Faster_RCNN(nn.Module):
             rois, scores, n_roi = self.prop_layer.forward_device(cls.detach(), reg.detach())
         return rois, scores, n_roi, cls, reg, cls_raw
 
-    def forward_first_stage(self, fpn_pyramid_out):
+    def forward_first_stage(self, fpn_pyramid_out, host_work=None):
         """fpn_pyramid_out: list of NCHW-shaped maps -> (rois [B,R,4] | empty, cls_scores, bbox_reg) (head.py:32-38)."""
         fm = [f.permute(0, 2, 3, 1).contiguous() for f in fpn_pyramid_out]
         rois, _, n_roi, cls, reg, _ = self.forward_first_stage_device(fm)
+        if host_work is not None:
+            host_work()
         n = int(n_roi.item())
         if n == 0:
             print('Not enough possible RoIs, RPN failed')

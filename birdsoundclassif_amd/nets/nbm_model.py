@@ -33,11 +33,12 @@ class NbmModel(nn.Module):
         features, _ = self.backbone(x)
         return self.fpn(self.attn(features))
 
-    def forward_first_stage(self, samples):
+    def forward_first_stage(self, samples, host_work=None):
         """samples [B,1,H,W] f32 on the GPU -> {'rois','rpn_cls_scores','rpn_bbox_reg','fpn_out'} (nbm_model.py:39-54).
-        Tensors are NCHW-shaped views of NHWC storage."""
+        Tensors are NCHW-shaped views of NHWC storage.  `host_work` (optional callable) runs after every kernel of the
+        first stage has been queued and before the host waits for the RoI count, i.e. hidden behind the GPU work."""
         fpn_out = self._fpn_nhwc(samples)
-        rois, cls, reg = self.head.forward_first_stage([f.permute(0, 3, 1, 2) for f in fpn_out])
+        rois, cls, reg = self.head.forward_first_stage([f.permute(0, 3, 1, 2) for f in fpn_out], host_work)
         return {'rois': rois, 'rpn_cls_scores': cls, 'rpn_bbox_reg': reg,
                 'fpn_out': [f.permute(0, 3, 1, 2) for f in fpn_out]}
 

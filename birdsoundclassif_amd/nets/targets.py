@@ -131,18 +131,19 @@ class ProposalTargetLayer(nn.Module):
             gta = gt[asg]
             fg = np.nonzero(mx > fg_t)[0]
             bg = np.nonzero((hi_t > mx) & (mx >= lo_t))[0]
-            other = list(set(range(len(mx))) - set(bg) - set(fg))
+            n_other = len(mx) - len(bg) - len(fg)          # fg and bg are disjoint; the set itself is built only if drawn from
             nfg = min(len(fg), int(cfg.rcnn_fg_prop * nb))
-            if len(bg) + len(other) < nb - nfg:
-                print(f'~~~~ NOT ENOUGH BG: {len(bg)} / IGNORED ROIS: {len(other)}, FILLING WITH POSITIVES: {len(fg)} ~~~~')
-                if len(bg) + len(other) < nb - len(fg):
+            if len(bg) + n_other < nb - nfg:
+                print(f'~~~~ NOT ENOUGH BG: {len(bg)} / IGNORED ROIS: {n_other}, FILLING WITH POSITIVES: {len(fg)} ~~~~')
+                if len(bg) + n_other < nb - len(fg):
                     print('~~~~ IMPOSSIBLE TO FILL THE RCNN BATCH, NOT ENOUGH ROIS ~~~~')
                     return None, None, None
-                nfg = max(nfg, nb - (len(bg) + len(other)))
+                nfg = max(nfg, nb - (len(bg) + n_other))
             nbg = min(len(bg), nb - nfg)
             fgi = np.random.choice(fg, nfg, replace=False)
             bgi = np.random.choice(bg, nbg, replace=False)
             if len(fgi) + len(bgi) < nb:
+                other = list(set(range(len(mx))) - set(bg) - set(fg))          # reference order: Python set iteration
                 bgi = np.hstack([bgi, np.random.choice(other, nb - len(fgi) - len(bgi), replace=False)])
             keep = np.hstack((fgi, bgi)).astype(np.int64)
             bl, br = lab[keep], allr[keep]

@@ -188,12 +188,18 @@ def build_optimizer(model, args):
 def step(model, criterion, batch, device, negative_sample):
     """One forward + loss evaluation (reference train.py:220-257)."""
     img, neg_img, bb_coord, bird_ids, lengths = batch
-    img, neg_img, bb_coord, bird_ids = img.to(device), neg_img.to(device), bb_coord.to(device), bird_ids.to(device)
+    img, neg_img = img.to(device), neg_img.to(device)
+    # Boxes and class ids are consumed by the host-side target layers (NumPy RNG, like the reference's `.cpu().numpy()`
+    # round trips): keep them on the host.  A device copy here would make every later `.cpu()` a stream-ordered wait
+    # for ALL queued GPU work (it cost 160 ms per step at B=128); loaders hand them over as CPU tensors anyway.
+    bb_coord, bird_ids = bb_coord.cpu(), bird_ids.cpu()
     loss = {}
     inpt = (neg_img if negative_sample else img)[:, None]
+    host_work = None
     if not negative_sample and hasattr(criterion, 'precompute_first_stage_targets'):
-        criterion.precompute_first_stage_targets(bb_coord, lengths)      # host work, hidden behind queued GPU work
-    out_first_stage = model.forward_first_stage(inpt)
+        # AnchorTargetLayer (host, NumPy RNG) runs while the GPU executes the first-stage forward queued before it
+        host_work = lambda: criterion.precompute_first_stage_targets(bb_coord, lengths)
+    out_first_stage = model.forward_first_stage(inpt, host_work) if host_work else model.forward_first_stage(inpt)
     loss.update(criterion.first_stage_loss(out_first_stage['rpn_cls_scores'], out_first_stage['rpn_bbox_reg'],
                                            bb_coord, lengths, negative_sample))
     if len(out_first_stage['rois']) == 0:            # "RPN failed": first-stage loss only

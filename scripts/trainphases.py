@@ -14,7 +14,7 @@ img = torch.from_numpy(np.tile(base, (-(-B//8),1,1))[:B].copy()).cuda()
 bbs, idss, lens = [], [], []
 for i in range(B):
     bb, ids, l = synth.label_batch(i % 8, 1); bbs.append(bb); idss.append(ids); lens += l
-bb, ids = torch.cat(bbs).cuda(), torch.cat(idss).cuda()
+bb, ids = torch.cat(bbs), torch.cat(idss)
 np.random.seed(0)
 def T():
     torch.cuda.synchronize(); return time.perf_counter()
