@@ -66,7 +66,7 @@ SIGNATURES = {
     'nbm_stft_db': [_P, _L, _I, _I, _I, _P, _I, _I, _I, _F, _P, _L, _I, _P, _P],
     'nbm_spec_windows': [_P, _L, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P],
     'nbm_init_conv': [_P, _L, _P, _P, _I, _P, _P],
-    'nbm_maxpool3x3s2': [_P, _I, _I, _I, _I, _P, _I, _I, _P],
+    'nbm_maxpool3x3s2': [_P, _I, _I, _I, _I, _P, _I, _I, _P, _P],
     'nbm_upsample_bilinear_add': [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P],
     'nbm_softmax_rows': [_P, _L, _I, _L, _P],
     'nbm_dwconv3x3': [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _L, _P, _I, _I, _P],
@@ -86,6 +86,7 @@ SIGNATURES = {
     'nbm_silu_bwd': [_P, _P, _P, _L, _P],
     'nbm_axpby': [_P, _P, _P, _F, _F, _L, _P],
     'nbm_colsum': [_P, _L, _I, _I, _P, _P],
+    'nbm_zero_insert': [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P],
     'nbm_maxpool3x3s2_bwd': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     'nbm_upsample_bilinear_bwd': [_P, _I, _I, _I, _I, _P, _I, _I, _P],
     'nbm_png_unfilter_gray8': [_P, _L, _I, _I, _I, _P, _L, _P, _P],

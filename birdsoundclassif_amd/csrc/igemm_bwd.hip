@@ -13,6 +13,7 @@
 // Same structure as igemm.hip: 128 x BN x 32 tiles, 4 waves, double-buffered LDS with one barrier per K-step, operands
 // fetched with branch-free raw buffer loads (invalid taps / rows get an out-of-range offset and read zeros), global
 // loads issued two tiles ahead and, like the LDS writes, scheduled between the MFMAs of the running K-step.
+#include <stdlib.h>
 #include "nbm_common.h"
 #include <type_traits>
 
@@ -285,7 +286,14 @@ __global__ __launch_bounds__(256, 2) void igemm_nn_kernel(const BwdParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------- TN
-template <int BN>
+// BMODE: how the X tile (im2col rows of one tap) is fetched
+//   B_SAME    stride-1 'same' convolution with Wo >= 32: input pixel = output pixel + constant, so every row has a
+//             constant byte offset from a per-K-step scalar base -> raw buffer loads, padding / tail rows read zeros
+//   B_STRIDED any stride / small maps, 16-byte channel chunks through pointers
+//   B_GENERIC unaligned or Cin % 4 != 0: scalar gather over the flattened (tap, c) axis
+enum { B_SAME = 0, B_STRIDED = 1, B_GENERIC = 2 };
+
+template <int BN, int BMODE, int SCHED = 0>
 __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(const BwdParams p) {
   constexpr int BM = 128, WM = 64, WN = BN / 2, MT = 2, NT = WN / 32;
   constexpr int AP = BM + 4, BP = BN + 4;
@@ -300,9 +308,10 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(const BwdParams p) {
   const int grp = blockIdx.z;
   const int taps = p.kh * p.kw;
   // N-tile -> (tap, c0)  [fast]   or   j0 over (tap, c) flattened  [generic]
-  const int ctiles = p.b_generic ? 1 : (p.Cin + BN - 1) / BN;
-  const int tap = p.b_generic ? 0 : tile_n / ctiles;
-  const int c0 = p.b_generic ? 0 : (tile_n - tap * ctiles) * BN;
+  constexpr bool GEN = BMODE == B_GENERIC;
+  const int ctiles = GEN ? 1 : (p.Cin + BN - 1) / BN;
+  const int tap = GEN ? 0 : tile_n / ctiles;
+  const int c0 = GEN ? 0 : (tile_n - tap * ctiles) * BN;
   const int j0 = tile_n * BN;                       // generic only
   const int tr = tap / p.kw, ts = tap - tr * p.kw;
 
@@ -344,6 +353,11 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(const BwdParams p) {
     b_ox[i] = rem - b_oy[i] * p.Wo;
   }
   int kt_load = 0;
+  // B_SAME: constant row offsets relative to the K-step base pixel (+ the tap's displacement)
+  unsigned b_rel[BPASS];
+#pragma unroll
+  for (int i = 0; i < BPASS; ++i) b_rel[i] = c_ok ? (unsigned)((br0 + BROWS * i) * p.x_ld + c0 + bc * 4) * 4u : OOB;
+  const long long dpix = (long long)(tr - p.pad) * p.W + (ts - p.pad);
 
   auto load_tiles = [&]() {
     const int mbase = m_begin + kt_load * BK;
@@ -351,7 +365,16 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(const BwdParams p) {
     const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(gg + (long long)mbase * p.g_ld, (unsigned)(rows * p.g_ld * 4));
 #pragma unroll
     for (int i = 0; i < APASS; ++i) ra[i] = buf_load4(rsrc_a, a_rel[i], 0);
-    if (!p.b_generic) {
+    if constexpr (BMODE == B_SAME) {
+      const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(xg + ((long long)mbase + dpix) * p.x_ld, (unsigned)(rows * p.x_ld * 4));
+#pragma unroll
+      for (int i = 0; i < BPASS; ++i) {
+        const bool ok = (unsigned)(b_oy[i] + tr - p.pad) < (unsigned)p.H && (unsigned)(b_ox[i] + ts - p.pad) < (unsigned)p.W;
+        rb[i] = buf_load4(rsrc_b, ok ? b_rel[i] : OOB, 0);
+        b_ox[i] += BK;                                                  // Wo >= BK on this path
+        if (b_ox[i] >= p.Wo) { b_ox[i] -= p.Wo; if (++b_oy[i] == p.Ho) b_oy[i] = 0; }
+      }
+    } else if constexpr (BMODE == B_STRIDED) {
 #pragma unroll
       for (int i = 0; i < BPASS; ++i) {
         const int m = mbase + br0 + BROWS * i;
@@ -446,23 +469,27 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(const BwdParams p) {
     mfma_group(Ab, Bb, 0);
     if constexpr (STORE) {
       store_lds(cur ^ 1);
-      __builtin_amdgcn_sched_group_barrier(0x100, 4 * (MT + NT), 0);
+      if constexpr (SCHED != 2) {
+        __builtin_amdgcn_sched_group_barrier(0x100, (SCHED == 1 ? 2 : 4) * (MT + NT), 0);
 #pragma unroll
-      for (int z = 0; z < APASS + BPASS; ++z) {
-        __builtin_amdgcn_sched_group_barrier(0x008, (4 * MT * NT) / (APASS + BPASS) > 0 ? (4 * MT * NT) / (APASS + BPASS) : 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        for (int z = 0; z < APASS + BPASS; ++z) {
+          __builtin_amdgcn_sched_group_barrier(0x008, (4 * MT * NT) / (APASS + BPASS) > 0 ? (4 * MT * NT) / (APASS + BPASS) : 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
       }
     }
     __builtin_amdgcn_sched_barrier(0);
     mfma_group(Ab, Bb, 1);
     if constexpr (LOAD) {
       load_tiles();
-      __builtin_amdgcn_sched_group_barrier(0x100, 4 * (MT + NT), 0);
+      if constexpr (SCHED != 2) {
+        __builtin_amdgcn_sched_group_barrier(0x100, (SCHED == 1 ? 2 : 4) * (MT + NT), 0);
 #pragma unroll
-      for (int z = 0; z < 4 * MT * NT; ++z) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
-        if (z < APASS + BPASS) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        for (int z = 0; z < 4 * MT * NT; ++z) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+          if (z < APASS + BPASS) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -483,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(const BwdParams p) {
   for (int j = 0; j < NT; ++j) {
     const int jj = wn0 + j * 32 + lrow;
     int col;
-    if (!p.b_generic) { const int c = c0 + jj; if (c >= p.Cin) continue; col = tap * p.Cin + c; }
+    if constexpr (!GEN) { const int c = c0 + jj; if (c >= p.Cin) continue; col = tap * p.Cin + c; }
     else { col = j0 + jj; if (col >= taps * p.Cin) continue; }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -576,7 +603,17 @@ extern "C" int nbm_conv_wgrad(const nbm_bwd_desc* d, void* stream) {
   p.k_chunk = (((p.M + splits - 1) / splits) + BK - 1) / BK * BK;
   splits = (p.M + p.k_chunk - 1) / p.k_chunk;
   dim3 grid(p.m_tiles * p.n_tiles, splits, d->groups);
-  if (wide) hipLaunchKernelGGL(igemm_tn_kernel<128>, grid, dim3(256), 0, st, p);
-  else hipLaunchKernelGGL(igemm_tn_kernel<64>, grid, dim3(256), 0, st, p);
+  const bool same = !p.b_generic && d->stride == 1 && d->Ho == d->H && d->Wo == d->W && d->Wo >= BK &&
+                    (long long)BK * d->x_ld * 4 < 0x40000000ll;
+  if (p.b_generic) hipLaunchKernelGGL((igemm_tn_kernel<64, B_GENERIC>), grid, dim3(256), 0, st, p);
+  else if (wide && same) {
+    static const int sched = getenv("NBM_TN_SCHED") ? atoi(getenv("NBM_TN_SCHED")) : 0;
+    if (sched == 1) hipLaunchKernelGGL((igemm_tn_kernel<128, B_SAME, 1>), grid, dim3(256), 0, st, p);
+    else if (sched == 2) hipLaunchKernelGGL((igemm_tn_kernel<128, B_SAME, 2>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((igemm_tn_kernel<128, B_SAME>), grid, dim3(256), 0, st, p);
+  }
+  else if (wide) hipLaunchKernelGGL((igemm_tn_kernel<128, B_STRIDED>), grid, dim3(256), 0, st, p);
+  else if (same) hipLaunchKernelGGL((igemm_tn_kernel<64, B_SAME>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((igemm_tn_kernel<64, B_STRIDED>), grid, dim3(256), 0, st, p);
   return nbm_launch_status();
 }

@@ -87,8 +87,10 @@ __global__ void init_conv_kernel(const float* __restrict__ x, long long n_pix, c
   }
 }
 
+// idx (optional, training): position r*3+s of the FIRST maximum in (r, s) scan order, torch's tie rule, one byte per output
+template <bool IDX>
 __global__ void maxpool3x3s2_kernel(const float* __restrict__ x, int B, int H, int W, int C4,
-                                    float* __restrict__ y, int Ho, int Wo) {
+                                    float* __restrict__ y, int Ho, int Wo, uint8_t* __restrict__ idx) {
   const long long total = (long long)B * Ho * Wo * C4;
   const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
   f32x4* y4 = reinterpret_cast<f32x4*>(y);
@@ -100,6 +102,7 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ x, int B, int H, i
     const int oy = (int)(t % Ho);
     const int b = (int)(t / Ho);
     f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    uint32_t where = 0;                                  // 4 x 8 bit
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const int iy = oy * 2 - 1 + r;
@@ -109,10 +112,17 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ x, int B, int H, i
         const int ix = ox * 2 - 1 + s;
         if ((unsigned)ix >= (unsigned)W) continue;
         const f32x4 v = x4[((long long)(b * H + iy) * W + ix) * C4 + c];
-        m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+        if constexpr (IDX) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (v[e] > m[e]) { m[e] = v[e]; where = (where & ~(0xFFu << (8 * e))) | ((uint32_t)(r * 3 + s) << (8 * e)); }
+        } else {
+          m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+        }
       }
     }
     y4[i] = m;
+    if constexpr (IDX) reinterpret_cast<uint32_t*>(idx)[i] = where;
   }
 }
 
@@ -335,12 +345,17 @@ extern "C" int nbm_init_conv(const float* x, int64_t n_pix, const float* w, cons
   return nbm_launch_status();
 }
 
-extern "C" int nbm_maxpool3x3s2(const float* x, int B, int H, int W, int C, float* y, int Ho, int Wo, void* stream) {
+extern "C" int nbm_maxpool3x3s2(const float* x, int B, int H, int W, int C, float* y, int Ho, int Wo, uint8_t* idx,
+                                void* stream) {
   if (!x || !y || B <= 0 || C <= 0 || (C & 3)) return NBM_EINVAL;
   if ((H + 2 - 3) / 2 + 1 != Ho || (W + 2 - 3) / 2 + 1 != Wo) return NBM_EINVAL;
-  if (!nbm_aligned16(x) || !nbm_aligned16(y)) return NBM_EALIGN;
-  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for((long long)B * Ho * Wo * (C / 4))), dim3(TPB), 0,
-                     (hipStream_t)stream, x, B, H, W, C / 4, y, Ho, Wo);
+  if (!nbm_aligned16(x) || !nbm_aligned16(y) || (((uintptr_t)idx) & 3u)) return NBM_EALIGN;
+  if (idx)
+    hipLaunchKernelGGL(maxpool3x3s2_kernel<true>, dim3(grid_for((long long)B * Ho * Wo * (C / 4))), dim3(TPB), 0,
+                       (hipStream_t)stream, x, B, H, W, C / 4, y, Ho, Wo, idx);
+  else
+    hipLaunchKernelGGL(maxpool3x3s2_kernel<false>, dim3(grid_for((long long)B * Ho * Wo * (C / 4))), dim3(TPB), 0,
+                       (hipStream_t)stream, x, B, H, W, C / 4, y, Ho, Wo, idx);
   return nbm_launch_status();
 }
 

@@ -45,39 +45,55 @@ __global__ void colsum_kernel(const float* __restrict__ g, long long M, int N, i
   if (sub == 0 && n < N) atomicAdd(out + n, (float)(part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]));
 }
 
-// gradient of 3x3/s2/p1 max pooling, gather form; ties resolved like torch CPU (first maximum in (r, s) scan order)
-__global__ void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ gx,
-                                   int B, int H, int W, int C, int Ho, int Wo) {
-  const long long total = (long long)B * H * W * C;
+// gradient of 3x3/s2/p1 max pooling, gather form over the arg-max positions the forward pass recorded (r*3+s, one byte
+// per output element): every input pixel looks at the <= 4 windows that contain it.  Reads idx + gy, writes gx once.
+__global__ void maxpool_bwd_kernel(const uint8_t* __restrict__ idx, const float* __restrict__ gy, float* __restrict__ gx,
+                                   int B, int H, int W, int C4, int Ho, int Wo) {
+  const long long total = (long long)B * H * W * C4;
+  const uint32_t* idx4 = reinterpret_cast<const uint32_t*>(idx);
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(gy);
+  f32x4* o4 = reinterpret_cast<f32x4*>(gx);
   GRID_STRIDE(i, total) {
-    const int c = (int)(i % C);
-    long long t = i / C;
+    const int c = (int)(i % C4);
+    long long t = i / C4;
     const int ix = (int)(t % W); t /= W;
     const int iy = (int)(t % H);
     const int b = (int)(t / H);
-    float acc = 0.f;
-    // windows containing (iy, ix): oy with oy*2-1 <= iy <= oy*2+1
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int oy = (iy >> 1); oy <= ((iy + 1) >> 1); ++oy) {
       if (oy >= Ho) continue;
+      const int r = iy - (oy * 2 - 1);
       for (int ox = (ix >> 1); ox <= ((ix + 1) >> 1); ++ox) {
         if (ox >= Wo) continue;
-        float best = -INFINITY; int by = -1, bx = -1;
+        const uint32_t me = (uint32_t)(r * 3 + ix - (ox * 2 - 1));
+        const long long o = ((long long)(b * Ho + oy) * Wo + ox) * C4 + c;
+        const uint32_t w4 = idx4[o];
+        const f32x4 g = g4[o];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          const int yy = oy * 2 - 1 + r;
-          if ((unsigned)yy >= (unsigned)H) continue;
-#pragma unroll
-          for (int s = 0; s < 3; ++s) {
-            const int xx = ox * 2 - 1 + s;
-            if ((unsigned)xx >= (unsigned)W) continue;
-            const float v = x[((long long)(b * H + yy) * W + xx) * C + c];
-            if (v > best || v != v) { best = v; by = yy; bx = xx; }
-          }
-        }
-        if (by == iy && bx == ix) acc += gy[((long long)(b * Ho + oy) * Wo + ox) * C + c];
+        for (int e = 0; e < 4; ++e)
+          if (((w4 >> (8 * e)) & 0xFFu) == me) acc[e] += g[e];
       }
     }
-    gx[i] = acc;
+    o4[i] = acc;
+  }
+}
+
+// out[b][y][x][:] = src[b][y/st][x/st][:] where both coordinates are multiples of st, else 0: the data gradient of a
+// strided 1x1 convolution is the compact GEMM result spread over the input grid
+__global__ void zero_insert_kernel(const float* __restrict__ src, int B, int Ho, int Wo, int C4, float* __restrict__ out,
+                                   int H, int W, int st) {
+  const long long total = (long long)B * H * W * C4;
+  const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+  f32x4* o4 = reinterpret_cast<f32x4*>(out);
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C4);
+    long long t = i / C4;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const int b = (int)(t / H);
+    const bool hit = (y % st == 0) && (x % st == 0) && (y / st < Ho) && (x / st < Wo);
+    o4[i] = hit ? s4[((long long)(b * Ho + y / st) * Wo + x / st) * C4 + c] : zero;
   }
 }
 
@@ -423,12 +439,22 @@ extern "C" int nbm_colsum(const float* g, int64_t M, int N, int ld, float* out, 
   hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, ST, g, (long long)M, N, ld, out);
   return nbm_launch_status();
 }
-extern "C" int nbm_maxpool3x3s2_bwd(const float* x, const float* gy, float* gx, int B, int H, int W, int C, int Ho,
+extern "C" int nbm_maxpool3x3s2_bwd(const uint8_t* idx, const float* gy, float* gx, int B, int H, int W, int C, int Ho,
                                     int Wo, void* stream) {
-  if (!x || !gy || !gx || B <= 0 || C <= 0) return NBM_EINVAL;
+  if (!idx || !gy || !gx || B <= 0 || C <= 0 || (C & 3)) return NBM_EINVAL;
   if ((H + 2 - 3) / 2 + 1 != Ho || (W + 2 - 3) / 2 + 1 != Wo) return NBM_EINVAL;
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((long long)B * H * W * C)), dim3(TPB), 0, ST, x, gy, gx, B, H, W, C,
-                     Ho, Wo);
+  if (!nbm_aligned16(gy) || !nbm_aligned16(gx) || (((uintptr_t)idx) & 3u)) return NBM_EALIGN;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((long long)B * H * W * (C / 4))), dim3(TPB), 0, ST, idx, gy, gx, B, H,
+                     W, C / 4, Ho, Wo);
+  return nbm_launch_status();
+}
+extern "C" int nbm_zero_insert(const float* src, int B, int Ho, int Wo, int C, float* out, int H, int W, int stride,
+                               void* stream) {
+  if (!src || !out || B <= 0 || C <= 0 || (C & 3) || stride <= 0 || Ho <= 0 || Wo <= 0 || H <= 0 || W <= 0) return NBM_EINVAL;
+  if ((H - 1) / stride + 1 != Ho || (W - 1) / stride + 1 != Wo) return NBM_EINVAL;
+  if (!nbm_aligned16(src) || !nbm_aligned16(out)) return NBM_EALIGN;
+  hipLaunchKernelGGL(zero_insert_kernel, dim3(grid_for((long long)B * H * W * (C / 4))), dim3(TPB), 0, ST, src, B, Ho, Wo,
+                     C / 4, out, H, W, stride);
   return nbm_launch_status();
 }
 extern "C" int nbm_upsample_bilinear_bwd(const float* gy, int B, int Hi, int Wi, int C, float* gsrc, int Ho, int Wo,

@@ -58,7 +58,14 @@ class Conv(Function):
         wk = _prep.krsc(weight) if weight.dim() == 4 else weight.detach()
         gp = _pad32_rows(g.view(-1, N), N)
         gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and kh == 1 and kw == 1 and stride > 1 and pad == 0 and Cin % 4 == 0:
+            # strided 1x1: only the pixels on the stride grid receive gradient -> GEMM on the compact grid, then spread
+            Ho, Wo = gy.shape[1:3]
+            gc = torch.empty((B, Ho, Wo, Cin), device=x.device, dtype=torch.float32)
+            ops.conv_dgrad(gp, wk, gc, B=B, H=Ho, W=Wo, Cin=Cin, N=N, g_ld=gp.shape[1], w_ld=wk.shape[1], a_scale=scale,
+                           alpha=alpha)
+            gx = ops.zero_insert(gc, H, W, stride)
+        elif ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
             ops.conv_dgrad(gp, wk, gx, B=B, H=H, W=W, Cin=Cin, N=N, kh=kh, kw=kw, stride=stride, pad=pad,
                            g_ld=gp.shape[1], w_ld=wk.shape[1], a_scale=scale, alpha=alpha)
@@ -118,15 +125,16 @@ class Stem(Function):
 class MaxPool(Function):
     @staticmethod
     def forward(ctx, x):
-        y = ops.maxpool3x3s2(x)
-        ctx.save_for_backward(x)
+        y, idx = ops.maxpool3x3s2(x, with_index=True)
+        ctx.save_for_backward(idx)
+        ctx.hw = x.shape[1:3]
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        (x,) = ctx.saved_tensors
-        return ops.maxpool3x3s2_bwd(x, gy.contiguous())
+        (idx,) = ctx.saved_tensors
+        return ops.maxpool3x3s2_bwd(idx, gy.contiguous(), *ctx.hw)
 
 
 class UpsampleAdd(Function):

@@ -171,13 +171,15 @@ def init_conv(x, w, b):
     return y
 
 
-def maxpool3x3s2(x):
+def maxpool3x3s2(x, with_index=False):
+    """-> y, or (y, idx uint8 [B,Ho,Wo,C]: window position of each maximum, for `maxpool3x3s2_bwd`)."""
     _chk(x, name='x')
     B, H, W, C_ = x.shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     y = torch.empty((B, Ho, Wo, C_), device=x.device, dtype=torch.float32)
-    check(lib().nbm_maxpool3x3s2(_ptr(x), B, H, W, C_, _ptr(y), Ho, Wo, _stream()), 'nbm_maxpool3x3s2')
-    return y
+    idx = torch.empty((B, Ho, Wo, C_), device=x.device, dtype=torch.uint8) if with_index else None
+    check(lib().nbm_maxpool3x3s2(_ptr(x), B, H, W, C_, _ptr(y), Ho, Wo, _ptr(idx), _stream()), 'nbm_maxpool3x3s2')
+    return (y, idx) if with_index else y
 
 
 def upsample_bilinear_add(src, Ho, Wo, add=None):
@@ -325,6 +327,26 @@ def rcnn_post(rois, n_roi, bbox_reg, bbox_cls, img_w, img_h, nms_thresh, min_sco
 from ._lib import BwdDesc  # noqa: E402
 
 
+class _timed:
+    """HIP-event bracket around one launch, recorded in PROFILE_BWD when that is a list (scripts/trainlayers.py)."""
+
+    def __init__(self, tag):
+        self.tag = tag
+
+    def __enter__(self):
+        if PROFILE_BWD is not None:
+            self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.ev[0].record()
+
+    def __exit__(self, *exc):
+        if PROFILE_BWD is not None:
+            self.ev[1].record()
+            PROFILE_BWD.append((self.tag, *self.ev))
+
+
+PROFILE_BWD = None
+
+
 def _bwd_desc(g, *, B, H, W, Cin, N, kh, kw, stride, pad, g_ld, groups=1, alpha=1.0):
     d = BwdDesc()
     d.g = g.data_ptr()
@@ -352,7 +374,8 @@ def conv_dgrad(g, w, out, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, g_ld=
     d.mask = mask.data_ptr() if mask is not None else None
     d.mask_ld = Cin if mask is not None else 0
     d.g_gs, d.w_gs, d.out_gs, d.res_gs = g_gs, w_gs, out_gs, res_gs
-    check(lib().nbm_conv_dgrad(C.byref(d), _stream()), 'nbm_conv_dgrad')
+    with _timed(('dgrad', B, H, W, Cin, N, kh, stride, groups)):
+        check(lib().nbm_conv_dgrad(C.byref(d), _stream()), 'nbm_conv_dgrad')
     return out
 
 
@@ -366,7 +389,8 @@ def conv_wgrad(g, x, out, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, g_ld=
     d.out_ld = kh * kw * Cin if out_ld is None else out_ld
     d.row_scale = row_scale.data_ptr() if row_scale is not None else None
     d.g_gs, d.x_gs, d.out_gs = g_gs, x_gs, out_gs
-    check(lib().nbm_conv_wgrad(C.byref(d), _stream()), 'nbm_conv_wgrad')
+    with _timed(('wgrad', B, H, W, Cin, N, kh, stride, groups)):
+        check(lib().nbm_conv_wgrad(C.byref(d), _stream()), 'nbm_conv_wgrad')
     return out
 
 
@@ -398,12 +422,19 @@ def colsum(g2d, n=None):
     return out
 
 
-def maxpool3x3s2_bwd(x, gy):
-    B, H, W, C_ = x.shape
-    gx = torch.empty_like(x)
-    check(lib().nbm_maxpool3x3s2_bwd(_ptr(_chk(x)), _ptr(_chk(gy)), _ptr(gx), B, H, W, C_, gy.shape[1], gy.shape[2],
-                                     _stream()), 'nbm_maxpool3x3s2_bwd')
+def maxpool3x3s2_bwd(idx, gy, H, W):
+    B, Ho, Wo, C_ = gy.shape
+    gx = torch.empty((B, H, W, C_), device=gy.device, dtype=torch.float32)
+    check(lib().nbm_maxpool3x3s2_bwd(_ptr(idx), _ptr(_chk(gy)), _ptr(gx), B, H, W, C_, Ho, Wo, _stream()),
+          'nbm_maxpool3x3s2_bwd')
     return gx
+
+
+def zero_insert(src, H, W, stride):
+    B, Ho, Wo, C_ = src.shape
+    out = torch.empty((B, H, W, C_), device=src.device, dtype=torch.float32)
+    check(lib().nbm_zero_insert(_ptr(_chk(src)), B, Ho, Wo, C_, _ptr(out), H, W, stride, _stream()), 'nbm_zero_insert')
+    return out
 
 
 def upsample_bilinear_bwd(gy, Hi, Wi):

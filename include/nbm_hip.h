@@ -106,8 +106,9 @@ int nbm_spec_windows(const float* db, int64_t db_bs, int db_ld, int batch, int n
 /* y[p][c] = x[p]*w[c] + b[c]  -- BackboneBase.init_conv (backbone.py:104-105,110-113), 1 -> C. */
 int nbm_init_conv(const float* x, int64_t n_pix, const float* w, const float* b, int C, float* y, void* stream);
 
-/* 3x3 / stride 2 / pad 1 max pooling -- torchvision ResNet `maxpool` (backbone.py:131). */
-int nbm_maxpool3x3s2(const float* x, int B, int H, int W, int C, float* y, int Ho, int Wo, void* stream);
+/* 3x3 / stride 2 / pad 1 max pooling -- torchvision ResNet `maxpool` (backbone.py:131).  idx (may be NULL; training):
+ * one byte per output element = r*3+s of the first maximum in scan order, consumed by nbm_maxpool3x3s2_bwd. */
+int nbm_maxpool3x3s2(const float* x, int B, int H, int W, int C, float* y, int Ho, int Wo, uint8_t* idx, void* stream);
 
 /* y = bilinear_align_corners(src -> Ho x Wo) [+ add]  -- fpn.py:143-144, layers.py:35-37. */
 int nbm_upsample_bilinear_add(const float* src, int B, int Hi, int Wi, int C, const float* add,
@@ -228,8 +229,11 @@ int nbm_silu_bwd(const float* gy, const float* x, float* out, int64_t n, void* s
 int nbm_axpby(const float* a, const float* b, float* out, float alpha, float beta, int64_t n, void* stream);
 /* out[n] = sum_m g[m][n] (bias gradients) */
 int nbm_colsum(const float* g, int64_t M, int N, int ld, float* out, void* stream);
-int nbm_maxpool3x3s2_bwd(const float* x, const float* gy, float* gx, int B, int H, int W, int C, int Ho, int Wo,
+int nbm_maxpool3x3s2_bwd(const uint8_t* idx, const float* gy, float* gx, int B, int H, int W, int C, int Ho, int Wo,
                          void* stream);
+/* out[b][y][x][:] = src[b][y/stride][x/stride][:] on the stride grid, 0 elsewhere: spreads the compact data gradient of
+ * a strided 1x1 convolution (ResNet downsample branches) over the input grid */
+int nbm_zero_insert(const float* src, int B, int Ho, int Wo, int C, float* out, int H, int W, int stride, void* stream);
 int nbm_upsample_bilinear_bwd(const float* gy, int B, int Hi, int Wi, int C, float* gsrc, int Ho, int Wo, void* stream);
 int nbm_softmax_rows_bwd(const float* p, const float* gp, float* out, int64_t rows, int cols, float alpha, void* stream);
 int nbm_pair_softmax_bwd(const float* y, const float* gy, float* gx, int64_t n_pairs, void* stream);
