@@ -594,12 +594,21 @@ extern "C" int nbm_conv_wgrad(const nbm_bwd_desc* d, void* stream) {
   const bool wide = !p.b_generic && d->Cin > 64;
   const int BN = wide ? 128 : 64;
   p.n_tiles = p.b_generic ? (taps * d->Cin + BN - 1) / BN : taps * ((d->Cin + BN - 1) / BN);
-  // split the pixel reduction so that the grid fills the chip (>= ~2048 workgroups) with >= 8 K-steps per split
+  // Split the pixel reduction so that the grid fills the chip in WHOLE rounds: 512 workgroups are resident at once
+  // (256 CUs x 2), all of equal length, so a grid of 4.01 rounds costs 5 (the old ">= 2048 workgroups" rule hit exactly
+  // that on the largest layer: 54 tiles x 38 splits = 2052).  Pick the split count with the best fill of its last
+  // round among those with >= 8 K-steps per split and <= 16 rounds; ties go to fewer splits (fewer atomics).
   const int tiles = p.m_tiles * p.n_tiles * d->groups;
-  int splits = (2048 + tiles - 1) / tiles;
   const int max_splits = (p.M + 8 * BK - 1) / (8 * BK);
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
+  const int slots = 512;
+  int splits = 1;
+  double best = -1.0;
+  for (int sp = 1; sp <= max_splits && (long long)sp * tiles <= 16ll * slots; ++sp) {
+    const long long wg = (long long)sp * tiles;
+    const long long rounds = (wg + slots - 1) / slots;
+    const double fill = (double)wg / (double)(rounds * slots);
+    if (fill > best + 0.005) { best = fill; splits = sp; }
+  }
   p.k_chunk = (((p.M + splits - 1) / splits) + BK - 1) / BK * BK;
   splits = (p.M + p.k_chunk - 1) / p.k_chunk;
   dim3 grid(p.m_tiles * p.n_tiles, splits, d->groups);
