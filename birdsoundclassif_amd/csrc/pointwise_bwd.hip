@@ -19,6 +19,159 @@ __global__ void relu_bwd_kernel(const float* __restrict__ gy, const float* __res
   GRID_STRIDE(i, n) out[i] = y[i] > 0.f ? gy[i] : 0.f;
 }
 
+__global__ void leaky_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y, float* __restrict__ out,
+                                 float slope, long long n) {
+  GRID_STRIDE(i, n) out[i] = y[i] > 0.f ? gy[i] : gy[i] * slope;
+}
+
+// LayerNorm backward, one wave per row: gx = rstd * (g*w - mean(g*w) - xhat * mean(g*w*xhat)); every wave keeps its
+// share of dW = sum g*xhat and dB = sum g in registers over the rows it visits and adds it to gw / gb (zeroed by the
+// caller) once at the end.  E <= 1024.
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ g, long long rows, int E, float eps,
+                                                            float* __restrict__ gx, float* __restrict__ gw,
+                                                            float* __restrict__ gb) {
+  const int lane = threadIdx.x & 63;
+  float aw[16], ab[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) aw[k] = ab[k] = 0.f;
+  for (long long row = blockIdx.x * 4ll + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * 4) {
+    const float* xr = x + row * E;
+    const float* gr = g + row * E;
+    float s = 0.f;
+    for (int c = lane; c < E; c += 64) s += xr[c];
+    const float mean = nbm_wave_sum(s) / (float)E;
+    float q = 0.f;
+    for (int c = lane; c < E; c += 64) { const float d = xr[c] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(nbm_wave_sum(q) / (float)E + eps);
+    float c1 = 0.f, c2 = 0.f;
+    for (int c = lane; c < E; c += 64) {
+      const float xh = (xr[c] - mean) * rstd, gw_ = gr[c] * w[c];
+      c1 += gw_;
+      c2 += gw_ * xh;
+    }
+    c1 = nbm_wave_sum(c1) / (float)E;
+    c2 = nbm_wave_sum(c2) / (float)E;
+    float* o = gx + row * E;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int c = lane + 64 * k;
+      if (c < E) {
+        const float xh = (xr[c] - mean) * rstd, gv = gr[c];
+        o[c] = rstd * (gv * w[c] - c1 - xh * c2);
+        aw[k] += gv * xh;
+        ab[k] += gv;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int c = lane + 64 * k;
+    if (c < E) { atomicAdd(gw + c, aw[k]); atomicAdd(gb + c, ab[k]); }
+  }
+}
+
+// Backward of nbm_mha_small (same token layout).  Pass 1, a wave per query row: recompute the probabilities, dP = dO V^T,
+// dS = P (dP - sum(P dP)), dQ = scale dS K; P and dS rows go to the workspace.  Pass 2, a wave per key row:
+// dK = scale dS^T Q, dV = P^T dO.
+#define MHA_SMAX 128
+__global__ __launch_bounds__(256) void mha_small_bwd_rows_kernel(
+    const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v, const float* __restrict__ go,
+    int q_ld, int k_ld, int v_ld, int go_ld, float* __restrict__ gq, int gq_ld, float* __restrict__ ws, int S, int nhead,
+    int hd, long long seq_stride, long long batch_stride, const int* __restrict__ n_valid, float scale) {
+  __shared__ float Ks[MHA_SMAX][65];
+  __shared__ float Vs[MHA_SMAX][65];
+  __shared__ float qs[4][64];
+  __shared__ float gs[4][64];
+  __shared__ float ds[4][MHA_SMAX];
+  const int n = blockIdx.x / nhead, h = blockIdx.x - n * nhead;
+  const int nv = n_valid ? min(*n_valid, S) : S;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < nv * hd; i += 256) {
+    const int j = i / hd, d = i - j * hd;
+    const long long row = j * seq_stride + n * batch_stride;
+    Ks[j][d] = k[row * k_ld + h * hd + d];
+    Vs[j][d] = v[row * v_ld + h * hd + d];
+  }
+  __syncthreads();
+  float* P = ws + (long long)blockIdx.x * 2 * S * S;
+  float* D = P + (long long)S * S;
+  for (int r = wave; r < nv; r += 4) {
+    const long long row = r * seq_stride + n * batch_stride;
+    if (lane < hd) {
+      qs[wave][lane] = q[row * q_ld + h * hd + lane] * scale;
+      gs[wave][lane] = go[row * go_ld + h * hd + lane];
+    }
+    __builtin_amdgcn_wave_barrier();
+    float sc[MHA_SMAX / 64], dp[MHA_SMAX / 64];
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < MHA_SMAX / 64; ++t) {
+      const int j = lane + 64 * t;
+      float a = -INFINITY, b = 0.f;
+      if (j < nv) {
+        a = 0.f;
+        for (int d = 0; d < hd; ++d) { a += qs[wave][d] * Ks[j][d]; b += gs[wave][d] * Vs[j][d]; }
+      }
+      sc[t] = a;
+      dp[t] = b;
+      m = fmaxf(m, a);
+    }
+    m = nbm_wave_max(m);
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < MHA_SMAX / 64; ++t) {
+      sc[t] = (lane + 64 * t < nv) ? expf(sc[t] - m) : 0.f;
+      sum += sc[t];
+    }
+    sum = nbm_wave_sum(sum);
+    float dot = 0.f;
+#pragma unroll
+    for (int t = 0; t < MHA_SMAX / 64; ++t) { sc[t] /= sum; dot += sc[t] * dp[t]; }
+    dot = nbm_wave_sum(dot);
+#pragma unroll
+    for (int t = 0; t < MHA_SMAX / 64; ++t) {
+      const int j = lane + 64 * t;
+      if (j < nv) {
+        const float dsv = sc[t] * (dp[t] - dot);
+        ds[wave][j] = dsv;
+        P[(long long)r * S + j] = sc[t];
+        D[(long long)r * S + j] = dsv;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < hd) {
+      float o = 0.f;
+      for (int j = 0; j < nv; ++j) o += ds[wave][j] * Ks[j][lane];
+      gq[row * gq_ld + h * hd + lane] = o * scale;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+__global__ __launch_bounds__(256) void mha_small_bwd_keys_kernel(
+    const float* __restrict__ q, const float* __restrict__ go, int q_ld, int go_ld, const float* __restrict__ ws,
+    float* __restrict__ gk, float* __restrict__ gv, int gk_ld, int gv_ld, int S, int nhead, int hd, long long seq_stride,
+    long long batch_stride, const int* __restrict__ n_valid, float scale) {
+  const int n = blockIdx.x / nhead, h = blockIdx.x - n * nhead;
+  const int nv = n_valid ? min(*n_valid, S) : S;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* P = ws + (long long)blockIdx.x * 2 * S * S;
+  const float* D = P + (long long)S * S;
+  if (lane >= hd) return;
+  for (int j = wave; j < nv; j += 4) {
+    float ak = 0.f, av = 0.f;
+    for (int r = 0; r < nv; ++r) {
+      const long long row = r * seq_stride + n * batch_stride;
+      ak += D[(long long)r * S + j] * q[row * q_ld + h * hd + lane];
+      av += P[(long long)r * S + j] * go[row * go_ld + h * hd + lane];
+    }
+    const long long rowj = j * seq_stride + n * batch_stride;
+    gk[rowj * gk_ld + h * hd + lane] = ak * scale;
+    gv[rowj * gv_ld + h * hd + lane] = av;
+  }
+}
+
 __global__ void silu_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x, float* __restrict__ out,
                                 long long n) {
   GRID_STRIDE(i, n) {
@@ -419,6 +572,32 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 extern "C" int nbm_relu_bwd(const float* gy, const float* y, float* out, int64_t n, void* stream) {
   if (!gy || !y || !out || n <= 0) return NBM_EINVAL;
   hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n)), dim3(TPB), 0, ST, gy, y, out, (long long)n);
+  return nbm_launch_status();
+}
+extern "C" int nbm_leaky_relu_bwd(const float* gy, const float* y, float* out, float slope, int64_t n, void* stream) {
+  if (!gy || !y || !out || n <= 0) return NBM_EINVAL;
+  hipLaunchKernelGGL(leaky_bwd_kernel, dim3(grid_for(n)), dim3(TPB), 0, ST, gy, y, out, slope, (long long)n);
+  return nbm_launch_status();
+}
+extern "C" int nbm_layernorm_bwd(const float* x, const float* w, const float* g, int64_t rows, int E, float eps, float* gx,
+                                 float* gw, float* gb, void* stream) {
+  if (!x || !w || !g || !gx || !gw || !gb || rows <= 0 || E <= 0 || E > 1024) return NBM_EINVAL;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid_for(rows, 4, 256)), dim3(256), 0, ST, x, w, g, (long long)rows, E, eps,
+                     gx, gw, gb);
+  return nbm_launch_status();
+}
+extern "C" int nbm_mha_small_bwd(const float* q, const float* k, const float* v, const float* go, int q_ld, int k_ld,
+                                 int v_ld, int go_ld, float* gq, float* gk, float* gv, int gq_ld, int gk_ld, int gv_ld,
+                                 float* workspace, int S, int N, int nhead, int hd, int64_t seq_stride,
+                                 int64_t batch_stride, const int32_t* n_valid, float scale, void* stream) {
+  if (!q || !k || !v || !go || !gq || !gk || !gv || !workspace) return NBM_EINVAL;
+  if (S <= 0 || S > MHA_SMAX || N <= 0 || nhead <= 0 || hd <= 0 || hd > 64) return NBM_EINVAL;
+  const int E = nhead * hd;
+  if (q_ld < E || k_ld < E || v_ld < E || go_ld < E || gq_ld < E || gk_ld < E || gv_ld < E) return NBM_EINVAL;
+  hipLaunchKernelGGL(mha_small_bwd_rows_kernel, dim3(N * nhead), dim3(256), 0, ST, q, k, v, go, q_ld, k_ld, v_ld, go_ld, gq,
+                     gq_ld, workspace, S, nhead, hd, (long long)seq_stride, (long long)batch_stride, n_valid, scale);
+  hipLaunchKernelGGL(mha_small_bwd_keys_kernel, dim3(N * nhead), dim3(256), 0, ST, q, go, q_ld, go_ld, workspace, gk, gv,
+                     gk_ld, gv_ld, S, nhead, hd, (long long)seq_stride, (long long)batch_stride, n_valid, scale);
   return nbm_launch_status();
 }
 extern "C" int nbm_silu_bwd(const float* gy, const float* x, float* out, int64_t n, void* stream) {

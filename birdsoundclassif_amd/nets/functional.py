@@ -12,7 +12,7 @@ from torch.autograd.function import once_differentiable
 from .. import ops
 from . import _prep
 
-ACT_NONE, ACT_RELU = ops.ACT_NONE, ops.ACT_RELU
+ACT_NONE, ACT_RELU, ACT_LEAKY = ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LEAKY
 
 
 def _pad32_rows(g2d, n):
@@ -43,7 +43,7 @@ class Conv(Function):
         y = ops.conv2d(x, wk, kh, kw, stride, pad, scale=scale, shift=sh, residual=residual, act=act, alpha=alpha)
         ctx.geom = (kh, kw, stride, pad, act, alpha)
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
-        ctx.save_for_backward(x, weight, scale, y if act == ACT_RELU else None)
+        ctx.save_for_backward(x, weight, scale, y if act in (ACT_RELU, ACT_LEAKY) else None)
         return y
 
     @staticmethod
@@ -52,7 +52,7 @@ class Conv(Function):
         x, weight, scale, y = ctx.saved_tensors
         kh, kw, stride, pad, act, alpha = ctx.geom
         gy = gy.contiguous()
-        g = ops.relu_bwd(gy, y) if act == ACT_RELU else gy
+        g = ops.relu_bwd(gy, y) if act == ACT_RELU else ops.leaky_relu_bwd(gy, y) if act == ACT_LEAKY else gy
         B, H, W, Cin = x.shape
         N = weight.shape[0]
         wk = _prep.krsc(weight) if weight.dim() == 4 else weight.detach()
@@ -84,9 +84,58 @@ def conv(x, weight, bias=None, scale=None, shift=None, residual=None, kh=1, kw=1
     return Conv.apply(x, weight, bias, scale, shift, residual, kh, kw, stride, pad, act, alpha)
 
 
-def linear(x2d, weight, bias=None):
+def linear(x2d, weight, bias=None, act=ACT_NONE, residual=None):
     M, K = x2d.shape
-    return Conv.apply(x2d.view(1, M, 1, K), weight, bias, None, None, None, 1, 1, 1, 0, ACT_NONE, 1.0).view(M, -1)
+    res = residual.view(1, M, 1, -1) if residual is not None else None
+    return Conv.apply(x2d.view(1, M, 1, K), weight, bias, None, None, res, 1, 1, 1, 0, act, 1.0).view(M, -1)
+
+
+class Add(Function):
+    """a + b (same shape) on the axpby kernel."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.axpby(a.contiguous(), b.contiguous())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        return g, g
+
+
+class LayerNorm(Function):
+    """nn.LayerNorm over the last axis of [rows, E] (Transformer_RCNN encoder, reference layers.py:618-621)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        ctx.save_for_backward(x, weight)
+        ctx.eps = eps
+        return ops.layernorm(x, weight.detach(), bias.detach(), eps)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        gx, gw, gb = ops.layernorm_bwd(x, weight.detach(), g.contiguous(), ctx.eps)
+        return gx, gw, gb, None
+
+
+class MhaSmall(Function):
+    """softmax(q k^T / sqrt(hd)) v per (batch entry, head) over short sequences (nn.MultiheadAttention core); the
+    probabilities are recomputed in the backward kernels."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, S, N, nhead, seq_stride, batch_stride, n_valid):
+        ctx.save_for_backward(q, k, v, n_valid)
+        ctx.geom = (S, N, nhead, seq_stride, batch_stride)
+        return ops.mha_small(q, k, v, S, N, nhead, seq_stride, batch_stride, n_valid)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, go):
+        q, k, v, n_valid = ctx.saved_tensors
+        gq, gk, gv = ops.mha_small_bwd(q, k, v, go.contiguous(), *ctx.geom, n_valid)
+        return gq, gk, gv, None, None, None, None, None, None
 
 
 class Stem(Function):

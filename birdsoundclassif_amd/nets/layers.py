@@ -284,7 +284,7 @@ class _Encoder(nn.Module):
 
 
 class Transformer_RCNN(nn.Module):
-    """reference layers.py:589-651 (`--tf_rcnn`), inference only.  Default flavour: post-norm ReLU encoder fed
+    """reference layers.py:589-651 (`--tf_rcnn`).  Default flavour: post-norm ReLU encoder fed
     rois_embed + pos_embed with batch_first=False, i.e. the reference attends ACROSS THE IMAGES OF THE BATCH for each RoI
     slot (sequence axis = bs, <= 128 here); `tf_pe_qk`: DETR flavour, attention across the RoIs of one image with
     q = k = src + pos and LeakyReLU.  Dropout is inactive in both (eval)."""
@@ -295,6 +295,8 @@ class Transformer_RCNN(nn.Module):
         in_dim = config.out_fpn_chan * config.roi_pool_h * config.roi_pool_w
         E = config.tf_model_dim
         self.tf_pe_qk = config.tf_pe_qk
+        if getattr(config, 'dropout', 0):
+            raise NotImplementedError('Transformer_RCNN: dropout > 0 is not implemented')
         if not self.tf_pe_qk and E != 512:
             raise ValueError('the reference hard-codes d_model=512 for the non-pe_qk encoder (layers.py:619)')
         self.nhead = config.tf_nhead
@@ -314,7 +316,7 @@ class Transformer_RCNN(nn.Module):
         """pool, pe: NHWC [B*R,2,2,C]; n_valid: device int32[1] RoIs per image that are real (pe_qk masks the rest)
         -> (bbox_reg [B*R, 4(1+nc)], bbox_classes [B*R, 1+nc] softmaxed)."""
         if torch.is_grad_enabled() and (self.training or pool.requires_grad):
-            raise NotImplementedError('training through Transformer_RCNN is not implemented (SURVEY.md 8f "next" row)')
+            return self._forward_train(pool, pe, B, R, n_valid)
         cn, M = pool.shape[-1], B * R
         lin = lambda m: (m.weight.detach(), m.bias.detach())
         pos = ops.linear(pe.view(M, -1), RCNN._hwc_weight(self.pos_embedding[0], cn), self.pos_embedding[0].bias.detach(),
@@ -343,6 +345,36 @@ class Transformer_RCNN(nn.Module):
             x = ops.layernorm(ops.linear(h, *lin(l.linear2), residual=x), *lin(l.norm2), eps=l.norm2.eps)
         reg = ops.linear(x, *lin(self.bbox_reg_layer))
         return reg, ops.softmax_rows_(ops.linear(x, *lin(self.bbox_classif_layer)))
+
+    def _forward_train(self, pool, pe, B, R, n_valid=None):
+        """Same computation on the differentiable operator layer (`functional`): every forward and backward step is a
+        HIP kernel; torch.autograd only sequences them."""
+        cn, M, E = pool.shape[-1], B * R, self.config.tf_model_dim
+        hwc = lambda lin: lin.weight.view(-1, cn, 4).permute(0, 2, 1).reshape(-1, 4 * cn)
+        pos = Fn.linear(pe.reshape(M, -1), hwc(self.pos_embedding[0]), self.pos_embedding[0].bias, act=Fn.ACT_LEAKY)
+        x = Fn.linear(pool.reshape(M, -1), hwc(self.rois_embedding[0]), self.rois_embedding[0].bias, act=Fn.ACT_LEAKY)
+        if self.tf_pe_qk:
+            geom, ff_act = (R, B, self.nhead, 1, R, n_valid), Fn.ACT_LEAKY
+        else:
+            x = Fn.Add.apply(x, pos)
+            geom, ff_act = (B, R, self.nhead, R, 1, None), Fn.ACT_RELU
+        for l in self.encoder.layers:
+            w, b = l.self_attn.in_proj_weight, l.self_attn.in_proj_bias
+            if self.tf_pe_qk:
+                qk = Fn.linear(Fn.Add.apply(x, pos), w[:2 * E], b[:2 * E])
+                q, k, v = qk[:, :E], qk[:, E:], Fn.linear(x, w[2 * E:], b[2 * E:])
+            else:
+                qkv = Fn.linear(x, w, b)
+                q, k, v = qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:]
+            a = Fn.MhaSmall.apply(q, k, v, *geom)
+            x = Fn.LayerNorm.apply(Fn.linear(a, l.self_attn.out_proj.weight, l.self_attn.out_proj.bias, residual=x),
+                                   l.norm1.weight, l.norm1.bias, l.norm1.eps)
+            h = Fn.linear(x, l.linear1.weight, l.linear1.bias, act=ff_act)
+            x = Fn.LayerNorm.apply(Fn.linear(h, l.linear2.weight, l.linear2.bias, residual=x),
+                                   l.norm2.weight, l.norm2.bias, l.norm2.eps)
+        reg = Fn.linear(x, self.bbox_reg_layer.weight, self.bbox_reg_layer.bias)
+        cls = Fn.linear(x, self.bbox_classif_layer.weight, self.bbox_classif_layer.bias)
+        return reg, Fn.SoftmaxRows.apply(cls)
 
     def forward(self, rois, pos):
         """[B,R,C,2,2] x2 -> (bbox_reg [B*R, 4(1+nc)], bbox_classes [B*R, 1+nc])."""

@@ -400,6 +400,36 @@ def relu_bwd(gy, y):
     return out
 
 
+def leaky_relu_bwd(gy, y, slope=0.01):
+    out = torch.empty_like(gy)
+    check(lib().nbm_leaky_relu_bwd(_ptr(_chk(gy)), _ptr(_chk(y)), _ptr(out), float(slope), gy.numel(), _stream()),
+          'nbm_leaky_relu_bwd')
+    return out
+
+
+def layernorm_bwd(x2d, w, g2d, eps=1e-5):
+    """-> (gx [rows,E], gw [E], gb [E])."""
+    rows, E = x2d.shape
+    gx = torch.empty_like(x2d)
+    gwb = torch.zeros((2, E), device=x2d.device, dtype=torch.float32)
+    check(lib().nbm_layernorm_bwd(_ptr(_chk(x2d)), _ptr(_chk(w)), _ptr(_chk(g2d)), rows, E, float(eps), _ptr(gx), _ptr(gwb[0]),
+                                  _ptr(gwb[1]), _stream()), 'nbm_layernorm_bwd')
+    return gx, gwb[0], gwb[1]
+
+
+def mha_small_bwd(q, k, v, go, S, N, nhead, seq_stride, batch_stride, n_valid=None):
+    """Gradients of `mha_small` wrt q, k, v (2-D row views, any row pitch) -> contiguous [S*N, E] each."""
+    E = q.shape[1]
+    hd = E // nhead
+    gq, gk, gv = (torch.zeros((q.shape[0], E), device=q.device, dtype=torch.float32) for _ in range(3))
+    ws = torch.empty((N * nhead, 2, S, S), device=q.device, dtype=torch.float32)
+    go = _chk(go)
+    check(lib().nbm_mha_small_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(go), q.stride(0), k.stride(0), v.stride(0), go.stride(0),
+                                  _ptr(gq), _ptr(gk), _ptr(gv), E, E, E, _ptr(ws), S, N, nhead, hd, seq_stride, batch_stride,
+                                  _ptr(n_valid), 1.0 / math.sqrt(hd), _stream()), 'nbm_mha_small_bwd')
+    return gq, gk, gv
+
+
 def silu_bwd(gy, x):
     out = torch.empty_like(gy)
     check(lib().nbm_silu_bwd(_ptr(_chk(gy)), _ptr(_chk(x)), _ptr(out), gy.numel(), _stream()), 'nbm_silu_bwd')

@@ -231,6 +231,17 @@ int nbm_axpby(const float* a, const float* b, float* out, float alpha, float bet
 int nbm_colsum(const float* g, int64_t M, int N, int ld, float* out, void* stream);
 int nbm_maxpool3x3s2_bwd(const uint8_t* idx, const float* gy, float* gx, int B, int H, int W, int C, int Ho, int Wo,
                          void* stream);
+/* out = gy * (y > 0 ? 1 : slope) -- nn.LeakyReLU backward (Transformer_RCNN embeddings / DETR-style feed-forward) */
+int nbm_leaky_relu_bwd(const float* gy, const float* y, float* out, float slope, int64_t n, void* stream);
+/* nn.LayerNorm backward over rows of E <= 1024 floats; gw, gb (E floats each) must be zeroed, they are added to */
+int nbm_layernorm_bwd(const float* x, const float* w, const float* g, int64_t rows, int E, float eps, float* gx, float* gw,
+                      float* gb, void* stream);
+/* backward of nbm_mha_small: gq/gk/gv get every VALID token row written (pre-zero them when *n_valid < S);
+ * workspace: 2*S*S floats per (batch entry, head) */
+int nbm_mha_small_bwd(const float* q, const float* k, const float* v, const float* go, int q_ld, int k_ld, int v_ld,
+                      int go_ld, float* gq, float* gk, float* gv, int gq_ld, int gk_ld, int gv_ld, float* workspace, int S,
+                      int N, int nhead, int hd, int64_t seq_stride, int64_t batch_stride, const int32_t* n_valid,
+                      float scale, void* stream);
 /* out[b][y][x][:] = src[b][y/stride][x/stride][:] on the stride grid, 0 elsewhere: spreads the compact data gradient of
  * a strided 1x1 convolution (ResNet downsample branches) over the input grid */
 int nbm_zero_insert(const float* src, int B, int Ho, int Wo, int C, float* out, int H, int W, int stride, void* stream);

@@ -79,6 +79,45 @@ def tf_rcnn_golden():
     np.savez_compressed(os.path.join(OUT, 'tf_rcnn_b3.npz'), **g)
 
 
+def tf_rcnn_train_golden():
+    """One positive optimisation step (reference train.py:205-257) with `--tf_rcnn`, both encoder flavours, B=2:
+    losses, clip-norm, sampled gradients of head / FPN / backbone parameters."""
+    t = {}
+    for tag, pe_qk in (('std', False), ('peqk', True)):
+        args = ref_import.default_args(tf_rcnn=True, tf_pe_qk=pe_qk)
+        model, crit = ref_import.build_reference_model(args, train=True)
+        sd = synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+        model.load_state_dict(sd)
+        model.train(), crit.train()
+        params = dict(model.named_parameters())
+        img = torch.from_numpy(synth.image_batch(0, 2))
+        bb, ids, lengths = synth.label_batch(0, 2)
+        np.random.seed(4321)
+        out1 = model.forward_first_stage(img[:, None])
+        loss = dict(crit.first_stage_loss(out1['rpn_cls_scores'], out1['rpn_bbox_reg'], bb, lengths, False))
+        pt = crit.generate_all_rois(out1['rois'], bb, ids, lengths)
+        out2 = model.forward_second_stage(out1['fpn_out'], pt['rois'], training=True)
+        loss.update(crit.second_stage_loss(out2['bbox_reg'], out2['bbox_classes'], pt['bbox_targets'], pt['labels'], False))
+        loss.update(crit.loss_cardinality(out2['bbox_classes'], pt['labels']))
+        for k, v in loss.items():
+            t[f'{tag}.loss.{k}'] = np.array(float(v), dtype=np.float64)
+        total = sum(loss[k] * crit.weight_dict[k] for k in loss if k in crit.weight_dict)
+        total.backward()
+        gn = torch.nn.utils.clip_grad_norm_(model.parameters(), args.clip_max_norm)
+        t[f'{tag}.grad_norm'] = np.array(float(gn), dtype=np.float64)
+        coef = min(1.0, args.clip_max_norm / (float(gn) + 1e-6))
+        r = 'head.fast_rcnn.rcnn.'
+        for n in ('backbone.0.body.layer2.1.conv2.weight', 'fpn.out_convs.3.weight', 'fpn.pt_wise.4.weight',
+                  r + 'pos_embedding.0.weight', r + 'rois_embedding.0.weight', r + 'rois_embedding.0.bias',
+                  r + 'encoder.layers.0.self_attn.in_proj_weight', r + 'encoder.layers.0.self_attn.in_proj_bias',
+                  r + 'encoder.layers.3.self_attn.out_proj.weight', r + 'encoder.layers.5.linear1.weight',
+                  r + 'encoder.layers.2.linear2.bias', r + 'encoder.layers.1.norm1.weight',
+                  r + 'encoder.layers.4.norm2.bias', r + 'bbox_reg_layer.weight', r + 'bbox_classif_layer.bias'):
+            pack(t, f'{tag}.grad.{n}', params[n].grad / coef, full_limit=8192)
+        print('tf_rcnn train', tag, {k: float(v) for k, v in loss.items()}, 'grad_norm', float(gn))
+    np.savez_compressed(os.path.join(OUT, 'train_tf_b2.npz'), **t)
+
+
 def img_dataset_golden():
     """`Img_dataset.__getitem__` (reference image_dataset.py:36-96) run for real on a synthetic dataset directory:
     imageio is absent here, so an `imageio.v2` stand-in whose `imread` is the oracle's PNG decoder is registered (the
@@ -142,11 +181,14 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     if '--tf-only' in sys.argv:
         return tf_rcnn_golden()
+    if '--tf-train-only' in sys.argv:
+        return tf_rcnn_train_golden()
     if '--metrics-only' in sys.argv:
         return metrics_golden()
     if '--dataset-only' in sys.argv:
         return img_dataset_golden()
     tf_rcnn_golden()
+    tf_rcnn_train_golden()
     img_dataset_golden()
     metrics_golden()
     args = ref_import.default_args()

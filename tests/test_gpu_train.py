@@ -299,3 +299,114 @@ def test_two_train_steps_vs_reference_golden():
         msd = model.state_dict()
         for name in [k[len(f's{si}.buffer.'):-len('.shape')] for k in g if k.startswith(f's{si}.buffer.') and k.endswith('.shape')]:
             check_packed(g, f's{si}.buffer.{name}', msd[name], atol=2e-5, rtol=2e-5)
+
+
+# --------------------------------------------------------------------------- Transformer_RCNN head
+def test_layernorm_and_leaky_linear_backward():
+    M, E = 300, 512
+    x = rnd('lnx', M, E).requires_grad_(True)
+    w = (1 + 0.1 * rnd('lnw', E)).requires_grad_(True)
+    b = (0.1 * rnd('lnb', E)).requires_grad_(True)
+    go = rnd('lng', M, E)
+    F.layer_norm(x, (E,), w, b, 1e-5).backward(go)
+    xd, wd, bd = (t.detach().cuda().requires_grad_(True) for t in (x, w, b))
+    y = Fn.LayerNorm.apply(xd, wd, bd, 1e-5)
+    close(y, F.layer_norm(x, (E,), w, b, 1e-5), 2e-6, 'layernorm fwd')
+    y.backward(go.cuda())
+    close(xd.grad, x.grad, 2e-5, 'layernorm dx'); close(wd.grad, w.grad, 2e-5, 'layernorm dw'); close(bd.grad, b.grad, 2e-5, 'layernorm db')
+    # linear + LeakyReLU + residual
+    x2 = rnd('llx', 200, 256).requires_grad_(True)
+    w2 = rnd('llw', 96, 256, scale=0.1).requires_grad_(True)
+    b2 = rnd('llb', 96, scale=0.5).requires_grad_(True)
+    g2 = rnd('llg', 200, 96)
+    F.leaky_relu(F.linear(x2, w2, b2)).backward(g2)
+    xd, wd, bd = (t.detach().cuda().requires_grad_(True) for t in (x2, w2, b2))
+    y = Fn.linear(xd, wd, bd, act=Fn.ACT_LEAKY)
+    close(y, F.leaky_relu(F.linear(x2, w2, b2)), 2e-6, 'leaky linear fwd')
+    y.backward(g2.cuda())
+    close(xd.grad, x2.grad, 2e-5, 'leaky dx'); close(wd.grad, w2.grad, 2e-5, 'leaky dw'); close(bd.grad, b2.grad, 2e-5, 'leaky db')
+
+
+@pytest.mark.parametrize('seq_major,S,N,nv', [(True, 128, 5, None), (False, 16, 7, 16), (False, 50, 3, 37), (True, 3, 16, None)])
+def test_mha_small_backward(seq_major, S, N, nv):
+    nh, E = 8, 512
+    hd = E // nh
+    qkv = rnd(('mhab', seq_major, S), S * N, 3 * E).requires_grad_(True)
+    go = rnd(('mhag', seq_major, S), S * N, E)
+    n_use = S if nv is None else nv
+    t = qkv.view(S, N, 3 * E) if seq_major else qkv.view(N, S, 3 * E).transpose(0, 1)
+    q, k, v = (t[..., i * E:(i + 1) * E].reshape(S, N * nh, hd).transpose(0, 1) for i in range(3))
+    att = torch.softmax((q[:, :n_use] @ k[:, :n_use].transpose(1, 2)) / hd ** 0.5, -1) @ v[:, :n_use]      # [N*nh, n_use, hd]
+    ref = att.transpose(0, 1).reshape(n_use, N, E)
+    gref = go.view(S, N, E) if seq_major else go.view(N, S, E).transpose(0, 1)
+    ref.backward(gref[:n_use])
+    qd = qkv.detach().cuda().requires_grad_(True)
+    cnt = None if nv is None else torch.tensor([nv], dtype=torch.int32, device='cuda')
+    ss, bs = (N, 1) if seq_major else (1, S)
+    out = Fn.MhaSmall.apply(qd[:, :E], qd[:, E:2 * E], qd[:, 2 * E:], S, N, nh, ss, bs, cnt)
+    got = out.view(S, N, E) if seq_major else out.view(N, S, E).transpose(0, 1)
+    close(got[:n_use], ref, 3e-6, 'mha fwd')
+    valid = torch.zeros(S, N, 1)
+    valid[:n_use] = 1
+    valid = (valid if seq_major else valid.transpose(0, 1)).reshape(S * N, 1)
+    out.backward((go * valid).cuda())
+    close(qd.grad, qkv.grad, 3e-5, 'mha dqkv')
+    assert float(qd.grad.cpu()[valid[:, 0] == 0].abs().max() if (valid == 0).any() else 0.0) == 0.0
+
+
+@pytest.mark.parametrize('pe_qk', [False, True])
+def test_transformer_rcnn_head_gradients_vs_oracle(pe_qk):
+    """Training-mode head (forward + every parameter / input gradient) against torch autograd through the oracle
+    restatement, which is itself pinned on the real reference (tests/golden/tf_rcnn_b3.npz)."""
+    from birdsoundclassif_amd.nets.layers import Transformer_RCNN
+    from birdsoundclassif_amd.train import default_args
+    args = default_args(device='cuda', tf_rcnn=True, tf_pe_qk=pe_qk, tf_num_encoder_layers=2)
+    head = Transformer_RCNN(args)
+    pre = 'head.fast_rcnn.rcnn.'
+    sd = synth.fill_state_dict({pre + k: tuple(v.shape) for k, v in head.state_dict().items()})
+    head.load_state_dict({k[len(pre):]: v for k, v in sd.items()})
+    head = head.cuda().train()
+    B, R, C = 5, 16, 256
+    pool = rnd(('tfpool', pe_qk), B, R, C, 2, 2).abs().requires_grad_(True)
+    pe = rnd(('tfpe', pe_qk), B, R, C, 2, 2)
+    r1, r2 = rnd('tfr1', B * R, 604), rnd('tfr2', B * R, 151)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    cfg = O.make_cfg(tf_rcnn=True, tf_pe_qk=pe_qk, tf_num_encoder_layers=2)
+    reg, cls = O.transformer_rcnn_forward(sdg, cfg, pool, pe)
+    ((reg * r1).sum() + (cls * r2).sum() * 50).backward()
+    pd = pool.detach().flatten(end_dim=1).permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(True)
+    ped = pe.flatten(end_dim=1).permute(0, 2, 3, 1).contiguous().cuda()
+    n = torch.full((1,), R, dtype=torch.int32, device='cuda')
+    greg, gcls = head.forward_nhwc(pd, ped, B, R, n)
+    close(greg, reg, 2e-5, 'tf reg'); close(gcls, cls, 2e-5, 'tf cls')
+    ((greg * r1.cuda()).sum() + (gcls * r2.cuda()).sum() * 50).backward()
+    close(pd.grad.view(B, R, 2, 2, C).permute(0, 1, 4, 2, 3), pool.grad, 2e-4, 'tf dpool')
+    for name, p in head.named_parameters():
+        close(p.grad, sdg[pre + name].grad, 3e-4, 'tf d' + name)
+
+
+@pytest.mark.parametrize('tag,pe_qk', [('std', False), ('peqk', True)])
+def test_tf_rcnn_train_step_vs_reference_golden(tag, pe_qk):
+    """One positive `train_one_step` with `--tf_rcnn` against the REAL reference (oracle/make_golden.py
+    tf_rcnn_train_golden): losses, clip-norm and sampled gradients from the head down to the backbone."""
+    from birdsoundclassif_amd.nets import build_model
+    from birdsoundclassif_amd.train import default_args, build_optimizer, train_one_step
+    g = load_golden('train_tf_b2.npz')
+    args = default_args(device='cuda', tf_rcnn=True, tf_pe_qk=pe_qk)
+    model, crit = build_model(args)
+    model.load_state_dict(filler_state_dict(tf_rcnn=True, tf_pe_qk=pe_qk))
+    model = model.cuda().train()
+    crit.train()
+    opt, _ = build_optimizer(model, args)
+    bb, ids, lengths = synth.label_batch(0, 2)
+    img = torch.from_numpy(synth.image_batch(0, 2))
+    params = dict(model.named_parameters())
+    np.random.seed(4321)
+    loss = train_one_step(model, crit, opt, [img, img, bb, ids, lengths], args.clip_max_norm, 'cuda', negative_sample=False)
+    for k, v in loss.items():
+        ref = float(g[f'{tag}.loss.{k}'])
+        assert abs(float(v) - ref) <= 2e-4 * max(1.0, abs(ref)), (k, float(v), ref)
+    gn_ref = float(g[f'{tag}.grad_norm'])
+    assert abs(opt.grad_norm() - gn_ref) <= 2e-3 * gn_ref, (opt.grad_norm(), gn_ref)
+    for name in [k[len(f'{tag}.grad.'):-len('.shape')] for k in g if k.startswith(f'{tag}.grad.') and k.endswith('.shape')]:
+        check_packed(g, f'{tag}.grad.{name}', params[name].grad, atol=2e-4 * gn_ref / 50, rtol=2e-3)
