@@ -25,7 +25,8 @@ class GemmDesc(C.Structure):
                 ('kh', C.c_int), ('kw', C.c_int), ('stride', C.c_int), ('pad', C.c_int),
                 ('Ho', C.c_int), ('Wo', C.c_int),
                 ('x_ld', C.c_int), ('w_ld', C.c_int), ('y_ld', C.c_int), ('res_ld', C.c_int),
-                ('alpha', C.c_float), ('act', C.c_int), ('shift_per_row', C.c_int)]
+                ('alpha', C.c_float), ('act', C.c_int), ('shift_per_row', C.c_int),
+                ('up', C.c_void_p), ('up_H', C.c_int), ('up_W', C.c_int)]
 
 
 class RoiDesc(C.Structure):

@@ -39,6 +39,8 @@ struct IgemmParams {
   int m_tiles, n_tiles;
   float alpha; int act; int shift_per_row;
   int vec_epi;           // epilogue may use 16-byte accesses (N % 4 == 0, pitches % 4 == 0, 16-byte aligned bases)
+  // fused top-down merge: y += bilinear_align_corners(up [B][up_H][up_W][N]) (vector epilogue only)
+  const float* up; int up_H, up_W; float up_sh, up_sw;
   // STFT epilogue
   int n_bins; float floor_amp; int db_ld; uint32_t* minmax;
 };
@@ -293,6 +295,24 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
             const f32x4 q = *reinterpret_cast<const f32x4*>(rg + (long long)m * p.res_ld + n);
             v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3];
           }
+          if (p.up) {       // same arithmetic as upsample_add_kernel (pointwise.hip): interp first, then + lateral
+            const int b = m / p.HoWo, rem = m - b * p.HoWo;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            const float fy = p.up_sh * oy, fx = p.up_sw * ox;
+            const int y0 = (int)fy, x0 = (int)fx;
+            const int y1 = y0 + (y0 < p.up_H - 1 ? 1 : 0), x1 = x0 + (x0 < p.up_W - 1 ? 1 : 0);
+            const float ly = fminf(fmaxf(fy - y0, 0.f), 1.f), lx = fminf(fmaxf(fx - x0, 0.f), 1.f);
+            const float hy = 1.f - ly, hx = 1.f - lx;
+            const long long rb = (long long)b * p.up_H;
+            const float* ub = p.up + n;
+            const f32x4 v00 = *reinterpret_cast<const f32x4*>(ub + ((rb + y0) * p.up_W + x0) * p.N);
+            const f32x4 v01 = *reinterpret_cast<const f32x4*>(ub + ((rb + y0) * p.up_W + x1) * p.N);
+            const f32x4 v10 = *reinterpret_cast<const f32x4*>(ub + ((rb + y1) * p.up_W + x0) * p.N);
+            const f32x4 v11 = *reinterpret_cast<const f32x4*>(ub + ((rb + y1) * p.up_W + x1) * p.N);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              v[e] = (hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e])) + v[e];
+          }
           if (p.act == NBM_ACT_RELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
@@ -395,6 +415,12 @@ extern "C" int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream) {
                (!d->scale || nbm_aligned16(d->scale)) && (!d->shift || d->shift_per_row || nbm_aligned16(d->shift)))
                   ? 1 : 0;
   if ((d->w_ld & 3) || (d->w_gs & 3) || !nbm_aligned16(d->w)) return NBM_EALIGN;
+  if (d->up) {
+    if (!p.vec_epi || d->groups != 1 || d->up_H <= 0 || d->up_W <= 0 || !nbm_aligned16(d->up)) return NBM_EUNSUPPORTED;
+    p.up = d->up; p.up_H = d->up_H; p.up_W = d->up_W;
+    p.up_sh = d->Ho > 1 ? (float)(d->up_H - 1) / (float)(d->Ho - 1) : 0.f;
+    p.up_sw = d->Wo > 1 ? (float)(d->up_W - 1) / (float)(d->Wo - 1) : 0.f;
+  }
   const bool fast = (d->Cin % BK) == 0 && (d->x_ld & 3) == 0 && (d->x_gs & 3) == 0 && nbm_aligned16(d->x);
   hipStream_t st = (hipStream_t)stream;
   const int BM = 128;

@@ -44,7 +44,7 @@ def lib():
 # --------------------------------------------------------------------------- implicit GEMM
 def gemm_conv(x, w, y, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, Ho=None, Wo=None,
               x_ld=None, w_ld=None, y_ld=None, scale=None, shift=None, residual=None, res_ld=None,
-              groups=1, x_gs=0, w_gs=0, y_gs=0, res_gs=0, alpha=1.0, act=ACT_NONE, shift_per_row=False):
+              groups=1, x_gs=0, w_gs=0, y_gs=0, res_gs=0, alpha=1.0, act=ACT_NONE, shift_per_row=False, up=None):
     """Raw call of nbm_gemm_conv (see include/nbm_hip.h for the exact semantics)."""
     Ho = (H + 2 * pad - kh) // stride + 1 if Ho is None else Ho
     Wo = (W + 2 * pad - kw) // stride + 1 if Wo is None else Wo
@@ -62,6 +62,8 @@ def gemm_conv(x, w, y, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, Ho=None,
     d.y_ld = N if y_ld is None else y_ld
     d.res_ld = (N if res_ld is None else res_ld) if residual is not None else 0
     d.alpha, d.act, d.shift_per_row = float(alpha), int(act), int(bool(shift_per_row))
+    if up is not None:                       # [B, up_H, up_W, N] coarse map merged in the epilogue
+        d.up, d.up_H, d.up_W = _chk(up, name='up').data_ptr(), up.shape[1], up.shape[2]
     if PROFILE is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
@@ -74,8 +76,8 @@ def gemm_conv(x, w, y, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, Ho=None,
 
 
 def conv2d(x, w, kh=1, kw=1, stride=1, pad=0, scale=None, shift=None, residual=None, act=ACT_NONE,
-           alpha=1.0, out=None, w_ld=None):
-    """x [B,H,W,Cin] NHWC, w [N, w_ld>=kh*kw*Cin] (KRSC rows) -> [B,Ho,Wo,N]."""
+           alpha=1.0, out=None, w_ld=None, up=None):
+    """x [B,H,W,Cin] NHWC, w [N, w_ld>=kh*kw*Cin] (KRSC rows) -> [B,Ho,Wo,N]; `up` [B,h,w,N]: + bilinear(up)."""
     _chk(x, name='x'), _chk(w, name='w')
     B, H, W, Cin = x.shape
     N = w.shape[0]
@@ -87,7 +89,7 @@ def conv2d(x, w, kh=1, kw=1, stride=1, pad=0, scale=None, shift=None, residual=N
         assert residual.shape == y.shape
     gemm_conv(x, w, y, B=B, H=H, W=W, Cin=Cin, N=N, kh=kh, kw=kw, stride=stride, pad=pad, Ho=Ho, Wo=Wo,
               w_ld=w.shape[1] if w_ld is None else w_ld, scale=scale, shift=shift, residual=residual,
-              alpha=alpha, act=act)
+              alpha=alpha, act=act, up=up)
     return y
 
 

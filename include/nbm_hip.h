@@ -67,6 +67,10 @@ typedef struct nbm_gemm_desc {
   float alpha;
   int act;               /* NBM_ACT_*                                                      */
   int shift_per_row;     /* 1: shift is indexed by m (row) instead of n                    */
+  const float* up;       /* optional [B][up_H][up_W][N]: y += bilinear_align_corners(up -> Ho x Wo), added after
+                            shift/residual and before act -- the FPN top-down merge fused into the lateral 1x1
+                            (fpn.py:143-144); needs the 16-byte epilogue (N % 4 == 0, aligned) and groups == 1  */
+  int up_H, up_W;
 } nbm_gemm_desc;
 
 int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream);

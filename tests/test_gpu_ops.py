@@ -246,3 +246,18 @@ def test_roi_pool_and_rcnn_post():
         assert r_ref.shape == r_got.shape and len(r_ref) > 0, (r_ref.shape, r_got.shape)
         assert np.array_equal(r_ref[:, :6], r_got[:, :6]), 'boxes / classes differ'
         assert np.abs(r_ref[:, 6] - r_got[:, 6]).max() == 0
+
+
+def test_conv_with_fused_topdown_merge():
+    """nbm_gemm_conv `up`: lateral 1x1 + bias + bilinear(align_corners) of the coarser map == the two separate kernels."""
+    B, H, W, Ci, N = 2, 23, 37, 64, 384
+    x = torch.from_numpy(synth.normal('upx', B * H * W * Ci).astype(np.float32).reshape(B, H, W, Ci)).cuda()
+    w = torch.from_numpy((synth.normal('upw', N * Ci) * 0.1).astype(np.float32).reshape(N, Ci)).cuda()
+    b = torch.from_numpy(synth.normal('upb', N).astype(np.float32)).cuda()
+    coarse = torch.from_numpy(synth.normal('upc', B * 12 * 19 * N).astype(np.float32).reshape(B, 12, 19, N)).cuda()
+    ref = ops.upsample_bilinear_add(coarse, H, W, add=ops.conv2d(x, w, shift=b, alpha=2.0))
+    got = ops.conv2d(x, w, shift=b, alpha=2.0, up=coarse)
+    assert (got - ref).abs().max().item() <= 1e-6
+    t = F.interpolate(coarse.permute(0, 3, 1, 2).cpu(), size=(H, W), mode='bilinear', align_corners=True)
+    t = t + F.conv2d(2.0 * x.permute(0, 3, 1, 2).cpu(), w.cpu()[:, :, None, None], b.cpu())
+    assert (got.cpu().permute(0, 3, 1, 2) - t).abs().max().item() < 2e-5
