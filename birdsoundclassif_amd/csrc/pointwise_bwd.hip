@@ -317,35 +317,37 @@ __global__ void pair_softmax_bwd_kernel(const float* __restrict__ y, const float
   }
 }
 
-// depthwise 3x3 (pad 1, multiplier mult, stride st): data gradient, gather form
-__global__ void dwconv_bwd_data_kernel(const float* __restrict__ g, int B, int H, int W, int Cin, int mult, int stride,
+// depthwise 3x3 (pad 1, multiplier mult, stride st): data gradient, gather form, 4 input channels per thread.
+// Only taps r with (iy + 1 - r) % st == 0 reach an output row: r starts at (iy + 1) % st and steps by st, so with the
+// RPN's stride 8 most pixels find no tap and just write zeros.
+template <int MULT>
+__global__ void dwconv_bwd_data_kernel(const float* __restrict__ g, int B, int H, int W, int Cin, int mult_rt, int stride,
                                        const float* __restrict__ w, float* __restrict__ gx, int Ho, int Wo) {
-  const int Cout = Cin * mult;
-  const long long total = (long long)B * H * W * Cin;
+  const int mult = MULT > 0 ? MULT : mult_rt;
+  const int Cout = Cin * mult, C4 = Cin >> 2;
+  const long long total = (long long)B * H * W * C4;
+  f32x4* o4 = reinterpret_cast<f32x4*>(gx);
   GRID_STRIDE(i, total) {
-    const int ci = (int)(i % Cin);
-    long long t = i / Cin;
+    const int c0 = (int)(i % C4) * 4;
+    long long t = i / C4;
     const int ix = (int)(t % W); t /= W;
     const int iy = (int)(t % H);
     const int b = (int)(t / H);
-    float acc = 0.f;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int ty = iy + 1 - r;
-      if (ty < 0 || ty % stride) continue;
-      const int oy = ty / stride;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int r = (iy + 1) % stride; r < 3 && r <= iy + 1; r += stride) {      // r <= iy + 1: output row >= 0
+      const int oy = (iy + 1 - r) / stride;
       if (oy >= Ho) continue;
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const int tx = ix + 1 - s;
-        if (tx < 0 || tx % stride) continue;
-        const int ox = tx / stride;
+      for (int s = (ix + 1) % stride; s < 3 && s <= ix + 1; s += stride) {
+        const int ox = (ix + 1 - s) / stride;
         if (ox >= Wo) continue;
-        const float* gp = g + ((long long)(b * Ho + oy) * Wo + ox) * Cout + ci * mult;
-        for (int e = 0; e < mult; ++e) acc += gp[e] * w[(ci * mult + e) * 9 + r * 3 + s];
+        const float* gp = g + ((long long)(b * Ho + oy) * Wo + ox) * Cout + c0 * mult;
+        const float* wp = w + (long long)c0 * mult * 9 + r * 3 + s;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          for (int e = 0; e < mult; ++e) acc[k] += gp[k * mult + e] * wp[(k * mult + e) * 9];
       }
     }
-    gx[i] = acc;
+    o4[i] = acc;
   }
 }
 
@@ -663,9 +665,13 @@ extern "C" int nbm_dwconv3x3_bwd(const float* x, const float* g, const float* w,
   if (!x || !g || !w || B <= 0 || Cin <= 0 || mult <= 0 || stride <= 0) return NBM_EINVAL;
   if ((H + 2 - 3) / stride + 1 != Ho || (W + 2 - 3) / stride + 1 != Wo) return NBM_EINVAL;
   const int Cout = Cin * mult;
-  if (gx)
-    hipLaunchKernelGGL(dwconv_bwd_data_kernel, dim3(grid_for((long long)B * H * W * Cin)), dim3(TPB), 0, ST, g, B, H, W,
-                       Cin, mult, stride, w, gx, Ho, Wo);
+  if (gx) {
+    if ((Cin & 3) || !nbm_aligned16(gx)) return NBM_EALIGN;
+    const dim3 grid(grid_for((long long)B * H * W * (Cin / 4)));
+    if (mult == 2) hipLaunchKernelGGL(dwconv_bwd_data_kernel<2>, grid, dim3(TPB), 0, ST, g, B, H, W, Cin, mult, stride, w, gx, Ho, Wo);
+    else if (mult == 4) hipLaunchKernelGGL(dwconv_bwd_data_kernel<4>, grid, dim3(TPB), 0, ST, g, B, H, W, Cin, mult, stride, w, gx, Ho, Wo);
+    else hipLaunchKernelGGL(dwconv_bwd_data_kernel<0>, grid, dim3(TPB), 0, ST, g, B, H, W, Cin, mult, stride, w, gx, Ho, Wo);
+  }
   if (gw) {
     hipError_t e = hipMemsetAsync(gw, 0, sizeof(float) * Cout * 9, ST);
     if (e == hipSuccess && gb) e = hipMemsetAsync(gb, 0, sizeof(float) * Cout, ST);

@@ -4,11 +4,8 @@ state_dict keys: `fpn.pt_wise.{i}` (bottom-up) and `fpn.out_convs.{i}` ('0' appl
 level, reference fpn.py:137-145 / SURVEY Appendix C-2).  The 3x3 384->256 output convolutions carry 70 %
 of the detector's forward FLOPs; they run on the fp32-MFMA implicit-GEMM kernel.
 """
-import torch
 import torch.nn as nn
 
-from .. import ops
-from . import _prep
 from . import functional as Fn
 from .self_attention import Scaled
 
@@ -22,39 +19,17 @@ class FPN(nn.Module):
 
     def forward(self, x):
         """x: bottom-up list of NHWC maps (or Scaled(map, factor)) -> bottom-up list of NHWC [B,h,w,out_cn]."""
-        if not torch.is_grad_enabled():
-            return self._forward_fused(x)
-        lat = []
-        for i, fm in enumerate(x):
-            t, alpha = (fm.tensor, fm.factor) if isinstance(fm, Scaled) else (fm, 1.0)
-            c = self.pt_wise[str(i)]
-            lat.append(Fn.conv(t, c.weight, bias=c.bias, alpha=alpha))
-        i = 0
-        out = lat.pop(-1)
-        c = self.out_convs[str(i)]
-        outs = [Fn.conv(out, c.weight, bias=c.bias, kh=3, kw=3, pad=1)]
-        while len(lat) > 0:
-            i += 1
-            p = lat.pop(-1)
-            out = Fn.UpsampleAdd.apply(out, p, p.shape[1], p.shape[2])
-            c = self.out_convs[str(i)]
-            outs.insert(0, Fn.conv(out, c.weight, bias=c.bias, kh=3, kw=3, pad=1))
-        return outs
-
-
-    def _forward_fused(self, x):
-        """Inference schedule: the top-down merge `bilinear(coarser) + lateral` (reference fpn.py:143-144) happens in
-        the epilogue of the lateral 1x1 GEMM, so the lateral maps are never written and re-read on their own."""
+        # The top-down merge `bilinear(coarser) + lateral` (reference fpn.py:143-144) happens in the epilogue of the
+        # lateral 1x1 GEMM, so the lateral maps are never written and re-read on their own.
         outs, merged = [], None
         for i in range(len(x) - 1, -1, -1):                       # coarsest level first
             fm = x[i]
             t, alpha = (fm.tensor, fm.factor) if isinstance(fm, Scaled) else (fm, 1.0)
             c = self.pt_wise[str(i)]
-            merged = ops.conv2d(t, _prep.krsc(c.weight), shift=c.bias.detach(), alpha=alpha, up=merged)
+            merged = Fn.conv(t, c.weight, bias=c.bias, alpha=alpha, up=merged)
             oc = self.out_convs[str(len(x) - 1 - i)]
-            outs.insert(0, ops.conv2d(merged, _prep.krsc(oc.weight), 3, 3, 1, 1, shift=oc.bias.detach()))
+            outs.insert(0, Fn.conv(merged, oc.weight, bias=oc.bias, kh=3, kw=3, pad=1))
         return outs
-
 
 def build_fpn(args, channels):
     if args.fpn != 'fpn':

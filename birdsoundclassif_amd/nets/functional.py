@@ -37,12 +37,13 @@ class Conv(Function):
     """y = act(alpha * conv(x, W) * scale + (bias | shift) + residual); also nn.Linear (x [1,M,1,K])."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, scale, shift, residual, kh, kw, stride, pad, act, alpha):
+    def forward(ctx, x, weight, bias, scale, shift, residual, kh, kw, stride, pad, act, alpha, up=None):
         wk = _prep.krsc(weight) if weight.dim() == 4 else weight.detach()
         sh = bias.detach() if bias is not None else shift
-        y = ops.conv2d(x, wk, kh, kw, stride, pad, scale=scale, shift=sh, residual=residual, act=act, alpha=alpha)
+        y = ops.conv2d(x, wk, kh, kw, stride, pad, scale=scale, shift=sh, residual=residual, act=act, alpha=alpha, up=up)
         ctx.geom = (kh, kw, stride, pad, act, alpha)
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
+        ctx.up_hw = tuple(up.shape[1:3]) if up is not None else None
         ctx.save_for_backward(x, weight, scale, y if act in (ACT_RELU, ACT_LEAKY) else None)
         return y
 
@@ -77,17 +78,22 @@ class Conv(Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = ops.colsum(gp, N)
         gres = g if (ctx.has_res and ctx.needs_input_grad[5]) else None
-        return gx, gw, gb, None, None, gres, None, None, None, None, None, None
+        gup = None
+        if ctx.up_hw is not None and ctx.needs_input_grad[12]:        # fused top-down merge: d/d(coarse map)
+            gup = ops.upsample_bilinear_bwd(g, *ctx.up_hw)
+        return gx, gw, gb, None, None, gres, None, None, None, None, None, None, gup
 
 
-def conv(x, weight, bias=None, scale=None, shift=None, residual=None, kh=1, kw=1, stride=1, pad=0, act=ACT_NONE, alpha=1.0):
-    return Conv.apply(x, weight, bias, scale, shift, residual, kh, kw, stride, pad, act, alpha)
+def conv(x, weight, bias=None, scale=None, shift=None, residual=None, kh=1, kw=1, stride=1, pad=0, act=ACT_NONE, alpha=1.0,
+         up=None):
+    """`up` [B,h,w,N]: + bilinear_align_corners(up) in the GEMM epilogue (FPN top-down merge, act must be NONE)."""
+    return Conv.apply(x, weight, bias, scale, shift, residual, kh, kw, stride, pad, act, alpha, up)
 
 
 def linear(x2d, weight, bias=None, act=ACT_NONE, residual=None):
     M, K = x2d.shape
     res = residual.view(1, M, 1, -1) if residual is not None else None
-    return Conv.apply(x2d.view(1, M, 1, K), weight, bias, None, None, res, 1, 1, 1, 0, act, 1.0).view(M, -1)
+    return Conv.apply(x2d.view(1, M, 1, K), weight, bias, None, None, res, 1, 1, 1, 0, act, 1.0, None).view(M, -1)
 
 
 class Add(Function):
