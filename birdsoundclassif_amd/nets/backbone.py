@@ -51,8 +51,16 @@ class _Bottleneck(nn.Module):
         self.bn3 = norm_layer(planes * 4)
         self.downsample = downsample
         self.stride = stride
+        # set by _ResNetBody: is the input a ReLU output / does the output feed anything besides the next block
+        self.mask_input, self.mask_gy = False, True
 
     def forward(self, x):
+        if torch.is_grad_enabled() and x.dim() == 4 and self.conv1.weight.shape[0] % 32 == 0:
+            ds = self.downsample
+            sd, bd = ds[1].affine() if ds is not None else (None, None)
+            return Fn.Bottleneck.apply(x, self.conv1.weight, self.conv2.weight, self.conv3.weight,
+                                       ds[0].weight if ds is not None else None, *self.bn1.affine(), *self.bn2.affine(),
+                                       *self.bn3.affine(), sd, bd, self.stride, self.mask_input, self.mask_gy)
         s, b = self.bn1.affine()
         o = Fn.conv(x, self.conv1.weight, scale=s, shift=b, act=ops.ACT_RELU)
         s, b = self.bn2.affine()
@@ -83,6 +91,8 @@ class _ResNetBody(nn.Module):
                 if bi == 0 and (st != 1 or inplanes != planes * 4):
                     ds = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=st, bias=False), norm_layer(planes * 4))
                 blocks.append(_Bottleneck(inplanes, planes, st, ds, norm_layer))
+                blocks[-1].mask_input = not (li == 1 and bi == 0)      # layer1.0 reads the max-pool output
+                blocks[-1].mask_gy = bi == n - 1                       # the layer output is a tap (several consumers)
                 inplanes = planes * 4
             setattr(self, f'layer{li}', nn.Sequential(*blocks))
 

@@ -84,6 +84,76 @@ class Conv(Function):
         return gx, gw, gb, None, None, gres, None, None, None, None, None, None, gup
 
 
+class Bottleneck(Function):
+    """One ResNet v1.5 bottleneck (conv1x1-BN-ReLU, conv3x3/s-BN-ReLU, conv1x1-BN, + shortcut, ReLU) with FrozenBN
+    affines, as ONE tape node.  The backward pass knows the block's structure, so the ReLU masks and the shortcut
+    addition ride in the data-gradient GEMM epilogues (`mask`, `residual`) instead of separate read-modify-write passes:
+      * `mask_input`: the block input is itself a ReLU output, so d/dx is returned already multiplied by (x > 0);
+      * `mask_gy`: the incoming gradient still has to be masked by (y > 0) -- true for blocks whose output has other
+        consumers (the layer taps); interior blocks receive it pre-masked from their successor's `mask_input`.
+    Masking is a 0/1 multiply, so a gradient that was masked early and is masked again after autograd's summation is
+    unchanged."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, w3, wd, s1, b1, s2, b2, s3, b3, sd, bd, stride, mask_input, mask_gy):
+        a1 = ops.conv2d(x, _prep.krsc(w1), scale=s1, shift=b1, act=ACT_RELU)
+        a2 = ops.conv2d(a1, _prep.krsc(w2), 3, 3, stride, 1, scale=s2, shift=b2, act=ACT_RELU)
+        idt = x if wd is None else ops.conv2d(x, _prep.krsc(wd), 1, 1, stride, 0, scale=sd, shift=bd)
+        y = ops.conv2d(a2, _prep.krsc(w3), scale=s3, shift=b3, residual=idt, act=ACT_RELU)
+        ctx.save_for_backward(x, a1, a2, y, w1, w2, w3, wd, s1, s2, s3, sd)
+        ctx.cfg = (stride, mask_input, mask_gy)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, a1, a2, y, w1, w2, w3, wd, s1, s2, s3, sd = ctx.saved_tensors
+        stride, mask_input, mask_gy = ctx.cfg
+        need = ctx.needs_input_grad
+        B, H, W, Cin = x.shape
+        Ho, Wo = y.shape[1:3]
+        P, N3 = w1.shape[0], w3.shape[0]
+        g3 = ops.relu_bwd(gy.contiguous(), y) if mask_gy else gy.contiguous()
+        g3r = g3.view(-1, N3)
+        k1, k2, k3 = _prep.krsc(w1), _prep.krsc(w2), _prep.krsc(w3)
+
+        def wgrad(g2d, inp, wk, weight, scale, **geom):
+            out = torch.zeros_like(wk)
+            ops.conv_wgrad(g2d, inp, out, row_scale=scale, g_ld=g2d.shape[1], out_ld=wk.shape[1], **geom)
+            return _w_to_ref_layout(out, weight)
+
+        gw3 = wgrad(g3r, a2, k3, w3, s3, B=B, H=Ho, W=Wo, Cin=P, N=N3) if need[3] else None
+        g2 = torch.empty_like(a2)
+        ops.conv_dgrad(g3r, k3, g2, B=B, H=Ho, W=Wo, Cin=P, N=N3, g_ld=N3, w_ld=k3.shape[1], a_scale=s3, mask=a2)
+        g2r = g2.view(-1, P)
+        geom2 = dict(B=B, H=H, W=W, Cin=P, N=P, kh=3, kw=3, stride=stride, pad=1)
+        gw2 = wgrad(g2r, a1, k2, w2, s2, **geom2) if need[2] else None
+        g1 = torch.empty_like(a1)
+        ops.conv_dgrad(g2r, k2, g1, g_ld=P, w_ld=k2.shape[1], a_scale=s2, mask=a1, **geom2)
+        g1r = g1.view(-1, P)
+        gwd = None
+        if wd is None:
+            gid = g3                                                     # identity shortcut
+        else:
+            kd = _prep.krsc(wd)
+            if need[4]:
+                gwd = wgrad(g3r, x, kd, wd, sd, B=B, H=H, W=W, Cin=Cin, N=N3, stride=stride)
+            if stride > 1:                                               # compact GEMM, then spread over the input grid
+                gc = torch.empty((B, Ho, Wo, Cin), device=x.device, dtype=torch.float32)
+                ops.conv_dgrad(g3r, kd, gc, B=B, H=Ho, W=Wo, Cin=Cin, N=N3, g_ld=N3, w_ld=kd.shape[1], a_scale=sd)
+                gid = ops.zero_insert(gc, H, W, stride)
+            else:
+                gid = torch.empty_like(x)
+                ops.conv_dgrad(g3r, kd, gid, B=B, H=H, W=W, Cin=Cin, N=N3, g_ld=N3, w_ld=kd.shape[1], a_scale=sd)
+        gw1 = wgrad(g1r, x, k1, w1, s1, B=B, H=H, W=W, Cin=Cin, N=P) if need[1] else None
+        gx = None
+        if need[0]:
+            gx = torch.empty_like(x)
+            ops.conv_dgrad(g1r, k1, gx, B=B, H=H, W=W, Cin=Cin, N=P, g_ld=P, w_ld=k1.shape[1], a_scale=s1, residual=gid,
+                           mask=x if mask_input else None)
+        return (gx, gw1, gw2, gw3, gwd) + (None,) * 11
+
+
 def conv(x, weight, bias=None, scale=None, shift=None, residual=None, kh=1, kw=1, stride=1, pad=0, act=ACT_NONE, alpha=1.0,
          up=None):
     """`up` [B,h,w,N]: + bilinear_align_corners(up) in the GEMM epilogue (FPN top-down merge, act must be NONE)."""

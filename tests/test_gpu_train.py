@@ -410,3 +410,47 @@ def test_tf_rcnn_train_step_vs_reference_golden(tag, pe_qk):
     assert abs(opt.grad_norm() - gn_ref) <= 2e-3 * gn_ref, (opt.grad_norm(), gn_ref)
     for name in [k[len(f'{tag}.grad.'):-len('.shape')] for k in g if k.startswith(f'{tag}.grad.') and k.endswith('.shape')]:
         check_packed(g, f'{tag}.grad.{name}', params[name].grad, atol=2e-4 * gn_ref / 50, rtol=2e-3)
+
+
+def test_fused_bottleneck_chain_backward():
+    """Fn.Bottleneck (one tape node per block, ReLU masks and shortcut add inside the dgrad epilogues) on a chain
+    downsample-block -> identity-block -> identity-block, the way _ResNetBody wires the mask flags, vs torch autograd."""
+    B, H, W, Cin, P, st = 2, 14, 18, 64, 32, 2
+    x = rnd('bnx', B, Cin, H, W).abs().requires_grad_(True)          # a ReLU output, like every block input but layer1.0
+    def mk(tag, co, ci, k):
+        return rnd(('bnw', tag), co, ci, k, k, scale=(2.0 / (ci * k * k)) ** 0.5).requires_grad_(True)
+    blocks = []
+    cin = Cin
+    for bi in range(3):
+        ws = dict(w1=mk((bi, 1), P, cin, 1), w2=mk((bi, 2), P, P, 3), w3=mk((bi, 3), 4 * P, P, 1),
+                  wd=mk((bi, 4), 4 * P, cin, 1) if bi == 0 else None)
+        aff = {k: (1 + 0.1 * rnd(('bns', bi, k), n), 0.1 * rnd(('bnb', bi, k), n))
+               for k, n in (('1', P), ('2', P), ('3', 4 * P), ('d', 4 * P))}
+        blocks.append((ws, aff, st if bi == 0 else 1))
+        cin = 4 * P
+    def bn(t, a):
+        return t * a[0].view(1, -1, 1, 1) + a[1].view(1, -1, 1, 1)
+    h = x
+    for ws, aff, s in blocks:
+        o = F.relu(bn(F.conv2d(h, ws['w1']), aff['1']))
+        o = F.relu(bn(F.conv2d(o, ws['w2'], stride=s, padding=1), aff['2']))
+        idt = h if ws['wd'] is None else bn(F.conv2d(h, ws['wd'], stride=s), aff['d'])
+        h = F.relu(bn(F.conv2d(o, ws['w3']), aff['3']) + idt)
+    go = rnd('bng', *h.shape)
+    h.backward(go)
+    xd = nhwc(x).requires_grad_(True)
+    dev = [{k: (v.detach().cuda().requires_grad_(True) if v is not None else None) for k, v in ws.items()} for ws, _, _ in blocks]
+    hd = xd
+    for bi, ((ws, aff, s), wdv) in enumerate(zip(blocks, dev)):
+        a = {k: (v[0].cuda(), v[1].cuda()) for k, v in aff.items()}
+        sd, bd = a['d'] if wdv['wd'] is not None else (None, None)
+        hd = Fn.Bottleneck.apply(hd, wdv['w1'], wdv['w2'], wdv['w3'], wdv['wd'], *a['1'], *a['2'], *a['3'], sd, bd, s,
+                                 True, bi == 2)
+    close(nchw(hd), h, 1e-5, 'bottleneck chain fwd')
+    hd.backward(nhwc(go))
+    # the chain input is declared a ReLU output (mask_input): d/dx carries the (x > 0) mask of the producer's ReLU
+    close(nchw(xd.grad), x.grad * (x > 0), 2e-5, 'bottleneck dx')
+    for bi, (ws, wdv) in enumerate(zip([b[0] for b in blocks], dev)):
+        for k in ('w1', 'w2', 'w3', 'wd'):
+            if ws[k] is not None:
+                close(wdv[k].grad, ws[k].grad, 3e-5, f'bottleneck {bi} d{k}')
