@@ -39,6 +39,7 @@ struct BwdParams {
   int b_generic;             // TN: gather the X tile element-wise (Cin % 4 != 0)
   int w_row;                 // NN: floats between W[n] and W[n+1] (= taps*Cin, or the padded pitch)
   int vec_epi;               // NN: 16-byte epilogue accesses are legal
+  float* bias_grad;          // TN: += sum_m g[m][n] (added by the workgroups of the first N-tile) or null
 };
 
 __device__ __forceinline__ int xcd_tile(int nwg, int bid) {
@@ -437,6 +438,9 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(const BwdParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  const bool do_bias = p.bias_grad != nullptr && tile_n == 0;
+  float bsum = 0.f;
+
   auto mfma_group = [&](const float* Ab, const float* Bb, int q) {
     float a[MT][4], b[NT][4];
 #pragma unroll
@@ -464,6 +468,11 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(const BwdParams p) {
     constexpr bool STORE = decltype(store_c)::value, LOAD = decltype(load_c)::value;
     const int cur = kt & 1;
     __syncthreads();
+    if (do_bias) {            // workgroup-uniform: column sums of the G tile (bias gradient), 16 pixels per thread
+      const float* Ar = As + (cur * BK + (tid >> 7) * 16) * AP + (tid & 127);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) bsum += Ar[e * AP];
+    }
     const float* Ab = As + (cur * BK + lh * 16) * AP + wm0 + lrow;
     const float* Bb = Bs + (cur * BK + lh * 16) * BP + wn0 + lrow;
     mfma_group(Ab, Bb, 0);
@@ -505,6 +514,10 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(const BwdParams p) {
     k_step(kt, F{}, F{});
   }
 
+  if (do_bias) {
+    const int n = bm0 + (tid & 127);
+    if (n < p.N) atomicAdd(p.bias_grad + (long long)grp * p.N + n, bsum);
+  }
   float* __restrict__ og = p.out + (long long)grp * p.out_gs;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -541,6 +554,7 @@ static int fill_common(const nbm_bwd_desc* d, BwdParams& p) {
   p.stride = d->stride; p.pad = d->pad; p.Ho = d->Ho; p.Wo = d->Wo;
   p.g_ld = d->g_ld; p.w_ld = d->w_ld; p.x_ld = d->x_ld; p.out_ld = d->out_ld; p.res_ld = d->res_ld; p.mask_ld = d->mask_ld;
   p.alpha = d->alpha;
+  p.bias_grad = d->bias_grad;
   return NBM_OK;
 }
 

@@ -70,12 +70,15 @@ class Conv(Function):
             gx = torch.empty_like(x)
             ops.conv_dgrad(gp, wk, gx, B=B, H=H, W=W, Cin=Cin, N=N, kh=kh, kw=kw, stride=stride, pad=pad,
                            g_ld=gp.shape[1], w_ld=wk.shape[1], a_scale=scale, alpha=alpha)
+        want_gb = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             gwk = torch.zeros_like(wk)
+            if want_gb:                                   # the bias gradient rides along in the weight-gradient kernel
+                gb = torch.zeros((N,), device=x.device, dtype=torch.float32)
             ops.conv_wgrad(gp, x, gwk, B=B, H=H, W=W, Cin=Cin, N=N, kh=kh, kw=kw, stride=stride, pad=pad,
-                           g_ld=gp.shape[1], out_ld=wk.shape[1], row_scale=scale, alpha=alpha)
+                           g_ld=gp.shape[1], out_ld=wk.shape[1], row_scale=scale, alpha=alpha, bias_grad=gb)
             gw = _w_to_ref_layout(gwk, weight)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        elif want_gb:
             gb = ops.colsum(gp, N)
         gres = g if (ctx.has_res and ctx.needs_input_grad[5]) else None
         gup = None

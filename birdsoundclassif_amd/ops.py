@@ -382,7 +382,7 @@ def conv_dgrad(g, w, out, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, g_ld=
 
 
 def conv_wgrad(g, x, out, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, g_ld=None, x_ld=None, out_ld=None,
-               row_scale=None, alpha=1.0, groups=1, g_gs=0, x_gs=0, out_gs=0):
+               row_scale=None, alpha=1.0, groups=1, g_gs=0, x_gs=0, out_gs=0, bias_grad=None):
     """Raw nbm_conv_wgrad: out[N][kh*kw*Cin] += g^T x im2col(x); `out` must be zeroed (or hold a partial sum)."""
     d = _bwd_desc(g, B=B, H=H, W=W, Cin=Cin, N=N, kh=kh, kw=kw, stride=stride, pad=pad,
                   g_ld=N if g_ld is None else g_ld, groups=groups, alpha=alpha)
@@ -391,6 +391,7 @@ def conv_wgrad(g, x, out, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, g_ld=
     d.out_ld = kh * kw * Cin if out_ld is None else out_ld
     d.row_scale = row_scale.data_ptr() if row_scale is not None else None
     d.g_gs, d.x_gs, d.out_gs = g_gs, x_gs, out_gs
+    d.bias_grad = bias_grad.data_ptr() if bias_grad is not None else None       # [N] zeros: += column sums of g
     with _timed(('wgrad', B, H, W, Cin, N, kh, stride, groups)):
         check(lib().nbm_conv_wgrad(C.byref(d), _stream()), 'nbm_conv_wgrad')
     return out

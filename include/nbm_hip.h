@@ -217,6 +217,7 @@ typedef struct nbm_bwd_desc {
   int B, H, W, Cin, N, kh, kw, stride, pad, Ho, Wo;   /* geometry of the FORWARD convolution                */
   int g_ld, w_ld, x_ld, out_ld, res_ld, mask_ld;
   float alpha;
+  float* bias_grad;      /* wgrad: [groups][N], += sum_m g[m][n] (the bias gradient rides along; zeroed by the caller) or NULL */
 } nbm_bwd_desc;
 
 /* dX[b][iy][ix][c] = alpha * sum_{r,s,n} g[b][(iy+pad-r)/stride][(ix+pad-s)/stride][n] * a_scale[n] * W[n][r][s][c]
