@@ -40,6 +40,9 @@ struct BwdParams {
   int w_row;                 // NN: floats between W[n] and W[n+1] (= taps*Cin, or the padded pitch)
   int vec_epi;               // NN: 16-byte epilogue accesses are legal
   float* bias_grad;          // TN: += sum_m g[m][n] (added by the workgroups of the first N-tile) or null
+  int phased;                // NN, stride 2: M tiles are grouped by the parity class of (iy + pad, ix + pad)
+  int ph_tiles[4];           //   M tiles of each class; tile_m = 4 * (tile within class) + class, so the four classes of
+                             //   one image region run side by side and fill the same DRAM pages together
 };
 
 __device__ __forceinline__ int xcd_tile(int nwg, int bid) {
@@ -74,8 +77,32 @@ __global__ __launch_bounds__(256, 2) void igemm_nn_kernel(const BwdParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
   const int lrow = lane & 31, lh = lane >> 5;
-  const int st = p.stride, taps = p.kh * p.kw;
+  const int st = p.stride;
   const int frm = (p.kh - 1) / st, fsm = (p.kw - 1) / st;      // largest tap shift in G rows / columns
+
+  // Row -> input pixel.  Plain: row q = bm0 + r enumerates (b, iy, ix) row-major.  Phased (stride 2): a pixel only
+  // receives the taps with r = (iy + pad) mod 2, s = (ix + pad) mod 2, so the M tiles are grouped by that parity class;
+  // a tile enumerates its class's sub-grid (b, u, v) -> (2u + y0, 2v + x0) and its K loop visits the class's taps only
+  // (1, 2, 2 or 4 of the 9 taps of a 3x3 instead of all 9 with 3/4 of the loads masked to zero).
+  int y0 = 0, x0 = 0, Hp = p.H, Wp = p.W, rows_here = p.M, q0 = bm0, r_begin = 0, s_begin = 0, t_step = 1;
+  if (p.phased) {
+    const int ph = tile_m & 3;
+    if ((tile_m >> 2) >= p.ph_tiles[ph]) return;               // classes differ by at most a row / column of tiles
+    q0 = (tile_m >> 2) * BM;
+    r_begin = ph >> 1; s_begin = ph & 1; t_step = 2;
+    y0 = (r_begin + p.pad) & 1; x0 = (s_begin + p.pad) & 1;
+    Hp = (p.H - y0 + 1) >> 1; Wp = (p.W - x0 + 1) >> 1;
+    rows_here = p.B * Hp * Wp;
+  }
+  auto decode = [&](int q, int& b, int& iy, int& ix) -> bool {
+    const bool ok = q < rows_here;
+    const int qq = ok ? q : 0, hw = Hp * Wp;
+    b = qq / hw;
+    const int rem = qq - b * hw, u = rem / Wp, v = rem - u * Wp;
+    iy = p.phased ? 2 * u + y0 : u;
+    ix = p.phased ? 2 * v + x0 : v;
+    return ok;
+  };
 
   // A staging: 128 rows x 8 chunks of 16 B.  Row i gathers G at (b, fy - r/st, fx - s/st) for the taps whose parity
   // matches; offsets are relative to a block-uniform base shifted by the largest tap so that they stay non-negative.
@@ -84,10 +111,8 @@ __global__ __launch_bounds__(256, 2) void igemm_nn_kernel(const BwdParams p) {
   unsigned long long a_taps[4];
   long long blk_base;
   {
-    const int m0 = bm0 < p.M ? bm0 : 0;
-    const int hw = p.H * p.W;
-    const int b = m0 / hw, rem = m0 - b * hw;
-    const int iy = rem / p.W, ix = rem - iy * p.W;
+    int b, iy, ix;
+    decode(q0, b, iy, ix);
     // column 0 of the first row's G row: with stride > 1 two consecutive input rows can map to the SAME G row, so the
     // first pixel of the tile is not necessarily the smallest address (offsets must stay non-negative)
     (void)ix;
@@ -95,12 +120,8 @@ __global__ __launch_bounds__(256, 2) void igemm_nn_kernel(const BwdParams p) {
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int m = bm0 + r0 + 32 * i;
-    const bool ok = m < p.M;
-    const int mm = ok ? m : 0;
-    const int hw = p.H * p.W;
-    const int b = mm / hw, rem = mm - b * hw;
-    const int iy = rem / p.W, ix = rem - iy * p.W;
+    int b, iy, ix;
+    const bool ok = decode(q0 + r0 + 32 * i, b, iy, ix);
     const int fy = (iy + p.pad) / st, fx = (ix + p.pad) / st;
     const int py = (iy + p.pad) - fy * st, px = (ix + p.pad) - fx * st;
     const long long base = ((long long)(b * p.Ho + fy) * p.Wo + fx) * p.g_ld;
@@ -129,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void igemm_nn_kernel(const BwdParams p) {
   const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(wg_, (unsigned)(wbytes < 0x7ffffff0ll ? wbytes : 0x7ffffff0ll));
 
   f32x4 ra[4], rb[BPASS], rsc = {1.f, 1.f, 1.f, 1.f};
-  int cur_r = 0, cur_s = 0, cur_n0 = 0;
+  int cur_r = r_begin, cur_s = s_begin, cur_n0 = 0;
 
   auto load_tiles = [&]() {
     const int tap = cur_r * p.kw + cur_s;
@@ -140,7 +161,8 @@ __global__ __launch_bounds__(256, 2) void igemm_nn_kernel(const BwdParams p) {
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) rb[i] = buf_load4(rsrc_b, b_rel[i], b_soff);
     if (p.a_scale) rsc = *reinterpret_cast<const f32x4*>(p.a_scale + cur_n0 + c4 * 4);
-    if (++cur_s == p.kw) { cur_s = 0; if (++cur_r == p.kh) { cur_r = 0; cur_n0 += BK; } }
+    cur_s += t_step;
+    if (cur_s >= p.kw) { cur_s = s_begin; cur_r += t_step; if (cur_r >= p.kh) { cur_r = r_begin; cur_n0 += BK; } }
   };
   auto store_lds = [&](int buf) {
 #pragma unroll
@@ -180,9 +202,13 @@ __global__ __launch_bounds__(256, 2) void igemm_nn_kernel(const BwdParams p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
   };
 
-  const int nk = ((p.N + BK - 1) / BK) * taps;
-  load_tiles();
-  store_lds(0);
+  const int n_r = r_begin < p.kh ? (p.kh - r_begin + t_step - 1) / t_step : 0;
+  const int n_s = s_begin < p.kw ? (p.kw - s_begin + t_step - 1) / t_step : 0;
+  const int nk = ((p.N + BK - 1) / BK) * n_r * n_s;          // 0: no tap reaches this parity class, dX = residual
+  if (nk > 0) {
+    load_tiles();
+    store_lds(0);
+  }
   if (nk > 1) load_tiles();
 
   auto k_step = [&](int kt, auto store_c, auto load_c) {
@@ -224,12 +250,18 @@ __global__ __launch_bounds__(256, 2) void igemm_nn_kernel(const BwdParams p) {
     int kt = 0;
     for (; kt + 2 < nk; ++kt) k_step(kt, T{}, T{});
     if (nk >= 2) { k_step(kt, T{}, F{}); ++kt; }
-    k_step(kt, F{}, F{});
+    if (nk >= 1) k_step(kt, F{}, F{});
   }
   __syncthreads();
 
   float* __restrict__ og = p.out + (long long)grp * p.out_gs;
   const float* __restrict__ rg = p.residual ? p.residual + (long long)grp * p.res_gs : nullptr;
+  auto out_pixel = [&](int q) -> long long {                  // output row of tile row q (q < rows_here)
+    if (!p.phased) return q;
+    int b, iy, ix;
+    decode(q, b, iy, ix);
+    return ((long long)b * p.H + iy) * p.W + ix;
+  };
   if (p.vec_epi) {
     // accumulator tile -> LDS -> 16-byte residual / mask loads and stores (see igemm.hip)
     constexpr int CP = BN + 4;
@@ -249,8 +281,8 @@ __global__ __launch_bounds__(256, 2) void igemm_nn_kernel(const BwdParams p) {
     if (c < p.Cin) {
 #pragma unroll 4
       for (int r = rr; r < BM; r += RPP) {
-        const int m = bm0 + r;
-        if (m >= p.M) break;
+        if (q0 + r >= rows_here) break;
+        const long long m = out_pixel(q0 + r);
         f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CP + cc * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
@@ -276,8 +308,9 @@ __global__ __launch_bounds__(256, 2) void igemm_nn_kernel(const BwdParams p) {
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int m = bm0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        if (m >= p.M) continue;
+        const int q = q0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (q >= rows_here) continue;
+        const long long m = out_pixel(q);
         float v = acc[i][j][e] * p.alpha;
         if (rg) v += rg[(long long)m * p.res_ld + c];
         if (p.mask && !(p.mask[(long long)m * p.mask_ld + c] > 0.f)) v = 0.f;
@@ -582,6 +615,17 @@ extern "C" int nbm_conv_dgrad(const nbm_bwd_desc* d, void* stream) {
                (!d->residual || ((d->res_ld & 3) == 0 && (d->res_gs & 3) == 0 && nbm_aligned16(d->residual))) &&
                (!d->mask || ((d->mask_ld & 3) == 0 && nbm_aligned16(d->mask)))) ? 1 : 0;
   p.m_tiles = (p.M + 127) / 128;
+  if (d->stride == 2) {                  // group the M tiles by parity class (see igemm_nn_kernel)
+    p.phased = 1;
+    int tmax = 0;
+    for (int ph = 0; ph < 4; ++ph) {
+      const int y0 = ((ph >> 1) + d->pad) & 1, x0 = ((ph & 1) + d->pad) & 1;
+      const long long rows = (long long)d->B * ((d->H - y0 + 1) >> 1) * ((d->W - x0 + 1) >> 1);
+      p.ph_tiles[ph] = (int)((rows + 127) / 128);
+      if (p.ph_tiles[ph] > tmax) tmax = p.ph_tiles[ph];
+    }
+    p.m_tiles = 4 * tmax;
+  }
   hipStream_t st = (hipStream_t)stream;
   if (d->Cin > 64) {
     p.n_tiles = (d->Cin + 127) / 128;

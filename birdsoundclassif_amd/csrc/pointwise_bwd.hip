@@ -231,25 +231,6 @@ __global__ void maxpool_bwd_kernel(const uint8_t* __restrict__ idx, const float*
   }
 }
 
-// out[b][y][x][:] = src[b][y/st][x/st][:] where both coordinates are multiples of st, else 0: the data gradient of a
-// strided 1x1 convolution is the compact GEMM result spread over the input grid
-__global__ void zero_insert_kernel(const float* __restrict__ src, int B, int Ho, int Wo, int C4, float* __restrict__ out,
-                                   int H, int W, int st) {
-  const long long total = (long long)B * H * W * C4;
-  const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
-  f32x4* o4 = reinterpret_cast<f32x4*>(out);
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  GRID_STRIDE(i, total) {
-    const int c = (int)(i % C4);
-    long long t = i / C4;
-    const int x = (int)(t % W); t /= W;
-    const int y = (int)(t % H);
-    const int b = (int)(t / H);
-    const bool hit = (y % st == 0) && (x % st == 0) && (y / st < Ho) && (x / st < Wo);
-    o4[i] = hit ? s4[((long long)(b * Ho + y / st) * Wo + x / st) * C4 + c] : zero;
-  }
-}
-
 // gradient of bilinear(align_corners) up-sampling wrt the coarse map, gather form
 __global__ void upsample_bwd_kernel(const float* __restrict__ gy, int B, int Hi, int Wi, int C4, float* __restrict__ gsrc,
                                     int Ho, int Wo, float sh, float sw) {
@@ -627,15 +608,6 @@ extern "C" int nbm_maxpool3x3s2_bwd(const uint8_t* idx, const float* gy, float* 
   if (!nbm_aligned16(gy) || !nbm_aligned16(gx) || (((uintptr_t)idx) & 3u)) return NBM_EALIGN;
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((long long)B * H * W * (C / 4))), dim3(TPB), 0, ST, idx, gy, gx, B, H,
                      W, C / 4, Ho, Wo);
-  return nbm_launch_status();
-}
-extern "C" int nbm_zero_insert(const float* src, int B, int Ho, int Wo, int C, float* out, int H, int W, int stride,
-                               void* stream) {
-  if (!src || !out || B <= 0 || C <= 0 || (C & 3) || stride <= 0 || Ho <= 0 || Wo <= 0 || H <= 0 || W <= 0) return NBM_EINVAL;
-  if ((H - 1) / stride + 1 != Ho || (W - 1) / stride + 1 != Wo) return NBM_EINVAL;
-  if (!nbm_aligned16(src) || !nbm_aligned16(out)) return NBM_EALIGN;
-  hipLaunchKernelGGL(zero_insert_kernel, dim3(grid_for((long long)B * H * W * (C / 4))), dim3(TPB), 0, ST, src, B, Ho, Wo,
-                     C / 4, out, H, W, stride);
   return nbm_launch_status();
 }
 extern "C" int nbm_upsample_bilinear_bwd(const float* gy, int B, int Hi, int Wi, int C, float* gsrc, int Ho, int Wo,

@@ -59,14 +59,7 @@ class Conv(Function):
         wk = _prep.krsc(weight) if weight.dim() == 4 else weight.detach()
         gp = _pad32_rows(g.view(-1, N), N)
         gx = gw = gb = None
-        if ctx.needs_input_grad[0] and kh == 1 and kw == 1 and stride > 1 and pad == 0 and Cin % 4 == 0:
-            # strided 1x1: only the pixels on the stride grid receive gradient -> GEMM on the compact grid, then spread
-            Ho, Wo = gy.shape[1:3]
-            gc = torch.empty((B, Ho, Wo, Cin), device=x.device, dtype=torch.float32)
-            ops.conv_dgrad(gp, wk, gc, B=B, H=Ho, W=Wo, Cin=Cin, N=N, g_ld=gp.shape[1], w_ld=wk.shape[1], a_scale=scale,
-                           alpha=alpha)
-            gx = ops.zero_insert(gc, H, W, stride)
-        elif ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
             ops.conv_dgrad(gp, wk, gx, B=B, H=H, W=W, Cin=Cin, N=N, kh=kh, kw=kw, stride=stride, pad=pad,
                            g_ld=gp.shape[1], w_ld=wk.shape[1], a_scale=scale, alpha=alpha)
@@ -141,13 +134,8 @@ class Bottleneck(Function):
             kd = _prep.krsc(wd)
             if need[4]:
                 gwd = wgrad(g3r, x, kd, wd, sd, B=B, H=H, W=W, Cin=Cin, N=N3, stride=stride)
-            if stride > 1:                                               # compact GEMM, then spread over the input grid
-                gc = torch.empty((B, Ho, Wo, Cin), device=x.device, dtype=torch.float32)
-                ops.conv_dgrad(g3r, kd, gc, B=B, H=Ho, W=Wo, Cin=Cin, N=N3, g_ld=N3, w_ld=kd.shape[1], a_scale=sd)
-                gid = ops.zero_insert(gc, H, W, stride)
-            else:
-                gid = torch.empty_like(x)
-                ops.conv_dgrad(g3r, kd, gid, B=B, H=H, W=W, Cin=Cin, N=N3, g_ld=N3, w_ld=kd.shape[1], a_scale=sd)
+            gid = torch.empty_like(x)                                    # strided 1x1: only the (even, even) class has a tap
+            ops.conv_dgrad(g3r, kd, gid, B=B, H=H, W=W, Cin=Cin, N=N3, stride=stride, g_ld=N3, w_ld=kd.shape[1], a_scale=sd)
         gw1 = wgrad(g1r, x, k1, w1, s1, B=B, H=H, W=W, Cin=Cin, N=P) if need[1] else None
         gx = None
         if need[0]:

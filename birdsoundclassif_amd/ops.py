@@ -463,13 +463,6 @@ def maxpool3x3s2_bwd(idx, gy, H, W):
     return gx
 
 
-def zero_insert(src, H, W, stride):
-    B, Ho, Wo, C_ = src.shape
-    out = torch.empty((B, H, W, C_), device=src.device, dtype=torch.float32)
-    check(lib().nbm_zero_insert(_ptr(_chk(src)), B, Ho, Wo, C_, _ptr(out), H, W, stride, _stream()), 'nbm_zero_insert')
-    return out
-
-
 def upsample_bilinear_bwd(gy, Hi, Wi):
     B, Ho, Wo, C_ = gy.shape
     gs = torch.empty((B, Hi, Wi, C_), device=gy.device, dtype=torch.float32)

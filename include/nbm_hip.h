@@ -221,7 +221,8 @@ typedef struct nbm_bwd_desc {
 } nbm_bwd_desc;
 
 /* dX[b][iy][ix][c] = alpha * sum_{r,s,n} g[b][(iy+pad-r)/stride][(ix+pad-s)/stride][n] * a_scale[n] * W[n][r][s][c]
- * (+ residual, ReLU mask).  g rows must be readable (zero padded) up to ceil(N/32)*32 floats.  Also the plain
+ * (+ residual, ReLU mask).  stride 2: the pixels are processed by parity class of (iy+pad, ix+pad), each class visiting
+ * only the taps that reach it (no multiply-by-structural-zero work).  g rows must be readable (zero padded) up to ceil(N/32)*32 floats.  Also the plain
  * C[M][Cin] = A[M][N] * B[N][Cin] ("NN") GEMM with H = M, W = 1, 1x1. */
 int nbm_conv_dgrad(const nbm_bwd_desc* d, void* stream);
 /* dW[n][(r,s,c)] += alpha * row_scale[n] * sum_m g[m][n] * x[pix(m)+(r,s)][c]; dW must be zeroed by the caller.
@@ -247,9 +248,6 @@ int nbm_mha_small_bwd(const float* q, const float* k, const float* v, const floa
                       int go_ld, float* gq, float* gk, float* gv, int gq_ld, int gk_ld, int gv_ld, float* workspace, int S,
                       int N, int nhead, int hd, int64_t seq_stride, int64_t batch_stride, const int32_t* n_valid,
                       float scale, void* stream);
-/* out[b][y][x][:] = src[b][y/stride][x/stride][:] on the stride grid, 0 elsewhere: spreads the compact data gradient of
- * a strided 1x1 convolution (ResNet downsample branches) over the input grid */
-int nbm_zero_insert(const float* src, int B, int Ho, int Wo, int C, float* out, int H, int W, int stride, void* stream);
 int nbm_upsample_bilinear_bwd(const float* gy, int B, int Hi, int Wi, int C, float* gsrc, int Ho, int Wo, void* stream);
 int nbm_softmax_rows_bwd(const float* p, const float* gp, float* out, int64_t rows, int cols, float alpha, void* stream);
 int nbm_pair_softmax_bwd(const float* y, const float* gy, float* gx, int64_t n_pairs, void* stream);

@@ -40,6 +40,9 @@ def close(got, ref, tol, name):
     (1, 14, 18, 128, 128, 3, 1, 1, True, False, 1.0, False),
     (2, 15, 17, 128, 128, 3, 2, 1, True, False, 1.0, False),
     (2, 12, 14, 256, 512, 1, 2, 0, False, False, 1.0, False),
+    (2, 16, 18, 64, 64, 3, 2, 1, True, False, 1.0, False),            # stride 2, even dims, 64-wide data-gradient tile
+    (1, 13, 16, 64, 128, 1, 2, 0, False, False, 1.0, True),
+    (3, 9, 150, 96, 64, 3, 2, 1, False, False, 1.0, True),            # parity classes spanning several M tiles
     (1, 11, 13, 384, 256, 3, 1, 1, False, False, 1.0, True),
     (2, 9, 10, 64, 384, 1, 1, 0, False, False, 2.0, True),
     (1, 9, 8, 256, 6, 1, 1, 0, False, False, 1.0, True),
