@@ -457,3 +457,31 @@ def test_fused_bottleneck_chain_backward():
         for k in ('w1', 'w2', 'w3', 'wd'):
             if ws[k] is not None:
                 close(wdv[k].grad, ws[k].grad, 3e-5, f'bottleneck {bi} d{k}')
+
+
+@pytest.mark.parametrize('override,expect', [
+    (dict(min_threshold=5000), {'first_class_loss', 'first_regression_loss'}),        # no box survives: "RPN failed"
+    (dict(post_nms_topN=4), {'first_class_loss', 'first_regression_loss'}),           # < 16 RoIs: ProposalTargetLayer -> None
+])
+def test_train_step_soft_failures_keep_first_stage_loss(override, expect, capsys):
+    """reference train.py:236-243: when the RPN yields no RoIs, or the proposal target layer cannot fill its batch, the
+    step optimises the first-stage losses only (the sentinels of layers.py:297-299,359-364)."""
+    from birdsoundclassif_amd.nets import build_model
+    from birdsoundclassif_amd.train import default_args, build_optimizer, train_one_step
+    args = default_args(device='cuda', **override)
+    model, crit = build_model(args)
+    model.load_state_dict(filler_state_dict())
+    model = model.cuda().train()
+    crit.train()
+    opt, _ = build_optimizer(model, args)
+    bb, ids, lengths = synth.label_batch(0, 2)
+    img = torch.from_numpy(synth.image_batch(0, 2))
+    before = model.fpn.out_convs['0'].weight.detach().clone()
+    head_before = model.head.fast_rcnn.rcnn.bbox_reg_layer.weight.detach().clone()
+    np.random.seed(7)
+    loss = train_one_step(model, crit, opt, [img, img, bb, ids, lengths], args.clip_max_norm, 'cuda', negative_sample=False)
+    assert set(loss) == expect and all(torch.isfinite(v) for v in loss.values())
+    assert not torch.equal(model.fpn.out_convs['0'].weight.detach(), before)            # first stage was optimised
+    assert torch.equal(model.head.fast_rcnn.rcnn.bbox_reg_layer.weight.detach(), head_before)   # no gradient: untouched
+    out = capsys.readouterr().out
+    assert ('RPN failed' in out) or ('IMPOSSIBLE TO FILL' in out)
