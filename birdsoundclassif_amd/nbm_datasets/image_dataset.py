@@ -18,6 +18,7 @@ import ast
 import ctypes as C
 import glob
 import os
+import re
 import struct
 import zlib
 
@@ -98,7 +99,9 @@ class Img_dataset(Dataset):
     def _annotations(self, rec):
         if rec not in self._annot:
             a = pd.read_csv(os.path.join(self.ds_p, 'positive_files', rec, 'annotations.csv'), sep=';')
-            self._annot[rec] = {int(i): (ast.literal_eval(c), ast.literal_eval(b))
+            # files written by the reference under NumPy >= 2 spell scalars as `np.int64(12)` (it reads them with eval)
+            lit = lambda t: ast.literal_eval(re.sub(r'np\.(?:int|float)\d+\((-?[\d.eE+-]+)\)', r'\1', t))
+            self._annot[rec] = {int(i): (lit(c), lit(b))
                                 for i, c, b in zip(a['index'], a['coord'], a['bird_id'])}
         return self._annot[rec]
 

@@ -150,8 +150,6 @@ class File_Processor:
     H_PIX, LOW_FREQ, FREQ = 375, 500, 44100
 
     def __init__(self, filepath, extra_str_label='', labels=None):
-        if labels is not None:
-            raise NotImplementedError('label merging (dataset preparation) is outside the hot-path scope')
         self.labels = labels
         self.ext = os.path.basename(filepath).split('.')[-1]
         self.filename = os.path.basename(filepath).replace('.' + self.ext, '').replace(extra_str_label, '')
@@ -179,4 +177,175 @@ class File_Processor:
         imgs, L = fe(torch.from_numpy(pcm)[None].to(fe.device), sr)
         self.spectrogram_length = L
         self.images_device = imgs[0]
-        return [im for im in imgs[0].cpu().numpy()], None
+        img_db = [im for im in imgs[0].cpu().numpy()]
+        if self.labels is None:
+            return img_db, None
+        self.LOW_FREQ = (self.LOW_IDX - 1) * self.FREQ_ACCURACY                  # prepare_dataset.py:137-138
+        self.HIGH_FREQ = (self.HIGH_IDX - 1) * self.FREQ_ACCURACY
+        labels_ = self.merge_and_filter_labels(img_db)
+        if labels_ is None:
+            print('Something went wrong with the annotation file, skipping~~')
+            return None, None
+        return img_db, labels_
+
+    def merge_and_filter_labels(self, img_db):
+        """Annotations of this file (seconds / Hz) -> one row per window that holds at least one box:
+        DataFrame {index, coord: [(x1,y1,x2,y2), ...] in window pixels, bird_id: [...]} (reference
+        prepare_dataset.py:297-375).  Rules kept: time -> column by truncation of t / DT, frequency clipped to the image
+        band and truncated to rows, degenerate boxes dropped, a box belongs to every window it intersects unless the
+        visible part is < 50 % of its width and < 20 px, or < 10 % and < 45 px; coordinates clipped to the window;
+        'noise' labels (bird_id -1) only survive in windows without a real label.  None when the file has no label
+        (the reference raises and skips the file)."""
+        import pandas as pd
+        lab = self.labels.loc[self.labels['filename'] == self.filename].copy()
+        if self.ext == 'mp3':                                            # Audacity offset of mp3 decoding, :309-311
+            for c in ('t_start', 't_end'):
+                lab[c] = lab[c] - 0.03
+        if len(lab) == 0:
+            return None
+        x1 = (lab['t_start'].astype(float) / self.DT).astype(int).to_numpy()
+        x2 = (lab['t_end'].astype(float) / self.DT).astype(int).to_numpy()
+        band = lambda c: ((lab[c].clip(lower=self.LOW_FREQ, upper=self.HIGH_FREQ) - self.LOW_FREQ)
+                          / self.FREQ_ACCURACY).astype(int).to_numpy()
+        y1, y2 = band('f_start'), band('f_end')
+        bird = lab['bird_id'].to_numpy()
+        keep = (y1 != y2) & (x2 - x1 + 1 > 0) & (y2 - y1 + 1 > 0)
+        x1, x2, y1, y2, bird = x1[keep], x2[keep], y1[keep], y2[keep], bird[keep]
+        w = x2 - x1 + 1
+        rows = []                                                        # (window, x1, y1, x2, y2, bird), label-major order
+        n_win = len(img_db)
+        starts = np.arange(n_win) * self.HOP_SPECTRO
+        ends = starts + self.W_PIX - 1
+        for j in range(len(x1)):
+            hit = ((x1[j] >= starts) & (x1[j] <= ends)) | ((x2[j] >= starts) & (x2[j] <= ends)) | \
+                  ((x1[j] < starts) & (x2[j] > ends))
+            for k in np.flatnonzero(hit):
+                inside = min(x2[j], ends[k]) - max(x1[j], starts[k]) + 1
+                if (inside < 0.5 * w[j] and inside < 20) or (inside < 0.1 * w[j] and inside < 45):
+                    continue
+                rows.append((int(k), max(int(x1[j] - starts[k]), 0), max(int(y1[j]), 0),
+                             min(int(x2[j] - starts[k]), self.W_PIX - 1), min(int(y2[j]), self.H_PIX - 1), int(bird[j])))
+        real = {}
+        for r in rows:
+            real[r[0]] = real.get(r[0], 0) + (r[5] != -1)
+        # the reference's inner merge drops windows that hold no real label at all, and then noise rows never survive
+        rows = [r for r in rows if real.get(r[0], 0) > 0 and r[5] != -1]
+        out = {}
+        for r in rows:
+            out.setdefault(r[0], ([], []))
+            out[r[0]][0].append(r[1:5])
+            out[r[0]][1].append(r[5])
+        idx = sorted(out)
+        return pd.DataFrame({'index': idx, 'coord': [out[k][0] for k in idx], 'bird_id': [out[k][1] for k in idx]})
+
+
+# =========================================================================== dataset preparation (SURVEY 8f-4)
+def read_txt_file(file, extra_str_label=''):
+    """Audacity spectral-label file -> DataFrame [t_start, t_end, f_start, f_end, species, filename], one row per
+    annotation (reference utils.py:59-92): a time line `t0<TAB>t1<TAB>species` followed by its frequency line
+    `\\<TAB>f0<TAB>f1`; a repeated time or frequency line inside one record is ignored, records missing either line are
+    dropped."""
+    import pandas as pd
+    rows, cur = [], None
+    with open(file, 'r') as f:
+        for line in f:
+            parts = line.rstrip('\n').split('\t')
+            if parts[0] == '\\':
+                if cur is not None and 'f' not in cur and len(parts) >= 3:
+                    cur['f'] = (parts[1], parts[2])
+            elif len(parts) >= 3:
+                cur = {'t': (parts[0], parts[1]), 'species': parts[2]}
+                rows.append(cur)
+    name = os.path.basename(file).split('.')[0].replace(extra_str_label, '')
+    recs = [(float(r['t'][0]), float(r['t'][1]), float(r['f'][0]), float(r['f'][1]), r['species'], name)
+            for r in rows if 'f' in r and r['species'] != '']
+    return pd.DataFrame(recs, columns=['t_start', 't_end', 'f_start', 'f_end', 'species', 'filename'])
+
+
+def create_label_dataset(directory, birds_dict, noise_labels=(), not_bird_labels=(), suppress_others=True,
+                         suppress_noise=True, other_id=None):
+    """All `*.txt` annotation files of a directory -> one label DataFrame with `bird_id` (reference utils.py:95-173).
+    Same steps: negative f_start clipped to 0, negative f_end -> 20 kHz, duplicates of (file, t_start, species) resolved in
+    favour of the widest frequency range, species -> id through `birds_dict`; `noise_labels` -> -1, `not_bird_labels` (and
+    any species containing 'autre') -> 0, unknown species -> `other_id` (default `birds_dict['Other']`).  The reference's
+    hand-curated spelling-correction table and label lists are data of its authors' corpus: pass your own."""
+    import pandas as pd
+    files = sorted(f for f in os.listdir(directory) if os.path.splitext(f)[-1] == '.txt')
+    labels = pd.concat([read_txt_file(os.path.join(directory, f)) for f in files])
+    labels['f_start'] = labels['f_start'].clip(lower=0)
+    labels.loc[labels['f_end'] < 0, 'f_end'] = 20000
+    labels['f_delta'] = labels['f_end'] - labels['f_start']
+    labels = labels.sort_values('f_delta', ascending=False, kind='stable').drop_duplicates(['filename', 't_start', 'species'])
+    labels = labels.sort_values(['filename', 't_start'], kind='stable').drop(columns='f_delta')
+    labels['bird_id'] = labels['species'].map(lambda x: birds_dict.get(x, np.nan))
+    labels.loc[labels['species'].isin(list(noise_labels)), 'bird_id'] = -1
+    others = labels['species'].map(lambda x: 'autre' in x.lower()) | labels['species'].isin(list(not_bird_labels))
+    labels.loc[others, 'bird_id'] = 0
+    labels['bird_id'] = labels['bird_id'].fillna(birds_dict['Other'] if other_id is None else other_id).astype(int)
+    if suppress_noise:
+        labels = labels.loc[labels['bird_id'] != -1]
+    if suppress_others:
+        labels = labels.loc[labels['bird_id'] != 0]
+    labels.index = range(len(labels))
+    return labels
+
+
+def write_png_gray8(path, img_u8):
+    """uint8 [H,W] -> 8-bit greyscale PNG (filter type 0 on every scanline; the counterpart of `imageio.imwrite`,
+    reference prepare_dataset.py:85-87)."""
+    import struct
+    import zlib
+    img = np.ascontiguousarray(img_u8, dtype=np.uint8)
+    H, W = img.shape
+    raw = np.zeros((H, W + 1), dtype=np.uint8)
+    raw[:, 1:] = img
+    def chunk(kind, data):
+        return struct.pack('>I', len(data)) + kind + data + struct.pack('>I', zlib.crc32(kind + data) & 0xFFFFFFFF)
+    with open(path, 'wb') as f:
+        f.write(b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', W, H, 8, 0, 0, 0, 0)) +
+                chunk(b'IDAT', zlib.compress(raw.tobytes(), 6)) + chunk(b'IEND', b''))
+
+
+def prepare_dataset(directory, out_directory, freq_accuracy=33.3, dt=0.003, overlap_spectro=0.2, w_pix=1024,
+                    annotations=True, labels=None, audio_format='wav', keep_files=None, device='cuda'):
+    """wav recordings (+ label DataFrame) -> the `Img_dataset` directory layout (reference prepare_dataset.py:12-89):
+    `positive_files/<dir>__<rec>/<dir>__<rec>__<window:05d>.png` + `annotations.csv` (sep ';', columns index / coord /
+    bird_id) for windows that hold a label, `negative_files/...` for the others (the first 1000 windows of a file only).
+    Spectrogram windows come from the device front end; `labels` is what `create_label_dataset` returns (required when
+    `annotations`).  Returns the number of (positive, negative) images written."""
+    import glob
+    top_dir = os.path.basename(os.path.normpath(directory))
+    if annotations and labels is None:
+        raise ValueError('annotations=True needs the label DataFrame (create_label_dataset)')
+    n_pos = n_neg = 0
+    for file in sorted(glob.glob(os.path.join(directory, f'*.{audio_format}'))):
+        fp = File_Processor(file, '', labels if annotations else None)
+        if keep_files is not None and fp.filename not in keep_files:
+            print(f'** File {fp.filename} not included, going to next file **')
+            continue
+        rec = top_dir + '__' + fp.filename.replace('#', '__')
+        out_pos_dir = os.path.join(out_directory, 'positive_files', rec)
+        out_neg_dir = os.path.join(out_directory, 'negative_files', rec)
+        if os.path.exists(out_pos_dir) or os.path.exists(out_neg_dir):
+            continue
+        print(f'~~~ Processing file {fp.filename} ~~~')
+        img_db, annots = fp.process_file(freq_accuracy=freq_accuracy, dt=dt, overlap_spectro=overlap_spectro, w_pix=w_pix,
+                                         device=device)
+        if img_db is None:
+            continue
+        pos_idx = set() if annots is None else set(int(i) for i in annots['index'].values)
+        if pos_idx:
+            os.makedirs(out_pos_dir, exist_ok=True)
+            annots.to_csv(os.path.join(out_pos_dir, 'annotations.csv'), sep=';', index=False)
+        if len(pos_idx) < len(img_db):
+            os.makedirs(out_neg_dir, exist_ok=True)
+        for i, img in enumerate(img_db):
+            name = '__'.join([top_dir, fp.filename.replace('#', '__'), format(i, '05d')]) + '.png'
+            u8 = np.round(img * 255).astype(np.uint8)
+            if i in pos_idx:
+                write_png_gray8(os.path.join(out_pos_dir, name), u8)
+                n_pos += 1
+            elif i <= 999:
+                write_png_gray8(os.path.join(out_neg_dir, name), u8)
+                n_neg += 1
+    return n_pos, n_neg

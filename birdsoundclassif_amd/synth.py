@@ -198,6 +198,23 @@ def annotation_text(seed=0, n=7):
     return ''.join(lines)
 
 
+def label_rows(seed=0, n=40, filename='recA', duration=42.0):
+    """Rows (t_start, t_end, f_start, f_end, species, filename, bird_id) of a synthetic annotation table: calls of
+    0.05-4 s between 200 Hz and 15 kHz (some outside the image band, some degenerate), a few spanning several windows,
+    noise labels (-1) and rows of another file."""
+    u = uniform(('labels', seed), 8 * n)
+    rows = []
+    for i in range(n):
+        t0 = duration * u[8 * i]
+        dur = 0.05 + 4.0 * u[8 * i + 1] ** 3 + (9.0 if u[8 * i + 6] > 0.93 else 0.0)
+        f0 = 200.0 + 13000.0 * u[8 * i + 2]
+        bw = 0.0 if u[8 * i + 7] > 0.95 else 30.0 + 5000.0 * u[8 * i + 3]
+        bird = -1 if u[8 * i + 4] > 0.85 else 1 + int(u[8 * i + 5] * 150) % 150
+        rows.append((round(t0, 6), round(t0 + dur, 6), round(f0, 3), round(f0 + bw, 3), f'sp{bird}',
+                     filename if u[8 * i + 6] > 0.1 else 'other_file', bird))
+    return rows
+
+
 # --------------------------------------------------------------------------- filler weights
 def fill_state_dict(shapes, seed=0):
     """Deterministic filler for a {name: shape} mapping (SURVEY Appendix B layout): conv/linear

@@ -175,6 +175,44 @@ def metrics_golden():
     print('metrics:', out['cases'][:3])
 
 
+def labels_golden():
+    """`File_Processor.merge_and_filter_labels` (prepare_dataset.py:297-375) and `read_txt_file` (utils.py:59-92) of the
+    reference; its module-level imports of ffmpeg / imageio / librosa / soundfile are satisfied by empty stand-ins
+    (none of them is touched by these two functions)."""
+    import json
+    import tempfile
+    import types
+    import pandas as pd
+    for name in ('ffmpeg', 'imageio', 'librosa', 'soundfile'):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    import matplotlib
+    matplotlib.use('Agg')
+    ref_import.import_nets()
+    from nbm_model.nbm_datasets.prepare_dataset import File_Processor
+    from nbm_model.nbm_datasets.utils import read_txt_file
+    out = {'merge': [], 'txt': []}
+    cols = ['t_start', 't_end', 'f_start', 'f_end', 'species', 'filename', 'bird_id']
+    for seed, ext, n_img in ((0, 'wav', 16), (1, 'mp3', 16), (2, 'wav', 3), (3, 'wav', 1)):
+        fp = File_Processor(f'/x/recA.{ext}', '', pd.DataFrame(synth.label_rows(seed), columns=cols))
+        fp.W_PIX, fp.HOP_SPECTRO, fp.DT, fp.FREQ_ACCURACY = 1024, 819, 132 / 44100, 44100 / 1324
+        fp.LOW_FREQ, fp.HIGH_FREQ = 15 * fp.FREQ_ACCURACY, 390 * fp.FREQ_ACCURACY
+        r = fp.merge_and_filter_labels([None] * n_img)
+        out['merge'].append({'index': [int(i) for i in r['index']],
+                             'coord': [[[int(v) for v in box] for box in c] for c in r['coord']],
+                             'bird_id': [[int(v) for v in b] for b in r['bird_id']]})
+    with tempfile.TemporaryDirectory() as d:
+        for seed in range(3):
+            p = os.path.join(d, f'rec{seed}.txt')
+            with open(p, 'w') as f:
+                f.write(synth.annotation_text(seed))
+            df = read_txt_file(p)
+            out['txt'].append([[float(r.t_start), float(r.t_end), float(r.f_start), float(r.f_end), str(r.species), str(r.filename)]
+                               for r in df.itertuples()])
+    with open(os.path.join(OUT, 'labels.json'), 'w') as f:
+        json.dump(out, f)
+    print('labels:', [len(m['index']) for m in out['merge']], [len(t) for t in out['txt']])
+
+
 def main():
     warnings.filterwarnings('ignore')
     torch.manual_seed(0)
@@ -183,6 +221,8 @@ def main():
         return tf_rcnn_golden()
     if '--tf-train-only' in sys.argv:
         return tf_rcnn_train_golden()
+    if '--labels-only' in sys.argv:
+        return labels_golden()
     if '--metrics-only' in sys.argv:
         return metrics_golden()
     if '--dataset-only' in sys.argv:
@@ -191,6 +231,7 @@ def main():
     tf_rcnn_train_golden()
     img_dataset_golden()
     metrics_golden()
+    labels_golden()
     args = ref_import.default_args()
     model, crit = ref_import.build_reference_model(args, train=False)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}

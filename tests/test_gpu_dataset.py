@@ -1,5 +1,7 @@
 """GPU parity, training-input stage: device PNG reconstruction and the batch augmentation kernel
 behind the reference's `Img_dataset` API, against the oracle and the REAL reference's outputs (img_dataset.npz)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -107,3 +109,43 @@ def test_device_collate_batch_equals_items_and_device_noise(tmp_path):
         assert items2[i]['flags'] == items[i]['flags'] and items2[i]['gain'] == items[i]['gain']
         d = (img2[i] - img[i]).double()
         assert abs(d.mean().item()) < 2e-3 and abs(img2[i].double().std().item() - img[i].double().std().item()) < 2e-3
+
+
+def test_prepare_dataset_roundtrip(tmp_path):
+    """wav + Audacity labels -> prepare_dataset (device front end, PNG + annotations.csv) -> Img_dataset (device PNG
+    reconstruction): the images are the 8-bit rounding of the front end's windows and the boxes are the merged labels."""
+    import pandas as pd
+    from birdsoundclassif_amd.nbm_datasets.image_dataset import Img_dataset
+    from birdsoundclassif_amd.nbm_datasets.prepare_dataset import (File_Processor, create_label_dataset, prepare_dataset)
+    src = tmp_path / 'site1'
+    src.mkdir()
+    pcm = np.concatenate([synth.clip_pcm16(20 + i) for i in range(3)])             # 9 s @ 22.05 kHz -> 4 windows
+    synth.write_wav(str(src / 'night#1.wav'), pcm)
+    synth.write_wav(str(src / 'quiet.wav'), synth.clip_pcm16(30))
+    (src / 'night#1.txt').write_text('0.400000\t1.100000\tsp3\n\\\t2000.0\t6000.0\n'
+                                     '2.900000\t3.300000\tsp7\n\\\t900.0\t3000.0\n'
+                                     '8.000000\t8.500000\tBackground\n\\\t600.0\t12000.0\n')
+    (src / 'quiet.txt').write_text('0.5\t0.9\tBackground\n\\\t600.0\t900.0\n')
+    birds = {'sp3': 3, 'sp7': 7, 'Other': 150}
+    labels = create_label_dataset(str(src), birds, noise_labels=('Background',), suppress_noise=False)
+    assert sorted(labels['bird_id'].tolist()) == [-1, -1, 3, 7]
+    out = tmp_path / 'dataset'
+    n_pos, n_neg = prepare_dataset(str(src), str(out), labels=labels)
+    fp = File_Processor(str(src / 'night#1.wav'), '', labels)
+    img_db, annots = fp.process_file()
+    assert (n_pos, n_neg) == (len(annots), len(img_db) - len(annots) + 1)           # + the single window of quiet.wav
+    assert sorted(os.listdir(out / 'positive_files')) == ['site1__night__1']
+    assert sorted(os.listdir(out / 'negative_files')) == ['site1__night__1', 'site1__quiet']
+    (out / 'hard_neg').mkdir()
+    ds = Img_dataset(str(out), transform=False)
+    assert len(ds) == n_pos
+    np.random.seed(0)
+    for idx, name in enumerate(ds.positive_files):
+        win = int(name.replace('.png', '').split('__')[-1])
+        img, neg, bb, ids = ds[idx]
+        ref = np.round(img_db[win] * 255).astype(np.uint8)
+        assert np.array_equal(np.round(img.cpu().numpy() * 255).astype(np.uint8), ref)
+        row = annots.loc[annots['index'] == win].iloc[0]
+        assert bb.numpy().tolist() == [list(map(float, c)) for c in row['coord']] and ids.numpy().tolist() == list(map(float, row['bird_id']))
+    # second call: existing recordings are skipped (reference prepare_dataset.py:49-50)
+    assert prepare_dataset(str(src), str(out), labels=labels) == (0, 0)
