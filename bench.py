@@ -144,7 +144,9 @@ def main():
         if share:
             dist.init_process_group('gloo')
         else:
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+            import datetime
+            # a collective that cannot complete raises after 5 minutes instead of hanging the bench
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local), timeout=datetime.timedelta(minutes=5))
 
     from birdsoundclassif_amd import ops, synth
     from birdsoundclassif_amd.nbm_datasets.prepare_dataset import SpectrogramFrontEnd
@@ -255,7 +257,10 @@ def main():
     if not a.no_train:
         del model
         torch.cuda.empty_cache()
-        train = train_bench(rank, world, dist, a.train_batch, a.train_steps, 1)
+        try:
+            train = train_bench(rank, world, dist, a.train_batch, a.train_steps, 1)
+        except Exception as exc:                  # the detect line above is the contract metric: never lose it
+            train = {'error': f'{type(exc).__name__}: {exc}'[:500]}
     if rank == 0:
         line = {'metric': 'clips/sec (3 s @ 22.05 kHz) detect fwd', 'value': world * B * a.steps / dt, 'unit': 'clips/s',
                 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
