@@ -79,7 +79,7 @@ def train_bench(rank, world, dist, batch, steps, warmup):
     return {'value': v, 'unit': 'clips/s', 'batch_per_gpu': batch, 'global_batch': world * batch, 'steps': steps,
             'ms_per_step': dt / steps * 1e3, 'parallelism': f'dp{world}',
             'frac_of_mfma_peak': v / world * TRAIN_GFLOP_PER_CLIP / 1e3 / FP32_MFMA_PEAK_TFLOPS,
-            'final_loss': {k: float(x) for k, x in loss.items()},
+            'final_loss': {k: float(x.detach()) if torch.is_tensor(x) else float(x) for k, x in loss.items()},
             'workload': 'BASELINE.json configs[2]/[3]: positive training step (fwd + bwd + clip + AdamW), fp32'}
 
 
