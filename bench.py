@@ -220,26 +220,38 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # roofline of the dominant kernel
-    fpn0 = [s.elapsed_time(e) for (tag, s, e) in prof if tag == (384, 256, 3, 188, 512)]
-    all_ms = sum(s.elapsed_time(e) for (_, s, e) in prof)
+    # roofline of the dominant kernel: the 16 Winograd-domain GEMMs of fpn.out_convs.4 (3x3 384->256 @188x512), one
+    # igemm launch with groups = 16 per batch chunk.  `achieved` counts the FLOPs that launch EXECUTES
+    # (2 * 16 * tiles * 384 * 256 = 1/2.25 of the direct-convolution count SURVEY uses); the layer-level figure next to
+    # it divides SURVEY's algorithmic 170.322 GFLOP/clip by the time of the whole layer (transforms + GEMMs).
+    dom = [(tag, s.elapsed_time(e)) for (tag, s, e) in prof
+           if len(tag) == 9 and tag[:3] == (384, 256, 1) and tag[6] == 16 and tag[8] == ('wino23', 188, 512)]
+    layer = [s.elapsed_time(e) for (tag, s, e) in prof if tag == ('wino23', 384, 256, 188, 512, B)]
+    all_ms = sum(s.elapsed_time(e) for (tag, s, e) in prof if tag[0] != 'wino23')
     roof = None
     traffic = None                      # HBM bytes per launch of the dominant kernel: PMC counters cannot be read live;
     try:                                # the value comes from the committed rocprofv3 --pmc passes of this same command
-        pj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_fpn0.json')))
+        pj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_dominant.json')))
         if B == 64:
             traffic = pj['traffic_bytes_per_launch']
     except Exception:
         traffic = None
-    if fpn0:
-        avg_ms = sum(fpn0) / len(fpn0)
-        ach = FPN0_GFLOP_PER_CLIP * B / avg_ms                 # GFLOP/ms == TFLOP/s
-        roof = {'bound': 'mfma', 'kernel': 'igemm_kernel<128,128,64,64,FAST,STD> (fpn.out_convs.4, 3x3 384->256 @188x512)',
+    if dom:
+        gflop = sum(2.0 * 16 * tag[3] * 384 * 256 / 1e9 for tag, _ in dom)
+        ms = sum(t for _, t in dom)
+        ach = gflop / ms                                       # GFLOP/ms == TFLOP/s
+        roof = {'bound': 'mfma', 'kernel': 'igemm_kernel<128,128,64,64,FAST,STD>, groups=16: Winograd F(2x2,3x3)-domain GEMMs '
+                                           'of fpn.out_convs.4 (3x3 384->256 @188x512)',
                 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS,
-                'traffic': traffic, 'traffic_unit': 'bytes/launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_fpn0.json; '
-                                                         'algorithmic 15.77e9)', 'avg_launch_ms': avg_ms, 'launches': len(fpn0),
+                'traffic': traffic, 'traffic_unit': 'bytes/launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_dominant.json)',
+                'avg_launch_ms': ms / len(dom), 'launches': len(dom), 'executed_GFLOP_per_launch': gflop / len(dom),
                 'all_igemm_ms_per_step': all_ms / a.steps,
-                'whole_step_frac_of_mfma_peak': (FWD_GFLOP_PER_CLIP * B * a.steps / (dt * 1e3)) / FP32_MFMA_PEAK_TFLOPS}
+                'whole_step_algorithmic_frac_of_mfma_peak': (FWD_GFLOP_PER_CLIP * B * a.steps / (dt * 1e3)) / FP32_MFMA_PEAK_TFLOPS}
+        if layer:
+            lms = sum(layer) / len(layer)
+            roof['layer'] = {'what': 'fpn.out_convs.4 as executed: input transform + 16 GEMMs + output transform',
+                             'ms': lms, 'algorithmic_GFLOP': FPN0_GFLOP_PER_CLIP * B,
+                             'direct_conv_equivalent_TFLOPs': FPN0_GFLOP_PER_CLIP * B / lms}
     # front end alone (HBM-bound stage of the path): live HIP events around K replays
     fe_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
     for s0, e0 in fe_ev:

@@ -41,6 +41,23 @@ def krsc(weight):
     return _cached(weight, 'krsc', make)
 
 
+_WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
+
+
+def wino23(weight, transposed=False):
+    """Winograd F(2x2,3x3) weights U[16][N][C] = (G g G^T)[i][j] of a [Cout, Cin, 3, 3] convolution, computed in float64 on
+    the device and rounded once.  `transposed`: the weights of the DATA-GRADIENT convolution (kernel rotated by 180 degrees,
+    channel roles swapped): U[16][Cin][Cout]."""
+    def make():
+        g = weight.detach().double()
+        if transposed:
+            g = g.flip(2, 3).transpose(0, 1)
+        G = torch.tensor(_WINO_G, dtype=torch.float64, device=g.device)
+        u = torch.einsum('ia,ncab,jb->ijnc', G, g, G)
+        return u.reshape(16, g.shape[0], g.shape[1]).float().contiguous()
+    return _cached(weight, 'wino23t' if transposed else 'wino23', make)
+
+
 def bn_affine(weight, bias, mean, var, eps, conv_bias=None):
     """Fold (conv bias +) BatchNorm running statistics into per-channel (scale, shift):
     y = (z + conv_bias - mean) * weight / sqrt(var + eps) + bias  =  z * scale + shift."""

@@ -33,14 +33,27 @@ def _w_to_ref_layout(gw, weight):
     return gw[:, :kh * kw * c].view(n, kh, kw, c).permute(0, 3, 1, 2)
 
 
+def _winograd_ok(x, weight, kh, kw, stride, pad):
+    """3x3 / stride 1 / pad 1 on an even-sized map with MFMA-friendly channel counts."""
+    if not (kh == 3 and kw == 3 and stride == 1 and pad == 1 and weight.dim() == 4 and x.dim() == 4):
+        return False
+    _, H, W, Cin = x.shape
+    return H % 2 == 0 and W % 2 == 0 and Cin % 32 == 0 and weight.shape[0] % 4 == 0 and Cin >= 128
+
+
 class Conv(Function):
     """y = act(alpha * conv(x, W) * scale + (bias | shift) + residual); also nn.Linear (x [1,M,1,K])."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, scale, shift, residual, kh, kw, stride, pad, act, alpha, up=None):
-        wk = _prep.krsc(weight) if weight.dim() == 4 else weight.detach()
         sh = bias.detach() if bias is not None else shift
-        y = ops.conv2d(x, wk, kh, kw, stride, pad, scale=scale, shift=sh, residual=residual, act=act, alpha=alpha, up=up)
+        ctx.wino = _winograd_ok(x, weight, kh, kw, stride, pad) and scale is None and residual is None and \
+            act == ACT_NONE and alpha == 1.0 and up is None
+        if ctx.wino:          # large 3x3 (FPN output convolutions): Winograd F(2x2,3x3), 2.25x fewer multiplies
+            y = ops.conv3x3_winograd(x, _prep.wino23(weight), sh)
+        else:
+            wk = _prep.krsc(weight) if weight.dim() == 4 else weight.detach()
+            y = ops.conv2d(x, wk, kh, kw, stride, pad, scale=scale, shift=sh, residual=residual, act=act, alpha=alpha, up=up)
         ctx.geom = (kh, kw, stride, pad, act, alpha)
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         ctx.up_hw = tuple(up.shape[1:3]) if up is not None else None
@@ -59,7 +72,11 @@ class Conv(Function):
         wk = _prep.krsc(weight) if weight.dim() == 4 else weight.detach()
         gp = _pad32_rows(g.view(-1, N), N)
         gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and ctx.wino and N % 32 == 0:
+            # data gradient of a 3x3 / stride 1 / pad 1 convolution = the same convolution with the kernel rotated by 180
+            # degrees and the channel roles swapped: Winograd again
+            gx = ops.conv3x3_winograd(g.view(B, H, W, N), _prep.wino23(weight, transposed=True), None)
+        elif ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
             ops.conv_dgrad(gp, wk, gx, B=B, H=H, W=W, Cin=Cin, N=N, kh=kh, kw=kw, stride=stride, pad=pad,
                            g_ld=gp.shape[1], w_ld=wk.shape[1], a_scale=scale, alpha=alpha)

@@ -15,8 +15,9 @@ from ._lib import GemmDesc, RoiDesc, check
 ACT_NONE, ACT_RELU, ACT_SILU, ACT_LEAKY = 0, 1, 2, 3
 
 # bench.py sets this to a list to time every implicit-GEMM launch with HIP events on the launch stream:
-# entries are ((Cin, N, kh, H, W), start_event, end_event).
+# entries are ((Cin, N, kh, H, W, B, groups, stride, label), start_event, end_event).
 PROFILE = None
+_PROFILE_LABEL = None          # set by composite ops (Winograd) so that their GEMM launches can be told apart
 
 
 def _stream():
@@ -69,7 +70,7 @@ def gemm_conv(x, w, y, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, Ho=None,
         ev0.record()
         check(lib().nbm_gemm_conv(C.byref(d), _stream()), 'nbm_gemm_conv')
         ev1.record()
-        PROFILE.append(((Cin, N, kh, H, W), ev0, ev1))
+        PROFILE.append(((Cin, N, kh, H, W, B, groups, stride, _PROFILE_LABEL), ev0, ev1))
         return y
     check(lib().nbm_gemm_conv(C.byref(d), _stream()), 'nbm_gemm_conv')
     return y
@@ -90,6 +91,45 @@ def conv2d(x, w, kh=1, kw=1, stride=1, pad=0, scale=None, shift=None, residual=N
     gemm_conv(x, w, y, B=B, H=H, W=W, Cin=Cin, N=N, kh=kh, kw=kw, stride=stride, pad=pad, Ho=Ho, Wo=Wo,
               w_ld=w.shape[1] if w_ld is None else w_ld, scale=scale, shift=shift, residual=residual,
               alpha=alpha, act=act, up=up)
+    return y
+
+
+WINO_CHUNK_BYTES = 24 << 30          # transformed-domain scratch (V + M) per batch chunk
+
+
+def conv3x3_winograd(x, U, bias=None):
+    """3x3 / stride 1 / pad 1 convolution through Winograd F(2x2,3x3): x [B,H,W,C] (H, W even), U [16,N,C] from
+    `_prep.wino23` -> [B,H,W,N].  Three launches per batch chunk: input transform, 16 grouped GEMMs on the fp32 MFMA
+    (2.25x fewer multiplies than the direct kernel), output transform (+ bias).  The batch is cut so that the transformed
+    operands (4x the input + 4x the output) stay within WINO_CHUNK_BYTES."""
+    _chk(x, name='x'), _chk(U, name='U')
+    B, H, W, C_ = x.shape
+    N = U.shape[1]
+    assert U.shape == (16, N, C_) and H % 2 == 0 and W % 2 == 0 and C_ % 32 == 0 and N % 4 == 0
+    y = torch.empty((B, H, W, N), device=x.device, dtype=torch.float32)
+    tiles = (H // 2) * (W // 2)
+    per_img = 16 * tiles * (C_ + N) * 4
+    chunk = max(1, min(B, WINO_CHUNK_BYTES // per_img))
+    V = torch.empty((16, chunk * tiles, C_), device=x.device, dtype=torch.float32)
+    M = torch.empty((16, chunk * tiles, N), device=x.device, dtype=torch.float32)
+    st = _stream()
+    if PROFILE is not None:                       # whole-op bracket (transforms + GEMMs) next to the per-GEMM entries
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    for b0 in range(0, B, chunk):
+        nb = min(chunk, B - b0)
+        T = nb * tiles
+        check(lib().nbm_wino23_input(_ptr(x[b0:b0 + nb]), nb, H, W, C_, _ptr(V), st), 'nbm_wino23_input')
+        global _PROFILE_LABEL
+        _PROFILE_LABEL = ('wino23', H, W)
+        try:
+            gemm_conv(V, U, M, B=1, H=T, W=1, Cin=C_, N=N, groups=16, x_gs=T * C_, w_gs=N * C_, y_gs=T * N)
+        finally:
+            _PROFILE_LABEL = None
+        check(lib().nbm_wino23_output(_ptr(M), _ptr(bias), nb, H, W, N, _ptr(y[b0:b0 + nb]), st), 'nbm_wino23_output')
+    if PROFILE is not None:
+        ev[1].record()
+        PROFILE.append((('wino23', C_, N, H, W, B), *ev))
     return y
 
 

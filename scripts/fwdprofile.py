@@ -17,12 +17,15 @@ agg = {}
 for (tag, s, e) in prof:
     agg.setdefault(tag, []).append(s.elapsed_time(e))
 rows = []
-for (Cin, N, k, H, W), ts in agg.items():
+for tag, ts in agg.items():
+    if tag[0] == 'wino23':
+        continue
+    Cin, N, k, H, W, Bb, G, st, _ = tag
     # stride unknown from the tag: FLOPs from output size is not recoverable; report time only + upper bound at stride 1
-    rows.append((sum(ts), len(ts), Cin, N, k, H, W))
+    rows.append((sum(ts), len(ts), Cin, N, k, H, W, Bb, G, st))
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print(f'total igemm {tot:.1f} ms')
-for t, n, Cin, N, k, H, W in rows[:40]:
-    fl = 2.0 * (B if H * W < 10**6 else 1) * H * W * N * Cin * k * k * n / 1e9   # GFLOP at stride 1
-    print(f'{t:8.2f} ms x{n:2d}  Cin={Cin:4d} N={N:4d} k={k} HxW={H}x{W}  <= {fl / t:7.1f} TF/s (stride-1 bound)')
+for t, n, Cin, N, k, H, W, Bb, G, st in rows[:40]:
+    fl = 2.0 * G * Bb * (-(-H // st)) * (-(-W // st)) * N * Cin * k * k * n / 1e9   # executed GFLOP ('same' geometry)
+    print(f'{t:8.2f} ms x{n:2d}  Cin={Cin:4d} N={N:4d} k={k} s={st} g={G} B={Bb} HxW={H}x{W}  {fl / t:7.1f} TF/s')
