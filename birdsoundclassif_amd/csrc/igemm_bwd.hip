@@ -40,6 +40,7 @@ struct BwdParams {
   int w_row;                 // NN: floats between W[n] and W[n+1] (= taps*Cin, or the padded pitch)
   int vec_epi;               // NN: 16-byte epilogue accesses are legal
   float* bias_grad;          // TN: += sum_m g[m][n] (added by the workgroups of the first N-tile) or null
+  int plain;                 // TN: 1x1 / stride 1 / pad 0 -- im2col row m IS input pixel m, no bounds to track
   int phased;                // NN, stride 2: M tiles are grouped by the parity class of (iy + pad, ix + pad)
   int ph_tiles[4];           //   M tiles of each class; tile_m = 4 * (tile within class) + class, so the four classes of
                              //   one image region run side by side and fill the same DRAM pages together
@@ -403,6 +404,10 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(const BwdParams p) {
       const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(xg + ((long long)mbase + dpix) * p.x_ld, (unsigned)(rows * p.x_ld * 4));
 #pragma unroll
       for (int i = 0; i < BPASS; ++i) {
+        if (p.plain) {                                                  // plain GEMM rows: always inside
+          rb[i] = buf_load4(rsrc_b, b_rel[i], 0);
+          continue;
+        }
         const bool ok = (unsigned)(b_oy[i] + tr - p.pad) < (unsigned)p.H && (unsigned)(b_ox[i] + ts - p.pad) < (unsigned)p.W;
         rb[i] = buf_load4(rsrc_b, ok ? b_rel[i] : OOB, 0);
         b_ox[i] += BK;                                                  // Wo >= BK on this path
@@ -670,7 +675,8 @@ extern "C" int nbm_conv_wgrad(const nbm_bwd_desc* d, void* stream) {
   p.k_chunk = (((p.M + splits - 1) / splits) + BK - 1) / BK * BK;
   splits = (p.M + p.k_chunk - 1) / p.k_chunk;
   dim3 grid(p.m_tiles * p.n_tiles, splits, d->groups);
-  const bool same = !p.b_generic && d->stride == 1 && d->Ho == d->H && d->Wo == d->W && d->Wo >= BK &&
+  p.plain = (d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0) ? 1 : 0;
+  const bool same = !p.b_generic && d->stride == 1 && d->Ho == d->H && d->Wo == d->W && (d->Wo >= BK || p.plain) &&
                     (long long)BK * d->x_ld * 4 < 0x40000000ll;
   if (p.b_generic) hipLaunchKernelGGL((igemm_tn_kernel<64, B_GENERIC>), grid, dim3(256), 0, st, p);
   else if (wide && same) {

@@ -91,6 +91,48 @@ __global__ __launch_bounds__(256) void wino23_output_kernel(const float* __restr
   }
 }
 
+// g [B][H][W][N] (gradient wrt the convolution output) -> dM [16][T][N] = (A g A^T) per 2x2 tile: the operand of the 16
+// weight-gradient GEMMs dU[xi] = dM[xi]^T V[xi].  Every thread also accumulates the plain sum of its pixels per channel
+// (bias gradient) over its grid-stride items -- its channel chunk is fixed because the stride is a multiple of N4.
+__global__ __launch_bounds__(256) void wino23_outgrad_kernel(const float* __restrict__ g, int B, int H, int W, int N4,
+                                                             float* __restrict__ dM, float* __restrict__ bias_grad) {
+  const int TH = H >> 1, TW = W >> 1;
+  const long long T = (long long)B * TH * TW;
+  const long long total = T * N4;
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+  f32x4* m4 = reinterpret_cast<f32x4*>(dM);
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+  int my_c = -1;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % N4);
+    my_c = c;
+    long long t = i / N4;
+    const int tx = (int)(t % TW);
+    long long r = t / TW;
+    const int ty = (int)(r % TH);
+    const int b = (int)(r / TH);
+    const long long row = ((long long)b * H + 2 * ty) * W + 2 * tx;
+    const f32x4 y00 = g4[row * N4 + c], y01 = g4[(row + 1) * N4 + c];
+    const f32x4 y10 = g4[(row + W) * N4 + c], y11 = g4[(row + W + 1) * N4 + c];
+    bsum += (y00 + y01) + (y10 + y11);
+    // rows of A = [1 0; 1 1; 1 -1; 0 -1]
+    const f32x4 r0[2] = {y00, y01}, r1[2] = {y00 + y10, y01 + y11}, r2[2] = {y00 - y10, y01 - y11}, r3[2] = {-y10, -y11};
+    const f32x4* rows[4] = {r0, r1, r2, r3};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const f32x4 p = rows[a][0], q = rows[a][1];
+      m4[((long long)(a * 4 + 0) * T + t) * N4 + c] = p;
+      m4[((long long)(a * 4 + 1) * T + t) * N4 + c] = p + q;
+      m4[((long long)(a * 4 + 2) * T + t) * N4 + c] = p - q;
+      m4[((long long)(a * 4 + 3) * T + t) * N4 + c] = -q;
+    }
+  }
+  if (bias_grad && my_c >= 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(bias_grad + my_c * 4 + e, bsum[e]);
+  }
+}
+
 inline int grid_for(long long n) {
   long long g = (n + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
@@ -103,6 +145,20 @@ extern "C" int nbm_wino23_input(const float* x, int B, int H, int W, int C, floa
   if (!nbm_aligned16(x) || !nbm_aligned16(V)) return NBM_EALIGN;
   const long long total = (long long)B * (H / 2) * (W / 2) * (C / 4);
   hipLaunchKernelGGL(wino23_input_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, B, H, W, C / 4, V);
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_wino23_outgrad(const float* g, int B, int H, int W, int N, float* dM, float* bias_grad, void* stream) {
+  if (!g || !dM || B <= 0 || H <= 0 || W <= 0 || N <= 0 || (H & 1) || (W & 1) || (N & 3)) return NBM_EINVAL;
+  if (!nbm_aligned16(g) || !nbm_aligned16(dM)) return NBM_EALIGN;
+  const int N4 = N / 4;
+  const long long total = (long long)B * (H / 2) * (W / 2) * N4;
+  // the grid stride must be a multiple of N4 so that a thread keeps one channel chunk: blocks of 256 threads, N4 | 256 * k
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  while ((blocks * 256) % N4) ++blocks;
+  hipLaunchKernelGGL(wino23_outgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, B, H, W, N4, dM,
+                     bias_grad);
   return nbm_launch_status();
 }
 

@@ -58,6 +58,13 @@ def wino23(weight, transposed=False):
     return _cached(weight, 'wino23t' if transposed else 'wino23', make)
 
 
+def wino23_weight_grad(dU):
+    """dU [16, N, C] (gradient wrt the transformed weights) -> dW [N, C, 3, 3] = G^T dU G."""
+    G = torch.tensor(_WINO_G, dtype=torch.float32, device=dU.device)
+    n, c = dU.shape[1:]
+    return torch.einsum('ia,ijnc,jb->ncab', G, dU.view(4, 4, n, c), G)
+
+
 def bn_affine(weight, bias, mean, var, eps, conv_bias=None):
     """Fold (conv bias +) BatchNorm running statistics into per-channel (scale, shift):
     y = (z + conv_bias - mean) * weight / sqrt(var + eps) + bias  =  z * scale + shift."""

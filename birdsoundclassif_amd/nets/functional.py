@@ -81,7 +81,11 @@ class Conv(Function):
             ops.conv_dgrad(gp, wk, gx, B=B, H=H, W=W, Cin=Cin, N=N, kh=kh, kw=kw, stride=stride, pad=pad,
                            g_ld=gp.shape[1], w_ld=wk.shape[1], a_scale=scale, alpha=alpha)
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and ctx.wino and N % 32 == 0:
+            # weight gradient in the Winograd domain: 16 TN GEMMs dU = dM^T V, mapped back with dW = G^T dU G
+            dU, gb = ops.conv3x3_winograd_wgrad(x, g.view(B, H, W, N), want_bias=want_gb)
+            gw = _prep.wino23_weight_grad(dU)
+        elif ctx.needs_input_grad[1]:
             gwk = torch.zeros_like(wk)
             if want_gb:                                   # the bias gradient rides along in the weight-gradient kernel
                 gb = torch.zeros((N,), device=x.device, dtype=torch.float32)

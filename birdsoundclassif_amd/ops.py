@@ -133,6 +133,31 @@ def conv3x3_winograd(x, U, bias=None):
     return y
 
 
+def conv3x3_winograd_wgrad(x, g, want_bias=False):
+    """Weight gradient of `conv3x3_winograd` in the transformed domain: x [B,H,W,C] (forward input), g [B,H,W,N]
+    (gradient wrt the output) -> (dU [16,N,C] with dU[xi] = dM[xi]^T V[xi], bias gradient [N] or None).  The caller maps dU
+    back with dW = G^T dU G (`_prep.wino23_weight_grad`)."""
+    _chk(x, name='x'), _chk(g, name='g')
+    B, H, W, C_ = x.shape
+    N = g.shape[-1]
+    assert g.shape[:3] == x.shape[:3] and H % 2 == 0 and W % 2 == 0 and C_ % 4 == 0 and N % 4 == 0
+    tiles = (H // 2) * (W // 2)
+    per_img = 16 * tiles * (C_ + N) * 4
+    chunk = max(1, min(B, WINO_CHUNK_BYTES // per_img))
+    V = torch.empty((16, chunk * tiles, C_), device=x.device, dtype=torch.float32)
+    dM = torch.empty((16, chunk * tiles, N), device=x.device, dtype=torch.float32)
+    dU = torch.zeros((16, N, C_), device=x.device, dtype=torch.float32)
+    gb = torch.zeros((N,), device=x.device, dtype=torch.float32) if want_bias else None
+    st = _stream()
+    for b0 in range(0, B, chunk):
+        nb = min(chunk, B - b0)
+        T = nb * tiles
+        check(lib().nbm_wino23_input(_ptr(x[b0:b0 + nb]), nb, H, W, C_, _ptr(V), st), 'nbm_wino23_input')
+        check(lib().nbm_wino23_outgrad(_ptr(g[b0:b0 + nb]), nb, H, W, N, _ptr(dM), _ptr(gb), st), 'nbm_wino23_outgrad')
+        conv_wgrad(dM, V, dU, B=1, H=T, W=1, Cin=C_, N=N, groups=16, g_gs=T * N, x_gs=T * C_, out_gs=N * C_)
+    return dU, gb
+
+
 def linear(x2d, w, bias=None, act=ACT_NONE, out=None, alpha=1.0, residual=None, y_ld=None):
     """x2d [M,K], w [N,K] -> [M,N] (= x @ w.T + bias)."""
     _chk(x2d, name='x'), _chk(w, name='w')

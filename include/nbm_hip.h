@@ -81,6 +81,9 @@ int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream);
  * T = B*(H/2)*(W/2) tiles; V: [16][T][C], M: [16][T][N]. */
 int nbm_wino23_input(const float* x, int B, int H, int W, int C, float* V, void* stream);
 int nbm_wino23_output(const float* M, const float* bias, int B, int H, int W, int N, float* y, void* stream);
+/* weight gradient side: dM[xi][t][n] = (A g A^T)[xi] of the 2x2 output-gradient tile; dU[xi] = dM[xi]^T V[xi] through
+ * nbm_conv_wgrad (groups = 16) and dW = G^T dU G on the host.  bias_grad [N] (may be NULL): += sum over pixels of g. */
+int nbm_wino23_outgrad(const float* g, int B, int H, int W, int N, float* dM, float* bias_grad, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Spectrogram front end.  Replaces File_Processor.load/spectrogram/split_power_spec

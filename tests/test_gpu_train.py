@@ -485,3 +485,32 @@ def test_train_step_soft_failures_keep_first_stage_loss(override, expect, capsys
     assert torch.equal(model.head.fast_rcnn.rcnn.bbox_reg_layer.weight.detach(), head_before)   # no gradient: untouched
     out = capsys.readouterr().out
     assert ('RPN failed' in out) or ('IMPOSSIBLE TO FILL' in out)
+
+
+def test_winograd_conv_forward_and_gradients():
+    """Conv on the Winograd F(2x2,3x3) path (3x3 / s1 / p1, even map, Cin >= 128: the FPN output convolutions): forward,
+    data gradient (Winograd with the rotated kernel), weight gradient (16 transformed-domain TN GEMMs + G^T dU G) and
+    bias gradient vs torch autograd, incl. a batch that is cut into several scratch chunks."""
+    from birdsoundclassif_amd import ops as _ops
+    for (B, H, W, Ci, Co), chunk_bytes in (((3, 12, 20, 128, 64), None), ((5, 10, 16, 160, 96), 16 * 40 * (160 + 96) * 4 * 2)):
+        x = rnd(('wx', B, H), B, Ci, H, W).requires_grad_(True)
+        w = rnd(('ww', B, H), Co, Ci, 3, 3, scale=(2.0 / (Ci * 9)) ** 0.5).requires_grad_(True)
+        b = rnd(('wb', B, H), Co, scale=0.1).requires_grad_(True)
+        gy = rnd(('wg', B, H), B, Co, H, W)
+        y = F.conv2d(x, w, b, padding=1)
+        y.backward(gy)
+        xd = nhwc(x).requires_grad_(True)
+        wd, bd = w.detach().cuda().requires_grad_(True), b.detach().cuda().requires_grad_(True)
+        old = _ops.WINO_CHUNK_BYTES
+        if chunk_bytes:
+            _ops.WINO_CHUNK_BYTES = chunk_bytes                      # 2 images per chunk -> 3 chunks, the last one short
+        try:
+            assert Fn._winograd_ok(xd, wd, 3, 3, 1, 1)
+            yd = Fn.conv(xd, wd, bias=bd, kh=3, kw=3, pad=1)
+            close(nchw(yd), y, 5e-6, 'winograd fwd')
+            yd.backward(nhwc(gy))
+        finally:
+            _ops.WINO_CHUNK_BYTES = old
+        close(nchw(xd.grad), x.grad, 1e-5, 'winograd dx')
+        close(wd.grad, w.grad, 2e-5, 'winograd dw')
+        close(bd.grad, b.grad, 2e-5, 'winograd db')
