@@ -8,10 +8,10 @@
 
 namespace {
 
-// x [B][H][W][C] -> V [16][T][C], T = B * (H/2) * (W/2); tile (ty, tx) reads rows 2ty-1 .. 2ty+2, cols 2tx-1 .. 2tx+2.
+// x [B][H][W][C] -> V [16][T][C], T = B * ceil(H/2) * ceil(W/2); tile (ty, tx) reads rows 2ty-1 .. 2ty+2, cols 2tx-1 .. 2tx+2.
 __global__ __launch_bounds__(256) void wino23_input_kernel(const float* __restrict__ x, int B, int H, int W, int C4,
                                                            float* __restrict__ V) {
-  const int TH = H >> 1, TW = W >> 1;
+  const int TH = (H + 1) >> 1, TW = (W + 1) >> 1;
   const long long T = (long long)B * TH * TW;
   const long long total = T * C4;
   const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void wino23_input_kernel(const float* __restri
 // M [16][T][N] (+ bias[N]) -> y [B][H][W][N]; A^T = [1 1 1 0; 0 1 -1 -1]
 __global__ __launch_bounds__(256) void wino23_output_kernel(const float* __restrict__ M, const float* __restrict__ bias,
                                                             int B, int H, int W, int N4, float* __restrict__ y) {
-  const int TH = H >> 1, TW = W >> 1;
+  const int TH = (H + 1) >> 1, TW = (W + 1) >> 1;
   const long long T = (long long)B * TH * TW;
   const long long total = T * N4;
   const f32x4* m4 = reinterpret_cast<const f32x4*>(M);
@@ -84,9 +84,10 @@ __global__ __launch_bounds__(256) void wino23_output_kernel(const float* __restr
     for (int p = 0; p < 2; ++p) {
       const f32x4 o0 = s[p][0] + s[p][1] + s[p][2] + bv;
       const f32x4 o1 = s[p][1] - s[p][2] - s[p][3] + bv;
+      if (2 * ty + p >= H) break;                                   // odd H: the last tile row is half outside
       const long long row = ((long long)b * H + 2 * ty + p) * W + 2 * tx;
       y4[row * N4 + c] = o0;
-      y4[(row + 1) * N4 + c] = o1;
+      if (2 * tx + 1 < W) y4[(row + 1) * N4 + c] = o1;
     }
   }
 }
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void wino23_output_kernel(const float* __restr
 // (bias gradient) over its grid-stride items -- its channel chunk is fixed because the stride is a multiple of N4.
 __global__ __launch_bounds__(256) void wino23_outgrad_kernel(const float* __restrict__ g, int B, int H, int W, int N4,
                                                              float* __restrict__ dM, float* __restrict__ bias_grad) {
-  const int TH = H >> 1, TW = W >> 1;
+  const int TH = (H + 1) >> 1, TW = (W + 1) >> 1;
   const long long T = (long long)B * TH * TW;
   const long long total = T * N4;
   const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
@@ -112,8 +113,10 @@ __global__ __launch_bounds__(256) void wino23_outgrad_kernel(const float* __rest
     const int ty = (int)(r % TH);
     const int b = (int)(r / TH);
     const long long row = ((long long)b * H + 2 * ty) * W + 2 * tx;
-    const f32x4 y00 = g4[row * N4 + c], y01 = g4[(row + 1) * N4 + c];
-    const f32x4 y10 = g4[(row + W) * N4 + c], y11 = g4[(row + W + 1) * N4 + c];
+    const bool in_y = 2 * ty + 1 < H, in_x = 2 * tx + 1 < W;          // odd sizes: the last tile row / column is half outside
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 y00 = g4[row * N4 + c], y01 = in_x ? g4[(row + 1) * N4 + c] : zero;
+    const f32x4 y10 = in_y ? g4[(row + W) * N4 + c] : zero, y11 = (in_y && in_x) ? g4[(row + W + 1) * N4 + c] : zero;
     bsum += (y00 + y01) + (y10 + y11);
     // rows of A = [1 0; 1 1; 1 -1; 0 -1]
     const f32x4 r0[2] = {y00, y01}, r1[2] = {y00 + y10, y01 + y11}, r2[2] = {y00 - y10, y01 - y11}, r3[2] = {-y10, -y11};
@@ -141,18 +144,18 @@ inline int grid_for(long long n) {
 }  // namespace
 
 extern "C" int nbm_wino23_input(const float* x, int B, int H, int W, int C, float* V, void* stream) {
-  if (!x || !V || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (H & 1) || (W & 1) || (C & 3)) return NBM_EINVAL;
+  if (!x || !V || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return NBM_EINVAL;
   if (!nbm_aligned16(x) || !nbm_aligned16(V)) return NBM_EALIGN;
-  const long long total = (long long)B * (H / 2) * (W / 2) * (C / 4);
+  const long long total = (long long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
   hipLaunchKernelGGL(wino23_input_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, B, H, W, C / 4, V);
   return nbm_launch_status();
 }
 
 extern "C" int nbm_wino23_outgrad(const float* g, int B, int H, int W, int N, float* dM, float* bias_grad, void* stream) {
-  if (!g || !dM || B <= 0 || H <= 0 || W <= 0 || N <= 0 || (H & 1) || (W & 1) || (N & 3)) return NBM_EINVAL;
+  if (!g || !dM || B <= 0 || H <= 0 || W <= 0 || N <= 0 || (N & 3)) return NBM_EINVAL;
   if (!nbm_aligned16(g) || !nbm_aligned16(dM)) return NBM_EALIGN;
   const int N4 = N / 4;
-  const long long total = (long long)B * (H / 2) * (W / 2) * N4;
+  const long long total = (long long)B * ((H + 1) / 2) * ((W + 1) / 2) * N4;
   // the grid stride must be a multiple of N4 so that a thread keeps one channel chunk: blocks of 256 threads, N4 | 256 * k
   long long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
@@ -163,9 +166,9 @@ extern "C" int nbm_wino23_outgrad(const float* g, int B, int H, int W, int N, fl
 }
 
 extern "C" int nbm_wino23_output(const float* M, const float* bias, int B, int H, int W, int N, float* y, void* stream) {
-  if (!M || !y || B <= 0 || H <= 0 || W <= 0 || N <= 0 || (H & 1) || (W & 1) || (N & 3)) return NBM_EINVAL;
+  if (!M || !y || B <= 0 || H <= 0 || W <= 0 || N <= 0 || (N & 3)) return NBM_EINVAL;
   if (!nbm_aligned16(M) || !nbm_aligned16(y) || (bias && !nbm_aligned16(bias))) return NBM_EALIGN;
-  const long long total = (long long)B * (H / 2) * (W / 2) * (N / 4);
+  const long long total = (long long)B * ((H + 1) / 2) * ((W + 1) / 2) * (N / 4);
   hipLaunchKernelGGL(wino23_output_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, M, bias, B, H, W, N / 4, y);
   return nbm_launch_status();
 }

@@ -34,11 +34,11 @@ def _w_to_ref_layout(gw, weight):
 
 
 def _winograd_ok(x, weight, kh, kw, stride, pad):
-    """3x3 / stride 1 / pad 1 on an even-sized map with MFMA-friendly channel counts."""
+    """3x3 / stride 1 / pad 1 with MFMA-friendly channel counts (odd map sizes cost one zero-padded tile row / column)."""
     if not (kh == 3 and kw == 3 and stride == 1 and pad == 1 and weight.dim() == 4 and x.dim() == 4):
         return False
     _, H, W, Cin = x.shape
-    return H % 2 == 0 and W % 2 == 0 and Cin % 32 == 0 and weight.shape[0] % 4 == 0 and Cin >= 128
+    return H >= 8 and W >= 8 and Cin % 32 == 0 and weight.shape[0] % 4 == 0 and Cin >= 128
 
 
 class Conv(Function):

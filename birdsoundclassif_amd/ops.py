@@ -98,16 +98,16 @@ WINO_CHUNK_BYTES = 24 << 30          # transformed-domain scratch (V + M) per ba
 
 
 def conv3x3_winograd(x, U, bias=None):
-    """3x3 / stride 1 / pad 1 convolution through Winograd F(2x2,3x3): x [B,H,W,C] (H, W even), U [16,N,C] from
+    """3x3 / stride 1 / pad 1 convolution through Winograd F(2x2,3x3): x [B,H,W,C], U [16,N,C] from
     `_prep.wino23` -> [B,H,W,N].  Three launches per batch chunk: input transform, 16 grouped GEMMs on the fp32 MFMA
     (2.25x fewer multiplies than the direct kernel), output transform (+ bias).  The batch is cut so that the transformed
     operands (4x the input + 4x the output) stay within WINO_CHUNK_BYTES."""
     _chk(x, name='x'), _chk(U, name='U')
     B, H, W, C_ = x.shape
     N = U.shape[1]
-    assert U.shape == (16, N, C_) and H % 2 == 0 and W % 2 == 0 and C_ % 32 == 0 and N % 4 == 0
+    assert U.shape == (16, N, C_) and C_ % 32 == 0 and N % 4 == 0
     y = torch.empty((B, H, W, N), device=x.device, dtype=torch.float32)
-    tiles = (H // 2) * (W // 2)
+    tiles = ((H + 1) // 2) * ((W + 1) // 2)
     per_img = 16 * tiles * (C_ + N) * 4
     chunk = max(1, min(B, WINO_CHUNK_BYTES // per_img))
     V = torch.empty((16, chunk * tiles, C_), device=x.device, dtype=torch.float32)
@@ -140,8 +140,8 @@ def conv3x3_winograd_wgrad(x, g, want_bias=False):
     _chk(x, name='x'), _chk(g, name='g')
     B, H, W, C_ = x.shape
     N = g.shape[-1]
-    assert g.shape[:3] == x.shape[:3] and H % 2 == 0 and W % 2 == 0 and C_ % 4 == 0 and N % 4 == 0
-    tiles = (H // 2) * (W // 2)
+    assert g.shape[:3] == x.shape[:3] and C_ % 4 == 0 and N % 4 == 0
+    tiles = ((H + 1) // 2) * ((W + 1) // 2)
     per_img = 16 * tiles * (C_ + N) * 4
     chunk = max(1, min(B, WINO_CHUNK_BYTES // per_img))
     V = torch.empty((16, chunk * tiles, C_), device=x.device, dtype=torch.float32)

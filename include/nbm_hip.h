@@ -75,10 +75,10 @@ typedef struct nbm_gemm_desc {
 
 int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream);
 
-/* Winograd F(2x2,3x3) transforms for 3x3 / stride 1 / pad 1 convolutions on even-sized maps (the FPN output convolutions,
+/* Winograd F(2x2,3x3) transforms for 3x3 / stride 1 / pad 1 convolutions (the FPN output convolutions,
  * fpn.py:137,145, and their data gradients).  V[xi][t][c] = (B^T d B)[xi] of the 4x4 input patch of tile t (zero padded);
  * the 16 GEMMs M[xi] = V[xi] x U[xi]^T run through nbm_gemm_conv with groups = 16; y = A^T M A + bias.
- * T = B*(H/2)*(W/2) tiles; V: [16][T][C], M: [16][T][N]. */
+ * T = B*ceil(H/2)*ceil(W/2) tiles (odd sizes: the last tile row / column is zero padded); V: [16][T][C], M: [16][T][N]. */
 int nbm_wino23_input(const float* x, int B, int H, int W, int C, float* V, void* stream);
 int nbm_wino23_output(const float* M, const float* bias, int B, int H, int W, int N, float* y, void* stream);
 /* weight gradient side: dM[xi][t][n] = (A g A^T)[xi] of the 2x2 output-gradient tile; dU[xi] = dM[xi]^T V[xi] through

@@ -492,7 +492,8 @@ def test_winograd_conv_forward_and_gradients():
     data gradient (Winograd with the rotated kernel), weight gradient (16 transformed-domain TN GEMMs + G^T dU G) and
     bias gradient vs torch autograd, incl. a batch that is cut into several scratch chunks."""
     from birdsoundclassif_amd import ops as _ops
-    for (B, H, W, Ci, Co), chunk_bytes in (((3, 12, 20, 128, 64), None), ((5, 10, 16, 160, 96), 16 * 40 * (160 + 96) * 4 * 2)):
+    for (B, H, W, Ci, Co), chunk_bytes in (((3, 12, 20, 128, 64), None), ((5, 10, 16, 160, 96), 16 * 40 * (160 + 96) * 4 * 2),
+                                           ((2, 11, 13, 128, 32), None)):                     # odd sizes
         x = rnd(('wx', B, H), B, Ci, H, W).requires_grad_(True)
         w = rnd(('ww', B, H), Co, Ci, 3, 3, scale=(2.0 / (Ci * 9)) ** 0.5).requires_grad_(True)
         b = rnd(('wb', B, H), Co, scale=0.1).requires_grad_(True)
