@@ -17,6 +17,7 @@
 //
 // Workgroup -> tile mapping is XCD-aware (bijective chunking of the grid over the 8 L2s) so the N-tiles
 // of one M-tile, which share the gathered A rows, run on the same XCD.
+#include <stdlib.h>
 #include "nbm_common.h"
 #include <type_traits>
 
@@ -45,17 +46,20 @@ struct IgemmParams {
   int n_bins; float floor_amp; int db_ld; uint32_t* minmax;
 };
 
-template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
+// STAGES = 2: the deep-K pipeline (double-buffered LDS, 2 workgroups per CU).  STAGES = 1: short-K layers (K <= 256: 1x1
+// convolutions whose time is output / residual traffic, not MFMA): single LDS buffer (36.8 KB) and an epilogue staged in
+// two halves, so THREE workgroups fit a CU and their load / compute / store phases overlap instead of serialising.
+template <int BM, int BN, int WM, int WN, int AMODE, int EPI, int STAGES = 2>
+__global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_kernel(const IgemmParams p) {
   constexpr int MT = WM / 32, NT = WN / 32;
   constexpr int WAVES_N = BN / WN;
   constexpr int AR = BM / 32, BR = BN / 32;  // rows per thread in the staging pass
   static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
 
-  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * PITCH];
-  nbm_stagger_priority();
-  float* As = lds;                       // [2][BM][PITCH]
-  float* Bs = lds + 2 * BM * PITCH;      // [2][BN][PITCH]
+  __shared__ __attribute__((aligned(16))) float lds[STAGES * (BM + BN) * PITCH];
+  if constexpr (STAGES == 2) nbm_stagger_priority();
+  float* As = lds;                       // [STAGES][BM][PITCH]
+  float* Bs = lds + STAGES * BM * PITCH; // [STAGES][BN][PITCH]
 
   // ---- XCD-aware tile id (bijective for any grid size)
   const int nwg = gridDim.x, bid = blockIdx.x;
@@ -193,9 +197,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
   //                          | MFMA groups 2, 3
   // so the global-load / address / ds_write instructions issue BETWEEN this wave's own MFMAs instead of in a separate
   // window in front of them (that window cost 15 % of the kernel: both waves of a SIMD hit it together).
-  load_tiles(0);
-  store_lds(0);
-  if (p.nk > 1) load_tiles(1);
+  if constexpr (STAGES == 2) {
+    load_tiles(0);
+    store_lds(0);
+    if (p.nk > 1) load_tiles(1);
+  }
 
   auto mfma_group = [&](const float* Ab, const float* Bb, int q) {
     f32x4 a[MT], b[NT];
@@ -246,13 +252,27 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     mfma_group(Ab, Bb, 2);
     mfma_group(Ab, Bb, 3);
   };
-  {
+  if constexpr (STAGES == 2) {
     using T = std::true_type;
     using F = std::false_type;
     int kt = 0;
     for (; kt + 2 < p.nk; ++kt) k_step(kt, T{}, T{});
     if (p.nk >= 2) { k_step(kt, T{}, F{}); ++kt; }
     k_step(kt, F{}, F{});
+  } else {
+    // short K: load -> LDS -> MFMA, the next tile's loads in flight during the MFMAs; the other two workgroups of the CU
+    // cover the barriers
+    load_tiles(0);
+    for (int kt = 0; kt < p.nk; ++kt) {
+      if (kt) __syncthreads();                       // everyone finished reading the previous tile
+      store_lds(0);
+      if (kt + 1 < p.nk) load_tiles(kt + 1);
+      __syncthreads();
+      const float* Ab = As + (wm0 + lrow) * PITCH + lh * 16;
+      const float* Bb = Bs + (wn0 + lrow) * PITCH + lh * 16;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mfma_group(Ab, Bb, q);
+    }
   }
   __syncthreads();
 
@@ -265,27 +285,36 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
       // lane finishes 4 consecutive channels: 16-byte residual / scale / shift loads and 16-byte stores instead of
       // 64 dword stores per lane (store-issue bound on the short-K 1x1 layers).
       constexpr int CP = BN + 4;
-      static_assert(BM * CP <= 2 * (BM + BN) * PITCH, "epilogue tile must fit the operand buffers");
+      constexpr int HALVES = STAGES == 1 ? BM / WM : 1;           // single-stage LDS holds WM rows of the tile at a time
+      constexpr int HROWS = BM / HALVES;
+      static_assert(HROWS * CP <= STAGES * (BM + BN) * PITCH, "epilogue tile must fit the operand buffers");
       float* Cs = lds;
+      constexpr int CH = BN / 4;                 // 16-byte chunks per tile row
+      constexpr int RPP = 256 / CH;              // rows per pass
+      const int cc = tid % CH, rr = tid / CH;
+      const int n = bn0 + cc * 4;
+      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+      if (n < p.N) {
+        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+        if (p.shift && !p.shift_per_row) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+      }
+#pragma unroll
+      for (int half = 0; half < HALVES; ++half) {
+      if (half) __syncthreads();
+      if (HALVES == 1 || wm0 == half * HROWS) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
           for (int e = 0; e < 16; ++e)
-            Cs[(wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * CP + wn0 + j * 32 + lrow] = acc[i][j][e];
+            Cs[((HALVES == 1 ? wm0 : 0) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * CP + wn0 + j * 32 + lrow] = acc[i][j][e];
+      }
       __syncthreads();
-      constexpr int CH = BN / 4;                 // 16-byte chunks per tile row
-      constexpr int RPP = 256 / CH;              // rows per pass
-      const int cc = tid % CH, rr = tid / CH;
-      const int n = bn0 + cc * 4;
       if (n < p.N) {
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
-        if (p.shift && !p.shift_per_row) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
 #pragma unroll 4
-        for (int r = rr; r < BM; r += RPP) {
-          const int m = bm0 + r;
+        for (int r = rr; r < HROWS; r += RPP) {
+          const int m = bm0 + half * HROWS + r;
           if (m >= p.M) break;
           f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CP + cc * 4);
           const float rs = (p.shift_per_row && p.shift) ? p.shift[m] : 0.f;
@@ -325,6 +354,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
           }
           *reinterpret_cast<f32x4*>(yg + (long long)m * p.y_ld + n) = v;
         }
+      }
       }
     } else {
 #pragma unroll
@@ -389,6 +419,12 @@ int launch(const IgemmParams& p, int groups, hipStream_t st) {
   return nbm_launch_status();
 }
 
+int launch_s1(const IgemmParams& p, int groups, hipStream_t st) {
+  dim3 grid(p.m_tiles * p.n_tiles, 1, groups);
+  hipLaunchKernelGGL((igemm_kernel<128, 128, 64, 64, A_FAST, EPI_STD, 1>), grid, dim3(256), 0, st, p);
+  return nbm_launch_status();
+}
+
 }  // namespace
 
 extern "C" int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream) {
@@ -427,6 +463,10 @@ extern "C" int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream) {
   p.m_tiles = (p.M + BM - 1) / BM;
   if (d->N > 64) {
     p.n_tiles = (d->N + 127) / 128;
+    // short K and a 16-byte epilogue: the three-workgroups-per-CU variant (see the template comment)
+    static const int shortk_max = getenv("NBM_SHORTK_MAX") ? atoi(getenv("NBM_SHORTK_MAX")) : 8;   // 0 disables
+    if (fast && p.vec_epi && p.nk <= shortk_max)
+      return launch_s1(p, d->groups, st);
     return fast ? launch<128, 128, 64, 64, A_FAST, EPI_STD>(p, d->groups, st)
                 : launch<128, 128, 64, 64, A_GENERIC, EPI_STD>(p, d->groups, st);
   } else if (d->N > 32) {
