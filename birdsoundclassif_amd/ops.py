@@ -95,6 +95,19 @@ def conv2d(x, w, kh=1, kw=1, stride=1, pad=0, scale=None, shift=None, residual=N
 
 
 WINO_CHUNK_BYTES = 24 << 30          # transformed-domain scratch (V + M) per batch chunk
+_WINO_SCRATCH = {}
+
+
+def _wino_scratch(device, n_v, n_m):
+    """Two views (V: n_v floats, M: n_m floats) of ONE persistent per-device scratch allocation.  Every Winograd call on
+    a device runs on the same stream, so reusing the buffer is stream-ordered; a fresh multi-GB torch.empty per call made
+    the caching allocator fall back to hipMalloc / hipFree (100 ms host stalls per training step)."""
+    need = n_v + n_m
+    buf = _WINO_SCRATCH.get(device)
+    if buf is None or buf.numel() < need:
+        _WINO_SCRATCH[device] = None
+        buf = _WINO_SCRATCH[device] = torch.empty((max(need, WINO_CHUNK_BYTES // 4),), device=device, dtype=torch.float32)
+    return buf[:n_v], buf[n_v:need]
 
 
 def conv3x3_winograd(x, U, bias=None):
@@ -110,8 +123,7 @@ def conv3x3_winograd(x, U, bias=None):
     tiles = ((H + 1) // 2) * ((W + 1) // 2)
     per_img = 16 * tiles * (C_ + N) * 4
     chunk = max(1, min(B, WINO_CHUNK_BYTES // per_img))
-    V = torch.empty((16, chunk * tiles, C_), device=x.device, dtype=torch.float32)
-    M = torch.empty((16, chunk * tiles, N), device=x.device, dtype=torch.float32)
+    V, M = _wino_scratch(x.device, 16 * chunk * tiles * C_, 16 * chunk * tiles * N)
     st = _stream()
     if PROFILE is not None:                       # whole-op bracket (transforms + GEMMs) next to the per-GEMM entries
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -144,8 +156,7 @@ def conv3x3_winograd_wgrad(x, g, want_bias=False):
     tiles = ((H + 1) // 2) * ((W + 1) // 2)
     per_img = 16 * tiles * (C_ + N) * 4
     chunk = max(1, min(B, WINO_CHUNK_BYTES // per_img))
-    V = torch.empty((16, chunk * tiles, C_), device=x.device, dtype=torch.float32)
-    dM = torch.empty((16, chunk * tiles, N), device=x.device, dtype=torch.float32)
+    V, dM = _wino_scratch(x.device, 16 * chunk * tiles * C_, 16 * chunk * tiles * N)
     dU = torch.zeros((16, N, C_), device=x.device, dtype=torch.float32)
     gb = torch.zeros((N,), device=x.device, dtype=torch.float32) if want_bias else None
     st = _stream()
