@@ -42,6 +42,16 @@ def krsc(weight):
 
 
 _WINO_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
+_WINO_G_DEV = {}
+
+
+def _wino_g(device, dtype):
+    """G on the device, uploaded once: a `torch.tensor(..., device=cuda)` per call is a pageable H2D copy, i.e. a stream
+    synchronisation in the middle of the step (the weights change every optimisation step, so the transform reruns)."""
+    key = (str(device), dtype)
+    if key not in _WINO_G_DEV:
+        _WINO_G_DEV[key] = torch.tensor(_WINO_G, dtype=dtype, device=device)
+    return _WINO_G_DEV[key]
 
 
 def wino23(weight, transposed=False):
@@ -52,7 +62,7 @@ def wino23(weight, transposed=False):
         g = weight.detach().double()
         if transposed:
             g = g.flip(2, 3).transpose(0, 1)
-        G = torch.tensor(_WINO_G, dtype=torch.float64, device=g.device)
+        G = _wino_g(g.device, torch.float64)
         u = torch.einsum('ia,ncab,jb->ijnc', G, g, G)
         return u.reshape(16, g.shape[0], g.shape[1]).float().contiguous()
     return _cached(weight, 'wino23t' if transposed else 'wino23', make)
@@ -60,7 +70,7 @@ def wino23(weight, transposed=False):
 
 def wino23_weight_grad(dU):
     """dU [16, N, C] (gradient wrt the transformed weights) -> dW [N, C, 3, 3] = G^T dU G."""
-    G = torch.tensor(_WINO_G, dtype=torch.float32, device=dU.device)
+    G = _wino_g(dU.device, torch.float32)
     n, c = dU.shape[1:]
     return torch.einsum('ia,ijnc,jb->ncab', G, dU.view(4, 4, n, c), G)
 
