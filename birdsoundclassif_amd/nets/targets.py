@@ -120,12 +120,38 @@ class ProposalTargetLayer(nn.Module):
         out_r = np.zeros((B, nb, 4), dtype=_F)
         out_t = np.zeros((B, nb, 4 * (1 + nc)), dtype=_F)
         out_l = np.zeros((B, nb), dtype=_F)
+        gt_keep = np.zeros((B, nb, 4), dtype=_F)
         idx = np.cumsum([0] + list(lengths))
+        # IoU / best-GT assignment for the whole batch in one shot (GT padded to the largest count; padded columns can
+        # never win the max), then the per-image sampling with the reference's RNG call order
+        R, gmax = rois_c.shape[1], max(lengths)
+        gt_pad = np.full((B, gmax, 4), -1, dtype=_F)
+        valid = np.zeros((B, gmax), dtype=bool)
+        for b, (i0, i1) in enumerate(zip(idx[:-1], idx[1:])):
+            gt_pad[b, :i1 - i0] = gt_c[i0:i1]
+            valid[b, :i1 - i0] = True
+        batched = all(gt_c[i0:i1].max() > -1 for i0, i1 in zip(idx[:-1], idx[1:]))
+        if batched:
+            all_pad = np.concatenate([rois_c, gt_pad], axis=1)                       # [B, R + gmax, 4]
+            a, g_ = all_pad[:, :, None, :], gt_pad[:, None, :, :]
+            xi = np.maximum(np.minimum(a[..., 2], g_[..., 2]) - np.maximum(a[..., 0], g_[..., 0]) + _F(1), _F(0))
+            yi = np.maximum(np.minimum(a[..., 3], g_[..., 3]) - np.maximum(a[..., 1], g_[..., 1]) + _F(1), _F(0))
+            inter = xi * yi
+            area_a = (a[..., 2] - a[..., 0] + _F(1)) * (a[..., 3] - a[..., 1] + _F(1))
+            area_g = (g_[..., 2] - g_[..., 0] + _F(1)) * (g_[..., 3] - g_[..., 1] + _F(1))
+            with np.errstate(divide='ignore', invalid='ignore'):
+                ov_all = inter / ((area_a + area_g) - inter)
+            ov_all[~np.broadcast_to(valid[:, None, :], ov_all.shape)] = -1
+            mx_all, asg_all = ov_all.max(axis=-1), ov_all.argmax(axis=-1)
         for b, (i0, i1) in enumerate(zip(idx[:-1], idx[1:])):
             gt = gt_c[i0:i1]
-            allr = np.concatenate([rois_c[b], gt], axis=0) if gt.max() > -1 else rois_c[b]
-            ov = box_iou_incl(allr, gt)
-            mx, asg = ov.max(axis=-1), ov.argmax(axis=-1)
+            if batched:
+                n_all = R + (i1 - i0)
+                allr, mx, asg = all_pad[b, :n_all], mx_all[b, :n_all], asg_all[b, :n_all]
+            else:
+                allr = np.concatenate([rois_c[b], gt], axis=0) if gt.max() > -1 else rois_c[b]
+                ov = box_iou_incl(allr, gt)
+                mx, asg = ov.max(axis=-1), ov.argmax(axis=-1)
             lab = ids_c[i0:i1][asg].copy()
             lab[mx < fg_t] = 0
             gta = gt[asg]
@@ -147,10 +173,12 @@ class ProposalTargetLayer(nn.Module):
                 bgi = np.hstack([bgi, np.random.choice(other, nb - len(fgi) - len(bgi), replace=False)])
             keep = np.hstack((fgi, bgi)).astype(np.int64)
             bl, br = lab[keep], allr[keep]
-            t4 = box_encode(br, gta[keep])
-            li = bl.astype(np.int64)
-            sel = np.nonzero(li >= 1)[0]                               # one slot of 4 per class (nets_utils.py:248-259)
-            for k in range(4):
-                out_t[b, sel, 4 * li[sel] + k] = t4[sel, k]
             out_r[b], out_l[b] = br, bl
+            gt_keep[b] = gta[keep]
+        # one encode for the whole batch (a torch.log call per image costs more in dispatch than in work)
+        t4 = box_encode(out_r.reshape(-1, 4), gt_keep.reshape(-1, 4)).reshape(B, nb, 4)
+        li = out_l.astype(np.int64)
+        bsel, rsel = np.nonzero(li >= 1)                               # one slot of 4 per class (nets_utils.py:248-259)
+        for k in range(4):
+            out_t[bsel, rsel, 4 * li[bsel, rsel] + k] = t4[bsel, rsel, k]
         return torch.from_numpy(out_r).to(device), torch.from_numpy(out_t).to(device), torch.from_numpy(out_l).to(device)
