@@ -85,7 +85,7 @@ SIGNATURES = {
     'nbm_conv_wgrad': [C.POINTER(BwdDesc), _P],
     'nbm_relu_bwd': [_P, _P, _P, _L, _P],
     'nbm_silu_bwd': [_P, _P, _P, _L, _P],
-    'nbm_axpby': [_P, _P, _P, _F, _F, _L, _P],
+    'nbm_axpby': [_P, _P, _P, _F, _F, _L, _L, _P],
     'nbm_colsum': [_P, _L, _I, _I, _P, _P],
     'nbm_leaky_relu_bwd': [_P, _P, _P, _F, _L, _P],
     'nbm_layernorm_bwd': [_P, _P, _P, _L, _I, _F, _P, _P, _P, _P],

@@ -181,8 +181,8 @@ __global__ void silu_bwd_kernel(const float* __restrict__ gy, const float* __res
 }
 
 __global__ void axpby_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
-                             float alpha, float beta, long long n) {
-  GRID_STRIDE(i, n) out[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
+                             float alpha, float beta, long long n, long long b_period) {
+  GRID_STRIDE(i, n) out[i] = alpha * a[i] + (b ? beta * b[b_period ? i % b_period : i] : 0.f);
 }
 
 // out[n] += sum_m g[m][n]   (block partial sums in double, one atomic per column per block)
@@ -588,9 +588,11 @@ extern "C" int nbm_silu_bwd(const float* gy, const float* x, float* out, int64_t
   hipLaunchKernelGGL(silu_bwd_kernel, dim3(grid_for(n)), dim3(TPB), 0, ST, gy, x, out, (long long)n);
   return nbm_launch_status();
 }
-extern "C" int nbm_axpby(const float* a, const float* b, float* out, float alpha, float beta, int64_t n, void* stream) {
-  if (!a || !out || n <= 0) return NBM_EINVAL;
-  hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(TPB), 0, ST, a, b, out, alpha, beta, (long long)n);
+extern "C" int nbm_axpby(const float* a, const float* b, float* out, float alpha, float beta, int64_t n, int64_t b_period,
+                         void* stream) {
+  if (!a || !out || n <= 0 || b_period < 0) return NBM_EINVAL;
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(TPB), 0, ST, a, b, out, alpha, beta, (long long)n,
+                     (long long)b_period);
   return nbm_launch_status();
 }
 extern "C" int nbm_colsum(const float* g, int64_t M, int N, int ld, float* out, void* stream) {

@@ -191,6 +191,33 @@ class Add(Function):
         return g, g
 
 
+class Scale(Function):
+    """alpha * x (materialises the `fm + Identity(fm)` levels of SAPyramid when no convolution follows to absorb it)."""
+
+    @staticmethod
+    def forward(ctx, x, alpha):
+        ctx.alpha = alpha
+        return ops.axpby(x.contiguous(), None, alpha=alpha)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        return ops.axpby(g.contiguous(), None, alpha=ctx.alpha), None
+
+
+class AddConst(Function):
+    """x + c with a constant c broadcast over the batch axis (sine position encoding of --add_posenc)."""
+
+    @staticmethod
+    def forward(ctx, x, c):
+        return ops.axpby(x.contiguous(), c)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        return g, None
+
+
 class LayerNorm(Function):
     """nn.LayerNorm over the last axis of [rows, E] (Transformer_RCNN encoder, reference layers.py:618-621)."""
 

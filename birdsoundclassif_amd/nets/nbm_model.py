@@ -9,7 +9,8 @@ from torch import nn
 
 from .backbone import build_backbone
 from .fpn import build_fpn
-from .self_attention import build_sa_layers
+from . import functional as Fn
+from .self_attention import build_sa_layers, materialize
 from .head import build_head
 
 
@@ -18,8 +19,6 @@ class NbmModel(nn.Module):
 
     def __init__(self, args, backbone, attn, fpn, head):
         super().__init__()
-        if getattr(args, 'fpn_first', False) or getattr(args, 'sandwich_attn', False) or getattr(args, 'add_posenc', False):
-            raise NotImplementedError('only the default ordering fpn(attn(backbone(x))) is on the hot path')
         self.args = args
         self.backbone = backbone
         self.attn = attn
@@ -31,6 +30,13 @@ class NbmModel(nn.Module):
             raise ValueError(f'expected [B,{self.args.inpt_channels},H,W], got {tuple(samples.shape)}')
         x = samples.permute(0, 2, 3, 1).contiguous()
         features, _ = self.backbone(x)
+        if getattr(self.args, 'add_posenc', False):                       # nbm_model.py:45-46
+            pe = self.backbone[1]
+            features = [Fn.AddConst.apply(f, pe(f)) for f in features]
+        if getattr(self.args, 'fpn_first', False):                        # nbm_model.py:47-52
+            return materialize(self.attn(self.fpn(features)))
+        if getattr(self.args, 'sandwich_attn', False):
+            return materialize(self.attn[1](self.fpn(self.attn[0](features))))
         return self.fpn(self.attn(features))
 
     def forward_first_stage(self, samples, host_work=None):
@@ -91,7 +97,13 @@ def build(args, train=True):
     from .criterion import SetCriterion
     device = torch.device(args.device)
     backbone = build_backbone(args)
-    attn = build_sa_layers(args, backbone.num_channels)
+    if getattr(args, 'fpn_first', False):                                 # nbm_model.py:349-354
+        attn_channels = [args.out_fpn_chan] * len(backbone.num_channels)
+    elif getattr(args, 'sandwich_attn', False):
+        attn_channels = (backbone.num_channels, [args.out_fpn_chan] * len(backbone.num_channels))
+    else:
+        attn_channels = backbone.num_channels
+    attn = build_sa_layers(args, attn_channels)
     fpn = build_fpn(args, backbone.num_channels)
     head = build_head(args)
     model = NbmModel(args, backbone, attn, fpn, head).to(device)

@@ -4,7 +4,7 @@ Only `one_dimension_positional_encoding` is on the hot path (RoI positional enco
 reference layers.py:437-438).  The sine image encoding that the reference's `Joiner` evaluates for
 every level (backbone.py:139-148) is discarded by the default config (nbm_model.py:45,
 `add_posenc=False`), so `build_position_encoding` returns a marker object and
-nothing is computed for it; `--add_posenc` / `learned` are rejected loudly.
+nothing is computed for it unless `--add_posenc` asks for it (nbm_model.py:45-46); `learned` is rejected loudly.
 """
 import torch
 
@@ -19,16 +19,36 @@ def one_dimension_positional_encoding(length, cn, temp=10000):
 
 
 class PositionEmbeddingSine(torch.nn.Module):
-    """Placeholder with no parameters (keeps `Joiner`'s two-slot layout so that state_dict keys keep the
-    `backbone.0.` prefix)."""
+    """reference position_encoding.py:18-56 with normalize=True, only_y_scale=True (the only variant whose channel count
+    matches the feature map it is added to -- the 2-D variant fails inside the reference itself).  No parameters; the
+    encoding depends on the map shape only, so it is built once per (h, w, C) on the host and kept on the device as an
+    NHWC table [h, w, C] that `functional.AddConst` broadcasts over the batch."""
+
+    def __init__(self):
+        super().__init__()
+        self._tables = {}
+
+    def table(self, h, w, c, device):
+        key = (h, w, c, str(device))
+        if key not in self._tables:
+            import math
+            y = torch.arange(1, h + 1, dtype=torch.float32)
+            y = y / (y[-1] + 1e-6) * (2 * math.pi)
+            dim_t = 10000 ** (2 * torch.div(torch.arange(c, dtype=torch.float32), 2, rounding_mode='trunc') / c)
+            e = y[:, None] / dim_t
+            pos = torch.stack((e[:, 0::2].sin(), e[:, 1::2].cos()), dim=2).flatten(1)               # [h, c]
+            self._tables[key] = pos[:, None, :].expand(h, w, c).contiguous().to(device)
+        return self._tables[key]
 
     def forward(self, x):
-        raise NotImplementedError('add_posenc is not part of the accelerated path (default config discards it)')
+        """x NHWC [B,h,w,C] -> the [h,w,C] table on x's device."""
+        return self.table(x.shape[1], x.shape[2], x.shape[3], x.device)
 
 
 def build_position_encoding(args):
-    if getattr(args, 'add_posenc', False):
-        raise NotImplementedError('--add_posenc is outside the hot-path scope (SURVEY.md §8)')
     if args.position_embedding not in ('v2', 'sine'):
-        raise ValueError(f'not supported {args.position_embedding}')
+        raise NotImplementedError(f'position_embedding={args.position_embedding}: only the sine encoding is implemented')
+    if getattr(args, 'add_posenc', False) and not getattr(args, 'one_dim_posenc', True):
+        raise ValueError('--add_posenc needs the one-dimensional encoding: the 2-D variant has twice the channels of the map '
+                         'it is added to and fails in the reference too (position_encoding.py:52)')
     return PositionEmbeddingSine()

@@ -67,7 +67,14 @@ class SAPyramid(nn.Module):
         return out
 
 
+def materialize(levels):
+    """Scaled(fm, f) -> f * fm: for consumers that cannot fold the factor into a GEMM epilogue (the heads, when the
+    pyramid runs AFTER the FPN: --fpn_first / --sandwich_attn)."""
+    return [Fn.Scale.apply(l.tensor, l.factor) if isinstance(l, Scaled) else l for l in levels]
+
+
 def build_sa_layers(args, channels):
+    """reference self_attention.py:79-82: a pair of pyramids for --sandwich_attn (before and after the FPN)."""
     if type(channels) == tuple:
-        raise NotImplementedError('--sandwich_attn is outside the hot-path scope')
+        return nn.ModuleList([SAPyramid(cns, args.pyramid_top_n_attn) for cns in channels])
     return SAPyramid(channels, args.pyramid_top_n_attn)

@@ -516,8 +516,14 @@ def silu_bwd(gy, x):
 
 
 def axpby(a, b=None, alpha=1.0, beta=1.0):
+    """alpha*a + beta*b; a smaller `b` is repeated along the leading axes (its size must divide a's)."""
     out = torch.empty_like(a)
-    check(lib().nbm_axpby(_ptr(_chk(a)), _ptr(b), _ptr(out), float(alpha), float(beta), a.numel(), _stream()), 'nbm_axpby')
+    period = 0
+    if b is not None and b.numel() != a.numel():
+        assert a.numel() % b.numel() == 0
+        period = b.numel()
+    check(lib().nbm_axpby(_ptr(_chk(a)), _ptr(b), _ptr(out), float(alpha), float(beta), a.numel(), period, _stream()),
+          'nbm_axpby')
     return out
 
 

@@ -241,8 +241,9 @@ int nbm_conv_wgrad(const nbm_bwd_desc* d, void* stream);
 
 int nbm_relu_bwd(const float* gy, const float* y, float* out, int64_t n, void* stream);
 int nbm_silu_bwd(const float* gy, const float* x, float* out, int64_t n, void* stream);
-/* out = alpha*a + beta*b (b may be NULL): explicit gradient accumulation */
-int nbm_axpby(const float* a, const float* b, float* out, float alpha, float beta, int64_t n, void* stream);
+/* out[i] = alpha*a[i] + beta*b[i % b_period] (b may be NULL; b_period 0: b has n elements): gradient accumulation, the
+ * doubled identity levels of SAPyramid (self_attention.py:76), `features + pos` of --add_posenc (nbm_model.py:45-46) */
+int nbm_axpby(const float* a, const float* b, float* out, float alpha, float beta, int64_t n, int64_t b_period, void* stream);
 /* out[n] = sum_m g[m][n] (bias gradients) */
 int nbm_colsum(const float* g, int64_t M, int N, int ld, float* out, void* stream);
 int nbm_maxpool3x3s2_bwd(const uint8_t* idx, const float* gy, float* gx, int B, int H, int W, int C, int Ho, int Wo,

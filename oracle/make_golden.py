@@ -79,6 +79,28 @@ def tf_rcnn_golden():
     np.savez_compressed(os.path.join(OUT, 'tf_rcnn_b3.npz'), **g)
 
 
+def variants_golden():
+    """Model-composition flags of nbm_model.py:45-52: --fpn_first, --sandwich_attn, --add_posenc (eval forward, B=2)."""
+    g = {}
+    for tag, kw in (('fpn_first', dict(fpn_first=True)), ('sandwich', dict(sandwich_attn=True)), ('posenc', dict(add_posenc=True))):
+        args = ref_import.default_args(**kw)
+        model, _ = ref_import.build_reference_model(args, train=False)
+        sd = synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+        model.load_state_dict(sd)
+        model.eval()
+        x = torch.from_numpy(synth.image_batch(0, 2))[:, None]
+        with torch.no_grad():
+            o = model.forward_first_stage(x)
+            for i, f in enumerate(o['fpn_out']):
+                pack(g, f'{tag}.fpn{i}', f, full_limit=10000)
+            pack(g, f'{tag}.rpn_cls_scores', o['rpn_cls_scores'], full_limit=10000)
+            pack(g, f'{tag}.rpn_bbox_reg', o['rpn_bbox_reg'], full_limit=10000)
+            pack(g, f'{tag}.rois', o['rois'])
+            pack_dets(g, f'{tag}.dets_min0.2', model(x, min_score=0.2))
+        print('variant', tag, tuple(o['rois'].shape), len(g[f'{tag}.dets_min0.2']))
+    np.savez_compressed(os.path.join(OUT, 'variants_b2.npz'), **g)
+
+
 def tf_rcnn_train_golden():
     """One positive optimisation step (reference train.py:205-257) with `--tf_rcnn`, both encoder flavours, B=2:
     losses, clip-norm, sampled gradients of head / FPN / backbone parameters."""
@@ -219,6 +241,8 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     if '--tf-only' in sys.argv:
         return tf_rcnn_golden()
+    if '--variants-only' in sys.argv:
+        return variants_golden()
     if '--tf-train-only' in sys.argv:
         return tf_rcnn_train_golden()
     if '--labels-only' in sys.argv:
@@ -228,6 +252,7 @@ def main():
     if '--dataset-only' in sys.argv:
         return img_dataset_golden()
     tf_rcnn_golden()
+    variants_golden()
     tf_rcnn_train_golden()
     img_dataset_golden()
     metrics_golden()
