@@ -100,6 +100,8 @@ SIGNATURES = {
     'nbm_wino23_input': [_P, _I, _I, _I, _I, _P, _P],
     'nbm_wino23_output': [_P, _P, _I, _I, _I, _I, _P, _P],
     'nbm_wino23_outgrad': [_P, _I, _I, _I, _I, _P, _P, _P],
+    'nbm_weighted_sum': [_P, _P, _P, _P, _P, _L, _P],
+    'nbm_weighted_sum_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P],
     'nbm_softmax_rows_bwd': [_P, _P, _P, _L, _I, _F, _P],
     'nbm_pair_softmax_bwd': [_P, _P, _P, _L, _P],
     'nbm_dwconv3x3_bwd': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P],

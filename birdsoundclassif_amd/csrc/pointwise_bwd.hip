@@ -185,6 +185,59 @@ __global__ void axpby_kernel(const float* __restrict__ a, const float* __restric
   GRID_STRIDE(i, n) out[i] = alpha * a[i] + (b ? beta * b[b_period ? i % b_period : i] : 0.f);
 }
 
+// BiFPN FusionModule (reference fpn.py:20-30): out = (sum_i relu(w_i) x_i) / (sum_i relu(w_i) + 1e-4), 2 or 3 inputs, the
+// learnable weights read from the device (no host round trip).
+__global__ void weighted_sum_kernel(const float* __restrict__ x0, const float* __restrict__ x1, const float* __restrict__ x2,
+                                    const float* __restrict__ wraw, float* __restrict__ out, long long n4) {
+  const float w0 = fmaxf(wraw[0], 0.f), w1 = fmaxf(wraw[1], 0.f), w2 = x2 ? fmaxf(wraw[2], 0.f) : 0.f;
+  const float den = (x2 ? (w0 + w1) + w2 : w0 + w1) + 1e-4f;
+  const f32x4 *a = reinterpret_cast<const f32x4*>(x0), *b = reinterpret_cast<const f32x4*>(x1),
+              *c = reinterpret_cast<const f32x4*>(x2);
+  f32x4* o = reinterpret_cast<f32x4*>(out);
+  GRID_STRIDE(i, n4) {
+    f32x4 num = a[i] * w0 + b[i] * w1;
+    if (x2) num = num + c[i] * w2;
+    o[i] = num / den;
+  }
+}
+
+// gx_i = g relu(w_i)/den; gw_i += [w_i > 0] sum g (x_i - out)/den   (gw zeroed by the caller)
+__global__ __launch_bounds__(256) void weighted_sum_bwd_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
+                                                               const float* __restrict__ x2, const float* __restrict__ wraw,
+                                                               const float* __restrict__ g, float* __restrict__ gx0,
+                                                               float* __restrict__ gx1, float* __restrict__ gx2,
+                                                               float* __restrict__ gw, long long n4) {
+  const float w0 = fmaxf(wraw[0], 0.f), w1 = fmaxf(wraw[1], 0.f), w2 = x2 ? fmaxf(wraw[2], 0.f) : 0.f;
+  const float den = (x2 ? (w0 + w1) + w2 : w0 + w1) + 1e-4f;
+  const f32x4 *a = reinterpret_cast<const f32x4*>(x0), *b = reinterpret_cast<const f32x4*>(x1),
+              *c = reinterpret_cast<const f32x4*>(x2), *gg = reinterpret_cast<const f32x4*>(g);
+  f32x4 *ga = reinterpret_cast<f32x4*>(gx0), *gb = reinterpret_cast<f32x4*>(gx1), *gc = reinterpret_cast<f32x4*>(gx2);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  GRID_STRIDE(i, n4) {
+    const f32x4 va = a[i], vb = b[i], gv = gg[i];
+    f32x4 num = va * w0 + vb * w1, vc = {0.f, 0.f, 0.f, 0.f};
+    if (x2) { vc = c[i]; num = num + vc * w2; }
+    const f32x4 o = num / den;
+    if (ga) ga[i] = gv * (w0 / den);
+    if (gb) gb[i] = gv * (w1 / den);
+    if (x2 && gc) gc[i] = gv * (w2 / den);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s0 += gv[e] * (va[e] - o[e]);
+      s1 += gv[e] * (vb[e] - o[e]);
+      s2 += gv[e] * (vc[e] - o[e]);
+    }
+  }
+  __shared__ float red[3][4];
+  s0 = nbm_wave_sum(s0); s1 = nbm_wave_sum(s1); s2 = nbm_wave_sum(s2);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s0; red[1][threadIdx.x >> 6] = s1; red[2][threadIdx.x >> 6] = s2; }
+  __syncthreads();
+  if (threadIdx.x < 3 && (threadIdx.x < 2 || x2)) {
+    const float t = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+    if (wraw[threadIdx.x] > 0.f) atomicAdd(gw + threadIdx.x, t / den);
+  }
+}
+
 // out[n] += sum_m g[m][n]   (block partial sums in double, one atomic per column per block)
 __global__ void colsum_kernel(const float* __restrict__ g, long long M, int N, int ld, float* __restrict__ out) {
   const int n = blockIdx.y * 64 + (threadIdx.x & 63);
@@ -593,6 +646,20 @@ extern "C" int nbm_axpby(const float* a, const float* b, float* out, float alpha
   if (!a || !out || n <= 0 || b_period < 0) return NBM_EINVAL;
   hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n)), dim3(TPB), 0, ST, a, b, out, alpha, beta, (long long)n,
                      (long long)b_period);
+  return nbm_launch_status();
+}
+extern "C" int nbm_weighted_sum(const float* x0, const float* x1, const float* x2, const float* weights, float* out, int64_t n,
+                                void* stream) {
+  if (!x0 || !x1 || !weights || !out || n <= 0 || (n & 3)) return NBM_EINVAL;
+  if (!nbm_aligned16(x0) || !nbm_aligned16(x1) || (x2 && !nbm_aligned16(x2)) || !nbm_aligned16(out)) return NBM_EALIGN;
+  hipLaunchKernelGGL(weighted_sum_kernel, dim3(grid_for(n / 4)), dim3(TPB), 0, ST, x0, x1, x2, weights, out, (long long)(n / 4));
+  return nbm_launch_status();
+}
+extern "C" int nbm_weighted_sum_bwd(const float* x0, const float* x1, const float* x2, const float* weights, const float* g,
+                                    float* gx0, float* gx1, float* gx2, float* gw, int64_t n, void* stream) {
+  if (!x0 || !x1 || !weights || !g || !gw || n <= 0 || (n & 3)) return NBM_EINVAL;
+  hipLaunchKernelGGL(weighted_sum_bwd_kernel, dim3(grid_for(n / 4, TPB, 2048)), dim3(256), 0, ST, x0, x1, x2, weights, g, gx0,
+                     gx1, gx2, gw, (long long)(n / 4));
   return nbm_launch_status();
 }
 extern "C" int nbm_colsum(const float* g, int64_t M, int N, int ld, float* out, void* stream) {

@@ -4,10 +4,92 @@ state_dict keys: `fpn.pt_wise.{i}` (bottom-up) and `fpn.out_convs.{i}` ('0' appl
 level, reference fpn.py:137-145 / SURVEY Appendix C-2).  The 3x3 384->256 output convolutions carry 70 %
 of the detector's forward FLOPs; they run on the fp32-MFMA implicit-GEMM kernel.
 """
+import torch
 import torch.nn as nn
 
 from . import functional as Fn
-from .self_attention import Scaled
+from .layers import DepthwiseSepConv2d
+from .self_attention import Scaled, materialize
+
+
+class FusionModule(nn.Module):
+    """reference fpn.py:9-30: ReLU'd learnable weights, `num / (sum + 1e-4)`, then a depthwise-separable block."""
+
+    def __init__(self, n_ends, cn):
+        super().__init__()
+        self.weights = nn.Parameter(torch.ones(n_ends), requires_grad=True)
+        self.conv = DepthwiseSepConv2d(cn, cn)
+        self.act = nn.ReLU()
+
+    def forward(self, inputs):
+        x2 = inputs[2] if len(inputs) == 3 else None
+        return self.conv(Fn.WeightedSum.apply(inputs[0], inputs[1], x2, self.weights))
+
+
+class Rescale(nn.Module):
+    """reference fpn.py:33-44: bilinear (align_corners) resize to the target level, then a 1x1 convolution when the
+    channel counts differ."""
+
+    def __init__(self, in_cn, out_cn):
+        super().__init__()
+        self.up = nn.Upsample(scale_factor=2)              # parameter-free member of the reference, unused there too
+        if in_cn != out_cn:
+            self.pt_wise = nn.Conv2d(in_cn, out_cn, 1)
+
+    def forward(self, x, out_size):
+        out = Fn.UpsampleAdd.apply(x, None, int(out_size[0]), int(out_size[1]))
+        if hasattr(self, 'pt_wise'):
+            out = Fn.conv(out, self.pt_wise.weight, bias=self.pt_wise.bias)
+        return out
+
+
+class BiFPNLayer(nn.Module):
+    """reference fpn.py:47-100; `channels` bottom-up, NHWC maps."""
+
+    def __init__(self, channels, output_channels=None):
+        super().__init__()
+        n = len(channels)
+        self.rescalings_td = nn.ModuleDict({str(i + 1): Rescale(in_cn, out_cn)
+                                            for i, (out_cn, in_cn) in enumerate(zip(channels[:-1], channels[1:]))})
+        self.rescalings_bu = nn.ModuleDict({str(i): Rescale(in_cn, out_cn)
+                                            for i, (in_cn, out_cn) in enumerate(zip(channels[:-1], channels[1:]))})
+        self.fusions_td = nn.ModuleDict({str(i + 1): FusionModule(2, cn) for i, cn in enumerate(channels[1:-1])})
+        self.fusions_bu = nn.ModuleDict({str(i): FusionModule(2 if i in [0, n - 1] else 3, cn) for i, cn in enumerate(channels)})
+        if output_channels is not None:
+            self.out_pt_wise_convs = nn.ModuleDict({str(i): nn.Conv2d(cn, output_channels, 1) for i, cn in enumerate(channels)})
+
+    def forward(self, inputs):
+        n = len(inputs)
+        sizes = [tuple(e.shape[1:3]) for e in inputs]
+        td_out = inputs[-1]
+        td = [td_out]
+        for i in range(n - 2, 0, -1):                                     # top-down
+            td_out = self.fusions_td[str(i)]([inputs[i], self.rescalings_td[str(i + 1)](td_out, sizes[i])])
+            td.insert(0, td_out)
+        td.insert(0, self.rescalings_td['1'](td_out, sizes[0]))
+        bu_out = self.fusions_bu['0']([inputs[0], td[0]])                 # bottom-up
+        bu = [bu_out]
+        for i in range(1, n - 1):
+            bu_out = self.fusions_bu[str(i)]([inputs[i], td[i], self.rescalings_bu[str(i - 1)](bu_out, sizes[i])])
+            bu.append(bu_out)
+        bu.append(self.fusions_bu[str(n - 1)]([inputs[-1], self.rescalings_bu[str(n - 2)](bu_out, sizes[-1])]))
+        if hasattr(self, 'out_pt_wise_convs'):
+            bu = [Fn.conv(b, c.weight, bias=c.bias) for b, c in ((bu[i], self.out_pt_wise_convs[str(i)]) for i in range(n))]
+        return bu
+
+
+class BiFPN(nn.Module):
+    """reference fpn.py:103-115 (`--fpn bifpn`)."""
+
+    def __init__(self, n_layers, channels, out_cn):
+        super().__init__()
+        self.layers = nn.ModuleList([BiFPNLayer(channels, out_cn if i == (n_layers - 1) else None) for i in range(n_layers)])
+
+    def forward(self, x):
+        x = materialize(x)                      # doubled identity levels of SAPyramid: no lateral GEMM to absorb the factor
+        for layer in self.layers:
+            x = layer(x)
+        return x
 
 
 class FPN(nn.Module):
@@ -32,6 +114,8 @@ class FPN(nn.Module):
         return outs
 
 def build_fpn(args, channels):
+    if args.fpn == 'bifpn':
+        return BiFPN(args.n_bifpn_layers, channels, args.out_fpn_chan)
     if args.fpn != 'fpn':
-        raise ValueError(f'not supported {args.fpn}: BiFPN is outside the hot-path scope (SURVEY.md §8f)')
+        raise ValueError(f'not supported {args.fpn}')
     return FPN(channels, args.fpn_p_chan, args.out_fpn_chan)

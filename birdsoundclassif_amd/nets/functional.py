@@ -218,6 +218,24 @@ class AddConst(Function):
         return g, None
 
 
+class WeightedSum(Function):
+    """BiFPN FusionModule arithmetic (reference fpn.py:20-30) for 2 or 3 inputs; x2 may be None."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, x2, weights):
+        xs = [x0.contiguous(), x1.contiguous()] + ([x2.contiguous()] if x2 is not None else [])
+        ctx.save_for_backward(*xs, weights)
+        return ops.weighted_sum(xs, weights.detach())
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        *xs, weights = ctx.saved_tensors
+        gxs, gw = ops.weighted_sum_bwd(list(xs), weights.detach(), g.contiguous(), ctx.needs_input_grad[:len(xs)])
+        gxs = list(gxs) + [None] * (3 - len(gxs))
+        return gxs[0], gxs[1], gxs[2], gw
+
+
 class LayerNorm(Function):
     """nn.LayerNorm over the last axis of [rows, E] (Transformer_RCNN encoder, reference layers.py:618-621)."""
 

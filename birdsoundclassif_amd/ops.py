@@ -527,6 +527,26 @@ def axpby(a, b=None, alpha=1.0, beta=1.0):
     return out
 
 
+def weighted_sum(xs, weights):
+    """BiFPN fusion of 2 or 3 same-shaped tensors with ReLU'd learnable weights [len(xs)] (device)."""
+    x2 = xs[2] if len(xs) == 3 else None
+    out = torch.empty_like(xs[0])
+    check(lib().nbm_weighted_sum(_ptr(_chk(xs[0])), _ptr(_chk(xs[1])), _ptr(x2), _ptr(_chk(weights)), _ptr(out), out.numel(),
+                                 _stream()), 'nbm_weighted_sum')
+    return out
+
+
+def weighted_sum_bwd(xs, weights, g, need):
+    """-> ([gx_i or None], gw [len(xs)])."""
+    x2 = xs[2] if len(xs) == 3 else None
+    gxs = [torch.empty_like(x) if nd else None for x, nd in zip(xs, need)] + [None] * (3 - len(xs))
+    gw = torch.zeros((len(xs),), device=g.device, dtype=torch.float32)
+    check(lib().nbm_weighted_sum_bwd(_ptr(_chk(xs[0])), _ptr(_chk(xs[1])), _ptr(x2), _ptr(_chk(weights)), _ptr(_chk(g)),
+                                     _ptr(gxs[0]), _ptr(gxs[1]), _ptr(gxs[2]), _ptr(gw), g.numel(), _stream()),
+          'nbm_weighted_sum_bwd')
+    return gxs[:len(xs)], gw
+
+
 def colsum(g2d, n=None):
     """g2d [M, ld] -> [n] column sums (n defaults to ld)."""
     _chk(g2d, name='g')

@@ -241,6 +241,8 @@ def fill_state_dict(shapes, seed=0):
                 v = 0.05 * normal(name, n, seed)
             else:  # running_var
                 v = 0.9 + 0.2 * uniform(name, n, seed)
+        elif leaf == 'weights':                          # BiFPN fusion weights (ReLU'd): mostly positive, some clipped
+            v = 0.8 + 0.6 * normal(name, n, seed)
         elif leaf == 'bias':
             v = 0.02 * normal(name, n, seed)
             if 'bbox_classif_layer' in name:

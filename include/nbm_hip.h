@@ -244,6 +244,13 @@ int nbm_silu_bwd(const float* gy, const float* x, float* out, int64_t n, void* s
 /* out[i] = alpha*a[i] + beta*b[i % b_period] (b may be NULL; b_period 0: b has n elements): gradient accumulation, the
  * doubled identity levels of SAPyramid (self_attention.py:76), `features + pos` of --add_posenc (nbm_model.py:45-46) */
 int nbm_axpby(const float* a, const float* b, float* out, float alpha, float beta, int64_t n, int64_t b_period, void* stream);
+/* BiFPN FusionModule (fpn.py:20-30): out = (sum_i relu(w_i) x_i) / (sum_i relu(w_i) + 1e-4), 2 inputs (x2 NULL) or 3;
+ * `weights` is the raw learnable parameter on the device.  Backward: gx_i (any may be NULL) and gw[i] += d/dw_i (zeroed
+ * by the caller). */
+int nbm_weighted_sum(const float* x0, const float* x1, const float* x2, const float* weights, float* out, int64_t n,
+                     void* stream);
+int nbm_weighted_sum_bwd(const float* x0, const float* x1, const float* x2, const float* weights, const float* g, float* gx0,
+                         float* gx1, float* gx2, float* gw, int64_t n, void* stream);
 /* out[n] = sum_m g[m][n] (bias gradients) */
 int nbm_colsum(const float* g, int64_t M, int N, int ld, float* out, void* stream);
 int nbm_maxpool3x3s2_bwd(const uint8_t* idx, const float* gy, float* gx, int B, int H, int W, int C, int Ho, int Wo,

@@ -80,9 +80,11 @@ def tf_rcnn_golden():
 
 
 def variants_golden():
-    """Model-composition flags of nbm_model.py:45-52: --fpn_first, --sandwich_attn, --add_posenc (eval forward, B=2)."""
+    """Model-composition flags of nbm_model.py:45-52: --fpn_first, --sandwich_attn, --add_posenc, and `--fpn bifpn`
+    (fpn.py:9-115, two layers) -- eval forward, B=2."""
     g = {}
-    for tag, kw in (('fpn_first', dict(fpn_first=True)), ('sandwich', dict(sandwich_attn=True)), ('posenc', dict(add_posenc=True))):
+    for tag, kw in (('fpn_first', dict(fpn_first=True)), ('sandwich', dict(sandwich_attn=True)), ('posenc', dict(add_posenc=True)),
+                    ('bifpn', dict(fpn='bifpn', n_bifpn_layers=2))):
         args = ref_import.default_args(**kw)
         model, _ = ref_import.build_reference_model(args, train=False)
         sd = synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})

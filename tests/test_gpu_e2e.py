@@ -222,7 +222,7 @@ def test_chunked_stft_of_a_long_row(monkeypatch):
 
 
 @pytest.mark.parametrize('tag,kw', [('fpn_first', dict(fpn_first=True)), ('sandwich', dict(sandwich_attn=True)),
-                                    ('posenc', dict(add_posenc=True))])
+                                    ('posenc', dict(add_posenc=True)), ('bifpn', dict(fpn='bifpn', n_bifpn_layers=2))])
 def test_composition_flags_vs_reference_golden(tag, kw):
     """--fpn_first / --sandwich_attn / --add_posenc (reference nbm_model.py:45-52) against the real reference's outputs,
     forward and one optimisation step's worth of backward (finite gradients everywhere)."""
@@ -241,13 +241,15 @@ def test_composition_flags_vs_reference_golden(tag, kw):
         check_packed(g, f'{tag}.rpn_cls_scores', o['rpn_cls_scores'], atol=1e-4)
         check_packed(g, f'{tag}.rpn_bbox_reg', o['rpn_bbox_reg'], atol=1e-4)
         ref_rois = g[f'{tag}.rois.full'].reshape(g[f'{tag}.rois.shape'])
-        assert (o['rois'].cpu().numpy() != ref_rois).any(-1).mean() <= 0.03        # unstable-argsort ties, see the CPU test
-        rows, ref = dets_to_rows(m(x, min_score=0.2)), g[f'{tag}.dets_min0.2']
-        assert abs(len(rows) - len(ref)) <= 2
+        if tag != 'bifpn':                                                          # see the CPU test
+            assert (o['rois'].cpu().numpy() != ref_rois).any(-1).mean() <= 0.03    # unstable-argsort ties
+            rows, ref = dets_to_rows(m(x, min_score=0.2)), g[f'{tag}.dets_min0.2']
+            assert abs(len(rows) - len(ref)) <= 2
     m.train(), crit.train()
     opt, _ = build_optimizer(m, args)
     bb, ids, lengths = synth.label_batch(0, 2)
     np.random.seed(3)
     loss = train_one_step(m, crit, opt, [x[:, 0], x[:, 0], bb, ids, lengths], args.clip_max_norm, 'cuda', negative_sample=False)
     assert all(np.isfinite(float(v.detach() if torch.is_tensor(v) else v)) for v in loss.values()) and np.isfinite(opt.grad_norm())
-    assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in m.named_parameters() if n.startswith('attn'))
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in m.named_parameters()
+               if n.startswith('attn') or n.startswith('fpn'))

@@ -515,3 +515,22 @@ def test_winograd_conv_forward_and_gradients():
         close(nchw(xd.grad), x.grad, 1e-5, 'winograd dx')
         close(wd.grad, w.grad, 2e-5, 'winograd dw')
         close(bd.grad, b.grad, 2e-5, 'winograd db')
+
+
+def test_weighted_sum_fusion_backward():
+    """BiFPN FusionModule arithmetic (2 and 3 inputs, one weight clipped by the ReLU) vs torch autograd."""
+    for n_in, wv in ((2, [0.7, 1.3]), (3, [0.9, -0.2, 0.4])):
+        xs = [rnd(('ws', n_in, i), 2, 5, 7, 16).requires_grad_(True) for i in range(n_in)]
+        w = torch.tensor(wv).requires_grad_(True)
+        g = rnd(('wsg', n_in), 2, 5, 7, 16)
+        r = F.relu(w)
+        (sum(ri * xi for ri, xi in zip(r, xs)) / (r.sum() + 1e-4)).backward(g)
+        xd = [x.detach().cuda().requires_grad_(True) for x in xs]
+        wd = w.detach().cuda().requires_grad_(True)
+        y = Fn.WeightedSum.apply(xd[0], xd[1], xd[2] if n_in == 3 else None, wd)
+        ref = sum(ri * xi for ri, xi in zip(r, xs)) / (r.sum() + 1e-4)
+        close(y, ref, 2e-6, 'weighted sum fwd')
+        y.backward(g.cuda())
+        for a, b in zip(xd, xs):
+            close(a.grad, b.grad, 2e-6, 'weighted sum dx')
+        close(wd.grad, w.grad, 2e-5, 'weighted sum dw')
