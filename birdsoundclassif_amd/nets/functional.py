@@ -33,9 +33,12 @@ def _w_to_ref_layout(gw, weight):
     return gw[:, :kh * kw * c].view(n, kh, kw, c).permute(0, 3, 1, 2)
 
 
+WINOGRAD = True          # module switch for A/B tests (tests/test_gpu_e2e.py compares both convolution paths)
+
+
 def _winograd_ok(x, weight, kh, kw, stride, pad):
     """3x3 / stride 1 / pad 1 with MFMA-friendly channel counts (odd map sizes cost one zero-padded tile row / column)."""
-    if not (kh == 3 and kw == 3 and stride == 1 and pad == 1 and weight.dim() == 4 and x.dim() == 4):
+    if not (kh == 3 and kw == 3 and stride == 1 and pad == 1 and weight.dim() == 4 and x.dim() == 4) or not WINOGRAD:
         return False
     _, H, W, Cin = x.shape
     return H >= 8 and W >= 8 and Cin % 32 == 0 and weight.shape[0] % 4 == 0 and Cin >= 128
