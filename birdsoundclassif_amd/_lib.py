@@ -97,9 +97,9 @@ SIGNATURES = {
     'nbm_randn_fill': [_U64, _L, _P, _P],
     'nbm_augment_batch': [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     'nbm_u8_to_unit': [_P, _L, _P, _P],
-    'nbm_wino23_input': [_P, _I, _I, _I, _I, _P, _P],
-    'nbm_wino23_output': [_P, _P, _I, _I, _I, _I, _P, _P],
-    'nbm_wino23_outgrad': [_P, _I, _I, _I, _I, _P, _P, _P],
+    'nbm_wino_input': [_P, _I, _I, _I, _I, _P, _I, _P],
+    'nbm_wino_output': [_P, _P, _I, _I, _I, _I, _P, _I, _P],
+    'nbm_wino_outgrad': [_P, _I, _I, _I, _I, _P, _P, _I, _P],
     'nbm_weighted_sum': [_P, _P, _P, _P, _P, _L, _P],
     'nbm_weighted_sum_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P],
     'nbm_softmax_rows_bwd': [_P, _P, _P, _L, _I, _F, _P],

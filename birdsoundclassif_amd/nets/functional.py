@@ -34,6 +34,7 @@ def _w_to_ref_layout(gw, weight):
 
 
 WINOGRAD = True          # module switch for A/B tests (tests/test_gpu_e2e.py compares both convolution paths)
+WINO_BWD_TILE = 4        # F(4x4,3x3) for the two backward convolutions (gradients tolerate its 2e-5 error); 2 = F(2x2,3x3)
 
 
 def _winograd_ok(x, weight, kh, kw, stride, pad):
@@ -78,7 +79,8 @@ class Conv(Function):
         if ctx.needs_input_grad[0] and ctx.wino and N % 32 == 0:
             # data gradient of a 3x3 / stride 1 / pad 1 convolution = the same convolution with the kernel rotated by 180
             # degrees and the channel roles swapped: Winograd again
-            gx = ops.conv3x3_winograd(g.view(B, H, W, N), _prep.wino23(weight, transposed=True), None)
+            gx = ops.conv3x3_winograd(g.view(B, H, W, N), _prep.wino23(weight, transposed=True, m=WINO_BWD_TILE), None,
+                                      m=WINO_BWD_TILE)
         elif ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
             ops.conv_dgrad(gp, wk, gx, B=B, H=H, W=W, Cin=Cin, N=N, kh=kh, kw=kw, stride=stride, pad=pad,
@@ -86,8 +88,8 @@ class Conv(Function):
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] and ctx.wino and N % 32 == 0:
             # weight gradient in the Winograd domain: 16 TN GEMMs dU = dM^T V, mapped back with dW = G^T dU G
-            dU, gb = ops.conv3x3_winograd_wgrad(x, g.view(B, H, W, N), want_bias=want_gb)
-            gw = _prep.wino23_weight_grad(dU)
+            dU, gb = ops.conv3x3_winograd_wgrad(x, g.view(B, H, W, N), want_bias=want_gb, m=WINO_BWD_TILE)
+            gw = _prep.wino23_weight_grad(dU, WINO_BWD_TILE)
         elif ctx.needs_input_grad[1]:
             gwk = torch.zeros_like(wk)
             if want_gb:                                   # the bias gradient rides along in the weight-gradient kernel

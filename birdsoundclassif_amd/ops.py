@@ -110,20 +110,22 @@ def _wino_scratch(device, n_v, n_m):
     return buf[:n_v], buf[n_v:need]
 
 
-def conv3x3_winograd(x, U, bias=None):
-    """3x3 / stride 1 / pad 1 convolution through Winograd F(2x2,3x3): x [B,H,W,C], U [16,N,C] from
-    `_prep.wino23` -> [B,H,W,N].  Three launches per batch chunk: input transform, 16 grouped GEMMs on the fp32 MFMA
-    (2.25x fewer multiplies than the direct kernel), output transform (+ bias).  The batch is cut so that the transformed
-    operands (4x the input + 4x the output) stay within WINO_CHUNK_BYTES."""
+def conv3x3_winograd(x, U, bias=None, m=2):
+    """3x3 / stride 1 / pad 1 convolution through Winograd F(m x m, 3x3): x [B,H,W,C], U [(m+2)^2,N,C] from
+    `_prep.wino23` -> [B,H,W,N].  Three launches per batch chunk: input transform, (m+2)^2 grouped GEMMs on the fp32 MFMA
+    (2.25x / 4x fewer multiplies than the direct kernel for m = 2 / 4), output transform (+ bias).  The batch is cut so
+    that the transformed operands stay within WINO_CHUNK_BYTES.  m = 2 is the forward setting (error ~3e-6), m = 4 the
+    backward one (~2e-5, see csrc/winograd.hip)."""
     _chk(x, name='x'), _chk(U, name='U')
     B, H, W, C_ = x.shape
     N = U.shape[1]
-    assert U.shape == (16, N, C_) and C_ % 32 == 0 and N % 4 == 0
+    nxi = (m + 2) ** 2
+    assert U.shape == (nxi, N, C_) and C_ % 32 == 0 and N % 4 == 0
     y = torch.empty((B, H, W, N), device=x.device, dtype=torch.float32)
-    tiles = ((H + 1) // 2) * ((W + 1) // 2)
-    per_img = 16 * tiles * (C_ + N) * 4
+    tiles = (-(-H // m)) * (-(-W // m))
+    per_img = nxi * tiles * (C_ + N) * 4
     chunk = max(1, min(B, WINO_CHUNK_BYTES // per_img))
-    V, M = _wino_scratch(x.device, 16 * chunk * tiles * C_, 16 * chunk * tiles * N)
+    V, M = _wino_scratch(x.device, nxi * chunk * tiles * C_, nxi * chunk * tiles * N)
     st = _stream()
     if PROFILE is not None:                       # whole-op bracket (transforms + GEMMs) next to the per-GEMM entries
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -131,41 +133,42 @@ def conv3x3_winograd(x, U, bias=None):
     for b0 in range(0, B, chunk):
         nb = min(chunk, B - b0)
         T = nb * tiles
-        check(lib().nbm_wino23_input(_ptr(x[b0:b0 + nb]), nb, H, W, C_, _ptr(V), st), 'nbm_wino23_input')
+        check(lib().nbm_wino_input(_ptr(x[b0:b0 + nb]), nb, H, W, C_, _ptr(V), m, st), 'nbm_wino_input')
         global _PROFILE_LABEL
         _PROFILE_LABEL = ('wino23', H, W)
         try:
-            gemm_conv(V, U, M, B=1, H=T, W=1, Cin=C_, N=N, groups=16, x_gs=T * C_, w_gs=N * C_, y_gs=T * N)
+            gemm_conv(V, U, M, B=1, H=T, W=1, Cin=C_, N=N, groups=nxi, x_gs=T * C_, w_gs=N * C_, y_gs=T * N)
         finally:
             _PROFILE_LABEL = None
-        check(lib().nbm_wino23_output(_ptr(M), _ptr(bias), nb, H, W, N, _ptr(y[b0:b0 + nb]), st), 'nbm_wino23_output')
+        check(lib().nbm_wino_output(_ptr(M), _ptr(bias), nb, H, W, N, _ptr(y[b0:b0 + nb]), m, st), 'nbm_wino_output')
     if PROFILE is not None:
         ev[1].record()
         PROFILE.append((('wino23', C_, N, H, W, B), *ev))
     return y
 
 
-def conv3x3_winograd_wgrad(x, g, want_bias=False):
-    """Weight gradient of `conv3x3_winograd` in the transformed domain: x [B,H,W,C] (forward input), g [B,H,W,N]
-    (gradient wrt the output) -> (dU [16,N,C] with dU[xi] = dM[xi]^T V[xi], bias gradient [N] or None).  The caller maps dU
-    back with dW = G^T dU G (`_prep.wino23_weight_grad`)."""
+def conv3x3_winograd_wgrad(x, g, want_bias=False, m=2):
+    """Weight gradient of a 3x3 / s1 / p1 convolution in the Winograd domain: x [B,H,W,C] (forward input), g [B,H,W,N]
+    (gradient wrt the output) -> (dU [(m+2)^2,N,C] with dU[xi] = dM[xi]^T V[xi], bias gradient [N] or None).  The caller
+    maps dU back with dW = G^T dU G (`_prep.wino23_weight_grad`)."""
     _chk(x, name='x'), _chk(g, name='g')
     B, H, W, C_ = x.shape
     N = g.shape[-1]
+    nxi = (m + 2) ** 2
     assert g.shape[:3] == x.shape[:3] and C_ % 4 == 0 and N % 4 == 0
-    tiles = ((H + 1) // 2) * ((W + 1) // 2)
-    per_img = 16 * tiles * (C_ + N) * 4
+    tiles = (-(-H // m)) * (-(-W // m))
+    per_img = nxi * tiles * (C_ + N) * 4
     chunk = max(1, min(B, WINO_CHUNK_BYTES // per_img))
-    V, dM = _wino_scratch(x.device, 16 * chunk * tiles * C_, 16 * chunk * tiles * N)
-    dU = torch.zeros((16, N, C_), device=x.device, dtype=torch.float32)
+    V, dM = _wino_scratch(x.device, nxi * chunk * tiles * C_, nxi * chunk * tiles * N)
+    dU = torch.zeros((nxi, N, C_), device=x.device, dtype=torch.float32)
     gb = torch.zeros((N,), device=x.device, dtype=torch.float32) if want_bias else None
     st = _stream()
     for b0 in range(0, B, chunk):
         nb = min(chunk, B - b0)
         T = nb * tiles
-        check(lib().nbm_wino23_input(_ptr(x[b0:b0 + nb]), nb, H, W, C_, _ptr(V), st), 'nbm_wino23_input')
-        check(lib().nbm_wino23_outgrad(_ptr(g[b0:b0 + nb]), nb, H, W, N, _ptr(dM), _ptr(gb), st), 'nbm_wino23_outgrad')
-        conv_wgrad(dM, V, dU, B=1, H=T, W=1, Cin=C_, N=N, groups=16, g_gs=T * N, x_gs=T * C_, out_gs=N * C_)
+        check(lib().nbm_wino_input(_ptr(x[b0:b0 + nb]), nb, H, W, C_, _ptr(V), m, st), 'nbm_wino_input')
+        check(lib().nbm_wino_outgrad(_ptr(g[b0:b0 + nb]), nb, H, W, N, _ptr(dM), _ptr(gb), m, st), 'nbm_wino_outgrad')
+        conv_wgrad(dM, V, dU, B=1, H=T, W=1, Cin=C_, N=N, groups=nxi, g_gs=T * N, x_gs=T * C_, out_gs=N * C_)
     return dU, gb
 
 

@@ -512,9 +512,19 @@ def test_winograd_conv_forward_and_gradients():
             yd.backward(nhwc(gy))
         finally:
             _ops.WINO_CHUNK_BYTES = old
-        close(nchw(xd.grad), x.grad, 1e-5, 'winograd dx')
-        close(wd.grad, w.grad, 2e-5, 'winograd dw')
+        close(nchw(xd.grad), x.grad, 2e-5, 'winograd dx')          # backward runs F(4x4,3x3): ~2e-5 of the largest value
+        close(wd.grad, w.grad, 3e-5, 'winograd dw')
         close(bd.grad, b.grad, 2e-5, 'winograd db')
+        # the F(2x2,3x3) backward setting (tighter) stays available
+        Fn.WINO_BWD_TILE = 2
+        try:
+            xd2 = nhwc(x).requires_grad_(True)
+            wd2, bd2 = w.detach().cuda().requires_grad_(True), b.detach().cuda().requires_grad_(True)
+            Fn.conv(xd2, wd2, bias=bd2, kh=3, kw=3, pad=1).backward(nhwc(gy))
+        finally:
+            Fn.WINO_BWD_TILE = 4
+        close(nchw(xd2.grad), x.grad, 1e-5, 'winograd F(2,3) dx')
+        close(wd2.grad, w.grad, 2e-5, 'winograd F(2,3) dw')
 
 
 def test_weighted_sum_fusion_backward():
