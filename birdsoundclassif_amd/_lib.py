@@ -98,7 +98,7 @@ SIGNATURES = {
     'nbm_augment_batch': [_P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     'nbm_u8_to_unit': [_P, _L, _P, _P],
     'nbm_wino_input': [_P, _I, _I, _I, _I, _P, _I, _P],
-    'nbm_wino_output': [_P, _P, _I, _I, _I, _I, _P, _I, _P],
+    'nbm_wino_output': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P],
     'nbm_wino_outgrad': [_P, _I, _I, _I, _I, _P, _P, _I, _P],
     'nbm_weighted_sum': [_P, _P, _P, _P, _P, _L, _P],
     'nbm_weighted_sum_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P],

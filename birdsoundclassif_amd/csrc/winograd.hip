@@ -56,8 +56,26 @@ __global__ __launch_bounds__(256) void wino23_input_kernel(const float* __restri
 }
 
 // M [16][T][N] (+ bias[N]) -> y [B][H][W][N]; A^T = [1 1 1 0; 0 1 -1 -1]
-__global__ __launch_bounds__(256) void wino23_output_kernel(const float* __restrict__ M, const float* __restrict__ bias,
-                                                            int B, int H, int W, int N4, float* __restrict__ y) {
+// epilogue shared by both output transforms: v * scale + shift, ReLU, producer mask (all optional)
+template <typename V>
+__device__ __forceinline__ V wino_epilogue(V v, V sc, V sh, bool relu, const V* mask, long long idx) {
+  v = v * sc + sh;
+  constexpr int n = sizeof(V) / sizeof(float);
+  if (relu) {
+#pragma unroll
+    for (int e = 0; e < n; ++e) v[e] = fmaxf(v[e], 0.f);
+  }
+  if (mask) {
+    const V q = mask[idx];
+#pragma unroll
+    for (int e = 0; e < n; ++e) if (!(q[e] > 0.f)) v[e] = 0.f;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256) void wino23_output_kernel(const float* __restrict__ M, const float* __restrict__ scale,
+                                                            const float* __restrict__ bias, const float* __restrict__ mask,
+                                                            int relu, int B, int H, int W, int N4, float* __restrict__ y) {
   const int TH = (H + 1) >> 1, TW = (W + 1) >> 1;
   const long long T = (long long)B * TH * TW;
   const long long total = T * N4;
@@ -78,16 +96,18 @@ __global__ __launch_bounds__(256) void wino23_output_kernel(const float* __restr
       s[0][q] = m0 + m1 + m2;
       s[1][q] = m1 - m2 - m3;
     }
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f}, sv = {1.f, 1.f, 1.f, 1.f};
     if (bias) bv = reinterpret_cast<const f32x4*>(bias)[c];
+    if (scale) sv = reinterpret_cast<const f32x4*>(scale)[c];
+    const f32x4* mk = reinterpret_cast<const f32x4*>(mask);
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      const f32x4 o0 = s[p][0] + s[p][1] + s[p][2] + bv;
-      const f32x4 o1 = s[p][1] - s[p][2] - s[p][3] + bv;
+      const f32x4 o0 = s[p][0] + s[p][1] + s[p][2];
+      const f32x4 o1 = s[p][1] - s[p][2] - s[p][3];
       if (2 * ty + p >= H) break;                                   // odd H: the last tile row is half outside
       const long long row = ((long long)b * H + 2 * ty + p) * W + 2 * tx;
-      y4[row * N4 + c] = o0;
-      if (2 * tx + 1 < W) y4[(row + 1) * N4 + c] = o1;
+      y4[row * N4 + c] = wino_epilogue(o0, sv, bv, relu, mk, row * N4 + c);
+      if (2 * tx + 1 < W) y4[(row + 1) * N4 + c] = wino_epilogue(o1, sv, bv, relu, mk, (row + 1) * N4 + c);
     }
   }
 }
@@ -203,8 +223,9 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restri
 }
 
 // M [36][T][N] (+ bias) -> y [B][H][W][N] = A^T m A per 4x4 tile (partial tiles at the bottom / right edge)
-__global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restrict__ M, const float* __restrict__ bias,
-                                                            int B, int H, int W, int N2, float* __restrict__ y) {
+__global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restrict__ M, const float* __restrict__ scale,
+                                                            const float* __restrict__ bias, const float* __restrict__ mask,
+                                                            int relu, int B, int H, int W, int N2, float* __restrict__ y) {
   const int TH = (H + 3) >> 2, TW = (W + 3) >> 2;
   const long long T = (long long)B * TH * TW;
   const long long total = T * N2;
@@ -232,8 +253,10 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restr
         s[p][q] = acc;
       }
     }
-    f32x2 bv = zero;
+    f32x2 bv = zero, sv = {1.f, 1.f};
     if (bias) bv = reinterpret_cast<const f32x2*>(bias)[c];
+    if (scale) sv = reinterpret_cast<const f32x2*>(scale)[c];
+    const f32x2* mk = reinterpret_cast<const f32x2*>(mask);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int oy = 4 * ty + p;
@@ -242,10 +265,11 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restr
       for (int o = 0; o < 4; ++o) {
         const int ox = 4 * tx + o;
         if (ox >= W) break;
-        f32x2 acc = bv;
+        f32x2 acc = zero;
 #pragma unroll
         for (int q = 0; q < 6; ++q) acc += s[p][q] * W43_AT[o][q];
-        y2[(((long long)b * H + oy) * W + ox) * N2 + c] = acc;
+        const long long idx = (((long long)b * H + oy) * W + ox) * N2 + c;
+        y2[idx] = wino_epilogue(acc, sv, bv, relu, mk, idx);
       }
     }
   }
@@ -339,13 +363,18 @@ extern "C" int nbm_wino_outgrad(const float* g, int B, int H, int W, int N, floa
   return nbm_launch_status();
 }
 
-extern "C" int nbm_wino_output(const float* M, const float* bias, int B, int H, int W, int N, float* y, int m, void* stream) {
+extern "C" int nbm_wino_output(const float* M, const float* scale, const float* shift, const float* mask, int relu, int B,
+                               int H, int W, int N, float* y, int m, void* stream) {
   if (!M || !y || B <= 0 || H <= 0 || W <= 0 || N <= 0 || (N & 3) || (m != 2 && m != 4)) return NBM_EINVAL;
-  if (!nbm_aligned16(M) || !nbm_aligned16(y) || (bias && !nbm_aligned16(bias))) return NBM_EALIGN;
+  if (!nbm_aligned16(M) || !nbm_aligned16(y) || (shift && !nbm_aligned16(shift)) || (scale && !nbm_aligned16(scale)) ||
+      (mask && !nbm_aligned16(mask)))
+    return NBM_EALIGN;
   const long long tiles = (long long)B * ((H + m - 1) / m) * ((W + m - 1) / m);
   if (m == 2)
-    hipLaunchKernelGGL(wino23_output_kernel, dim3(grid_for(tiles * (N / 4))), dim3(256), 0, (hipStream_t)stream, M, bias, B, H, W, N / 4, y);
+    hipLaunchKernelGGL(wino23_output_kernel, dim3(grid_for(tiles * (N / 4))), dim3(256), 0, (hipStream_t)stream, M, scale, shift,
+                       mask, relu, B, H, W, N / 4, y);
   else
-    hipLaunchKernelGGL(wino43_output_kernel, dim3(grid_for(tiles * (N / 2))), dim3(256), 0, (hipStream_t)stream, M, bias, B, H, W, N / 2, y);
+    hipLaunchKernelGGL(wino43_output_kernel, dim3(grid_for(tiles * (N / 2))), dim3(256), 0, (hipStream_t)stream, M, scale, shift,
+                       mask, relu, B, H, W, N / 2, y);
   return nbm_launch_status();
 }

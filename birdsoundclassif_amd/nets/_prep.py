@@ -57,18 +57,22 @@ def _wino_g(device, dtype, m=2):
     return _WINO_G_DEV[key]
 
 
-def wino23(weight, transposed=False, m=2):
+def wino23(weight, transposed=False, m=2, scale=None):
     """Winograd F(m x m, 3x3) weights U[(m+2)^2][N][C] = (G g G^T)[i][j] of a [Cout, Cin, 3, 3] convolution, computed in
     float64 on the device and rounded once.  `transposed`: the weights of the DATA-GRADIENT convolution (kernel rotated by
-    180 degrees, channel roles swapped): U[..][Cin][Cout]."""
+    180 degrees, channel roles swapped): U[..][Cin][Cout]; `scale` [Cout] (transposed only): the FrozenBN scale that
+    multiplies the incoming gradient per output channel, folded into the weights."""
     def make():
         g = weight.detach().double()
+        if scale is not None:
+            g = g * scale.detach().double().view(-1, 1, 1, 1)
         if transposed:
             g = g.flip(2, 3).transpose(0, 1)
         G = _wino_g(g.device, torch.float64, m)
         u = torch.einsum('ia,ncab,jb->ijnc', G, g, G)
         return u.reshape((m + 2) ** 2, g.shape[0], g.shape[1]).float().contiguous()
-    return _cached(weight, ('wino', m, transposed), make)
+    tag = ('wino', m, transposed) if scale is None else ('wino', m, transposed, scale.data_ptr(), scale._version)
+    return _cached(weight, tag, make)
 
 
 def wino23_weight_grad(dU, m=2):

@@ -64,7 +64,11 @@ class _Bottleneck(nn.Module):
         s, b = self.bn1.affine()
         o = Fn.conv(x, self.conv1.weight, scale=s, shift=b, act=ops.ACT_RELU)
         s, b = self.bn2.affine()
-        o = Fn.conv(o, self.conv2.weight, scale=s, shift=b, kh=3, kw=3, stride=self.stride, pad=1, act=ops.ACT_RELU)
+        if self.stride == 1 and Fn._winograd_ok(o, self.conv2.weight, 3, 3, 1, 1):
+            # >= 128 channels: Winograd F(2x2,3x3) with FrozenBN + ReLU in the output transform (same as Fn.Bottleneck)
+            o = ops.conv3x3_winograd(o, _prep.wino23(self.conv2.weight), b, scale=s, relu=True)
+        else:
+            o = Fn.conv(o, self.conv2.weight, scale=s, shift=b, kh=3, kw=3, stride=self.stride, pad=1, act=ops.ACT_RELU)
         if self.downsample is not None:
             s, b = self.downsample[1].affine()
             idt = Fn.conv(x, self.downsample[0].weight, scale=s, shift=b, stride=self.stride)

@@ -119,18 +119,22 @@ class Bottleneck(Function):
     @staticmethod
     def forward(ctx, x, w1, w2, w3, wd, s1, b1, s2, b2, s3, b3, sd, bd, stride, mask_input, mask_gy):
         a1 = ops.conv2d(x, _prep.krsc(w1), scale=s1, shift=b1, act=ACT_RELU)
-        a2 = ops.conv2d(a1, _prep.krsc(w2), 3, 3, stride, 1, scale=s2, shift=b2, act=ACT_RELU)
+        wino = stride == 1 and _winograd_ok(a1, w2, 3, 3, 1, 1)
+        if wino:              # 3x3 / stride 1 with >= 128 channels: Winograd, FrozenBN + ReLU in the output transform
+            a2 = ops.conv3x3_winograd(a1, _prep.wino23(w2), b2, scale=s2, relu=True)
+        else:
+            a2 = ops.conv2d(a1, _prep.krsc(w2), 3, 3, stride, 1, scale=s2, shift=b2, act=ACT_RELU)
         idt = x if wd is None else ops.conv2d(x, _prep.krsc(wd), 1, 1, stride, 0, scale=sd, shift=bd)
         y = ops.conv2d(a2, _prep.krsc(w3), scale=s3, shift=b3, residual=idt, act=ACT_RELU)
         ctx.save_for_backward(x, a1, a2, y, w1, w2, w3, wd, s1, s2, s3, sd)
-        ctx.cfg = (stride, mask_input, mask_gy)
+        ctx.cfg = (stride, mask_input, mask_gy, wino)
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
         x, a1, a2, y, w1, w2, w3, wd, s1, s2, s3, sd = ctx.saved_tensors
-        stride, mask_input, mask_gy = ctx.cfg
+        stride, mask_input, mask_gy, wino = ctx.cfg
         need = ctx.needs_input_grad
         B, H, W, Cin = x.shape
         Ho, Wo = y.shape[1:3]
@@ -149,9 +153,17 @@ class Bottleneck(Function):
         ops.conv_dgrad(g3r, k3, g2, B=B, H=Ho, W=Wo, Cin=P, N=N3, g_ld=N3, w_ld=k3.shape[1], a_scale=s3, mask=a2)
         g2r = g2.view(-1, P)
         geom2 = dict(B=B, H=H, W=W, Cin=P, N=P, kh=3, kw=3, stride=stride, pad=1)
-        gw2 = wgrad(g2r, a1, k2, w2, s2, **geom2) if need[2] else None
-        g1 = torch.empty_like(a1)
-        ops.conv_dgrad(g2r, k2, g1, g_ld=P, w_ld=k2.shape[1], a_scale=s2, mask=a1, **geom2)
+        if wino:              # both gradients of the 3x3 in the Winograd domain (F(4x4,3x3)); BN scale folded into the weights
+            m = WINO_BWD_TILE
+            gw2 = None
+            if need[2]:
+                dU, _ = ops.conv3x3_winograd_wgrad(a1, g2, m=m)
+                gw2 = _prep.wino23_weight_grad(dU, m) * s2.view(-1, 1, 1, 1)
+            g1 = ops.conv3x3_winograd(g2, _prep.wino23(w2, transposed=True, m=m, scale=s2), None, m=m, mask=a1)
+        else:
+            gw2 = wgrad(g2r, a1, k2, w2, s2, **geom2) if need[2] else None
+            g1 = torch.empty_like(a1)
+            ops.conv_dgrad(g2r, k2, g1, g_ld=P, w_ld=k2.shape[1], a_scale=s2, mask=a1, **geom2)
         g1r = g1.view(-1, P)
         gwd = None
         if wd is None:

@@ -110,12 +110,12 @@ def _wino_scratch(device, n_v, n_m):
     return buf[:n_v], buf[n_v:need]
 
 
-def conv3x3_winograd(x, U, bias=None, m=2):
+def conv3x3_winograd(x, U, bias=None, m=2, scale=None, relu=False, mask=None):
     """3x3 / stride 1 / pad 1 convolution through Winograd F(m x m, 3x3): x [B,H,W,C], U [(m+2)^2,N,C] from
     `_prep.wino23` -> [B,H,W,N].  Three launches per batch chunk: input transform, (m+2)^2 grouped GEMMs on the fp32 MFMA
     (2.25x / 4x fewer multiplies than the direct kernel for m = 2 / 4), output transform (+ bias).  The batch is cut so
     that the transformed operands stay within WINO_CHUNK_BYTES.  m = 2 is the forward setting (error ~3e-6), m = 4 the
-    backward one (~2e-5, see csrc/winograd.hip)."""
+    backward one (~2e-5, see csrc/winograd.hip).  Epilogue: y = relu?((.) * scale + bias), zeroed where mask <= 0."""
     _chk(x, name='x'), _chk(U, name='U')
     B, H, W, C_ = x.shape
     N = U.shape[1]
@@ -140,7 +140,8 @@ def conv3x3_winograd(x, U, bias=None, m=2):
             gemm_conv(V, U, M, B=1, H=T, W=1, Cin=C_, N=N, groups=nxi, x_gs=T * C_, w_gs=N * C_, y_gs=T * N)
         finally:
             _PROFILE_LABEL = None
-        check(lib().nbm_wino_output(_ptr(M), _ptr(bias), nb, H, W, N, _ptr(y[b0:b0 + nb]), m, st), 'nbm_wino_output')
+        check(lib().nbm_wino_output(_ptr(M), _ptr(scale), _ptr(bias), _ptr(mask[b0:b0 + nb]) if mask is not None else None,
+                                    int(relu), nb, H, W, N, _ptr(y[b0:b0 + nb]), m, st), 'nbm_wino_output')
     if PROFILE is not None:
         ev[1].record()
         PROFILE.append((('wino23', C_, N, H, W, B), *ev))

@@ -80,9 +80,11 @@ int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream);
  * bit-identical to the reference); m = 4: F(4x4,3x3) with interpolation points {0, 1, -1, 1/2, -2, inf}, 36 planes, used by
  * the two backward convolutions only (error ~2e-5).  V[xi][t][c] = (B^T d B)[xi] of the (m+2)x(m+2) input patch of tile t
  * (zero padded); the (m+2)^2 GEMMs M[xi] = V[xi] x U[xi]^T run through nbm_gemm_conv with groups = (m+2)^2;
- * y = A^T M A + bias.  T = B*ceil(H/m)*ceil(W/m) tiles; V: [(m+2)^2][T][C], M: [(m+2)^2][T][N]. */
+ * y = act((A^T M A) * scale + shift), zeroed where mask <= 0 (scale / shift / mask may be NULL: FrozenBN + ReLU of the ResNet
+ * 3x3 layers, the producer's ReLU mask of a data gradient).  T = B*ceil(H/m)*ceil(W/m) tiles; V: [(m+2)^2][T][C], M: [(m+2)^2][T][N]. */
 int nbm_wino_input(const float* x, int B, int H, int W, int C, float* V, int m, void* stream);
-int nbm_wino_output(const float* M, const float* bias, int B, int H, int W, int N, float* y, int m, void* stream);
+int nbm_wino_output(const float* M, const float* scale, const float* shift, const float* mask, int relu, int B, int H, int W,
+                    int N, float* y, int m, void* stream);
 /* weight gradient side: dM[xi][t][n] = (A g A^T)[xi] of the m x m output-gradient tile; dU[xi] = dM[xi]^T V[xi] through
  * nbm_conv_wgrad (groups = (m+2)^2) and dW = G^T dU G on the host.  bias_grad [N] (may be NULL): += sum over pixels of g. */
 int nbm_wino_outgrad(const float* g, int B, int H, int W, int N, float* dM, float* bias_grad, int m, void* stream);

@@ -415,10 +415,13 @@ def test_tf_rcnn_train_step_vs_reference_golden(tag, pe_qk):
         check_packed(g, f'{tag}.grad.{name}', params[name].grad, atol=2e-4 * gn_ref / 50, rtol=2e-3)
 
 
-def test_fused_bottleneck_chain_backward():
+@pytest.mark.parametrize('P', [32, 128])
+def test_fused_bottleneck_chain_backward(P):
     """Fn.Bottleneck (one tape node per block, ReLU masks and shortcut add inside the dgrad epilogues) on a chain
-    downsample-block -> identity-block -> identity-block, the way _ResNetBody wires the mask flags, vs torch autograd."""
-    B, H, W, Cin, P, st = 2, 14, 18, 64, 32, 2
+    downsample-block -> identity-block -> identity-block, the way _ResNetBody wires the mask flags, vs torch autograd.
+    P = 128: the stride-1 3x3 convolutions take the Winograd path (F(2x2,3x3) forward with FrozenBN + ReLU in the output
+    transform, F(4x4,3x3) for both gradients)."""
+    B, H, W, Cin, st = 2, 18, 22, 64, 2
     x = rnd('bnx', B, Cin, H, W).abs().requires_grad_(True)          # a ReLU output, like every block input but layer1.0
     def mk(tag, co, ci, k):
         return rnd(('bnw', tag), co, ci, k, k, scale=(2.0 / (ci * k * k)) ** 0.5).requires_grad_(True)
@@ -452,11 +455,11 @@ def test_fused_bottleneck_chain_backward():
     close(nchw(hd), h, 1e-5, 'bottleneck chain fwd')
     hd.backward(nhwc(go))
     # the chain input is declared a ReLU output (mask_input): d/dx carries the (x > 0) mask of the producer's ReLU
-    close(nchw(xd.grad), x.grad * (x > 0), 2e-5, 'bottleneck dx')
+    close(nchw(xd.grad), x.grad * (x > 0), 3e-5, 'bottleneck dx')
     for bi, (ws, wdv) in enumerate(zip([b[0] for b in blocks], dev)):
         for k in ('w1', 'w2', 'w3', 'wd'):
             if ws[k] is not None:
-                close(wdv[k].grad, ws[k].grad, 3e-5, f'bottleneck {bi} d{k}')
+                close(wdv[k].grad, ws[k].grad, 5e-5, f'bottleneck {bi} d{k}')
 
 
 @pytest.mark.parametrize('override,expect', [
