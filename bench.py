@@ -78,7 +78,9 @@ def train_bench(rank, world, dist, batch, steps, warmup):
     v = world * batch * steps / dt
     return {'value': v, 'unit': 'clips/s', 'batch_per_gpu': batch, 'global_batch': world * batch, 'steps': steps,
             'ms_per_step': dt / steps * 1e3, 'parallelism': f'dp{world}',
-            'frac_of_mfma_peak': v / world * TRAIN_GFLOP_PER_CLIP / 1e3 / FP32_MFMA_PEAK_TFLOPS,
+            'algorithmic_frac_of_mfma_peak': v / world * TRAIN_GFLOP_PER_CLIP / 1e3 / FP32_MFMA_PEAK_TFLOPS,
+            'note': 'algorithmic = SURVEY direct-convolution FLOPs (993.45 GFLOP / clip); can exceed 1 because the large 3x3 '
+                    'convolutions execute 2.25x (forward) / 4x (backward) fewer multiplies in the Winograd domain',
             'final_loss': {k: float(x.detach()) if torch.is_tensor(x) else float(x) for k, x in loss.items()},
             'workload': 'BASELINE.json configs[2]/[3]: positive training step (fwd + bwd + clip + AdamW), fp32'}
 
