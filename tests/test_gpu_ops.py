@@ -261,3 +261,18 @@ def test_conv_with_fused_topdown_merge():
     t = F.interpolate(coarse.permute(0, 3, 1, 2).cpu(), size=(H, W), mode='bilinear', align_corners=True)
     t = t + F.conv2d(2.0 * x.permute(0, 3, 1, 2).cpu(), w.cpu()[:, :, None, None], b.cpu())
     assert (got.cpu().permute(0, 3, 1, 2) - t).abs().max().item() < 2e-5
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """examples/cabi_gemm_conv.c: the library driven from C with hipMalloc'd buffers -- no Python object crosses the ABI."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / 'cabi_gemm_conv')
+    libdir = os.path.join(root, 'birdsoundclassif_amd')
+    subprocess.run(['gcc', '-D__HIP_PLATFORM_AMD__', '-I/opt/rocm/include', '-I' + os.path.join(root, 'include'),
+                    os.path.join(root, 'examples', 'cabi_gemm_conv.c'), '-L' + libdir, '-lnbm_hip', '-L/opt/rocm/lib', '-lamdhip64',
+                    '-lm', '-Wl,-rpath,' + libdir, '-Wl,-rpath,/opt/rocm/lib', '-o', exe], check=True, capture_output=True, timeout=300)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert 'max |err|' in out.stdout
