@@ -290,9 +290,8 @@ def create_label_dataset(directory, birds_dict, noise_labels=(), not_bird_labels
     return labels
 
 
-def write_png_gray8(path, img_u8):
-    """uint8 [H,W] -> 8-bit greyscale PNG (filter type 0 on every scanline; the counterpart of `imageio.imwrite`,
-    reference prepare_dataset.py:85-87)."""
+def encode_png_gray8(img_u8):
+    """uint8 [H,W] -> bytes of an 8-bit greyscale PNG (filter type 0 on every scanline)."""
     import struct
     import zlib
     img = np.ascontiguousarray(img_u8, dtype=np.uint8)
@@ -301,9 +300,14 @@ def write_png_gray8(path, img_u8):
     raw[:, 1:] = img
     def chunk(kind, data):
         return struct.pack('>I', len(data)) + kind + data + struct.pack('>I', zlib.crc32(kind + data) & 0xFFFFFFFF)
+    return (b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', W, H, 8, 0, 0, 0, 0)) +
+            chunk(b'IDAT', zlib.compress(raw.tobytes(), 6)) + chunk(b'IEND', b''))
+
+
+def write_png_gray8(path, img_u8):
+    """The counterpart of `imageio.imwrite` (reference prepare_dataset.py:85-87)."""
     with open(path, 'wb') as f:
-        f.write(b'\x89PNG\r\n\x1a\n' + chunk(b'IHDR', struct.pack('>IIBBBBB', W, H, 8, 0, 0, 0, 0)) +
-                chunk(b'IDAT', zlib.compress(raw.tobytes(), 6)) + chunk(b'IEND', b''))
+        f.write(encode_png_gray8(img_u8))
 
 
 def prepare_dataset(directory, out_directory, freq_accuracy=33.3, dt=0.003, overlap_spectro=0.2, w_pix=1024,

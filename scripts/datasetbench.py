@@ -10,11 +10,11 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from birdsoundclassif_amd import synth                                    # noqa: E402
 from birdsoundclassif_amd.nbm_datasets.image_dataset import Img_dataset   # noqa: E402
-from oracle import png_ref                                                # noqa: E402  (dataset writer only)
+from birdsoundclassif_amd.nbm_datasets.prepare_dataset import encode_png_gray8   # noqa: E402
 
 B = int(os.environ.get('B', 128))
 with tempfile.TemporaryDirectory() as root:
-    synth.write_image_dataset(root, png_ref.encode_png_gray8)
+    synth.write_image_dataset(root, encode_png_gray8)
     for host_noise in (True, False):
         ds = Img_dataset(root, transform=True, host_noise=host_noise)
         np.random.seed(0), torch.manual_seed(0)
