@@ -22,41 +22,66 @@ Scaled = namedtuple('Scaled', ['tensor', 'factor'])
 
 
 class SelfAttention(nn.Module):
+    """reference self_attention.py:10-56.  `downscale_factor` / `position_encoding` are the `pyramid_top_n_attn ==
+    n_levels` configuration: the input gets + 0.5 * frequency encoding, and with a downscale factor the module returns the
+    down-and-up interpolated INPUT -- the attention the reference computes there is discarded (:52-54, SURVEY Appendix
+    C-6), so it is not computed here."""
 
     def __init__(self, input_dim, inner_dim, downscale_factor=1, position_encoding=False):
         super().__init__()
-        if downscale_factor != 1 or position_encoding:
-            raise NotImplementedError('pyramid_top_n_attn == n_levels variant (Appendix C-6) is outside the hot-path scope')
         self.query = nn.Linear(input_dim, inner_dim)
         self.key = nn.Linear(input_dim, inner_dim)
         self.value = nn.Linear(input_dim, inner_dim)
         self.final_projection = nn.Linear(inner_dim, input_dim)
         self.inner_dim = inner_dim
+        self.downscale_factor = downscale_factor
+        self.position_encoding = position_encoding
+        self._pe = {}
+
+    def _half_pe(self, h, w, c, device, sign):
+        """+-0.5 * one_dimension_positional_encoding(h, c) as an NHWC table [h, w, c] (self_attention.py:28-31)."""
+        key = (h, w, c, str(device), sign)
+        if key not in self._pe:
+            from .position_encoding import one_dimension_positional_encoding
+            t = (0.5 * sign) * one_dimension_positional_encoding(h, c)
+            self._pe[key] = t[:, None, :].expand(h, w, c).contiguous().to(device)
+        return self._pe[key]
 
     def forward(self, inpt, residual=True):
-        """inpt NHWC [B,h,w,C] -> NHWC [B,h,w,C] = (inpt +) attention(inpt)."""
+        """inpt NHWC [B,h,w,C] -> NHWC [B,h,w,C] = (inpt +) module(inpt)."""
         B, h, w, Cc = inpt.shape
+        if not residual:
+            raise NotImplementedError('SelfAttention without the SAPyramid residual is not on the hot path')
+        x = inpt
+        if self.position_encoding:
+            x = Fn.AddConst.apply(inpt, self._half_pe(h, w, Cc, inpt.device, 1.0))
+        if self.downscale_factor > 1:
+            f = self.downscale_factor
+            small = Fn.UpsampleAdd.apply(x, None, h // f, w // f)
+            return Fn.Add.apply(inpt, Fn.UpsampleAdd.apply(small, None, h, w))
         L, d = h * w, self.inner_dim
         if L % 32:
             raise NotImplementedError(f'attention over {h}x{w} tokens: the P.V GEMM needs H*W % 32 == 0')
-        if not residual:
-            raise NotImplementedError('SelfAttention without the SAPyramid residual is not on the hot path')
         inv = float(np.float32(1.0) / np.float32(np.round(np.sqrt(d), 2)))            # self_attention.py:47
-        out = Fn.Attention.apply(inpt.view(B, L, Cc), self.query.weight, self.query.bias, self.key.weight, self.key.bias,
+        out = Fn.Attention.apply(x.view(B, L, Cc), self.query.weight, self.query.bias, self.key.weight, self.key.bias,
                                  self.value.weight, self.value.bias, self.final_projection.weight,
-                                 self.final_projection.bias, inv)
-        return out.view(B, h, w, Cc)
+                                 self.final_projection.bias, inv).view(B, h, w, Cc)        # = x + attention(x)
+        if self.position_encoding:                     # the pyramid's residual is the ORIGINAL map, not map + encoding
+            out = Fn.AddConst.apply(out, self._half_pe(h, w, Cc, inpt.device, -1.0))
+        return out
 
 
 class SAPyramid(nn.Module):
 
     def __init__(self, channels, top_n):
         super().__init__()
-        if top_n == len(channels):
-            raise NotImplementedError('pyramid_top_n_attn == n_levels variant is outside the hot-path scope')
-        self.attention_modules = nn.ModuleDict({
-            str(i): SelfAttention(cn, cn // 2) if (i >= (len(channels) - top_n)) else nn.Identity()
-            for (i, cn) in enumerate(channels)})
+        if top_n == len(channels):                     # self_attention.py:63-66
+            self.attention_modules = nn.ModuleDict({str(i): SelfAttention(cn, cn, max(1, 2 ** (3 - i)), True)
+                                                    for (i, cn) in enumerate(channels)})
+        else:
+            self.attention_modules = nn.ModuleDict({
+                str(i): SelfAttention(cn, cn // 2) if (i >= (len(channels) - top_n)) else nn.Identity()
+                for (i, cn) in enumerate(channels)})
 
     def forward(self, x):
         """x: bottom-up list of NHWC maps -> list of `fm + module(fm)`; identity levels as Scaled(fm, 2.0)."""

@@ -84,7 +84,7 @@ def variants_golden():
     (fpn.py:9-115, two layers) -- eval forward, B=2."""
     g = {}
     for tag, kw in (('fpn_first', dict(fpn_first=True)), ('sandwich', dict(sandwich_attn=True)), ('posenc', dict(add_posenc=True)),
-                    ('bifpn', dict(fpn='bifpn', n_bifpn_layers=2))):
+                    ('bifpn', dict(fpn='bifpn', n_bifpn_layers=2)), ('attn5', dict(pyramid_top_n_attn=5))):
         args = ref_import.default_args(**kw)
         model, _ = ref_import.build_reference_model(args, train=False)
         sd = synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})

@@ -222,7 +222,8 @@ def test_chunked_stft_of_a_long_row(monkeypatch):
 
 
 @pytest.mark.parametrize('tag,kw', [('fpn_first', dict(fpn_first=True)), ('sandwich', dict(sandwich_attn=True)),
-                                    ('posenc', dict(add_posenc=True)), ('bifpn', dict(fpn='bifpn', n_bifpn_layers=2))])
+                                    ('posenc', dict(add_posenc=True)), ('bifpn', dict(fpn='bifpn', n_bifpn_layers=2)),
+                                    ('attn5', dict(pyramid_top_n_attn=5))])
 def test_composition_flags_vs_reference_golden(tag, kw):
     """--fpn_first / --sandwich_attn / --add_posenc (reference nbm_model.py:45-52) against the real reference's outputs,
     forward and one optimisation step's worth of backward (finite gradients everywhere)."""

@@ -131,7 +131,8 @@ def test_merge_images_vs_golden():
 
 
 @pytest.mark.parametrize('tag,kw', [('fpn_first', dict(fpn_first=True)), ('sandwich', dict(sandwich_attn=True)),
-                                    ('posenc', dict(add_posenc=True)), ('bifpn', dict(fpn='bifpn', n_bifpn_layers=2))])
+                                    ('posenc', dict(add_posenc=True)), ('bifpn', dict(fpn='bifpn', n_bifpn_layers=2)),
+                                    ('attn5', dict(pyramid_top_n_attn=5))])
 def test_composition_flags_vs_golden(tag, kw):
     """--fpn_first / --sandwich_attn / --add_posenc (reference nbm_model.py:45-52)."""
     g = load_golden('variants_b2.npz')
