@@ -102,15 +102,25 @@ def hann_periodic(n):
     return 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n) / n)
 
 
-def stft_mag(y, n_fft, hop, pad_mode='constant'):
-    """|librosa.stft(y, n_fft, hop_length=hop)| with librosa defaults (win_length=n_fft, periodic Hann,
-    center=True): [1+n_fft//2, 1+len(y)//hop] float64."""
+def stft(y, n_fft, hop, pad_mode='constant'):
+    """librosa.stft(y, n_fft, hop_length=hop) with librosa defaults (win_length=n_fft, periodic Hann,
+    center=True): complex128 [1+n_fft//2, 1+len(y)//hop].  Frames are transformed in blocks so that a
+    19-minute chunk does not materialise a 4 GB frame matrix."""
     y = np.asarray(y, dtype=np.float64)
     yp = np.pad(y, n_fft // 2, mode=pad_mode)
     n_frames = 1 + (len(yp) - n_fft) // hop
-    idx = np.arange(n_fft)[None, :] + hop * np.arange(n_frames)[:, None]
-    frames = yp[idx] * hann_periodic(n_fft)[None, :]
-    return np.abs(scipy.fft.rfft(frames, axis=1)).T
+    win = hann_periodic(n_fft)[None, :]
+    out = np.empty((1 + n_fft // 2, n_frames), dtype=np.complex128)
+    for t0 in range(0, n_frames, 4096):
+        t1 = min(n_frames, t0 + 4096)
+        idx = np.arange(n_fft)[None, :] + hop * np.arange(t0, t1)[:, None]
+        out[:, t0:t1] = scipy.fft.rfft(yp[idx] * win, axis=1).T
+    return out
+
+
+def stft_mag(y, n_fft, hop, pad_mode='constant'):
+    """|stft(...)|: [1+n_fft//2, 1+len(y)//hop] float64."""
+    return np.abs(stft(y, n_fft, hop, pad_mode))
 
 
 def amp_to_db(x, min_level_db=-100):
@@ -119,10 +129,10 @@ def amp_to_db(x, min_level_db=-100):
     return 20 * np.log10(np.maximum(min_level, x))
 
 
-def spectrogram(y, c, pad_mode='constant'):
-    """File_Processor.spectrogram prepare_dataset.py:233-252: STFT in chunks of 5e7 samples, dB, crop,
-    min/max over the WHOLE file.  Returns list of float64 [375, L_k] in [0,1]."""
-    max_l = int(5e7)
+def spectrogram(y, c, pad_mode='constant', max_l=int(5e7)):
+    """File_Processor.spectrogram prepare_dataset.py:233-252: STFT in chunks of 5e7 samples (every chunk is
+    centre-padded on its own by librosa), dB, crop, min/max over the WHOLE file.  Returns list of float64
+    [375, L_k] in [0,1].  `max_l` is the reference's hard-coded chunk length (tests scale it down)."""
     parts = []
     for k in range(int(len(y) / max_l) + 1):
         m = stft_mag(y[k * max_l:(k + 1) * max_l], c['WIN_LENGTH'], c['HOP_LENGTH'], pad_mode)
@@ -134,28 +144,48 @@ def spectrogram(y, c, pad_mode='constant'):
 
 
 # --------------------------------------------------------------------------- F4: windows
-def split_power_spec(parts, c):
-    """File_Processor.split_power_spec prepare_dataset.py:255-294 (labels=None branch)."""
-    spec = np.concatenate(parts, axis=1)            # chunk-boundary bookkeeping (:263-278) == slicing the concat
-    L = spec.shape[1]
+def window_columns(chunk_lengths, c, label_t_end_max=None):
+    """Column bookkeeping of File_Processor.split_power_spec (prepare_dataset.py:255-294) as index vectors:
+    for every window the list of source columns of the chunk-concatenated spectrogram.
+
+    * window k covers columns [k*hop, k*hop + W) (:264-266);
+    * a window that runs past the end of the file is cut at the end of the CHUNK its first column lies in
+      (:270-278: `e_bin_idx` is None and `next_bin` False there, so the following chunks are dropped) -- for a
+      single-chunk file that is simply the end of the file;
+    * the last window is then grown to W columns by repeated `np.pad(mode='reflect')` in steps of
+      `min(empty_width, missing)` columns, `empty_width` starting at W when the file has no label and at
+      `L - int(t_end.max() / DT)` when it has (:280-292), and growing by every step."""
     W, hop = c['W_PIX'], c['HOP_SPECTRO']
-    imgs = [spec[:, k * hop:k * hop + W] for k in range(max(1, int(1 + np.ceil((L - W) / hop))))]
-    if imgs[-1].shape[1] < W:
-        empty = L - (L - W)                         # max_pix = max_l - W_PIX (:285) => empty_width = W_PIX
-        while imgs[-1].shape[1] < W:
-            pad = max(1, min(empty, W - imgs[-1].shape[1]))
-            imgs[-1] = np.pad(imgs[-1], ((0, 0), (0, pad)), mode='reflect')
+    cum = np.cumsum([0] + [int(n) for n in chunk_lengths])
+    L = int(cum[-1])
+    cols = []
+    for k in range(max(1, int(1 + np.ceil((L - W) / hop)))):
+        start, end = k * hop, k * hop + W
+        if end > L:
+            end = int(cum[np.searchsorted(cum, start, side='right')])      # end of the chunk holding `start`
+        cols.append(np.arange(start, end, dtype=np.int64))
+    if len(cols[-1]) < W:
+        empty = W if label_t_end_max is None else L - int(label_t_end_max / c['DT'])
+        while len(cols[-1]) < W:
+            pad = max(1, min(empty, W - len(cols[-1])))
+            cols[-1] = np.pad(cols[-1], (0, pad), mode='reflect')
             empty += pad
-    return imgs
+    return cols
 
 
-def process_waveform(y, pad_mode='constant', **kw):
+def split_power_spec(parts, c, label_t_end_max=None):
+    """File_Processor.split_power_spec prepare_dataset.py:255-294."""
+    spec = np.concatenate(parts, axis=1)
+    return [spec[:, j] for j in window_columns([p.shape[1] for p in parts], c, label_t_end_max)]
+
+
+def process_waveform(y, pad_mode='constant', max_l=int(5e7), label_t_end_max=None, **kw):
     """process_file prepare_dataset.py:108-157 from an already loaded 44.1 kHz float waveform.
     Returns (list of float32 [375,1024], meta dict with W_PIX, HOP_SPECTRO, spectrogram_length)."""
     c = constants(**kw)
-    parts = spectrogram(y, c, pad_mode)
+    parts = spectrogram(y, c, pad_mode, max_l)
     c['spectrogram_length'] = int(sum(p.shape[1] for p in parts))
-    return [im.astype(np.float32) for im in split_power_spec(parts, c)], c
+    return [im.astype(np.float32) for im in split_power_spec(parts, c, label_t_end_max)], c
 
 
 def process_file(path, pad_mode='constant', **kw):

@@ -237,6 +237,110 @@ def labels_golden():
     print('labels:', [len(m['index']) for m in out['merge']], [len(t) for t in out['txt']])
 
 
+FRONTEND_CASES = (
+    # name, clip seed, samples @22.05 kHz (up-sampled 2x by the oracle's resampler before the reference sees them),
+    # STFT chunk length (None = the reference's 5e7), labels
+    ('clip3s', 0, 66150, None, False),       # configs[1] unit: one 3 s clip, 1003 frames, 21 reflected columns
+    ('win4', 1, 209905, None, False),        # 3181 frames: 4 windows, the last one 300 columns short
+    ('short', 2, 11025, None, False),        # 168 frames: padding longer than the data (repeated reflection)
+    ('chunkq', 3, 220000, 200000, False),    # chunks 200000/200000/40000: last window cut at a chunk end (:270-278)
+    ('chunkn', 4, 275000, 200000, False),    # chunks 200000/200000/150000: windows straddling chunk ends
+    ('labels', 5, 100000, None, True),       # 1516 frames, labels end early: stepwise reflect padding (:283-292)
+)
+
+
+def install_frontend_stubs():
+    """The reference's third-party imports for `nbm_datasets.prepare_dataset`: `librosa.core.load` / `librosa.stft`
+    are the oracle's wav reader and float64 STFT (the two steps that stay unpinned), the rest are empty."""
+    import types
+    from . import frontend_ref as FR
+    lib, core = types.ModuleType('librosa'), types.ModuleType('librosa.core')
+
+    def load(path, sr=None):
+        pcm, rate = FR.read_wav_pcm16(path)
+        return pcm.astype(np.float32) / np.float32(32768.0), rate
+    core.load = lib.load = load
+    lib.core = core
+    lib.stft = lambda y, n_fft=2048, hop_length=None: FR.stft(y, n_fft, hop_length, 'constant')
+    sys.modules['librosa'], sys.modules['librosa.core'] = lib, core
+    for name in ('ffmpeg', 'imageio', 'soundfile'):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    import matplotlib
+    matplotlib.use('Agg')
+    ref_import.import_nets()
+    from nbm_model.nbm_datasets import prepare_dataset as PD
+    return PD
+
+
+def reference_file_processor(PD, max_l=None):
+    """The reference's File_Processor; with `max_l` its `spectrogram` method is re-compiled from its own source with
+    the hard-coded chunk length 5e7 (prepare_dataset.py:234) replaced, so that the chunk bookkeeping runs on a
+    small file."""
+    if max_l is None:
+        return PD.File_Processor
+    import ast
+    import inspect
+    import textwrap
+    tree = ast.parse(textwrap.dedent(inspect.getsource(PD.File_Processor.spectrogram)))
+    hits = [n for n in ast.walk(tree) if isinstance(n, ast.Constant) and n.value == 5e7]
+    assert len(hits) == 1
+    hits[0].value = max_l
+    ns = dict(PD.__dict__)
+    exec(compile(tree, f'prepare_dataset.py:spectrogram[max_l={max_l}]', 'exec'), ns)
+    return type('File_Processor_small_chunks', (PD.File_Processor,), {'spectrogram': ns['spectrogram']})
+
+
+def frontend_case_inputs(name, seed, n22, labels):
+    """44.1 kHz PCM16 of a case (+ its label rows): regenerated identically by the tests."""
+    from . import frontend_ref as FR
+    pcm44 = FR.upsample2x_pcm16(synth.clip_pcm16(seed, n22))
+    rows = None
+    if labels:
+        # the last call ends at 4.4 s = column 1470 of 1516: `empty_width` starts at 46 and the padding goes 46, 92, 184, 5
+        rows = [r for r in synth.label_rows(seed, n=12, filename=name, duration=3.0) if r[1] < 4.3]
+        rows.append((4.1, 4.4, 2000.0, 5000.0, 'sp7', name, 7))
+    return pcm44, rows
+
+
+def run_reference_frontend(PD, name, seed, n22, max_l, labels, tmpdir):
+    import pandas as pd
+    pcm44, rows = frontend_case_inputs(name, seed, n22, labels)
+    path = os.path.join(tmpdir, name + '.wav')
+    synth.write_wav(path, pcm44, 44100)
+    lab = None
+    if rows is not None:
+        lab = pd.DataFrame(rows, columns=['t_start', 't_end', 'f_start', 'f_end', 'species', 'filename', 'bird_id'])
+    fp = reference_file_processor(PD, max_l)(path, '', lab)
+    imgs, annots = fp.process_file()
+    return fp, imgs, annots
+
+
+def frontend_golden():
+    """The REAL `File_Processor.process_file` (prepare_dataset.py:108-157, 228-294) on small wav files ->
+    tests/golden/frontend.npz.  Pins the constants, amp_to_db, the crop, the per-file min/max over chunks, the chunk /
+    window bookkeeping and the reflect padding of the reference's own code; `librosa.stft` and the file reader are the
+    oracle's (stubs above), i.e. the STFT core and the resampler remain unpinned."""
+    import tempfile
+    PD = install_frontend_stubs()
+    g = {}
+    with tempfile.TemporaryDirectory() as d:
+        for name, seed, n22, max_l, labels in FRONTEND_CASES:
+            fp, imgs, annots = run_reference_frontend(PD, name, seed, n22, max_l, labels, d)
+            for k in ('W_PIX', 'HOP_SPECTRO', 'WIN_LENGTH', 'HOP_LENGTH', 'FREQ_ACCURACY', 'DT', 'LOW_IDX', 'HIGH_IDX',
+                      'LOW_FREQ', 'HIGH_FREQ', 'spectrogram_length'):
+                g[f'{name}.{k}'] = np.array(getattr(fp, k), dtype=np.float64)
+            g[f'{name}.n_img'] = np.array(len(imgs))
+            for i, im in enumerate(imgs):
+                pack(g, f'{name}.img{i}', torch.from_numpy(np.asarray(im, dtype=np.float32)), full_limit=0)
+            last = np.asarray(imgs[-1], dtype=np.float32)
+            g[f'{name}.last_rows'] = last[[0, 187, 374]]                 # whole rows: the padding pattern
+            if labels:
+                g[f'{name}.annot_index'] = np.asarray([int(i) for i in annots['index']], dtype=np.int64)
+                g[f'{name}.t_end_max'] = np.array(max(r[1] for r in frontend_case_inputs(name, seed, n22, True)[1]))
+            print('frontend', name, 'L', int(fp.spectrogram_length), 'windows', len(imgs))
+    np.savez_compressed(os.path.join(OUT, 'frontend.npz'), **g)
+
+
 def main():
     warnings.filterwarnings('ignore')
     torch.manual_seed(0)
@@ -249,6 +353,8 @@ def main():
         return tf_rcnn_train_golden()
     if '--labels-only' in sys.argv:
         return labels_golden()
+    if '--frontend-only' in sys.argv:
+        return frontend_golden()
     if '--metrics-only' in sys.argv:
         return metrics_golden()
     if '--dataset-only' in sys.argv:
@@ -259,6 +365,7 @@ def main():
     img_dataset_golden()
     metrics_golden()
     labels_golden()
+    frontend_golden()
     args = ref_import.default_args()
     model, crit = ref_import.build_reference_model(args, train=False)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
