@@ -27,7 +27,7 @@ constexpr int BK = 32;
 constexpr int PITCH = 36;  // floats per LDS row (32 + 4 pad)
 
 enum { A_FAST = 0, A_GENERIC = 1 };
-enum { EPI_STD = 0, EPI_STFT = 1 };
+enum { EPI_STD = 0 };
 
 struct IgemmParams {
   const float* x; const float* w; float* y;
@@ -42,8 +42,6 @@ struct IgemmParams {
   int vec_epi;           // epilogue may use 16-byte accesses (N % 4 == 0, pitches % 4 == 0, 16-byte aligned bases)
   // fused top-down merge: y += bilinear_align_corners(up [B][up_H][up_W][N]) (vector epilogue only)
   const float* up; int up_H, up_W; float up_sh, up_sw;
-  // STFT epilogue
-  int n_bins; float floor_amp; int db_ld; uint32_t* minmax;
 };
 
 // STAGES = 2: the deep-K pipeline (double-buffered LDS, 2 workgroups per CU).  STAGES = 1: short-K layers (K <= 256: 1x1
@@ -381,34 +379,6 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_kernel(const I
       }
     }
     }
-  } else {
-    // STFT: acc[0][j] = Re (cos rows), acc[1][j] = Im (sin rows) of 32 bins x 32 frames.
-    static_assert(EPI == EPI_STD || MT == 2, "STFT epilogue pairs two M tiles");
-    float* __restrict__ yg = p.y + (long long)g * p.y_gs;
-    float vmin = INFINITY, vmax = -INFINITY;
-    const int bin0 = (bm0 + wm0) >> 1;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int t = bn0 + wn0 + j * 32 + lrow;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int bin = bin0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        const float re = acc[0][j][e], im = acc[MT - 1][j][e];
-        const float mag = sqrtf(re * re + im * im);
-        const float db = 20.0f * log10f(fmaxf(p.floor_amp, mag));
-        if (bin < p.n_bins && t < p.N) {
-          yg[(long long)bin * p.db_ld + t] = db;
-          vmin = fminf(vmin, db);
-          vmax = fmaxf(vmax, db);
-        }
-      }
-    }
-    vmin = nbm_wave_min(vmin);
-    vmax = nbm_wave_max(vmax);
-    if (lane == 0 && vmin <= vmax) {
-      atomicMin(p.minmax + 2 * g, nbm_f2key(vmin));
-      atomicMax(p.minmax + 2 * g + 1, nbm_f2key(vmax));
-    }
   }
 }
 
@@ -478,25 +448,4 @@ extern "C" int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream) {
     return fast ? launch<128, 32, 32, 32, A_FAST, EPI_STD>(p, d->groups, st)
                 : launch<128, 32, 32, 32, A_GENERIC, EPI_STD>(p, d->groups, st);
   }
-}
-
-// db[b][f][t] = 20 log10(max(floor, |DFT|)) -- see nbm_hip.h.  M = basis rows (cos/sin blocks), N = frames.
-extern "C" int nbm_stft_db(const float* wave, int64_t wave_ld, int batch, int n_frames, int hop,
-                           const float* basis, int basis_rows, int basis_ld, int n_bins, float floor_amp,
-                           float* db, int64_t db_bs, int db_ld, uint32_t* minmax, void* stream) {
-  if (!wave || !basis || !db || !minmax || batch <= 0 || n_frames <= 0 || hop <= 0) return NBM_EINVAL;
-  if (basis_rows % 128 || basis_ld % BK || n_bins > basis_rows / 2 || db_ld < n_frames) return NBM_EINVAL;
-  if ((hop & 3) || (wave_ld & 3) || !nbm_aligned16(wave) || !nbm_aligned16(basis)) return NBM_EALIGN;
-  if ((int64_t)(n_frames - 1) * hop + basis_ld > wave_ld) return NBM_EINVAL;  // last frame must stay inside its row
-  IgemmParams p{};
-  p.x = basis; p.w = wave; p.y = db;
-  p.x_gs = 0; p.w_gs = wave_ld; p.y_gs = db_bs;
-  p.M = basis_rows; p.N = n_frames; p.K = basis_ld; p.nk = basis_ld / BK;
-  p.H = basis_rows; p.W = 1; p.Cin = basis_ld; p.kh = 1; p.kw = 1; p.stride = 1; p.pad = 0;
-  p.Ho = basis_rows; p.Wo = 1; p.HoWo = basis_rows;
-  p.x_ld = basis_ld; p.w_ld = hop; p.y_ld = db_ld;
-  p.alpha = 1.f;
-  p.n_bins = n_bins; p.floor_amp = floor_amp; p.db_ld = db_ld; p.minmax = minmax;
-  p.m_tiles = basis_rows / 128; p.n_tiles = (n_frames + 127) / 128;
-  return launch<128, 128, 64, 64, A_FAST, EPI_STFT>(p, batch, (hipStream_t)stream);
 }

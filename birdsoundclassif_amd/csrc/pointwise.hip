@@ -12,37 +12,39 @@ inline int grid_for(long long n, int per_block = TPB, int cap = 256 * 16) {
 }
 
 // ------------------------------------------------------------------ front end
+// sample i (0 <= i < n_out) of the 44.1 kHz signal as a 16-bit integer
+__device__ __forceinline__ int pcm16_sample(const int16_t* __restrict__ x, int n, int upsample,
+                                            const int32_t* __restrict__ hq, long long i) {
+  if (!upsample) return x[i];
+  if ((i & 1) == 0) return x[i >> 1];
+  const int n0 = (int)(i >> 1);
+  long long acc = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int ia = n0 - k, ib = n0 + 1 + k;
+    const int xa = (ia >= 0 && ia < n) ? x[ia] : 0;
+    const int xb = (ib >= 0 && ib < n) ? x[ib] : 0;
+    acc += (long long)hq[k] * (xa + xb);
+  }
+  long long q = (acc + 16384) >> 15;
+  return (int)(q < -32768 ? -32768 : (q > 32767 ? 32767 : q));
+}
+
 __global__ void pcm16_to_wave_kernel(const int16_t* __restrict__ pcm, long long pcm_ld, int n, int upsample,
-                                     const int32_t* __restrict__ hq, float* __restrict__ out, long long out_ld,
-                                     int lead) {
+                                     const int32_t* __restrict__ hq, long long first, long long count,
+                                     float* __restrict__ out, long long out_ld, int lead, int reflect) {
   const int b = blockIdx.y;
   const int16_t* x = pcm + (long long)b * pcm_ld;
   float* o = out + (long long)b * out_ld;
-  const int n_out = upsample ? 2 * n : n;
   for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < out_ld;
        j += (long long)gridDim.x * blockDim.x) {
-    const long long i = j - lead;
+    long long i = j - lead;                                            // index inside the piece [first, first + count)
     float v = 0.f;
-    if (i >= 0 && i < n_out) {
-      if (!upsample) {
-        v = (float)x[i] * (1.0f / 32768.0f);
-      } else if ((i & 1) == 0) {
-        v = (float)x[i >> 1] * (1.0f / 32768.0f);
-      } else {
-        const int n0 = (int)(i >> 1);
-        long long acc = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          const int ia = n0 - k, ib = n0 + 1 + k;
-          const int xa = (ia >= 0 && ia < n) ? x[ia] : 0;
-          const int xb = (ib >= 0 && ib < n) ? x[ib] : 0;
-          acc += (long long)hq[k] * (xa + xb);
-        }
-        long long q = (acc + 16384) >> 15;
-        q = q < -32768 ? -32768 : (q > 32767 ? 32767 : q);
-        v = (float)q * (1.0f / 32768.0f);
-      }
+    if (reflect && i >= -(long long)lead && i < count + lead) {       // np.pad(mode='reflect') of the piece: lead < count
+      if (i < 0) i = -i;
+      else if (i >= count) i = 2 * (count - 1) - i;
     }
+    if (i >= 0 && i < count) v = (float)pcm16_sample(x, n, upsample, hq, first + i) * (1.0f / 32768.0f);
     o[j] = v;
   }
 }
@@ -53,25 +55,21 @@ __global__ void minmax_init_kernel(uint32_t* mm, int batch) {
 }
 
 __global__ void spec_windows_kernel(const float* __restrict__ db, long long db_bs, int db_ld, int n_bins,
-                                    int n_frames, const uint32_t* __restrict__ minmax, float* __restrict__ img,
-                                    int n_img, int w_pix, int hop_img) {
+                                    const uint32_t* __restrict__ minmax, float* __restrict__ img,
+                                    int n_img, int w_pix, int hop_img, const int32_t* __restrict__ last_cols) {
   const int b = blockIdx.z, k = blockIdx.y;
   const float lo = nbm_key2f(minmax[2 * b]), hi = nbm_key2f(minmax[2 * b + 1]);
   const float range = hi - lo;
   const float* src = db + (long long)b * db_bs;
   float* dst = img + ((long long)b * n_img + k) * n_bins * w_pix;
   const int start = k * hop_img;
-  const int avail = n_frames - start;  // columns of this window that exist (>= 1)
+  const bool last = k == n_img - 1;
   const long long total = (long long)n_bins * w_pix;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
     const int f = (int)(i / w_pix), c = (int)(i - (long long)f * w_pix);
-    int j = c;
-    if (c >= avail) {  // np.pad(mode='reflect'): periodic extension with period 2 (avail - 1)
-      if (avail <= 1) j = 0;
-      else { const int per = 2 * (avail - 1); j = c % per; if (j >= avail) j = per - j; }
-    }
-    dst[i] = (src[(long long)f * db_ld + start + j] - lo) / range;
+    const int col = last ? last_cols[c] : start + c;
+    dst[i] = (src[(long long)f * db_ld + col] - lo) / range;
   }
 }
 
@@ -310,12 +308,17 @@ __global__ void pair_softmax_kernel(const float* __restrict__ x, long long n_pix
 extern "C" const char* nbm_version(void) { return "nbm_hip 0.1 (gfx950)"; }
 
 extern "C" int nbm_pcm16_to_wave(const int16_t* pcm, int64_t pcm_ld, int batch, int n, int upsample,
-                                 const int32_t* hq, float* out, int64_t out_ld, int lead, void* stream) {
+                                 const int32_t* hq, int64_t first, int64_t count, float* out, int64_t out_ld, int lead,
+                                 int pad_mode, void* stream) {
   if (!pcm || !out || batch <= 0 || n <= 0 || lead < 0 || (upsample && !hq)) return NBM_EINVAL;
-  if ((int64_t)lead + (upsample ? 2 * (int64_t)n : n) > out_ld) return NBM_EINVAL;
+  const int64_t n_out = upsample ? 2 * (int64_t)n : n;
+  if (first < 0 || count <= 0 || first + count > n_out) return NBM_EINVAL;
+  if (pad_mode != 0 && pad_mode != 1) return NBM_EINVAL;
+  if ((int64_t)lead + count + (pad_mode ? lead : 0) > out_ld) return NBM_EINVAL;
+  if (pad_mode == 1 && lead >= count) return NBM_EINVAL;            // librosa raises for such short signals too
   dim3 grid(grid_for(out_ld, TPB, 1024), batch);
   hipLaunchKernelGGL(pcm16_to_wave_kernel, grid, dim3(TPB), 0, (hipStream_t)stream, pcm, (long long)pcm_ld, n,
-                     upsample, hq, out, (long long)out_ld, lead);
+                     upsample, hq, (long long)first, (long long)count, out, (long long)out_ld, lead, pad_mode);
   return nbm_launch_status();
 }
 
@@ -327,13 +330,13 @@ extern "C" int nbm_minmax_init(uint32_t* minmax, int batch, void* stream) {
 
 extern "C" int nbm_spec_windows(const float* db, int64_t db_bs, int db_ld, int batch, int n_bins, int n_frames,
                                 const uint32_t* minmax, float* img, int n_img, int w_pix, int hop_img,
-                                void* stream) {
-  if (!db || !minmax || !img || batch <= 0 || n_img <= 0 || n_frames <= 0) return NBM_EINVAL;
+                                const int32_t* last_cols, void* stream) {
+  if (!db || !minmax || !img || !last_cols || batch <= 0 || n_img <= 0 || n_frames <= 0) return NBM_EINVAL;
   if ((n_img - 1) * hop_img >= n_frames) return NBM_EINVAL;  // every window must own >= 1 real column
   if ((n_img - 2) * (long long)hop_img + w_pix > n_frames && n_img > 1) return NBM_EINVAL;  // only the last may be short
   dim3 grid(grid_for((long long)n_bins * w_pix, TPB, 512), n_img, batch);
   hipLaunchKernelGGL(spec_windows_kernel, grid, dim3(TPB), 0, (hipStream_t)stream, db, (long long)db_bs, db_ld,
-                     n_bins, n_frames, minmax, img, n_img, w_pix, hop_img);
+                     n_bins, minmax, img, n_img, w_pix, hop_img, last_cols);
   return nbm_launch_status();
 }
 

@@ -1,7 +1,7 @@
 """Spectrogram front end (reference nbm_model/nbm_datasets/prepare_dataset.py `File_Processor`), on HIP.
 
     PCM16 -> [2x half-band up-sampling to 44.1 kHz] -> centre-padded fp32 waveform            (nbm_pcm16_to_wave)
-          -> STFT (n_fft = win = 1324, hop 132, periodic Hann) as a DFT-GEMM on the fp32 MFMA,
+          -> STFT (n_fft = win = 1324, hop 132, periodic Hann) as two real DFT-GEMMs on the fp64 MFMA,
              |.| -> 20 log10(max(floor, .)) for rows [16:391], running min/max per file            (nbm_stft_db)
           -> (x - min)/(max - min), 1024-column windows with hop 819, reflect-padded last window   (nbm_spec_windows)
 
@@ -31,22 +31,49 @@ def upsample2x_coeffs():
     return q.astype(np.int32)
 
 
-def dft_basis(n_fft, low_bin, n_bins):
-    """fp32 [rows, ld] DFT basis with the periodic Hann window folded in; rows come in blocks of 64 =
-    32 cosine rows + 32 sine rows of the same 32 bins (the kernel pairs them in registers)."""
-    n_blk = -(-n_bins // 32)
-    rows = -(-(n_blk * 64) // 128) * 128
-    ld = -(-n_fft // 32) * 32
-    n = np.arange(n_fft, dtype=np.float64)
-    win = 0.5 - 0.5 * np.cos(2 * np.pi * n / n_fft)
-    basis = np.zeros((rows, ld), dtype=np.float64)
-    for j in range(n_blk):
-        nb = min(32, n_bins - 32 * j)
-        f = (low_bin + 32 * j + np.arange(nb))[:, None]
-        ang = 2 * np.pi * ((f * n[None, :]) % n_fft) / n_fft
-        basis[64 * j:64 * j + nb, :n_fft] = win * np.cos(ang)
-        basis[64 * j + 32:64 * j + 32 + nb, :n_fft] = -win * np.sin(ang)
-    return torch.from_numpy(basis.astype(np.float32))
+def dft_basis_f64(n_fft, low_bin, n_bins):
+    """float64 [bin tiles, k steps, 64, 2] DFT basis of `nbm_stft_db` in MFMA fragment order: entry (bt, ks, l) holds
+    {w[k] cos(2 pi f k / N), w[k] sin(2 pi f k / N)} for f = low_bin + 16 bt + (l & 15), k = 4 ks + (l >> 4), with the
+    periodic Hann window w (librosa's default) folded in, the k = N/2 column halved (the kernel feeds x[k] + x[N-k] =
+    2 x[N/2] there) and zeros for k > N/2 and for bins beyond n_bins.  Angles are reduced in integers (f k mod N)."""
+    if n_fft % 2:
+        raise NotImplementedError('odd n_fft')
+    half = n_fft // 2
+    n_ks = -(-(half + 1) // 4)
+    n_bt = -(-n_bins // 128) * 8
+    k = np.arange(4 * n_ks, dtype=np.int64)
+    win = np.where(k <= half, 0.5 - 0.5 * np.cos(2 * np.pi * k / n_fft), 0.0)       # w[0] = 0 exactly
+    win[half] *= 0.5
+    f = low_bin + np.arange(16 * n_bt, dtype=np.int64)
+    ang = 2 * np.pi * ((f[:, None] * k[None, :]) % n_fft) / n_fft
+    valid = (np.arange(16 * n_bt) < n_bins)[:, None]
+    cos = np.where(valid, win * np.cos(ang), 0.0).reshape(n_bt, 16, n_ks, 4)        # [bt, l & 15, ks, l >> 4]
+    sin = np.where(valid, win * np.sin(ang), 0.0).reshape(n_bt, 16, n_ks, 4)
+    frag = np.stack([cos, sin], axis=-1).transpose(0, 2, 3, 1, 4)                    # [bt, ks, l >> 4, l & 15, 2]
+    return torch.from_numpy(np.ascontiguousarray(frag).reshape(n_bt, n_ks, 64, 2))
+
+
+def window_columns(chunk_lengths, w_pix, hop_img, label_end_col=None):
+    """Source columns of every window of `File_Processor.split_power_spec` (reference prepare_dataset.py:255-294) in the
+    chunk-concatenated spectrogram: window k = columns [k hop, k hop + W); a window that runs past the end of the file
+    stops at the end of the CHUNK its first column is in (:270-278 drop the later chunks there; for the usual one-chunk
+    file that is the end of the file); the last window is then grown to W columns by np.pad(mode='reflect') in steps of
+    min(empty_width, missing), `empty_width` starting at W (no labels) or at L - label_end_col (:283-287) and growing by
+    every step.  Returns (number of windows, int32 column list of the LAST window)."""
+    cum = np.cumsum([0] + [int(n) for n in chunk_lengths])
+    L = int(cum[-1])
+    n_img = max(1, int(1 + np.ceil((L - w_pix) / hop_img)))
+    start = (n_img - 1) * hop_img
+    end = start + w_pix
+    if end > L:
+        end = int(cum[np.searchsorted(cum, start, side='right')])
+    cols = np.arange(start, end, dtype=np.int32)
+    empty = w_pix if label_end_col is None else L - int(label_end_col)
+    while len(cols) < w_pix:
+        pad = max(1, min(empty, w_pix - len(cols)))
+        cols = np.pad(cols, (0, pad), mode='reflect')
+        empty += pad
+    return n_img, cols
 
 
 class SpectrogramFrontEnd:
@@ -54,8 +81,14 @@ class SpectrogramFrontEnd:
 
     H_PIX, LOW_FREQ, FREQ = 375, 500, 44100            # prepare_dataset.py:96-98
 
-    def __init__(self, device='cuda', freq_accuracy=33.3, dt=0.003, overlap_spectro=0.2, w_pix=1024):
+    def __init__(self, device='cuda', freq_accuracy=33.3, dt=0.003, overlap_spectro=0.2, w_pix=1024,
+                 pad_mode='constant'):
+        """`pad_mode`: how `librosa.stft(center=True)` pads each chunk -- 'constant' (zeros, librosa >= 0.10, default)
+        or 'reflect' (librosa <= 0.9); the reference does not pin its librosa version (prepare_dataset.py:237)."""
+        if pad_mode not in ('constant', 'reflect'):
+            raise ValueError(f'pad_mode {pad_mode!r}')
         self.device = torch.device(device)
+        self.pad_mode = pad_mode
         self.W_PIX = w_pix
         self.HOP_SPECTRO = int((1 - overlap_spectro) * w_pix)                       # :115
         self.WIN_LENGTH = int(self.FREQ / freq_accuracy)                             # :125
@@ -68,8 +101,9 @@ class SpectrogramFrontEnd:
         self.floor_amp = float(np.exp(-100 / 20 * np.log(10)))                       # amp_to_db :228-230
         if self.HOP_LENGTH % 4:
             raise NotImplementedError('hop length must be a multiple of 4 samples (16-byte aligned frame rows)')
-        self.basis = dft_basis(self.WIN_LENGTH, self.LOW_IDX, self.H_PIX).to(self.device)
+        self.basis = dft_basis_f64(self.WIN_LENGTH, self.LOW_IDX, self.H_PIX).to(self.device)
         self.hq = torch.from_numpy(upsample2x_coeffs()).to(self.device)
+        self._cols = {}
 
     def n_frames(self, n_samples_44k):
         return 1 + n_samples_44k // self.HOP_LENGTH                                  # librosa.stft, center=True
@@ -87,47 +121,64 @@ class SpectrogramFrontEnd:
             return True
         raise NotImplementedError(f'sample rate {sr}: only 44100 and 22050 Hz inputs are supported')
 
-    def _stft_chunk(self, pcm, up, out=None, col0=0):
-        n44 = pcm.shape[1] * (2 if up else 1)
-        L = self.n_frames(n44)
+    def _stft_chunk(self, pcm, up, first, count, out=None, col0=0):
+        """STFT of the piece [first, first + count) of the 44.1 kHz signal of every row."""
+        L = self.n_frames(count)
         lead = self.WIN_LENGTH // 2
-        ld = max(lead + n44 + lead, (L - 1) * self.HOP_LENGTH + self.basis.shape[1])
+        ld = max(lead + count + lead, (L - 1) * self.HOP_LENGTH + self.WIN_LENGTH)
         ld = -(-ld // 4) * 4
-        wave_f = ops.pcm16_to_wave(pcm.contiguous(), ld, lead, up, self.hq)
-        db, mm = ops.stft_db(wave_f, L, self.HOP_LENGTH, self.basis, self.H_PIX, self.floor_amp, out=out, col0=col0)
+        wave_f = ops.pcm16_to_wave(pcm, ld, lead, up, self.hq, self.pad_mode == 'reflect', first, count)
+        db, mm = ops.stft_db(wave_f, L, self.HOP_LENGTH, self.WIN_LENGTH, self.basis, self.H_PIX, self.floor_amp,
+                             out=out, col0=col0)
         return db, mm, L
 
     def spectrogram_db(self, pcm, sr):
-        """pcm int16 [batch, n] on the device -> (db [batch,375,L], minmax, L).  Rows longer than 5e7 samples (19 min)
-        are transformed chunk by chunk like the reference (every chunk is centre-padded on its own, the min/max runs
-        over the whole row)."""
+        """pcm int16 [batch, n] on the device -> (db [batch,375,L], minmax, [L_0, L_1, ...] frames per chunk).  Rows longer
+        than 5e7 samples (19 min) are transformed chunk by chunk like the reference (the WHOLE row is resampled first,
+        every chunk is centre-padded on its own, the min/max runs over the whole row)."""
         if pcm.dtype != torch.int16 or pcm.dim() != 2:
             raise TypeError('pcm must be int16 [batch, n]')
         up = self._rate(sr)
+        pcm = pcm.contiguous()
         n44 = pcm.shape[1] * (2 if up else 1)
         if n44 > self.MAX_FILE - self.MAX_FILE % self.FREQ:
             raise NotImplementedError('files longer than 1.5e8 samples: the reference re-enters process_file per 56-minute '
                                       'split and returns nested lists that its own run_detection cannot batch '
                                       '(prepare_dataset.py:187-225); split such recordings before detection')
-        if n44 <= self.MAX_CHUNK:
-            return self._stft_chunk(pcm, up)
-        step_in = self.MAX_CHUNK // (2 if up else 1)
-        pieces = [pcm[:, k * step_in:(k + 1) * step_in] for k in range(int(n44 / self.MAX_CHUNK) + 1)]
-        pieces = [p for p in pieces if p.shape[1] > 0]
-        Ls = [self.n_frames(p.shape[1] * (2 if up else 1)) for p in pieces]
+        if n44 < self.MAX_CHUNK:
+            db, mm, L = self._stft_chunk(pcm, up, 0, n44)
+            return db, mm, [L]
+        bounds = [(k * self.MAX_CHUNK, min(n44, (k + 1) * self.MAX_CHUNK)) for k in range(int(n44 / self.MAX_CHUNK) + 1)]
+        if bounds[-1][0] == bounds[-1][1]:
+            raise ValueError('file length is an exact multiple of the STFT chunk length: the reference calls librosa.stft '
+                             'on an empty chunk there and fails (prepare_dataset.py:236-237)')
+        Ls = [self.n_frames(b - a) for a, b in bounds]
         db = torch.empty((pcm.shape[0], self.H_PIX, sum(Ls)), device=pcm.device, dtype=torch.float32)
         mm = torch.empty((pcm.shape[0], 2), device=pcm.device, dtype=torch.int32)
         ops.check(ops.lib().nbm_minmax_init(ops._ptr(mm), pcm.shape[0], ops._stream()), 'nbm_minmax_init')
         col = 0
-        for p, L in zip(pieces, Ls):
-            self._stft_chunk(p, up, out=(db, mm), col0=col)
+        for (a, b), L in zip(bounds, Ls):
+            self._stft_chunk(pcm, up, a, b - a, out=(db, mm), col0=col)
             col += L
-        return db, mm, sum(Ls)
+        return db, mm, Ls
 
-    def __call__(self, pcm, sr):
-        """pcm int16 [batch, n] (device) -> images f32 [batch, n_img, 375, w_pix] in [0,1], spectrogram length."""
-        db, mm, L = self.spectrogram_db(pcm, sr)
-        return ops.spec_windows(db, mm, L, self.n_images(L), self.W_PIX, self.HOP_SPECTRO), L
+    def last_window_columns(self, chunk_lengths, label_end_col=None):
+        key = (tuple(chunk_lengths), label_end_col)
+        if key not in self._cols:
+            if len(self._cols) > 64:
+                self._cols.clear()
+            n_img, cols = window_columns(chunk_lengths, self.W_PIX, self.HOP_SPECTRO, label_end_col)
+            self._cols[key] = (n_img, torch.from_numpy(cols).to(self.device))
+        return self._cols[key]
+
+    def __call__(self, pcm, sr, label_end_col=None):
+        """pcm int16 [batch, n] (device) -> images f32 [batch, n_img, 375, w_pix] in [0,1], spectrogram length.
+        `label_end_col`: int(t_end.max() / DT) of the file's annotations when it has any (it changes the reference's
+        padding of the last window, prepare_dataset.py:283-287)."""
+        db, mm, Ls = self.spectrogram_db(pcm, sr)
+        L = int(sum(Ls))
+        n_img, cols = self.last_window_columns(Ls, label_end_col)
+        return ops.spec_windows(db, mm, L, n_img, self.W_PIX, self.HOP_SPECTRO, cols), L
 
 
 def read_wav_pcm16(path):
@@ -162,11 +213,12 @@ class File_Processor:
             print('File loading failed')
             return None
 
-    def process_file(self, freq_accuracy=33.3, dt=0.003, overlap_spectro=0.2, w_pix=1024, device='cuda'):
+    def process_file(self, freq_accuracy=33.3, dt=0.003, overlap_spectro=0.2, w_pix=1024, device='cuda',
+                     pad_mode='constant'):
         """-> (list of np.float32 [375, w_pix], None); (None, None) when the file cannot be read."""
-        key = (freq_accuracy, dt, overlap_spectro, w_pix, str(device))
+        key = (freq_accuracy, dt, overlap_spectro, w_pix, str(device), pad_mode)
         if key not in _FE:
-            _FE[key] = SpectrogramFrontEnd(device, freq_accuracy, dt, overlap_spectro, w_pix)
+            _FE[key] = SpectrogramFrontEnd(device, freq_accuracy, dt, overlap_spectro, w_pix, pad_mode)
         fe = _FE[key]
         for k in ('W_PIX', 'HOP_SPECTRO', 'WIN_LENGTH', 'HOP_LENGTH', 'FREQ_ACCURACY', 'DT', 'LOW_IDX', 'HIGH_IDX'):
             setattr(self, k, getattr(fe, k))
@@ -174,7 +226,12 @@ class File_Processor:
         if data is None:
             return None, None
         pcm, sr = data
-        imgs, L = fe(torch.from_numpy(pcm)[None].to(fe.device), sr)
+        label_end_col = None
+        if self.labels is not None:
+            own = self.labels.loc[self.labels['filename'] == self.filename]
+            if len(own) > 0:
+                label_end_col = int(own['t_end'].max() / fe.DT)                   # prepare_dataset.py:283-284
+        imgs, L = fe(torch.from_numpy(pcm)[None].to(fe.device), sr, label_end_col)
         self.spectrogram_length = L
         self.images_device = imgs[0]
         img_db = [im for im in imgs[0].cpu().numpy()]

@@ -199,23 +199,29 @@ def bgemm_nt(a, b, out=None, alpha=1.0, shift=None, shift_per_row=False, residua
 
 
 # --------------------------------------------------------------------------- front end
-def pcm16_to_wave(pcm, out_ld, lead, upsample, hq=None):
-    """pcm int16 [batch, n] -> f32 [batch, out_ld] zero-padded (lead zeros in front)."""
+def pcm16_to_wave(pcm, out_ld, lead, upsample, hq=None, reflect=False, first=0, count=None):
+    """pcm int16 [batch, n] -> f32 [batch, out_ld]: `lead` padding samples, the piece [first, first + count) of the
+    44.1 kHz signal (the input itself, or its 2x up-sampling when `upsample`; default: all of it), `lead` padding
+    samples, zeros.  Padding = zeros (librosa >= 0.10 `pad_mode='constant'`) or the mirrored piece (`reflect`,
+    librosa <= 0.9)."""
     _chk(pcm, torch.int16, 'pcm')
     batch, n = pcm.shape
+    if count is None:
+        count = (2 * n if upsample else n) - first
     out = torch.empty((batch, out_ld), device=pcm.device, dtype=torch.float32)
     if upsample:
         _chk(hq, torch.int32, 'hq')
-    check(lib().nbm_pcm16_to_wave(_ptr(pcm), n, batch, n, int(bool(upsample)), _ptr(hq), _ptr(out), out_ld, lead,
-                                  _stream()), 'nbm_pcm16_to_wave')
+    check(lib().nbm_pcm16_to_wave(_ptr(pcm), n, batch, n, int(bool(upsample)), _ptr(hq), first, count, _ptr(out), out_ld,
+                                  lead, int(bool(reflect)), _stream()), 'nbm_pcm16_to_wave')
     return out
 
 
-def stft_db(wave, n_frames, hop, basis, n_bins, floor_amp, db_ld=None, out=None, col0=0):
+def stft_db(wave, n_frames, hop, n_fft, basis, n_bins, floor_amp, db_ld=None, out=None, col0=0):
     """wave f32 [batch, wave_ld] (already centre-padded) -> (db [batch, n_bins, db_ld], minmax u32 [batch,2]).
+    `basis`: float64 [bin tiles, k steps, 64, 2] in MFMA fragment order (prepare_dataset.dft_basis_f64).
     `out=(db, minmax)` + `col0`: write the frames at column offset col0 of an existing spectrogram and keep accumulating
     its min/max (chunked STFT of a long file, reference prepare_dataset.py:234-237)."""
-    _chk(wave, name='wave'), _chk(basis, name='basis')
+    _chk(wave, name='wave'), _chk(basis, torch.float64, 'basis')
     batch, wave_ld = wave.shape
     if out is None:
         db_ld = n_frames if db_ld is None else db_ld
@@ -226,19 +232,21 @@ def stft_db(wave, n_frames, hop, basis, n_bins, floor_amp, db_ld=None, out=None,
         db, mm = out
         db_ld = db.shape[-1]
         assert col0 + n_frames <= db_ld and db.shape[0] == batch
-    check(lib().nbm_stft_db(_ptr(wave), wave_ld, batch, n_frames, hop, _ptr(basis), basis.shape[0], basis.shape[1],
-                            n_bins, float(floor_amp), C.c_void_p(db.data_ptr() + 4 * col0), n_bins * db_ld, db_ld, _ptr(mm),
-                            _stream()), 'nbm_stft_db')
+    check(lib().nbm_stft_db(_ptr(wave), wave_ld, batch, n_frames, hop, n_fft, _ptr(basis), basis.shape[0],
+                            basis.shape[1], n_bins, float(floor_amp), C.c_void_p(db.data_ptr() + 4 * col0),
+                            n_bins * db_ld, db_ld, _ptr(mm), _stream()), 'nbm_stft_db')
     return db, mm
 
 
-def spec_windows(db, minmax, n_frames, n_img, w_pix, hop_img):
-    """db [batch, n_bins, db_ld] + min/max -> img [batch, n_img, n_bins, w_pix] normalised to [0,1]."""
-    _chk(db, name='db')
+def spec_windows(db, minmax, n_frames, n_img, w_pix, hop_img, last_cols):
+    """db [batch, n_bins, db_ld] + min/max -> img [batch, n_img, n_bins, w_pix] normalised to [0,1]; the last window
+    reads the columns `last_cols` (int32 [w_pix] on the device)."""
+    _chk(db, name='db'), _chk(last_cols, torch.int32, 'last_cols')
+    assert last_cols.numel() == w_pix
     batch, n_bins, db_ld = db.shape
     img = torch.empty((batch, n_img, n_bins, w_pix), device=db.device, dtype=torch.float32)
     check(lib().nbm_spec_windows(_ptr(db), n_bins * db_ld, db_ld, batch, n_bins, n_frames, _ptr(minmax), _ptr(img),
-                                 n_img, w_pix, hop_img, _stream()), 'nbm_spec_windows')
+                                 n_img, w_pix, hop_img, _ptr(last_cols), _stream()), 'nbm_spec_windows')
     return img
 
 

@@ -95,27 +95,38 @@ int nbm_wino_outgrad(const float* g, int B, int H, int W, int N, float* dM, floa
  * ffmpeg 2x resample (third-party).
  */
 
-/* PCM16 -> zero-padded fp32 waveform rows: out[b][lead + i] = pcm/32768 (upsample=0) or the 2x
- * half-band integer interpolation (upsample=1, output length 2n); everything else in the row
- * [0, out_ld) is written as 0.  hq = 16 Q15 odd-phase taps (oracle/frontend_ref.py:upsample2x_coeffs). */
+/* PCM16 -> centre-padded fp32 waveform rows of one STFT chunk.  The 44.1 kHz signal y of row b is pcm/32768
+ * (upsample=0, length n) or its 2x half-band integer interpolation (upsample=1, length 2n; hq = 16 Q15 odd-phase taps,
+ * oracle/frontend_ref.py:upsample2x_coeffs); the piece y[first, first+count) is written to out[b][lead ...].
+ * pad_mode 0 ('constant', librosa >= 0.10): everything else in the row [0, out_ld) is 0.  pad_mode 1 ('reflect',
+ * librosa <= 0.9): the `lead` samples in front of and behind the piece mirror it (np.pad(mode='reflect'), needs
+ * lead < count), the rest of the row is 0. */
 int nbm_pcm16_to_wave(const int16_t* pcm, int64_t pcm_ld, int batch, int n, int upsample,
-                      const int32_t* hq, float* out, int64_t out_ld, int lead, void* stream);
+                      const int32_t* hq, int64_t first, int64_t count, float* out, int64_t out_ld, int lead,
+                      int pad_mode, void* stream);
 
-/* STFT magnitude in dB for bins [low_bin, low_bin+n_bins) as a DFT-GEMM on the fp32 MFMA:
- *   db[b][f][t] = 20 log10(max(floor, | sum_n basis[f][n] * wave[b][t*hop + n] |))
- * basis: [ceil(n_bins/32)*64][basis_ld] rows in blocks of 64 = 32 cos rows then 32 sin rows (window
- * folded in, zero beyond n_fft and beyond n_bins).  minmax[b] = {min, max} over the clip as
- * order-preserving uint32 keys; must be initialised with nbm_minmax_init.  */
+/* STFT magnitude in dB for n_bins bins on the fp64 MFMA (librosa.stft + np.abs + amp_to_db + crop,
+ * prepare_dataset.py:228-247):
+ *   db[b][f][t] = 20 log10(max(floor, | sum_n w[n] wave[b][t*hop + n] exp(-2 pi i (low_bin + f) n / n_fft) |))
+ * for a symmetric window with w[0] = 0 (periodic Hann), evaluated as two real GEMMs over k = 0 .. n_fft/2 on
+ * s[k] = x[k] + x[N-k] and d[k] = x[k] - x[N-k] (csrc/stft.hip).  basis: float64, MFMA fragment order
+ * [basis_bin_tiles][basis_ksteps][64 lanes]{cos, sin}, lane l of (tile bt, step ks) = bin bt*16 + (l & 15),
+ * k = 4 ks + (l >> 4); window folded in, the k = n_fft/2 column halved, zero beyond n_fft/2 and beyond n_bins
+ * (prepare_dataset.py:dft_basis_f64 builds it).  basis_bin_tiles % 8 == 0.  wave rows are already centre-padded;
+ * hop % 4 == 0.  minmax[b] = {min, max} over the row as order-preserving uint32 keys, accumulated into
+ * (initialise with nbm_minmax_init). */
 int nbm_minmax_init(uint32_t* minmax, int batch, void* stream);
-int nbm_stft_db(const float* wave, int64_t wave_ld, int batch, int n_frames, int hop,
-                const float* basis, int basis_rows, int basis_ld, int n_bins, float floor_amp,
+int nbm_stft_db(const float* wave, int64_t wave_ld, int batch, int n_frames, int hop, int n_fft,
+                const double* basis, int basis_bin_tiles, int basis_ksteps, int n_bins, float floor_amp,
                 float* db, int64_t db_bs, int db_ld, uint32_t* minmax, void* stream);
 
-/* (x - min)/(max - min) + window split (hop_img) + reflect padding of the last window:
- * img[b][k][f][c], k < n_img, c < w_pix.  minmax_group: clips [g*minmax_group, (g+1)*minmax_group)
- * share one min/max (a long file cut in chunks); 1 = per clip. */
+/* (x - min)/(max - min) + window split (File_Processor.split_power_spec, prepare_dataset.py:255-294):
+ * img[b][k][f][c] = norm(db[b][f][k*hop_img + c]) for k < n_img - 1; the LAST window takes its columns from
+ * last_cols[c] (w_pix absolute column indices < n_frames, device memory): the host lists there the reference's chunk-end
+ * cut and its stepwise reflect padding (prepare_dataset.py:window_columns). */
 int nbm_spec_windows(const float* db, int64_t db_bs, int db_ld, int batch, int n_bins, int n_frames,
-                     const uint32_t* minmax, float* img, int n_img, int w_pix, int hop_img, void* stream);
+                     const uint32_t* minmax, float* img, int n_img, int w_pix, int hop_img,
+                     const int32_t* last_cols, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Point-wise / small-window detector stages (NHWC fp32).
