@@ -91,8 +91,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 self._flat.append(None)
                 continue
             dev = ps[0].device
-            if dev.type != 'cuda':
-                raise RuntimeError('FusedAdamW needs the parameters on the GPU (no CPU fallback)')
+            self._check_device(dev)
             al = lambda k: (k + 63) // 64 * 64          # every view starts 256-byte aligned (kernels need 16 B)
             n = sum(al(p.numel()) for p in ps)
             fp = torch.zeros(n, device=dev, dtype=torch.float32)
@@ -115,8 +114,46 @@ class FusedAdamW(torch.optim.Optimizer):
         from .nets import _prep
         _prep.bump()
 
+    @staticmethod
+    def _check_device(dev):
+        if dev.type != 'cuda':
+            raise RuntimeError('FusedAdamW needs the parameters on the GPU (no CPU fallback)')
+
     def _mark(self, p):
         self._touched.add(id(p))
+
+    def all_params(self):
+        """Every parameter in flat-buffer order (the order of the `touched` bitmap exchanged between ranks)."""
+        return [p for f in self._flat if f is not None for (p, _, _) in f['spans']]
+
+    def touched_bitmap(self):
+        """int32 [n_params] on the host: 1 where the parameter received a gradient in the last backward."""
+        return torch.tensor([1 if id(p) in self._touched else 0 for p in self.all_params()], dtype=torch.int32)
+
+    def set_touched_bitmap(self, bits):
+        self._touched = {id(p) for p, b in zip(self.all_params(), bits.tolist()) if b}
+
+    def load_state_dict(self, state_dict):
+        """torch's loader replaces `state[p]` by fresh tensors; the kernels read the FLAT moment buffers, so copy the
+        loaded moments into their spans and point the state back at the views (step counts are kept).  Without this a
+        resumed run would continue with m = v = 0 and a large step count, i.e. without bias correction."""
+        super().load_state_dict(state_dict)
+        for f in self._flat:
+            if f is None:
+                continue
+            for (p, off, _) in f['spans']:
+                st = self.state.get(p)
+                if not st:                             # parameter never stepped before the checkpoint
+                    self.state[p] = st = {'step': 0}
+                k = p.numel()
+                for name, buf in (('exp_avg', f['m']), ('exp_avg_sq', f['v'])):
+                    view = buf[off:off + k].view(p.shape)
+                    if name in st and st[name].data_ptr() != view.data_ptr():
+                        view.copy_(st[name].to(view.device, torch.float32))
+                    elif name not in st:
+                        view.zero_()
+                    st[name] = view
+                st['step'] = int(st.get('step', 0))
 
     def mark_all(self):
         """Treat every parameter as having received a gradient (for gradients written into `p.grad` by hand)."""
@@ -218,15 +255,39 @@ def step(model, criterion, batch, device, negative_sample):
     return loss
 
 
+_FLAG_GROUP = {}
+
+
+def _host_group():
+    """Process group for small HOST-side exchanges (the `touched` bitmap): the default group when it is gloo, else a
+    gloo side group created once (collectively, at the first data-parallel step)."""
+    import datetime
+    import torch.distributed as dist
+    if dist.get_backend() == 'gloo':
+        return None
+    if 'g' not in _FLAG_GROUP:
+        _FLAG_GROUP['g'] = dist.new_group(backend='gloo', timeout=datetime.timedelta(hours=2))
+    return _FLAG_GROUP['g']
+
+
 def allreduce_grads(optimizer_or_model):
     """Data-parallel exchange step (NEW capability): average the fp32 gradients of all ranks -- one
     collective per flat gradient buffer (RCCL all-reduce over xGMI when the backend is nccl; gloo in the CPU tests).
-    No-op when torch.distributed is not initialised or world_size == 1."""
+    No-op when torch.distributed is not initialised or world_size == 1.
+
+    With `FusedAdamW` the set of parameters that received a gradient is made the UNION over the ranks first: the soft
+    failure paths of `step` ("RPN failed", proposal batch cannot be filled -- data dependent, reference train.py:232-247)
+    leave the second-stage parameters without a gradient on one rank only; that rank must still apply the averaged
+    gradient and advance its Adam step count like its peers, or the replicas drift apart for good.  The bitmap is a
+    ~400-entry host tensor exchanged over gloo, so it never waits for the GPU."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return
     world = dist.get_world_size()
     if hasattr(optimizer_or_model, 'flat_grads'):
+        bits = optimizer_or_model.touched_bitmap()
+        dist.all_reduce(bits, op=dist.ReduceOp.MAX, group=_host_group())
+        optimizer_or_model.set_touched_bitmap(bits)
         bufs = optimizer_or_model.flat_grads()
     else:                                             # plain module: flatten once (used by the gloo CPU tests)
         grads = [p.grad for p in optimizer_or_model.parameters() if p.grad is not None]
@@ -450,7 +511,11 @@ if __name__ == '__main__':
     _p = argparse.ArgumentParser('NbmModel training and evaluation script', parents=[get_args_parser()])
     _args = _p.parse_args()
     if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+        import datetime
         import torch.distributed as _dist
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
-        _dist.init_process_group('nccl')
+        _lr = int(os.environ.get('LOCAL_RANK', '0'))
+        torch.cuda.set_device(_lr)
+        # ranks > 0 wait in the next all-reduce while rank 0 validates and runs the test-set detection: give the
+        # collective watchdog room for that instead of its 10-minute default
+        _dist.init_process_group('nccl', timeout=datetime.timedelta(hours=2), device_id=torch.device('cuda', _lr))
     main(_args)

@@ -1,5 +1,7 @@
 """CPU, world_size 2 (gloo): the data-parallel exchange step `allreduce_grads` averages gradients across ranks
-(DP is a NEW capability; ranks hold different batches, one all-reduce per step)."""
+(DP is a NEW capability; ranks hold different batches, one all-reduce per step) -- on a plain module and on
+the branch the GPU path takes: `FusedAdamW`'s flat gradient buffers + the `touched` bitmap union, with the two HIP
+entry points of the update (`ops.sqnorm_accum`, `ops.adamw_step`) replaced by a torch CPU restatement of the kernels."""
 import os
 import socket
 
@@ -54,3 +56,153 @@ def test_allreduce_is_noop_without_process_group():
     g = m.weight.grad.clone()
     allreduce_grads(m)
     assert torch.equal(m.weight.grad, g)
+
+
+# --------------------------------------------------------------------------- FusedAdamW flat-buffer branch
+def cpu_sqnorm_accum(g, out):
+    """csrc/pointwise_bwd.hip sqnorm_kernel: out (float64[1]) += sum g^2."""
+    out += (g.double() ** 2).sum()
+
+
+def cpu_adamw_step(p, g, m, v, lr, beta1, beta2, eps, wd, step, sqnorm=None, max_norm=0.0):
+    """csrc/pointwise_bwd.hip adamw_kernel, same operation order, in fp32."""
+    f = torch.float32
+    coef = torch.tensor(1.0, dtype=f)
+    if sqnorm is not None and max_norm > 0:
+        total = sqnorm.sqrt().to(f)
+        coef = torch.minimum(torch.tensor(max_norm, dtype=f) / (total + torch.tensor(1e-6, dtype=f)), torch.tensor(1.0, dtype=f))
+    bc1 = torch.tensor(1.0 - beta1 ** step, dtype=f)
+    bc2s = torch.tensor((1.0 - beta2 ** step) ** 0.5, dtype=f)
+    gi = g * coef
+    p.mul_(1.0 - lr * wd)
+    m.mul_(beta1).add_(gi, alpha=1.0 - beta1)
+    v.mul_(beta2).addcmul_(gi, gi, value=1.0 - beta2)
+    p.sub_((lr / bc1) * (m / (v.sqrt() / bc2s + eps)))
+
+
+def patch_cpu_optimizer(monkeypatch=None):
+    from birdsoundclassif_amd import ops, train
+    from birdsoundclassif_amd.nets import _prep
+    set_ = (lambda o, k, v: setattr(o, k, v)) if monkeypatch is None else monkeypatch.setattr
+    set_(ops, 'sqnorm_accum', cpu_sqnorm_accum)
+    set_(ops, 'adamw_step', cpu_adamw_step)
+    set_(train.FusedAdamW, '_check_device', staticmethod(lambda dev: None))
+
+
+class TwoStage(torch.nn.Module):
+    """`first` always gets a gradient; `second` only when the step reaches the second stage (train.py:step)."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.first = torch.nn.Linear(8, 6)
+        self.second = torch.nn.Linear(6, 3)
+        self.backbone_like = torch.nn.Linear(8, 6)             # second parameter group (lr_backbone)
+
+    def loss(self, x, second_stage):
+        h = self.first(x) + self.backbone_like(x)
+        l1 = (h ** 2).mean()
+        return l1 + (self.second(torch.tanh(h)) ** 2).mean() if second_stage else l1
+
+
+def _groups(m):
+    return [{'params': list(m.first.parameters()) + list(m.second.parameters())},
+            {'params': list(m.backbone_like.parameters()), 'lr': 1e-3}]
+
+
+def _fused_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    patch_cpu_optimizer()
+    from birdsoundclassif_amd.train import FusedAdamW, allreduce_grads
+    m = TwoStage()
+    ref = TwoStage()                                           # single-process torch AdamW on the averaged gradients
+    opt = FusedAdamW(_groups(m), lr=1e-2, weight_decay=1e-2)
+    opt_ref = torch.optim.AdamW(_groups(ref), lr=1e-2, weight_decay=1e-2)
+    ok = True
+    # step 0: rank 0 "RPN failed" (first stage only), rank 1 full step; step 1: the other way round; step 2: both fail
+    plan = [(False, True), (True, False), (False, False)]
+    for it, stages in enumerate(plan):
+        x = [torch.full((4, 8), 0.1 * (r + 1) + 0.05 * it) + torch.arange(8.0) * 0.01 for r in range(world)]
+        opt.zero_grad()
+        m.loss(x[rank], stages[rank]).backward()
+        allreduce_grads(opt)
+        opt.step(max_norm=0.05)
+        # reference: average of the per-rank gradients (a rank that skipped the second stage contributes zeros); a
+        # parameter that NO rank touched keeps grad None and is skipped, like torch.optim.AdamW does
+        opt_ref.zero_grad()
+        grads = []
+        for r in range(world):
+            for p_ in ref.parameters():
+                p_.grad = None
+            ref.loss(x[r], stages[r]).backward()
+            grads.append([None if p_.grad is None else p_.grad.clone() for p_ in ref.parameters()])
+        for i, p_ in enumerate(ref.parameters()):
+            gs = [g[i] for g in grads if g[i] is not None]
+            p_.grad = None if not gs else sum(gs) / world
+        torch.nn.utils.clip_grad_norm_([p_ for p_ in ref.parameters() if p_.grad is not None], 0.05)
+        opt_ref.step()
+        for (n_, a), b in zip(m.named_parameters(), ref.parameters()):
+            ok = ok and torch.allclose(a, b, atol=2e-7, rtol=1e-6)
+    # replicas identical bit for bit, step counts identical
+    for p_ in m.parameters():
+        lst = [torch.zeros_like(p_.data) for _ in range(world)]
+        dist.all_gather(lst, p_.data.contiguous())
+        ok = ok and all(torch.equal(lst[0], t) for t in lst)
+    steps = torch.tensor([opt.state[p_]['step'] for p_ in opt.all_params()], dtype=torch.int64)
+    lst = [torch.zeros_like(steps) for _ in range(world)]
+    dist.all_gather(lst, steps)
+    ok = ok and all(torch.equal(lst[0], t) for t in lst)
+    # second-stage parameters stepped twice (steps 0 and 1), the others three times
+    exp = [3, 3, 2, 2, 3, 3]
+    out[rank] = bool(ok) and steps.tolist() == exp
+    dist.destroy_process_group()
+
+
+def test_fused_adamw_flat_path_world2_with_a_soft_failure_on_one_rank():
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_fused_worker, args=(world, port, out), nprocs=world, join=True)
+        assert dict(out) == {0: True, 1: True}
+
+
+def test_fused_adamw_load_state_dict_restores_the_flat_moments(monkeypatch, tmp_path):
+    """Checkpoint -> fresh optimizer -> load_state_dict: the kernels read the flat moment buffers, so those must hold
+    the loaded moments (and the state must view them); the continued run equals the uninterrupted one."""
+    patch_cpu_optimizer(monkeypatch)
+    from birdsoundclassif_amd.train import FusedAdamW
+
+    def run(m, opt, its):
+        for it in its:
+            opt.zero_grad()
+            m.loss(torch.full((4, 8), 0.1 + 0.05 * it) + torch.arange(8.0) * 0.01, it % 2 == 0).backward()
+            opt.step(max_norm=0.05)
+
+    a = TwoStage()
+    oa = FusedAdamW(_groups(a), lr=1e-2, weight_decay=1e-2)
+    run(a, oa, range(3))
+    torch.save({'model': a.state_dict(), 'optim': oa.state_dict()}, tmp_path / 'c.pt')
+    run(a, oa, range(3, 5))
+
+    b = TwoStage()
+    ob = FusedAdamW(_groups(b), lr=1e-2, weight_decay=1e-2)
+    ck = torch.load(tmp_path / 'c.pt', weights_only=False)
+    b.load_state_dict(ck['model'])
+    ob.load_state_dict(ck['optim'])
+    for f in ob._flat:
+        lo, hi = f['m'].data_ptr(), f['m'].data_ptr() + 4 * f['m'].numel()
+        for (p_, off, k) in f['spans']:
+            st = ob.state[p_]
+            assert lo <= st['exp_avg'].data_ptr() < hi and st['exp_avg'].data_ptr() == f['m'][off:].data_ptr()
+            assert st['exp_avg_sq'].data_ptr() == f['v'][off:].data_ptr()
+            assert p_.data_ptr() == f['p'][off:].data_ptr() and p_.grad.data_ptr() == f['g'][off:].data_ptr()
+    assert [ob.state[p_]['step'] for p_ in ob.all_params()] == [3, 3, 2, 2, 3, 3]
+    assert float(ob._flat[0]['m'].abs().sum()) > 0
+    run(b, ob, range(3, 5))
+    for p_, q_ in zip(a.parameters(), b.parameters()):
+        assert torch.equal(p_, q_)
+    # a later checkpoint of the resumed run stores the LIVE moments
+    sd = ob.state_dict()['state']
+    assert torch.equal(sd[0]['exp_avg'], ob._flat[0]['m'][:48].view(6, 8))

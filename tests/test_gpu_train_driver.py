@@ -58,3 +58,45 @@ def test_main_loop_trains_validates_tests_and_resumes(tmp_path, monkeypatch):
     T.save(str(save_dir), model, 7, 123, 0.5, 'last', opt, sch, np.array([2]), np.array([0, 1]))
     args.max_steps = 125
     assert T.main(args) == 125
+
+
+def test_resume_continues_bit_for_bit(tmp_path):
+    """N steps -> save -> resume into a FRESH model + optimizer -> one more step == N + 1 uninterrupted steps (the Adam
+    moments live in the optimizer's flat buffers; `load_state_dict` must put the loaded ones there)."""
+    from birdsoundclassif_amd import train as T
+    from birdsoundclassif_amd.nets import build_model, _prep
+    args = T.default_args(device='cuda')
+    img = torch.from_numpy(synth.image_batch(0, 2))
+    neg_img = torch.from_numpy(synth.image_batch(100, 2))
+    bb, ids, lengths = synth.label_batch(0, 2)
+    batch = [img, neg_img, bb, ids, lengths]
+
+    def fresh():
+        model, crit = build_model(args)
+        model.load_state_dict(filler_state_dict())
+        model = model.cuda().train()
+        crit.train()
+        opt, sch = T.build_optimizer(model, args)
+        return model, crit, opt, sch
+
+    def run(model, crit, opt, steps):
+        for i in steps:
+            np.random.seed(100 + i)
+            T.train_one_step(model, crit, opt, batch, args.clip_max_norm, 'cuda', negative_sample=(i == 1))
+
+    a, ca, oa, sa = fresh()
+    run(a, ca, oa, range(2))                                   # one positive, one negative step
+    T.save(str(tmp_path), a, 0, 2, 99, 'last', oa, sa, np.array([0]), np.array([1]))
+    run(a, ca, oa, range(2, 3))
+
+    b, cb, ob, sb = fresh()
+    b, ob, sb, *_ = T.resume_training(str(tmp_path), b, ob, sb, args.lr_drop)
+    f = ob._flat[0]
+    st = ob.state[f['spans'][0][0]]
+    assert st['exp_avg'].data_ptr() == f['m'].data_ptr() and float(f['m'].abs().sum()) > 0 and st['step'] == 2
+    # buffers (BatchNorm running statistics) travel with the checkpoint too
+    run(b, cb, ob, range(2, 3))
+    for (n, p), q in zip(a.named_parameters(), b.parameters()):
+        assert torch.equal(p, q), n
+    for (n, p), q in zip(a.named_buffers(), b.named_buffers()):
+        assert torch.equal(p, q[1]), n
