@@ -60,7 +60,7 @@ def test_main_loop_trains_validates_tests_and_resumes(tmp_path, monkeypatch):
     assert T.main(args) == 125
 
 
-def test_resume_continues_bit_for_bit(tmp_path):
+def test_resume_continues_the_uninterrupted_run(tmp_path):
     """N steps -> save -> resume into a FRESH model + optimizer -> one more step == N + 1 uninterrupted steps (the Adam
     moments live in the optimizer's flat buffers; `load_state_dict` must put the loaded ones there)."""
     from birdsoundclassif_amd import train as T
@@ -96,7 +96,9 @@ def test_resume_continues_bit_for_bit(tmp_path):
     assert st['exp_avg'].data_ptr() == f['m'].data_ptr() and float(f['m'].abs().sum()) > 0 and st['step'] == 2
     # buffers (BatchNorm running statistics) travel with the checkpoint too
     run(b, cb, ob, range(2, 3))
+    # the weight-gradient kernels sum with fp32 atomics (arrival order), so two runs agree to rounding, not bit for bit;
+    # a resume that lost the moments is off by ~3 lr = 3e-4 (no bias correction at step count 3 with m = v = 0)
     for (n, p), q in zip(a.named_parameters(), b.parameters()):
-        assert torch.equal(p, q), n
+        assert float((p - q).abs().max()) < 2e-6, n
     for (n, p), q in zip(a.named_buffers(), b.named_buffers()):
-        assert torch.equal(p, q[1]), n
+        assert float((p.float() - q[1].float()).abs().max()) < 1e-5, n
