@@ -4,10 +4,12 @@ Checkpoints keep the reference layout (conv weight [Cout, Cin, kh, kw]); the imp
 wants KRSC rows [Cout, kh*kw*Cin] (k contiguous, padded to a multiple of 32 floats when Cin is not).
 Prepared copies are cached per parameter and invalidated by torch's version counter.
 """
+import weakref
+
 import torch
 import torch.nn.functional as F
 
-_cache = {}
+_cache = {}         # (id(tensor), tag) -> (weakref to the tensor, version tuple, prepared value)
 _epoch = 0          # bumped whenever a kernel rewrote parameters / buffers through raw pointers
 
 
@@ -18,15 +20,25 @@ def bump():
     _epoch += 1
 
 
+def _evict(obj_id):
+    for k in [k for k in _cache if k[0] == obj_id]:
+        _cache.pop(k, None)
+
+
 def _cached(key_t, tag, fn):
+    """Prepared copy of `key_t`.  An entry belongs to ONE tensor object: it keeps a weak reference to it and is only
+    valid while that referent is alive and is `key_t` itself -- CPython reuses ids and the caching allocator reuses
+    device addresses, so (id, data_ptr, version) alone can match a different model's parameter after the first model was
+    freed.  Entries are dropped when their tensor dies (the prepared copies would otherwise leak on the device)."""
     key = (id(key_t), tag)
     ver = (key_t.data_ptr(), key_t._version, key_t.device, _epoch)
     hit = _cache.get(key)
-    if hit is not None and hit[0] == ver:
-        return hit[1]
+    if hit is not None and hit[0]() is key_t and hit[1] == ver:
+        return hit[2]
     with torch.no_grad():
         val = fn()
-    _cache[key] = (ver, val)
+    obj_id = id(key_t)
+    _cache[key] = (weakref.ref(key_t, lambda _r, obj_id=obj_id: _evict(obj_id)), ver, val)
     return val
 
 

@@ -94,19 +94,23 @@ def conv2d(x, w, kh=1, kw=1, stride=1, pad=0, scale=None, shift=None, residual=N
     return y
 
 
-WINO_CHUNK_BYTES = 24 << 30          # transformed-domain scratch (V + M) per batch chunk
+WINO_CHUNK_BYTES = 24 << 30          # cap of the transformed-domain scratch (V + M) per batch chunk
 _WINO_SCRATCH = {}
 
 
 def _wino_scratch(device, n_v, n_m):
     """Two views (V: n_v floats, M: n_m floats) of ONE persistent per-device scratch allocation.  Every Winograd call on
     a device runs on the same stream, so reusing the buffer is stream-ordered; a fresh multi-GB torch.empty per call made
-    the caching allocator fall back to hipMalloc / hipFree (100 ms host stalls per training step)."""
+    the caching allocator fall back to hipMalloc / hipFree (100 ms host stalls per training step).  The buffer is sized to
+    what the largest call so far needed (<= WINO_CHUNK_BYTES by construction of the batch chunks) and grows geometrically:
+    a B = 1 detect process holds 0.4 GB, not the 24 GB a B = 64 step uses."""
     need = n_v + n_m
     buf = _WINO_SCRATCH.get(device)
     if buf is None or buf.numel() < need:
-        _WINO_SCRATCH[device] = None
-        buf = _WINO_SCRATCH[device] = torch.empty((max(need, WINO_CHUNK_BYTES // 4),), device=device, dtype=torch.float32)
+        have = 0 if buf is None else buf.numel()
+        _WINO_SCRATCH[device] = buf = None          # release before growing
+        size = min(max(need, 2 * have), max(need, WINO_CHUNK_BYTES // 4))
+        buf = _WINO_SCRATCH[device] = torch.empty((size,), device=device, dtype=torch.float32)
     return buf[:n_v], buf[n_v:need]
 
 
