@@ -70,7 +70,7 @@ def test_config2_b128_train_steps_positive_and_negative():
     img8 = torch.from_numpy(synth.image_batch(0, 8))
     neg8 = torch.from_numpy(synth.image_batch(100, 8))
     bb8, ids8, len8 = synth.label_batch(0, 8)
-    tile = lambda t, k: torch.cat([t] * k, 0)
+    tile = lambda t, k: torch.cat([t] * k, 0) if torch.is_tensor(t) else list(t) * k
     batches = {8: [img8, neg8, bb8, ids8, len8],
                128: [tile(img8, 16), tile(neg8, 16), tile(bb8, 16), tile(ids8, 16), tile(len8, 16)]}
     out = {}
@@ -81,7 +81,12 @@ def test_config2_b128_train_steps_positive_and_negative():
         # RPN outputs of the step's forward (train mode: BatchNorm on batch statistics, identical for a tiled batch)
         with torch.no_grad():
             o1 = model.forward_first_stage(batch[0][:, None].cuda())
-        rpn = (o1['rpn_cls_scores'].float().cpu(), o1['rpn_bbox_reg'].float().cpu())
+            rpn = (o1['rpn_cls_scores'].float().cpu(), o1['rpn_bbox_reg'].float().cpu())
+            # the negative-image first-stage loss involves no sampling (top anchor per image, Appendix C-15a): evaluated
+            # on the SAME fresh weights at both batch sizes it must agree
+            o1 = model.forward_first_stage(batch[1][:, None].cuda())
+            fresh_neg = float(crit.first_stage_loss(o1['rpn_cls_scores'], o1['rpn_bbox_reg'], batch[2], batch[4], True)
+                              ['first_neg_class_loss'])
         del o1
         model, crit = build(train=True)                                  # fresh BatchNorm buffers for the measured steps
         opt, _ = T.build_optimizer(model, args)
@@ -104,13 +109,13 @@ def test_config2_b128_train_steps_positive_and_negative():
         ref = O.first_stage_loss(O.make_cfg(), rpn[0], rpn[1], batch[2], batch[4])
         for k in ('first_class_loss', 'first_regression_loss'):
             assert abs(pos[k] - float(ref[k])) < 2e-4 * max(1.0, abs(float(ref[k]))), (B, k, pos[k], float(ref[k]))
-        out[B] = dict(rpn=rpn, pos=pos, neg=neg, peak=peak, gn=(gn_pos, gn_neg))
+        out[B] = dict(rpn=rpn, pos=pos, neg=neg, peak=peak, gn=(gn_pos, gn_neg), fresh_neg=fresh_neg)
         del model, crit, opt
         torch.cuda.empty_cache()
     # the tiled 128-batch reproduces the 8-batch: RPN outputs copy by copy, and the loss that involves no sampling
     for a, b in zip(out[128]['rpn'], out[8]['rpn']):
         assert float((a.view(16, *b.shape) - b[None]).abs().max()) < 1e-4
-    assert abs(out[128]['neg']['first_neg_class_loss'] - out[8]['neg']['first_neg_class_loss']) < 2e-4
+    assert abs(out[128]['fresh_neg'] - out[8]['fresh_neg']) < 2e-4 and out[8]['fresh_neg'] > 0
     print(f"B=128 train: positive {out[128]['pos']}, negative {out[128]['neg']}, grad norms {out[128]['gn']}, "
           f"peak memory {out[128]['peak']:.1f} GiB")
     assert out[128]['peak'] < 270
