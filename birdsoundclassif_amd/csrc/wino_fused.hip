@@ -1,0 +1,430 @@
+// Winograd F(2x2,3x3) forward convolution, transforms fused into the GEMM (the FPN output convolutions, reference
+// fpn.py:137,145 -- 68 % of the forward FLOPs -- and the ResNet 3x3 / stride-1 layers).
+//
+//   y[b][2ty+p][2tx+q][n] = epi( sum_{i,j} AT[p][i] AT[q][j] * ( sum_c V[i][j][t][c] U[i][j][n][c] ) ),   V = B^T d B
+//
+// Round 1 ran three kernels: x -> V[16][T][C] (591 MB per 188x512 image), 16 grouped GEMMs -> M[16][T][N] (394 MB), M -> y.
+// Now:
+//  * wino23_rows_kernel applies only the ROW half of the input transform: R[i][b][ty][xp][c] = (B^T d)_i for the four row
+//    combinations of tile row ty, kept as full-width image rows (xp = x + 1, one zero column on each side).  Neighbouring
+//    tiles share their columns there, so R is 2x the input instead of 4x (297 MB per image instead of 591).
+//  * wino23_fused_kernel: ONE workgroup owns a [128 tiles x BN channels] block for ALL 16 planes.  The COLUMN half of the
+//    input transform happens while the A operand is staged: V[i][j] = R_i[2tx + k1] +- R_i[2tx + k2] (two buffer loads
+//    with scalar column offsets, one fma on the way to LDS).  The 16 x (C / 32) K-steps run as one continuous software
+//    pipeline (same staging as igemm.hip: raw buffer loads two steps ahead -> registers -> padded LDS rows, one barrier
+//    per step); the plane product stays in a scratch accumulator and, after the last K-step of a plane, is added with its
+//    +-1 weights into the four output accumulators Y[p][q].  M never exists; the epilogue (scale, bias / FrozenBN shift,
+//    ReLU, producer mask) writes y directly, 16 bytes per lane through an LDS-staged tile.  The per-tile fixed cost of the
+//    GEMM (prologue + epilogue ~ 1.7 K-steps) is paid once per 192 K-steps instead of once per 12.
+//
+// Two shapes: BN = 128 (wave tile 64 x 64: 64 scratch + 256 output accumulator registers, ONE wave per SIMD) and BN = 64
+// (wave tile 64 x 32: 32 + 128, two workgroups per CU like igemm.hip).
+#include "nbm_common.h"
+#include <type_traits>
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NBM_KEEP(x) asm volatile("" : "+v"(x))      // the value stays live and opaque (timing-only ablations)
+#else
+#define NBM_KEEP(x) (void)(x)
+#endif
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int PITCH = 36;     // floats per LDS row (32 + 4 pad): conflict-free ds_read_b128
+constexpr int BM = 128;
+
+struct WinoFusedParams {
+  const float* R; const float* U; float* y;
+  const float* scale; const float* shift; const float* mask;
+  long long r_gs;               // floats between the four row-combination images of R (= B * TH * WP * C)
+  int u_gs;                     // floats between planes of U (= N * C)
+  int T, N, C, nk;
+  int H, W, TH, TW, THW, WP;
+  int m_tiles, n_tiles, relu;
+};
+
+// x [B][H][W][C] -> R [4][B][TH][WP][C], WP = 2 TW + 2: R[i][b][ty][x + 1] = sum_a BT[i][a] x[b][2ty - 1 + a][x] with
+// BT = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]; rows / columns outside the image are zero.
+__global__ __launch_bounds__(256) void wino23_rows_kernel(const float* __restrict__ x, int B, int H, int W, int C4,
+                                                          int TH, int WP, float* __restrict__ R) {
+  const long long per_plane = (long long)B * TH * WP * C4;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  f32x4* r4 = reinterpret_cast<f32x4*>(R);
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < per_plane; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % C4);
+    long long t = idx / C4;
+    const int xp = (int)(t % WP);
+    t /= WP;
+    const int ty = (int)(t % TH), b = (int)(t / TH);
+    const int ix = xp - 1;
+    f32x4 d[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int iy = 2 * ty - 1 + a;
+      const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      d[a] = ok ? x4[(((long long)b * H + iy) * W + ix) * C4 + c] : zero;
+    }
+    r4[idx] = d[0] - d[2];
+    r4[idx + per_plane] = d[1] + d[2];
+    r4[idx + 2 * per_plane] = d[2] - d[1];
+    r4[idx + 3 * per_plane] = d[1] - d[3];
+  }
+}
+
+// ABL: timing-only ablations for scripts/wino_fused_probe.py (results are wrong): 1 = no flush, 2 = no epilogue,
+// 4 = every workgroup reads the same L2-resident A tile
+template <int BN, int WN, int ABL = 0>
+__global__ __launch_bounds__(256, BN == 128 ? 1 : 2) void wino23_fused_kernel(const WinoFusedParams p) {
+  constexpr int WM = 64;
+  constexpr int MT = WM / 32, NT = WN / 32;
+  constexpr int WAVES_N = BN / WN;
+  constexpr int AR = BM / 32, BR = BN / 32;
+  static_assert((BM / WM) * WAVES_N == 4, "4 waves per workgroup");
+
+  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * PITCH];
+  if constexpr (BN != 128) nbm_stagger_priority();
+  float* As = lds;
+  float* Bs = lds + 2 * BM * PITCH;
+
+  // ---- XCD-aware tile id (bijective for any grid size): the N tiles of one M tile share an L2
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tile_m = wg / p.n_tiles, tile_n = wg - tile_m * p.n_tiles;
+  const int bm0 = tile_m * BM, bn0 = tile_n * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
+  const int lrow = lane & 31, lh = lane >> 5;
+  const int c4 = tid & 7, r0 = tid >> 3;
+
+  // A rows: tile t = (b, ty, tx) starts at column 2 tx of image row (b, ty) of R; byte offsets relative to the block's
+  // first tile.  Rows beyond T (and B rows beyond N) get an out-of-range offset: the buffer range check returns zeros.
+  unsigned a_rel[AR], b_rel[BR];
+  long long blk_base;
+  {
+    const int t = bm0 < p.T ? bm0 : 0;
+    const int bi = t / p.THW, rem = t - bi * p.THW;
+    const int ty = rem / p.TW, tx = rem - ty * p.TW;
+    blk_base = (((long long)bi * p.TH + ty) * p.WP + 2 * tx) * p.C;
+  }
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    const int t = bm0 + r0 + 32 * i;
+    if (t < p.T) {
+      const int bi = t / p.THW, rem = t - bi * p.THW;
+      const int ty = rem / p.TW, tx = rem - ty * p.TW;
+      const long long off = (((long long)bi * p.TH + ty) * p.WP + 2 * tx) * p.C - blk_base;   // rows ascend with t
+      a_rel[i] = (unsigned)((off + c4 * 4) * 4);
+    } else {
+      a_rel[i] = 0x80000000u;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < BR; ++i) {
+    const int n = bn0 + r0 + 32 * i;
+    b_rel[i] = n < p.N ? (unsigned)((n * p.C + c4 * 4) * 4) : 0x80000000u;
+  }
+  const float* a_plane0 = (ABL & 4) ? p.R : p.R + blk_base;
+  const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.U), 0, 0x7ffffff0, 0x00020000);
+
+  f32x4 ra[AR], ra2[AR], rb[BR];
+  float a_sign = 1.f;             // sign of the second column of the tile being staged
+  int ld_xi = 0, ld_c0 = 0;       // cursor of the NEXT tile to load: plane, first channel
+
+  // V[i][j] = R_i[k1] + s R_i[k2] with (k1, k2, s) = (0,2,-), (1,2,+), (2,1,-), (1,3,-) for j = 0..3 (rows of B^T)
+  auto load_tiles = [&]() {
+    const int i = ld_xi >> 2, j = ld_xi & 3;
+    const int k1 = j == 0 ? 0 : (j == 2 ? 2 : 1), k2 = j == 2 ? 1 : (j == 3 ? 3 : 2);
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a_plane0 + ((ABL & 4) ? 0ll : (long long)i * p.r_gs)), 0, 0x7ffffff0, 0x00020000);
+    const unsigned a_soff1 = (unsigned)((k1 * p.C + ld_c0) * 4), a_soff2 = (unsigned)((k2 * p.C + ld_c0) * 4);
+    const unsigned b_soff = (unsigned)((ld_xi * p.u_gs + ld_c0) * 4);
+#pragma unroll
+    for (int r = 0; r < AR; ++r) {
+      ra[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, a_rel[r], a_soff1, 0));
+      ra2[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, a_rel[r], a_soff2, 0));
+    }
+#pragma unroll
+    for (int r = 0; r < BR; ++r)
+      rb[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_rel[r], b_soff, 0));
+    ld_c0 += BK;
+    if (ld_c0 == p.C) { ld_c0 = 0; ++ld_xi; }
+  };
+  // sign of the tile that the NEXT store_lds writes; tiles are stored in load order, one step behind the loads
+  int st_xi = 0, st_c0 = 0;
+  auto store_lds = [&](int buf) {
+    const float sgn = (st_xi & 3) == 1 ? 1.f : -1.f;
+#pragma unroll
+    for (int r = 0; r < AR; ++r) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaf(sgn, ra2[r][e], ra[r][e]);
+      *reinterpret_cast<f32x4*>(As + (buf * BM + r0 + 32 * r) * PITCH + c4 * 4) = v;
+    }
+#pragma unroll
+    for (int r = 0; r < BR; ++r)
+      *reinterpret_cast<f32x4*>(Bs + (buf * BN + r0 + 32 * r) * PITCH + c4 * 4) = rb[r];
+    st_c0 += BK;
+    if (st_c0 == p.C) { st_c0 = 0; ++st_xi; }
+  };
+  (void)a_sign;
+
+  f32x16 acc[MT][NT];               // product of the current plane
+  f32x16 Y[2][2][MT][NT];           // output accumulators, [p][q]
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        acc[i][j][e] = 0.f;
+        Y[0][0][i][j][e] = 0.f; Y[0][1][i][j][e] = 0.f; Y[1][0][i][j][e] = 0.f; Y[1][1][i][j][e] = 0.f;
+      }
+
+  // One K-step = 4 groups of 4 k-pairs.  The fragments of group q + 1 are read from LDS while the 4 MT NT MFMAs of group q
+  // run (register double buffer fa / fb): with one wave per SIMD nothing else covers the ~130-cycle LDS latency, which
+  // would otherwise sit in front of every group (4 x per step = 12 % of a 4096-cycle step).
+  f32x4 fa[2][MT], fb[2][NT];
+  auto read_frags = [&](const float* Ab, const float* Bb, int q, int s) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) fa[s][i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * PITCH + q * 4);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) fb[s][j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * PITCH + q * 4);
+  };
+  auto mfma_group = [&](int s) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s][i][e], fb[s][j][e], acc[i][j], 0, 0, 0);
+  };
+
+  int cur = 0;
+  auto k_step = [&](auto store_c, auto load_c) {
+    constexpr bool STORE = decltype(store_c)::value, LOAD = decltype(load_c)::value;
+    constexpr int NM = 4 * MT * NT;             // MFMAs per group
+    __syncthreads();
+    const float* Ab = As + (cur * BM + wm0 + lrow) * PITCH + lh * 16;
+    const float* Bb = Bs + (cur * BN + wn0 + lrow) * PITCH + lh * 16;
+    read_frags(Ab, Bb, 0, 0);
+    // ---- group 0 (+ LDS writes of the next tile)
+    read_frags(Ab, Bb, 1, 1);
+    mfma_group(0);
+    if constexpr (STORE) store_lds(cur ^ 1);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MT + NT), 0);
+    if constexpr (STORE) {
+#pragma unroll
+      for (int z = 0; z < AR + BR; ++z) {
+        __builtin_amdgcn_sched_group_barrier(0x008, NM / (AR + BR) > 0 ? NM / (AR + BR) : 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- group 1 (+ global loads two tiles ahead)
+    read_frags(Ab, Bb, 2, 0);
+    mfma_group(1);
+    if constexpr (LOAD) load_tiles();
+    __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
+    if constexpr (LOAD) {
+#pragma unroll
+      for (int z = 0; z < 2 * AR + BR; ++z) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- groups 2, 3
+    read_frags(Ab, Bb, 3, 1);
+    mfma_group(0);
+    __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_group(1);
+    cur ^= 1;
+  };
+
+  // Y[p][q] += AT[p][i] * AT[q][j] * acc;  acc = 0.   AT = [1 1 1 0; 0 1 -1 -1]; the weights are wave-uniform +-1 / 0.
+  auto flush = [&](int xi) {
+    const int i = xi >> 2, j = xi & 3;
+    const float ai[2] = {i < 3 ? 1.f : 0.f, i == 0 ? 0.f : (i == 1 ? 1.f : -1.f)};
+    const float aj[2] = {j < 3 ? 1.f : 0.f, j == 0 ? 0.f : (j == 1 ? 1.f : -1.f)};
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        const float c = ai[pp] * aj[qq];
+        if (c != 0.f) {
+#pragma unroll
+          for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+#pragma unroll
+              for (int e = 0; e < 16; ++e) Y[pp][qq][a][b][e] = fmaf(c, acc[a][b][e], Y[pp][qq][a][b][e]);
+        }
+      }
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+  };
+
+  using TT = std::true_type;
+  using FF = std::false_type;
+  load_tiles();
+  store_lds(0);
+  load_tiles();
+  for (int xi = 0; xi < 16; ++xi) {
+    if (xi < 15) {
+      for (int kt = 0; kt < p.nk; ++kt) k_step(TT{}, TT{});
+    } else {
+      for (int kt = 0; kt + 2 < p.nk; ++kt) k_step(TT{}, TT{});
+      k_step(TT{}, FF{});
+      k_step(FF{}, FF{});
+    }
+    if constexpr (!(ABL & 1)) {
+      flush(xi);
+    } else {                                   // keep the plane product alive (cdna guide rule 17) without the VALU work
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) NBM_KEEP(acc[a][b]);
+    }
+  }
+  __syncthreads();
+  if constexpr (ABL & 2) {
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int b = 0; b < NT; ++b) {
+        NBM_KEEP(acc[a][b]);
+        NBM_KEEP(Y[0][0][a][b]); NBM_KEEP(Y[0][1][a][b]); NBM_KEEP(Y[1][0][a][b]); NBM_KEEP(Y[1][1][a][b]);
+      }
+    return;
+  }
+
+  // ---- epilogue: four passes (p, q) through an LDS-staged [128 tiles][BN] tile, 16-byte stores along the channels.
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+  constexpr int CP = BN + 4;
+  static_assert(BM * CP + 2 * BM <= 2 * (BM + BN) * PITCH, "epilogue tile + row table must fit the operand buffers");
+  float* Cs = lds;
+  // per tile row of the block: element index of output pixel (2 ty, 2 tx) and which of its 2 x 2 pixels exist
+  // (odd sizes: the last tile row / column is half outside) -- computed once, the four passes only look it up
+  long long* row_pix = reinterpret_cast<long long*>(lds + BM * CP);          // [BM]; BM * CP * 4 is a multiple of 16
+  if (tid < BM) {
+    const int t = bm0 + tid;
+    long long v = -1;
+    if (t < p.T) {
+      const int bi = t / p.THW, rem = t - bi * p.THW;
+      const int ty = rem / p.TW, tx = rem - ty * p.TW;
+      const long long pix = ((long long)bi * p.H + 2 * ty) * p.W + 2 * tx;
+      v = (pix << 2) | (2 * ty + 1 < p.H ? 2 : 0) | (2 * tx + 1 < p.W ? 1 : 0);
+    }
+    row_pix[tid] = v;
+  }
+  constexpr int CH = BN / 4;
+  constexpr int RPP = 256 / CH;
+  const int cc = tid % CH, rr = tid / CH;
+  const int n = bn0 + cc * 4;
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  if (n < p.N) {
+    if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+    if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+  }
+#pragma unroll
+  for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) {
+      if (pp | qq) __syncthreads();
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+          for (int e = 0; e < 16; ++e)
+            Cs[(wm0 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * CP + wn0 + b * 32 + lrow] = Y[pp][qq][a][b][e];
+      __syncthreads();
+      if (n < p.N) {
+        const int need = (pp ? 2 : 0) | (qq ? 1 : 0);
+#pragma unroll 4
+        for (int r = rr; r < BM; r += RPP) {
+          const long long rp = row_pix[r];
+          if (rp < 0) break;
+          if ((rp & need) != need) continue;
+          f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CP + cc * 4);
+          const long long idx = ((rp >> 2) + pp * p.W + qq) * p.N + n;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[e] + sh[e];
+          if (p.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          if (p.mask) {
+            const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + idx);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (!(mk[e] > 0.f)) v[e] = 0.f;
+          }
+          *reinterpret_cast<f32x4*>(p.y + idx) = v;
+        }
+      }
+    }
+}
+
+}  // namespace
+
+// x -> R (row half of the input transform) -- see nbm_hip.h.
+extern "C" int nbm_wino23_rows(const float* x, int B, int H, int W, int C, float* R, void* stream) {
+  if (!x || !R || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return NBM_EINVAL;
+  if (!nbm_aligned16(x) || !nbm_aligned16(R)) return NBM_EALIGN;
+  const int TH = (H + 1) >> 1, TW = (W + 1) >> 1, WP = 2 * TW + 2;
+  const long long n = (long long)B * TH * WP * (C / 4);
+  long long g = (n + 255) / 256;
+  if (g > 65536) g = 65536;
+  hipLaunchKernelGGL(wino23_rows_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, B, H, W, C / 4, TH, WP, R);
+  return nbm_launch_status();
+}
+
+// y = epi(conv3x3(x)) from the row-transformed input R [4][B][TH][WP][C] and the weights U [16][N][C] -- see nbm_hip.h.
+extern "C" int nbm_wino23_conv_fused(const float* R, const float* U, const float* scale, const float* shift,
+                                     const float* mask, int relu, int B, int H, int W, int C, int N, float* y,
+                                     int variant, void* stream) {
+  if (!R || !U || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0) return NBM_EINVAL;
+  if ((C % BK) || C / BK < 2 || (N & 3)) return NBM_EUNSUPPORTED;
+  if (!nbm_aligned16(R) || !nbm_aligned16(U) || !nbm_aligned16(y) || (shift && !nbm_aligned16(shift)) ||
+      (scale && !nbm_aligned16(scale)) || (mask && !nbm_aligned16(mask)))
+    return NBM_EALIGN;
+  WinoFusedParams p{};
+  p.TH = (H + 1) >> 1; p.TW = (W + 1) >> 1; p.THW = p.TH * p.TW; p.WP = 2 * p.TW + 2;
+  const long long T = (long long)B * p.THW;
+  // 32-bit byte offsets inside the kernel: the rows of one 128-tile block (<= 128 image rows of R apart), one row
+  // combination of R behind the block base, and the whole of U
+  if (T > 0x7fffff00ll || (long long)N * C * 16 * 4 > 0x7fffffffll) return NBM_EUNSUPPORTED;
+  if ((130ll * p.WP + 4) * C * 4 > 0x7fffffffll) return NBM_EUNSUPPORTED;
+  p.R = R; p.U = U; p.y = y; p.scale = scale; p.shift = shift; p.mask = mask; p.relu = relu;
+  p.T = (int)T; p.N = N; p.C = C; p.nk = C / BK; p.H = H; p.W = W;
+  p.r_gs = (long long)B * p.TH * p.WP * C; p.u_gs = N * C;
+  p.m_tiles = (int)((T + BM - 1) / BM);
+  hipStream_t st = (hipStream_t)stream;
+  const int abl = variant / 1000;
+  variant %= 1000;
+  const bool wide = variant == 128 || (variant == 0 && N % 128 == 0);
+  p.n_tiles = wide ? (N + 127) / 128 : (N + 63) / 64;
+  const dim3 grid(p.m_tiles * p.n_tiles), block(256);
+#define NBM_WF(BN_, WN_, A_) hipLaunchKernelGGL((wino23_fused_kernel<BN_, WN_, A_>), grid, block, 0, st, p)
+  if (wide) {
+    switch (abl) { case 0: NBM_WF(128, 64, 0); break; case 1: NBM_WF(128, 64, 1); break; case 2: NBM_WF(128, 64, 2); break;
+                   case 3: NBM_WF(128, 64, 3); break; case 7: NBM_WF(128, 64, 7); break; default: return NBM_EINVAL; }
+  } else {
+    switch (abl) { case 0: NBM_WF(64, 32, 0); break; case 1: NBM_WF(64, 32, 1); break; case 2: NBM_WF(64, 32, 2); break;
+                   case 3: NBM_WF(64, 32, 3); break; case 7: NBM_WF(64, 32, 7); break; default: return NBM_EINVAL; }
+  }
+#undef NBM_WF
+  return nbm_launch_status();
+}

@@ -5,6 +5,7 @@ streams); all arithmetic happens in the hand-written kernels.  Activations are N
 Every function raises if the tensor is not a contiguous float32 CUDA tensor -- there is no CPU path.
 """
 import ctypes as C
+import os
 import math
 
 import torch
@@ -114,12 +115,18 @@ def _wino_scratch(device, n_v, n_m):
     return buf[:n_v], buf[n_v:need]
 
 
+WINO_FUSED_VARIANT = int(os.environ.get('NBM_WINO_FUSED_VARIANT', '0'))     # 0 auto, 128 / 64: channel-tile width
+
+
 def conv3x3_winograd(x, U, bias=None, m=2, scale=None, relu=False, mask=None):
     """3x3 / stride 1 / pad 1 convolution through Winograd F(m x m, 3x3): x [B,H,W,C], U [(m+2)^2,N,C] from
-    `_prep.wino23` -> [B,H,W,N].  Three launches per batch chunk: input transform, (m+2)^2 grouped GEMMs on the fp32 MFMA
-    (2.25x / 4x fewer multiplies than the direct kernel for m = 2 / 4), output transform (+ bias).  The batch is cut so
-    that the transformed operands stay within WINO_CHUNK_BYTES.  m = 2 is the forward setting (error ~3e-6), m = 4 the
-    backward one (~2e-5, see csrc/winograd.hip).  Epilogue: y = relu?((.) * scale + bias), zeroed where mask <= 0."""
+    `_prep.wino23` -> [B,H,W,N].  m = 2 (the forward setting, error ~3e-6): row half of the input transform (2x the input
+    in HBM), then ONE kernel that finishes the input transform while staging its operand, runs the 16 transformed-domain
+    GEMMs on the fp32 MFMA and applies the output transform + epilogue in its accumulators (csrc/wino_fused.hip; neither
+    the transformed input V nor the products M ever reach HBM).  m = 4 (backward only, ~2e-5, see csrc/winograd.hip): input
+    transform, 36 grouped GEMMs, output transform.  2.25x / 4x fewer multiplies than the direct kernel.  The batch is cut
+    so that the transformed operands stay within WINO_CHUNK_BYTES.  Epilogue: y = relu?((.) * scale + bias), zeroed where
+    mask <= 0."""
     _chk(x, name='x'), _chk(U, name='U')
     B, H, W, C_ = x.shape
     N = U.shape[1]
@@ -127,9 +134,16 @@ def conv3x3_winograd(x, U, bias=None, m=2, scale=None, relu=False, mask=None):
     assert U.shape == (nxi, N, C_) and C_ % 32 == 0 and N % 4 == 0
     y = torch.empty((B, H, W, N), device=x.device, dtype=torch.float32)
     tiles = (-(-H // m)) * (-(-W // m))
-    per_img = nxi * tiles * (C_ + N) * 4
+    fused = m == 2
+    if fused:                                     # R: four row-combination images, 2 (TW + 1) columns per tile row
+        per_img = 4 * (-(-H // 2)) * (2 * (-(-W // 2)) + 2) * C_ * 4
+    else:
+        per_img = nxi * tiles * (C_ + N) * 4
     chunk = max(1, min(B, WINO_CHUNK_BYTES // per_img))
-    V, M = _wino_scratch(x.device, nxi * chunk * tiles * C_, nxi * chunk * tiles * N)
+    if fused:
+        V, M = _wino_scratch(x.device, chunk * per_img // 4, 0)
+    else:
+        V, M = _wino_scratch(x.device, nxi * chunk * tiles * C_, nxi * chunk * tiles * N)
     st = _stream()
     if PROFILE is not None:                       # whole-op bracket (transforms + GEMMs) next to the per-GEMM entries
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -137,6 +151,18 @@ def conv3x3_winograd(x, U, bias=None, m=2, scale=None, relu=False, mask=None):
     for b0 in range(0, B, chunk):
         nb = min(chunk, B - b0)
         T = nb * tiles
+        mk = _ptr(mask[b0:b0 + nb]) if mask is not None else None
+        if fused:
+            check(lib().nbm_wino23_rows(_ptr(x[b0:b0 + nb]), nb, H, W, C_, _ptr(V), st), 'nbm_wino23_rows')
+            if PROFILE is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            check(lib().nbm_wino23_conv_fused(_ptr(V), _ptr(U), _ptr(scale), _ptr(bias), mk, int(relu), nb, H, W, C_, N,
+                                              _ptr(y[b0:b0 + nb]), WINO_FUSED_VARIANT, st), 'nbm_wino23_conv_fused')
+            if PROFILE is not None:
+                e1.record()
+                PROFILE.append(((C_, N, 1, T, 1, 1, nxi, 1, ('wino23', H, W)), e0, e1))
+            continue
         check(lib().nbm_wino_input(_ptr(x[b0:b0 + nb]), nb, H, W, C_, _ptr(V), m, st), 'nbm_wino_input')
         global _PROFILE_LABEL
         _PROFILE_LABEL = ('wino23', H, W)
@@ -144,8 +170,8 @@ def conv3x3_winograd(x, U, bias=None, m=2, scale=None, relu=False, mask=None):
             gemm_conv(V, U, M, B=1, H=T, W=1, Cin=C_, N=N, groups=nxi, x_gs=T * C_, w_gs=N * C_, y_gs=T * N)
         finally:
             _PROFILE_LABEL = None
-        check(lib().nbm_wino_output(_ptr(M), _ptr(scale), _ptr(bias), _ptr(mask[b0:b0 + nb]) if mask is not None else None,
-                                    int(relu), nb, H, W, N, _ptr(y[b0:b0 + nb]), m, st), 'nbm_wino_output')
+        check(lib().nbm_wino_output(_ptr(M), _ptr(scale), _ptr(bias), mk, int(relu), nb, H, W, N, _ptr(y[b0:b0 + nb]), m, st),
+              'nbm_wino_output')
     if PROFILE is not None:
         ev[1].record()
         PROFILE.append((('wino23', C_, N, H, W, B), *ev))

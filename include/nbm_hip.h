@@ -89,6 +89,17 @@ int nbm_wino_output(const float* M, const float* scale, const float* shift, cons
  * nbm_conv_wgrad (groups = (m+2)^2) and dW = G^T dU G on the host.  bias_grad [N] (may be NULL): += sum over pixels of g. */
 int nbm_wino_outgrad(const float* g, int B, int H, int W, int N, float* dM, float* bias_grad, int m, void* stream);
 
+/* Winograd F(2x2,3x3) forward convolution in two launches (csrc/wino_fused.hip):
+ *   nbm_wino23_rows:       x [B][H][W][C] -> R [4][B][TH][WP][C], TH = ceil(H/2), WP = 2 ceil(W/2) + 2: the four row
+ *                          combinations (B^T d)_i of every tile row as zero-bordered image rows (2x the input);
+ *   nbm_wino23_conv_fused: R, U [16][N][C] (G g G^T) -> y [B][H][W][N] = mask(relu(conv * scale + shift)); the column half
+ *                          of the input transform, the 16 transformed-domain GEMMs (fp32 MFMA) and the output transform
+ *                          run in one kernel.  scale / shift / mask optional.  C % 32 == 0, C >= 64, N % 4 == 0.
+ *                          variant: 0 = automatic, 128 / 64 = channel-tile width. */
+int nbm_wino23_rows(const float* x, int B, int H, int W, int C, float* R, void* stream);
+int nbm_wino23_conv_fused(const float* R, const float* U, const float* scale, const float* shift, const float* mask,
+                          int relu, int B, int H, int W, int C, int N, float* y, int variant, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Spectrogram front end.  Replaces File_Processor.load/spectrogram/split_power_spec
  * (nbm_model/nbm_datasets/prepare_dataset.py:160-184, 228-252, 255-294) incl. librosa.stft and the
