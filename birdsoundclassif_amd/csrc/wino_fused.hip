@@ -185,8 +185,11 @@ __global__ __launch_bounds__(256, BN == 128 ? 1 : 2) void wino23_fused_kernel(co
       }
 
   // One K-step = 4 groups of 4 k-pairs.  The fragments of group q + 1 are read from LDS while the 4 MT NT MFMAs of group q
-  // run (register double buffer fa / fb): with one wave per SIMD nothing else covers the ~130-cycle LDS latency, which
-  // would otherwise sit in front of every group (4 x per step = 12 % of a 4096-cycle step).
+  // run (register double buffer fa / fb).  sched_group_barrier pins the interleave below: without it the same code runs
+  // 19 % slower.  Measured and dropped (scripts/wino_fused_probe.py, 188x512 x 26 images, 16.2 ms as is): three LDS stages
+  // with the barrier behind the LDS writes, so that the first fragments of step k+1 are prefetched in G3 of step k
+  // (18.9 ms: the compiler bunches G0's MFMAs and spills); plane-dependent scalars (buffer descriptor, column offsets)
+  // kept as loop-carried state instead of being re-derived every step (17.9 ms: the VMEM interleave pattern breaks).
   f32x4 fa[2][MT], fb[2][NT];
   auto read_frags = [&](const float* Ab, const float* Bb, int q, int s) {
 #pragma unroll
