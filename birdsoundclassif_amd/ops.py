@@ -134,7 +134,7 @@ def conv3x3_winograd(x, U, bias=None, m=2, scale=None, relu=False, mask=None):
     assert U.shape == (nxi, N, C_) and C_ % 32 == 0 and N % 4 == 0
     y = torch.empty((B, H, W, N), device=x.device, dtype=torch.float32)
     tiles = (-(-H // m)) * (-(-W // m))
-    fused = m == 2
+    fused = m == 2 and C_ >= 64                  # the fused pipeline wants >= 2 K-steps per plane (every real layer has)
     if fused:                                     # R: four row-combination images, 2 (TW + 1) columns per tile row
         per_img = 4 * (-(-H // 2)) * (2 * (-(-W // 2)) + 2) * C_ * 4
     else:
