@@ -11,9 +11,9 @@ One "step" = one pass of the hot path over one batch of synthetic input per rank
 Workload = BASELINE.json configs[1] (batch 64 per GPU, fp32).  Multi-GPU: clips are independent, every rank
 runs its own batch (weak scaling, no data-path collective); value = all clips of all ranks / max-over-ranks time.
 
-Prints ONE JSON line on rank 0, carrying `roofline` (dominant kernel: the FPN 3x3 384->256 implicit GEMM at
-188x512, timed live with HIP events on the launch stream) and `cpu_baseline` (the oracle port on the host cores,
-bounded sample, N=1 only).
+Prints ONE JSON line on rank 0, carrying `roofline` (dominant kernel: the fused Winograd kernel of the FPN 3x3
+384->256 convolution at 188x512, timed live with HIP events on the launch stream) and `cpu_baseline` (the oracle port
+on the host cores, bounded sample, N=1 only).
 """
 import argparse
 import json
@@ -28,15 +28,18 @@ import numpy as np   # noqa: E402
 import torch         # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+FP64_MFMA_PEAK_TFLOPS = 78.6           # v_mfma_f64_16x16x4_f64: half the fp32 rate on this part (64 cycles / 2048 FLOP / SIMD)
 FPN0_GFLOP_PER_CLIP = 170.322          # fpn.out_convs.4, 3x3 384->256 @188x512
 FWD_GFLOP_PER_CLIP = 325.56            # SURVEY.md §6 (conv + addmm + bmm, forward)
 TRAIN_GFLOP_PER_CLIP = 993.45          # SURVEY.md §6 (fwd + bwd, positive step)
 
 
-def train_bench(rank, world, dist, batch, steps, warmup):
+def train_bench(rank, world, dist, batch, steps, warmup, mix_steps=10):
     """BASELINE.json configs[2]/[3]: data-parallel training step, `batch` synthetic clips + random boxes/labels per GPU,
-    HIP fwd/bwd + fused clip/AdamW, one RCCL all-reduce of the flat fp32 gradients per step when world > 1."""
-    from birdsoundclassif_amd import synth
+    HIP fwd/bwd + fused clip/AdamW, one RCCL all-reduce of the flat fp32 gradients per step when world > 1.
+    Timed twice: `steps` positive steps (the headline of this leg), then `mix_steps` steps in the reference's schedule
+    (train.py:343: every `neg_step_freq` = 10th step trains on the negative images, 1000 RoIs per image through the head)."""
+    from birdsoundclassif_amd import ops, synth
     from birdsoundclassif_amd.nets import build_model
     from birdsoundclassif_amd.train import default_args, build_optimizer, train_one_step
     args = default_args(device='cuda')
@@ -47,12 +50,13 @@ def train_bench(rank, world, dist, batch, steps, warmup):
     opt, _ = build_optimizer(model, args)
     base = synth.image_batch(rank * 8, 8)
     img = torch.from_numpy(np.tile(base, (-(-batch // 8), 1, 1))[:batch].copy()).cuda()
+    neg = torch.from_numpy(np.tile(synth.image_batch(100 + rank * 8, 8), (-(-batch // 8), 1, 1))[:batch].copy()).cuda()
     bbs, idss, lens = [], [], []
     for i in range(batch):
         bb, ids, ln = synth.label_batch(rank * 8 + i % 8, 1)
         bbs.append(bb), idss.append(ids)
         lens += ln
-    data = [img, img, torch.cat(bbs), torch.cat(idss), lens]      # labels stay on the host, as a DataLoader delivers them
+    data = [img, neg, torch.cat(bbs), torch.cat(idss), lens]      # labels stay on the host, as a DataLoader delivers them
     np.random.seed(1000 + rank)
 
     def sync_all():
@@ -61,26 +65,70 @@ def train_bench(rank, world, dist, batch, steps, warmup):
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed(schedule):
+        sync_all()
+        t0 = time.perf_counter()
+        for negative in schedule:
+            loss = train_one_step(model, crit, opt, data, args.clip_max_norm, 'cuda', negative_sample=negative)
+        sync_all()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, loss
+
     for _ in range(warmup):
         train_one_step(model, crit, opt, data, args.clip_max_norm, 'cuda', negative_sample=False)
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = train_one_step(model, crit, opt, data, args.clip_max_norm, 'cuda', negative_sample=False)
-    sync_all()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device='cuda', dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    ops.FLOPS = [0.0]                      # executed MFMA FLOPs of every GEMM launch (Winograd-domain counts where that path runs)
+    ops.PROFILE_BWD = []                   # live HIP events around every data- / weight-gradient launch
+    dt, loss = timed([False] * steps)
+    exec_gflop_per_clip = ops.FLOPS[0] / (steps * batch) / 1e9
+    prof, ops.PROFILE_BWD, ops.FLOPS = ops.PROFILE_BWD, None, None
+    # dominant backward kernel: igemm_tn_kernel<128,0,0> (weight gradients); its largest launches are the 36
+    # Winograd F(4x4,3x3)-domain TN GEMMs of fpn.out_convs.4 (groups = 36, one launch per batch chunk)
+    wg = {}
+    for tag, e0, e1 in prof:
+        if tag[0] == 'wgrad':
+            wg.setdefault(tag, []).append(e0.elapsed_time(e1))
+    bwd_roof = None
+    if wg:
+        def gflop(t):
+            _, b, H, W, Cin, N, k, stride, groups = t
+            return 2.0 * b * ((H - 1) // stride + 1) * ((W - 1) // stride + 1) * N * Cin * k * k * groups / 1e9
+        top = max(wg, key=lambda t: sum(wg[t]))
+        ach = gflop(top) * len(wg[top]) / sum(wg[top])
+        all_ms = sum(sum(v) for v in wg.values())
+        all_gf = sum(gflop(t) * len(v) for t, v in wg.items())
+        bwd_roof = {'bound': 'mfma', 'kernel': 'igemm_tn_kernel<128,0,0>: weight-gradient GEMMs; largest = the launches of '
+                                                f'(B,H,W,Cin,N,k,stride,groups) = {top[1:]}',
+                    'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS,
+                    'avg_launch_ms': sum(wg[top]) / len(wg[top]), 'launches': len(wg[top]),
+                    'executed_GFLOP_per_launch': gflop(top),
+                    'all_wgrad_ms_per_step': all_ms / steps, 'all_wgrad_TFLOPs': all_gf / all_ms,
+                    'traffic': None, 'traffic_note': 'FETCH_SIZE / WRITE_SIZE / MFMA-busy of this kernel: profiles/r02_pmc_wgrad.txt'}
+    pos = {'ms_per_step': dt / steps * 1e3, 'clips_per_s': world * batch * steps / dt}
+    # the reference's schedule: one negative step in ten
+    mix = None
+    if mix_steps:
+        dtm, _ = timed([(i % 10) == 9 for i in range(mix_steps)])
+        mix = {'steps': mix_steps, 'negative_every': 10, 'ms_per_step': dtm / mix_steps * 1e3,
+               'clips_per_s': world * batch * mix_steps / dtm}
     del model, opt
     torch.cuda.empty_cache()
-    v = world * batch * steps / dt
+    v = pos['clips_per_s']
+    exec_tflops = v / world * exec_gflop_per_clip / 1e3
     return {'value': v, 'unit': 'clips/s', 'batch_per_gpu': batch, 'global_batch': world * batch, 'steps': steps,
-            'ms_per_step': dt / steps * 1e3, 'parallelism': f'dp{world}',
-            'algorithmic_frac_of_mfma_peak': v / world * TRAIN_GFLOP_PER_CLIP / 1e3 / FP32_MFMA_PEAK_TFLOPS,
-            'note': 'algorithmic = SURVEY direct-convolution FLOPs (993.45 GFLOP / clip); can exceed 1 because the large 3x3 '
-                    'convolutions execute 2.25x (forward) / 4x (backward) fewer multiplies in the Winograd domain',
+            'ms_per_step': pos['ms_per_step'], 'parallelism': f'dp{world}',
+            'executed_GFLOP_per_clip': exec_gflop_per_clip, 'executed_TFLOPs_per_gpu': exec_tflops,
+            'executed_frac_of_mfma_peak': exec_tflops / FP32_MFMA_PEAK_TFLOPS,
+            'direct_conv_equivalent_GFLOP_per_clip': TRAIN_GFLOP_PER_CLIP,
+            'direct_conv_equivalent_TFLOPs_per_gpu': v / world * TRAIN_GFLOP_PER_CLIP / 1e3,
+            'note': 'executed = MFMA FLOPs the launches really perform (Winograd-domain counts for the 3x3 / stride-1 layers: '
+                    'F(2x2,3x3) forward, F(4x4,3x3) data and weight gradients); direct_conv_equivalent = SURVEY 993.45 GFLOP/clip '
+                    'and is NOT a roofline figure',
+            'reference_schedule_9_positive_1_negative': mix,
+            'roofline_backward': bwd_roof,
             'final_loss': {k: float(x.detach()) if torch.is_tensor(x) else float(x) for k, x in loss.items()},
             'workload': 'BASELINE.json configs[2]/[3]: positive training step (fwd + bwd + clip + AdamW), fp32'}
 
@@ -222,10 +270,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # roofline of the dominant kernel: the 16 Winograd-domain GEMMs of fpn.out_convs.4 (3x3 384->256 @188x512), one
-    # igemm launch with groups = 16 per batch chunk.  `achieved` counts the FLOPs that launch EXECUTES
-    # (2 * 16 * tiles * 384 * 256 = 1/2.25 of the direct-convolution count SURVEY uses); the layer-level figure next to
-    # it divides SURVEY's algorithmic 170.322 GFLOP/clip by the time of the whole layer (transforms + GEMMs).
+    # roofline of the dominant kernel: wino23_fused_kernel<128,64> on fpn.out_convs.4 (3x3 384->256 @188x512): the 16
+    # Winograd-domain GEMMs + both fused transform halves, one launch per batch chunk.  `achieved` counts the MFMA FLOPs
+    # that launch EXECUTES (2 * 16 * tiles * 384 * 256 = 1/2.25 of the direct-convolution count SURVEY uses) over its HIP
+    # event time; the layer-level figure next to it is the whole layer (row transform + fused kernel).
     dom = [(tag, s.elapsed_time(e)) for (tag, s, e) in prof
            if len(tag) == 9 and tag[:3] == (384, 256, 1) and tag[6] == 16 and tag[8] == ('wino23', 188, 512)]
     layer = [s.elapsed_time(e) for (tag, s, e) in prof if tag == ('wino23', 384, 256, 188, 512, B)]
@@ -233,7 +281,7 @@ def main():
     roof = None
     traffic = None                      # HBM bytes per launch of the dominant kernel: PMC counters cannot be read live;
     try:                                # the value comes from the committed rocprofv3 --pmc passes of this same command
-        pj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_dominant.json')))
+        pj = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_dominant.json')))
         if B == 64:
             traffic = pj['traffic_bytes_per_launch']
     except Exception:
@@ -242,17 +290,17 @@ def main():
         gflop = sum(2.0 * 16 * tag[3] * 384 * 256 / 1e9 for tag, _ in dom)
         ms = sum(t for _, t in dom)
         ach = gflop / ms                                       # GFLOP/ms == TFLOP/s
-        roof = {'bound': 'mfma', 'kernel': 'igemm_kernel<128,128,64,64,FAST,STD>, groups=16: Winograd F(2x2,3x3)-domain GEMMs '
-                                           'of fpn.out_convs.4 (3x3 384->256 @188x512)',
+        roof = {'bound': 'mfma', 'kernel': 'wino23_fused_kernel<128,64>: fpn.out_convs.4 (3x3 384->256 @188x512) = column half '
+                                           'of the Winograd input transform + 16 transformed-domain GEMMs + output transform',
                 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS,
-                'traffic': traffic, 'traffic_unit': 'bytes/launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_dominant.json)',
+                'traffic': traffic, 'traffic_unit': 'bytes/launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r02_pmc_dominant.json)',
                 'avg_launch_ms': ms / len(dom), 'launches': len(dom), 'executed_GFLOP_per_launch': gflop / len(dom),
                 'all_igemm_ms_per_step': all_ms / a.steps,
-                'whole_step_algorithmic_frac_of_mfma_peak': (FWD_GFLOP_PER_CLIP * B * a.steps / (dt * 1e3)) / FP32_MFMA_PEAK_TFLOPS}
+                'whole_step_direct_conv_equivalent_TFLOPs': FWD_GFLOP_PER_CLIP * B * a.steps / (dt * 1e3)}
         if layer:
             lms = sum(layer) / len(layer)
-            roof['layer'] = {'what': 'fpn.out_convs.4 as executed: input transform + 16 GEMMs + output transform',
-                             'ms': lms, 'algorithmic_GFLOP': FPN0_GFLOP_PER_CLIP * B,
+            roof['layer'] = {'what': 'fpn.out_convs.4 as executed: row transform + fused Winograd kernel', 'ms': lms,
+                             'executed_frac_of_mfma_peak': gflop / len(layer) / lms / FP32_MFMA_PEAK_TFLOPS,
                              'direct_conv_equivalent_TFLOPs': FPN0_GFLOP_PER_CLIP * B / lms}
     # front end alone (HBM-bound stage of the path): live HIP events around K replays
     fe_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
@@ -262,11 +310,12 @@ def main():
         e0.record()
     torch.cuda.synchronize()
     fe_ms = sorted(s0.elapsed_time(e0) for s0, e0 in fe_ev)[len(fe_ev) // 2]
+    fe_flop = 2.0 * 2 * 384 * 664 * 1024            # per clip: Re and Im GEMMs, 384 x 664 x 1024 (bins x k x frames, padded)
     frontend = {'ms_per_batch': fe_ms, 'clips_per_s': B / fe_ms * 1e3,
                 'hbm_algorithmic_GBps': B * 1.668e6 / (fe_ms * 1e-3) / 1e9, 'hbm_peak_GBps': 8000.0,
-                'dft_gemm_TFLOPs': B * 2 * 768 * 1344 * 1003 / (fe_ms * 1e-3) / 1e12, 'mfma_f32_peak_TFLOPs': FP32_MFMA_PEAK_TFLOPS,
-                'note': 'PCM16 -> 2x up-sample -> STFT-dB (DFT as fp32-MFMA GEMM) -> normalise/window; algorithmic bytes '
-                        '1.668 MB/clip (SURVEY 8d); the stage is bound by the DFT-GEMM, not by HBM'}
+                'dft_gemm_executed_TFLOPs_f64': B * fe_flop / (fe_ms * 1e-3) / 1e12, 'mfma_f64_peak_TFLOPs': FP64_MFMA_PEAK_TFLOPS,
+                'note': 'PCM16 -> 2x up-sample -> STFT-dB (folded real DFT on the fp64 MFMA, csrc/stft.hip) -> normalise/window; '
+                        'algorithmic bytes 1.668 MB/clip (SURVEY 8d); the stage is bound by the DFT-GEMMs, not by HBM'}
     train = None
     if not a.no_train:
         del model

@@ -18,6 +18,7 @@ ACT_NONE, ACT_RELU, ACT_SILU, ACT_LEAKY = 0, 1, 2, 3
 # bench.py sets this to a list to time every implicit-GEMM launch with HIP events on the launch stream:
 # entries are ((Cin, N, kh, H, W, B, groups, stride, label), start_event, end_event).
 PROFILE = None
+FLOPS = None                   # [float]: executed MFMA FLOPs of every GEMM launch since it was set (bench.py accounting)
 _PROFILE_LABEL = None          # set by composite ops (Winograd) so that their GEMM launches can be told apart
 
 
@@ -66,6 +67,8 @@ def gemm_conv(x, w, y, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, Ho=None,
     d.alpha, d.act, d.shift_per_row = float(alpha), int(act), int(bool(shift_per_row))
     if up is not None:                       # [B, up_H, up_W, N] coarse map merged in the epilogue
         d.up, d.up_H, d.up_W = _chk(up, name='up').data_ptr(), up.shape[1], up.shape[2]
+    if FLOPS is not None:
+        FLOPS[0] += 2.0 * B * Ho * Wo * N * kh * kw * Cin * groups
     if PROFILE is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
@@ -154,6 +157,8 @@ def conv3x3_winograd(x, U, bias=None, m=2, scale=None, relu=False, mask=None):
         mk = _ptr(mask[b0:b0 + nb]) if mask is not None else None
         if fused:
             check(lib().nbm_wino23_rows(_ptr(x[b0:b0 + nb]), nb, H, W, C_, _ptr(V), st), 'nbm_wino23_rows')
+            if FLOPS is not None:
+                FLOPS[0] += 2.0 * nxi * T * C_ * N
             if PROFILE is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -494,6 +499,8 @@ def conv_dgrad(g, w, out, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, g_ld=
     d.mask = mask.data_ptr() if mask is not None else None
     d.mask_ld = Cin if mask is not None else 0
     d.g_gs, d.w_gs, d.out_gs, d.res_gs = g_gs, w_gs, out_gs, res_gs
+    if FLOPS is not None:          # executed: the stride-2 kernels visit only the taps that reach each parity class
+        FLOPS[0] += 2.0 * B * d.Ho * d.Wo * N * kh * kw * Cin * groups
     with _timed(('dgrad', B, H, W, Cin, N, kh, stride, groups)):
         check(lib().nbm_conv_dgrad(C.byref(d), _stream()), 'nbm_conv_dgrad')
     return out
@@ -510,6 +517,8 @@ def conv_wgrad(g, x, out, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, g_ld=
     d.row_scale = row_scale.data_ptr() if row_scale is not None else None
     d.g_gs, d.x_gs, d.out_gs = g_gs, x_gs, out_gs
     d.bias_grad = bias_grad.data_ptr() if bias_grad is not None else None       # [N] zeros: += column sums of g
+    if FLOPS is not None:
+        FLOPS[0] += 2.0 * B * d.Ho * d.Wo * N * kh * kw * Cin * groups
     with _timed(('wgrad', B, H, W, Cin, N, kh, stride, groups)):
         check(lib().nbm_conv_wgrad(C.byref(d), _stream()), 'nbm_conv_wgrad')
     return out
