@@ -1,31 +1,47 @@
-import sys, os, time, torch, numpy as np
+"""Per-launch table of one detect() forward at batch B (HIP events around every implicit-GEMM / fused-Winograd launch,
+in launch order = layer order): time, executed TFLOP/s, algorithmic GB/s (input + weights + output once).
+`python fwdprofile.py [B] [direct]` -- `direct` switches the Winograd path off (the direct 3x3 kernel everywhere)."""
+import sys, os, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from birdsoundclassif_amd import ops, synth
-from birdsoundclassif_amd.nets import build_model
+from birdsoundclassif_amd.nets import build_model, functional as Fn
 from birdsoundclassif_amd.train import default_args
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+if 'direct' in sys.argv:
+    Fn.WINOGRAD = False
 model, _ = build_model(default_args(device='cuda'))
 model.load_state_dict(synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}))
 model = model.cuda().eval()
 x = torch.from_numpy(np.tile(synth.image_batch(0, 8), (B // 8, 1, 1))).cuda()[:, None]
 with torch.no_grad():
-    model.detect(x); torch.cuda.synchronize()
-    ops.PROFILE = []
-    model.detect(x); torch.cuda.synchronize()
-prof, ops.PROFILE = ops.PROFILE, None
-agg = {}
-for (tag, s, e) in prof:
-    agg.setdefault(tag, []).append(s.elapsed_time(e))
+    model.detect(x); model.detect(x); torch.cuda.synchronize()
+    runs = []
+    for _ in range(3):
+        ops.PROFILE = []
+        model.detect(x); torch.cuda.synchronize()
+        runs.append(ops.PROFILE)
+        ops.PROFILE = None
 rows = []
-for tag, ts in agg.items():
+for i, (tag, s, e) in enumerate(runs[0]):
+    ms = min(r[i][1].elapsed_time(r[i][2]) for r in runs)                 # same launch sequence in every run
+    rows.append((tag, ms))
+print(f'detect forward, B = {B}, {"direct 3x3 everywhere" if not Fn.WINOGRAD else "Winograd F(2x2,3x3) for 3x3/s1 with >= 128 channels"}; '
+      f'best of 3 runs per launch')
+print('   ms    TF/s(exec)  GB/s(alg)  launch')
+tot = 0.0
+for tag, ms in rows:
     if tag[0] == 'wino23':
+        _, C, N, H, W, b = tag
+        print(f'{ms:8.3f}      -         -      = whole Winograd layer above: 3x3 {C}->{N} @{H}x{W} B={b} (row transform + fused kernel)')
         continue
-    Cin, N, k, H, W, Bb, G, st, _ = tag
-    # stride unknown from the tag: FLOPs from output size is not recoverable; report time only + upper bound at stride 1
-    rows.append((sum(ts), len(ts), Cin, N, k, H, W, Bb, G, st))
-rows.sort(reverse=True)
-tot = sum(r[0] for r in rows)
-print(f'total igemm {tot:.1f} ms')
-for t, n, Cin, N, k, H, W, Bb, G, st in rows[:40]:
-    fl = 2.0 * G * Bb * (-(-H // st)) * (-(-W // st)) * N * Cin * k * k * n / 1e9   # executed GFLOP ('same' geometry)
-    print(f'{t:8.2f} ms x{n:2d}  Cin={Cin:4d} N={N:4d} k={k} s={st} g={G} B={Bb} HxW={H}x{W}  {fl / t:7.1f} TF/s')
+    Cin, N, k, H, W, Bb, G, st, label = tag
+    Ho, Wo = -(-H // st), -(-W // st)
+    fl = 2.0 * G * Bb * Ho * Wo * N * Cin * k * k / 1e9
+    by = 4.0 * G * (Bb * H * W * Cin + Bb * Ho * Wo * N + N * Cin * k * k) / 1e9
+    what = f'{k}x{k} s{st} {Cin}->{N} @{H}x{W} B={Bb}' + (f' groups={G}' if G > 1 else '')
+    if label is not None:
+        what = f'fused Winograd kernel of 3x3 {Cin}->{N} @{label[1]}x{label[2]} ({G} planes x {H} tiles)'
+        by = 4.0 * (H * 4 * Cin * 0.5 + H * 4 * N + G * N * Cin) / 1e9          # R (2x input) + y + U
+    tot += ms
+    print(f'{ms:8.3f}  {fl / ms:8.1f}  {by / ms * 1e3:9.0f}   {what}')
+print(f'total of the GEMM-type launches: {tot:.1f} ms')
