@@ -189,7 +189,10 @@ __global__ __launch_bounds__(256, BN == 128 ? 1 : 2) void wino23_fused_kernel(co
   // 19 % slower.  Measured and dropped (scripts/wino_fused_probe.py, 188x512 x 26 images, 16.2 ms as is): three LDS stages
   // with the barrier behind the LDS writes, so that the first fragments of step k+1 are prefetched in G3 of step k
   // (18.9 ms: the compiler bunches G0's MFMAs and spills); plane-dependent scalars (buffer descriptor, column offsets)
-  // kept as loop-carried state instead of being re-derived every step (17.9 ms: the VMEM interleave pattern breaks).
+  // kept as loop-carried state instead of being re-derived every step (17.9 ms: the conditional update splits the step's
+  // scheduling region); the same state kept per plane in an explicit plane loop with the last two steps of every plane
+  // peeled (main loop 15.1 instead of 15.4 ms, but the five inlined step bodies push the allocator into 98-128 spilled
+  // registers around the flush: 17.2 ms).
   f32x4 fa[2][MT], fb[2][NT];
   auto read_frags = [&](const float* Ab, const float* Bb, int q, int s) {
 #pragma unroll
