@@ -63,6 +63,7 @@ _P, _I, _L, _F, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 SIGNATURES = {
     'nbm_gemm_conv': [C.POINTER(GemmDesc), _P],
     'nbm_pcm16_to_wave': [_P, _L, _I, _I, _I, _P, _L, _L, _P, _L, _I, _I, _P],
+    'nbm_resample_to_wave': [_P, _L, _I, _L, _I, _I, _P, _I, _L, _L, _P, _L, _I, _I, _I, _P],
     'nbm_minmax_init': [_P, _I, _P],
     'nbm_stft_db': [_P, _L, _I, _I, _I, _I, _P, _I, _I, _I, _F, _P, _L, _I, _P, _P],
     'nbm_spec_windows': [_P, _L, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _P],

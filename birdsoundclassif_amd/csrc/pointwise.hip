@@ -49,6 +49,54 @@ __global__ void pcm16_to_wave_kernel(const int16_t* __restrict__ pcm, long long 
   }
 }
 
+// Generic front-end input: fp32 samples at any rate -> the piece [first, first + count) of the 44.1 kHz signal, centre
+// padded like pcm16_to_wave_kernel.  L == M == 1: the samples themselves (float / 24- / 32-bit files at 44.1 kHz).
+// Otherwise a rational L / M polyphase resampler: y[m] = sum_k taps[(m M) mod L][k] * x[floor(m M / L) - T/2 + 1 + k],
+// taps [L][T] float64 (Kaiser-windowed sinc built on the host), accumulated in float64 in a fixed order (reproducible bit
+// for bit on any device), then rounded to the 16-bit grid like the `ffmpeg -acodec pcm_s16le -ar 44100` step of the
+// reference (prepare_dataset.py:175-178) when quant16 is set.
+__global__ void resample_to_wave_kernel(const float* __restrict__ x, long long x_ld, long long n, int L, int M,
+                                        const double* __restrict__ taps, int T, long long first, long long count,
+                                        float* __restrict__ out, long long out_ld, int lead, int reflect, int quant16) {
+  const int b = blockIdx.y;
+  const float* xb = x + (long long)b * x_ld;
+  float* o = out + (long long)b * out_ld;
+  for (long long j = blockIdx.x * (long long)blockDim.x + threadIdx.x; j < out_ld;
+       j += (long long)gridDim.x * blockDim.x) {
+    long long i = j - lead;
+    float v = 0.f;
+    if (reflect && i >= -(long long)lead && i < count + lead) {
+      if (i < 0) i = -i;
+      else if (i >= count) i = 2 * (count - 1) - i;
+    }
+    if (i >= 0 && i < count) {
+      const long long m = first + i;
+      if (L == 1 && M == 1) {
+        v = xb[m];
+      } else {
+        const long long pos = m * M;
+        const long long n0 = pos / L;
+        const int ph = (int)(pos - n0 * L);
+        const double* h = taps + (long long)ph * T;
+        const long long nb = n0 - T / 2 + 1;
+        double acc = 0.0;
+        for (int k = 0; k < T; ++k) {
+          const long long q = nb + k;
+          if (q >= 0 && q < n) acc = fma(h[k], (double)xb[q], acc);
+        }
+        if (quant16) {
+          double r = rint(acc * 32768.0);
+          r = r < -32768.0 ? -32768.0 : (r > 32767.0 ? 32767.0 : r);
+          v = (float)(r * (1.0 / 32768.0));
+        } else {
+          v = (float)acc;
+        }
+      }
+    }
+    o[j] = v;
+  }
+}
+
 __global__ void minmax_init_kernel(uint32_t* mm, int batch) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < batch) { mm[2 * i] = 0xFFFFFFFFu; mm[2 * i + 1] = 0u; }
@@ -319,6 +367,23 @@ extern "C" int nbm_pcm16_to_wave(const int16_t* pcm, int64_t pcm_ld, int batch, 
   dim3 grid(grid_for(out_ld, TPB, 1024), batch);
   hipLaunchKernelGGL(pcm16_to_wave_kernel, grid, dim3(TPB), 0, (hipStream_t)stream, pcm, (long long)pcm_ld, n,
                      upsample, hq, (long long)first, (long long)count, out, (long long)out_ld, lead, pad_mode);
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_resample_to_wave(const float* x, int64_t x_ld, int batch, int64_t n, int L, int M, const double* taps,
+                                    int T, int64_t first, int64_t count, float* out, int64_t out_ld, int lead, int pad_mode,
+                                    int quant16, void* stream) {
+  if (!x || !out || batch <= 0 || n <= 0 || L <= 0 || M <= 0 || lead < 0) return NBM_EINVAL;
+  const bool copy = L == 1 && M == 1;
+  if (!copy && (!taps || T <= 0 || (T & 1))) return NBM_EINVAL;
+  const int64_t n_out = copy ? n : (n * L + M - 1) / M;            // output samples whose centre lies inside the input
+  if (first < 0 || count <= 0 || first + count > n_out) return NBM_EINVAL;
+  if (pad_mode != 0 && pad_mode != 1) return NBM_EINVAL;
+  if ((int64_t)lead + count + (pad_mode ? lead : 0) > out_ld) return NBM_EINVAL;
+  if (pad_mode == 1 && lead >= count) return NBM_EINVAL;
+  dim3 grid(grid_for(out_ld, TPB, 1024), batch);
+  hipLaunchKernelGGL(resample_to_wave_kernel, grid, dim3(TPB), 0, (hipStream_t)stream, x, (long long)x_ld, (long long)n, L,
+                     M, taps, T, (long long)first, (long long)count, out, (long long)out_ld, lead, pad_mode, quant16);
   return nbm_launch_status();
 }
 

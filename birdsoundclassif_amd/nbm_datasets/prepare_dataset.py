@@ -104,6 +104,7 @@ class SpectrogramFrontEnd:
         self.basis = dft_basis_f64(self.WIN_LENGTH, self.LOW_IDX, self.H_PIX).to(self.device)
         self.hq = torch.from_numpy(upsample2x_coeffs()).to(self.device)
         self._cols = {}
+        self._taps = {}
 
     def n_frames(self, n_samples_44k):
         return 1 + n_samples_44k // self.HOP_LENGTH                                  # librosa.stft, center=True
@@ -114,51 +115,71 @@ class SpectrogramFrontEnd:
     MAX_CHUNK = int(5e7)           # STFT chunk length in 44.1 kHz samples (reference prepare_dataset.py:234)
     MAX_FILE = int(15e7)           # beyond this the reference goes through process_long_file (:187-225)
 
-    def _rate(self, sr):
+    def _source(self, dtype, n, sr):
+        """How the 44.1 kHz signal is obtained from the input rows `x` (int16 PCM or float32 samples in [-1, 1)):
+        -> (kind, n44, extra).  int16 at 44.1 / 22.05 kHz keeps the exact integer path (`nbm_pcm16_to_wave`); everything
+        else goes through `nbm_resample_to_wave`: float32 rows at 44.1 kHz are used as they are (what librosa.load hands
+        the reference for 24-bit / 32-bit / float files), any other rate is resampled by the rational polyphase filter of
+        `resample_taps` and rounded to the 16-bit grid, like the reference's ffmpeg step (prepare_dataset.py:175-178)."""
+        if dtype == torch.int16 and sr == self.FREQ:
+            return 'pcm16', n, False
+        if dtype == torch.int16 and sr * 2 == self.FREQ:
+            return 'pcm16', 2 * n, True
+        if dtype not in (torch.int16, torch.float32):
+            raise TypeError('input rows must be int16 PCM or float32 samples')
         if sr == self.FREQ:
-            return False
-        if sr * 2 == self.FREQ:
-            return True
-        raise NotImplementedError(f'sample rate {sr}: only 44100 and 22050 Hz inputs are supported')
+            return 'f32', n, (1, 1, None)
+        if sr not in self._taps:
+            L, M, taps = resample_taps(sr, self.FREQ)
+            self._taps[sr] = (L, M, torch.from_numpy(taps).to(self.device))
+        L, M, taps = self._taps[sr]
+        return 'f32', -(-n * L // M), (L, M, taps)
 
-    def _stft_chunk(self, pcm, up, first, count, out=None, col0=0):
+    def _stft_chunk(self, x, src, first, count, out=None, col0=0):
         """STFT of the piece [first, first + count) of the 44.1 kHz signal of every row."""
+        kind, _, extra = src
         L = self.n_frames(count)
         lead = self.WIN_LENGTH // 2
         ld = max(lead + count + lead, (L - 1) * self.HOP_LENGTH + self.WIN_LENGTH)
         ld = -(-ld // 4) * 4
-        wave_f = ops.pcm16_to_wave(pcm, ld, lead, up, self.hq, self.pad_mode == 'reflect', first, count)
+        reflect = self.pad_mode == 'reflect'
+        if kind == 'pcm16':
+            wave_f = ops.pcm16_to_wave(x, ld, lead, extra, self.hq, reflect, first, count)
+        else:
+            wave_f = ops.resample_to_wave(x, ld, lead, extra[0], extra[1], extra[2], reflect, first, count,
+                                          quant16=extra[2] is not None)
         db, mm = ops.stft_db(wave_f, L, self.HOP_LENGTH, self.WIN_LENGTH, self.basis, self.H_PIX, self.floor_amp,
                              out=out, col0=col0)
         return db, mm, L
 
-    def spectrogram_db(self, pcm, sr):
-        """pcm int16 [batch, n] on the device -> (db [batch,375,L], minmax, [L_0, L_1, ...] frames per chunk).  Rows longer
-        than 5e7 samples (19 min) are transformed chunk by chunk like the reference (the WHOLE row is resampled first,
-        every chunk is centre-padded on its own, the min/max runs over the whole row)."""
-        if pcm.dtype != torch.int16 or pcm.dim() != 2:
-            raise TypeError('pcm must be int16 [batch, n]')
-        up = self._rate(sr)
-        pcm = pcm.contiguous()
-        n44 = pcm.shape[1] * (2 if up else 1)
+    def spectrogram_db(self, x, sr):
+        """x int16 / float32 [batch, n] on the device -> (db [batch,375,L], minmax, [L_0, L_1, ...] frames per chunk).  Rows
+        longer than 5e7 samples (19 min) are transformed chunk by chunk like the reference (the WHOLE row is resampled
+        first, every chunk is centre-padded on its own, the min/max runs over the whole row)."""
+        if x.dim() != 2:
+            raise TypeError('input must be [batch, n]')
+        x = x.contiguous()
+        src = self._source(x.dtype, x.shape[1], sr)
+        if src[0] == 'f32' and x.dtype == torch.int16:
+            x = x.to(torch.float32) * (1.0 / 32768.0)             # exact
+        n44 = src[1]
         if n44 > self.MAX_FILE - self.MAX_FILE % self.FREQ:
-            raise NotImplementedError('files longer than 1.5e8 samples: the reference re-enters process_file per 56-minute '
-                                      'split and returns nested lists that its own run_detection cannot batch '
-                                      '(prepare_dataset.py:187-225); split such recordings before detection')
+            raise ValueError('rows longer than 1.5e8 samples are split by File_Processor.process_long_file first '
+                             '(prepare_dataset.py:187-225)')
         if n44 < self.MAX_CHUNK:
-            db, mm, L = self._stft_chunk(pcm, up, 0, n44)
+            db, mm, L = self._stft_chunk(x, src, 0, n44)
             return db, mm, [L]
         bounds = [(k * self.MAX_CHUNK, min(n44, (k + 1) * self.MAX_CHUNK)) for k in range(int(n44 / self.MAX_CHUNK) + 1)]
         if bounds[-1][0] == bounds[-1][1]:
             raise ValueError('file length is an exact multiple of the STFT chunk length: the reference calls librosa.stft '
                              'on an empty chunk there and fails (prepare_dataset.py:236-237)')
         Ls = [self.n_frames(b - a) for a, b in bounds]
-        db = torch.empty((pcm.shape[0], self.H_PIX, sum(Ls)), device=pcm.device, dtype=torch.float32)
-        mm = torch.empty((pcm.shape[0], 2), device=pcm.device, dtype=torch.int32)
-        ops.check(ops.lib().nbm_minmax_init(ops._ptr(mm), pcm.shape[0], ops._stream()), 'nbm_minmax_init')
+        db = torch.empty((x.shape[0], self.H_PIX, sum(Ls)), device=x.device, dtype=torch.float32)
+        mm = torch.empty((x.shape[0], 2), device=x.device, dtype=torch.int32)
+        ops.check(ops.lib().nbm_minmax_init(ops._ptr(mm), x.shape[0], ops._stream()), 'nbm_minmax_init')
         col = 0
         for (a, b), L in zip(bounds, Ls):
-            self._stft_chunk(pcm, up, a, b - a, out=(db, mm), col0=col)
+            self._stft_chunk(x, src, a, b - a, out=(db, mm), col0=col)
             col += L
         return db, mm, Ls
 
@@ -172,7 +193,8 @@ class SpectrogramFrontEnd:
         return self._cols[key]
 
     def __call__(self, pcm, sr, label_end_col=None):
-        """pcm int16 [batch, n] (device) -> images f32 [batch, n_img, 375, w_pix] in [0,1], spectrogram length.
+        """pcm int16 (or float32 samples) [batch, n] (device) -> images f32 [batch, n_img, 375, w_pix] in [0,1],
+        spectrogram length.
         `label_end_col`: int(t_end.max() / DT) of the file's annotations when it has any (it changes the reference's
         padding of the last window, prepare_dataset.py:283-287)."""
         db, mm, Ls = self.spectrogram_db(pcm, sr)
@@ -181,15 +203,94 @@ class SpectrogramFrontEnd:
         return ops.spec_windows(db, mm, L, n_img, self.W_PIX, self.HOP_SPECTRO, cols), L
 
 
+RESAMPLE_ZEROS = 16          # zero crossings of the windowed sinc on each side
+RESAMPLE_ROLLOFF = 0.95
+
+
+def resample_taps(sr, target=44100):
+    """Polyphase taps of the rational resampler sr -> target (reference: `ffmpeg -ar 44100`, prepare_dataset.py:175-178,
+    third-party and absent; this build owns the filter): target / sr = L / M reduced, y[m] = sum_n x[n] g(m M / L - n) with
+    g(tau) = rho s sinc(rho s tau) kaiser_8(tau s / 16), s = min(1, L / M), rho = 0.95, |tau| < 16 / s.  Returns
+    (L, M, float64 [L, T]): row `ph` holds the taps of output phase ph for the inputs floor(m M / L) - T/2 + 1 + k,
+    k = 0 .. T-1, each row normalised to unit DC gain."""
+    from math import gcd
+    g = gcd(int(sr), int(target))
+    L, M = int(target) // g, int(sr) // g
+    sc = min(1.0, L / M)
+    half = int(np.ceil(RESAMPLE_ZEROS / sc))
+    T = 2 * half
+    k = np.arange(T, dtype=np.float64)
+    ph = np.arange(L, dtype=np.float64)[:, None] / L
+    tau = ph + (T // 2 - 1) - k[None, :]
+    u = tau * sc / RESAMPLE_ZEROS
+    win = np.where(np.abs(u) < 1.0, np.i0(8.0 * np.sqrt(np.clip(1.0 - u * u, 0.0, None))) / np.i0(8.0), 0.0)
+    h = RESAMPLE_ROLLOFF * sc * np.sinc(RESAMPLE_ROLLOFF * sc * tau) * win
+    return L, M, np.ascontiguousarray(h / h.sum(1, keepdims=True))
+
+
+def read_wav(path):
+    """RIFF/WAVE file -> (samples, sample rate): mono 16-bit PCM as int16 [n] (the exact-integer fast path), everything
+    else as float32 [n] in [-1, 1) the way librosa.load(sr=None) returns it (prepare_dataset.py:162): 8-bit (unsigned),
+    16-, 24-, 32-bit PCM scaled by 2^-(bits-1), IEEE float 32 / 64, WAVE_FORMAT_EXTENSIBLE of those; several channels are
+    averaged in float32 (librosa.to_mono)."""
+    import struct
+    with open(path, 'rb') as f:
+        raw = f.read()
+    if raw[:4] != b'RIFF' or raw[8:12] != b'WAVE':
+        raise ValueError('not a RIFF/WAVE file')
+    pos, fmt, data = 12, None, None
+    while pos + 8 <= len(raw):
+        cid, size = raw[pos:pos + 4], struct.unpack('<I', raw[pos + 4:pos + 8])[0]
+        body = raw[pos + 8:pos + 8 + size]
+        if cid == b'fmt ':
+            fmt = body
+        elif cid == b'data':
+            data = body
+        pos += 8 + size + (size & 1)
+    if fmt is None or data is None:
+        raise ValueError('wav file without fmt / data chunk')
+    tag, nch, sr, _, _, bits = struct.unpack('<HHIIHH', fmt[:16])
+    if tag == 0xFFFE and len(fmt) >= 26:                                  # extensible: the sub-format GUID starts with the tag
+        tag = struct.unpack('<H', fmt[24:26])[0]
+    n = len(data) // (nch * (bits // 8))
+    data = data[:n * nch * (bits // 8)]
+    if tag == 1 and bits == 16:
+        x = np.frombuffer(data, dtype='<i2').reshape(n, nch)
+        if nch == 1:
+            return np.array(x[:, 0], dtype=np.int16), sr                  # own, writable copy
+        y = x.astype(np.float32) / np.float32(32768.0)
+    elif tag == 1 and bits == 8:
+        y = (np.frombuffer(data, dtype=np.uint8).reshape(n, nch).astype(np.float32) - np.float32(128.0)) / np.float32(128.0)
+    elif tag == 1 and bits == 24:
+        b = np.frombuffer(data, dtype=np.uint8).reshape(n, nch, 3).astype(np.int32)
+        v = b[..., 0] | (b[..., 1] << 8) | (b[..., 2] << 16)
+        v = np.where(v >= 1 << 23, v - (1 << 24), v)
+        y = v.astype(np.float32) / np.float32(8388608.0)
+    elif tag == 1 and bits == 32:
+        y = (np.frombuffer(data, dtype='<i4').reshape(n, nch).astype(np.float64) / 2147483648.0).astype(np.float32)
+    elif tag == 3 and bits in (32, 64):
+        y = np.frombuffer(data, dtype='<f4' if bits == 32 else '<f8').reshape(n, nch).astype(np.float32)
+    else:
+        raise NotImplementedError(f'wav format tag {tag} with {bits} bits per sample')
+    return (y[:, 0].copy() if nch == 1 else y.mean(1, dtype=np.float32)), sr
+
+
 def read_wav_pcm16(path):
-    with wave.open(path, 'rb') as f:
-        if f.getsampwidth() != 2:
-            raise NotImplementedError('only 16-bit PCM wav files are supported')
-        sr, nch, n = f.getframerate(), f.getnchannels(), f.getnframes()
-        x = np.frombuffer(f.readframes(n), dtype='<i2').reshape(-1, nch)
-    if nch > 1:
-        x = np.round(x.astype(np.float64).mean(1)).astype(np.int16)[:, None]
-    return np.array(x[:, 0], dtype=np.int16), sr          # own, writable copy
+    """Mono 16-bit PCM only (the bulk-inference shard format)."""
+    x, sr = read_wav(path)
+    if x.dtype != np.int16:
+        raise NotImplementedError('bulk inference expects mono 16-bit PCM wav files')
+    return x, sr
+
+
+def soundfile_pcm16_round_trip(x):
+    """What `soundfile.write(path, data, sr)` + `librosa.load` do to a float signal on a wav file (reference
+    process_long_file, prepare_dataset.py:197-199, 217): libsndfile stores float data as 16-bit PCM with
+    lrint(x * 32767) (its default normalisation) and the samples come back as k / 32768.  int16 input k means x = k / 32768."""
+    if x.dtype == np.int16:
+        k = x.astype(np.int32)
+        return np.rint(k.astype(np.float64) * (32767.0 / 32768.0)).astype(np.int16)
+    return np.clip(np.rint(x.astype(np.float64) * 32767.0), -32768, 32767).astype(np.int16)
 
 
 _FE = {}
@@ -208,30 +309,40 @@ class File_Processor:
 
     def load(self):
         try:
-            return read_wav_pcm16(self.filepath)
+            return read_wav(self.filepath)
         except Exception:
             print('File loading failed')
             return None
 
-    def process_file(self, freq_accuracy=33.3, dt=0.003, overlap_spectro=0.2, w_pix=1024, device='cuda',
-                     pad_mode='constant'):
-        """-> (list of np.float32 [375, w_pix], None); (None, None) when the file cannot be read."""
+    def _front_end(self, freq_accuracy, dt, overlap_spectro, w_pix, device, pad_mode):
         key = (freq_accuracy, dt, overlap_spectro, w_pix, str(device), pad_mode)
         if key not in _FE:
             _FE[key] = SpectrogramFrontEnd(device, freq_accuracy, dt, overlap_spectro, w_pix, pad_mode)
-        fe = _FE[key]
-        for k in ('W_PIX', 'HOP_SPECTRO', 'WIN_LENGTH', 'HOP_LENGTH', 'FREQ_ACCURACY', 'DT', 'LOW_IDX', 'HIGH_IDX'):
-            setattr(self, k, getattr(fe, k))
-        data = self.load()
+        return _FE[key]
+
+    def process_file(self, freq_accuracy=33.3, dt=0.003, overlap_spectro=0.2, w_pix=1024, device='cuda',
+                     pad_mode='constant', data=None):
+        """-> (list of np.float32 [375, w_pix], annotations or None); (None, None) when the file cannot be read.  Files
+        longer than 1.5e8 samples at 44.1 kHz (56 min) return what the reference's `process_long_file` returns: a list of
+        such lists, one per split, and the list of the splits' annotation frames."""
+        fe = self._front_end(freq_accuracy, dt, overlap_spectro, w_pix, device, pad_mode)
+        self.W_PIX, self.HOP_SPECTRO = fe.W_PIX, fe.HOP_SPECTRO                 # prepare_dataset.py:114-115
+        if data is None:
+            data = self.load()
         if data is None:
             return None, None
-        pcm, sr = data
+        samples, sr = data
+        long_out = self.process_long_file(samples, sr, fe, (freq_accuracy, dt, overlap_spectro, w_pix, device, pad_mode))
+        if long_out is not None:
+            return long_out
+        for k in ('WIN_LENGTH', 'HOP_LENGTH', 'FREQ_ACCURACY', 'DT', 'LOW_IDX', 'HIGH_IDX'):
+            setattr(self, k, getattr(fe, k))
         label_end_col = None
         if self.labels is not None:
             own = self.labels.loc[self.labels['filename'] == self.filename]
             if len(own) > 0:
                 label_end_col = int(own['t_end'].max() / fe.DT)                   # prepare_dataset.py:283-284
-        imgs, L = fe(torch.from_numpy(pcm)[None].to(fe.device), sr, label_end_col)
+        imgs, L = fe(torch.from_numpy(samples)[None].to(fe.device), sr, label_end_col)
         self.spectrogram_length = L
         self.images_device = imgs[0]
         img_db = [im for im in imgs[0].cpu().numpy()]
@@ -244,6 +355,53 @@ class File_Processor:
             print('Something went wrong with the annotation file, skipping~~')
             return None, None
         return img_db, labels_
+
+    def process_long_file(self, samples, sr, fe, settings):
+        """reference prepare_dataset.py:187-225: a file longer than max_l = 15e7 - 15e7 % 44100 samples (at 44.1 kHz) is cut
+        into pieces of max_l samples; every piece goes through soundfile.write -> a fresh File_Processor.process_file
+        (its own min / max normalisation, its own windows), with the annotations shifted into the piece's time frame
+        (kept when they START inside it, their end clipped to it).  Returns (list of image lists, list of annotation
+        frames) like the reference, or None for ordinary files.  The temporary wav round trip of the reference quantises
+        the float samples to 16 bits with libsndfile's x * 32767 rule: reproduced by `soundfile_pcm16_round_trip`."""
+        max_l = fe.MAX_FILE - fe.MAX_FILE % self.FREQ
+        src = fe._source(torch.from_numpy(samples[:1]).dtype, len(samples), sr)
+        if src[1] <= max_l:
+            return None
+        if not (sr == self.FREQ):
+            # the reference resamples the whole file first (load), then cuts; do the same on the host grid: the resampled
+            # signal is int16-valued, so fetch it from the device path once
+            x = torch.from_numpy(samples)[None].to(fe.device)
+            if src[0] == 'f32' and x.dtype == torch.int16:
+                x = x.to(torch.float32) * (1.0 / 32768.0)
+            lead = 0
+            if src[0] == 'pcm16':
+                w = ops.pcm16_to_wave(x.contiguous(), -(-src[1] // 4) * 4, lead, src[2], fe.hq)
+            else:
+                w = ops.resample_to_wave(x.contiguous(), -(-src[1] // 4) * 4, lead, src[2][0], src[2][1], src[2][2])
+            samples = torch.round(w[0, :src[1]] * 32768.0).to(torch.int16).cpu().numpy()
+            sr = self.FREQ
+        print('Long file, processing in several steps...')
+        time_increment = max_l / self.FREQ
+        img_db, annotations = [], []
+        for k in range(int(len(samples) / max_l) + 1):
+            piece = soundfile_pcm16_round_trip(samples[k * max_l:(k + 1) * max_l])
+            print(f'~~ Processing split # {k} ~~')
+            labels = None
+            if self.labels is not None:
+                labels = self.labels.loc[self.labels['filename'] == self.filename].copy()
+                for col in ('t_start', 't_end'):
+                    labels[col] = labels[col] - k * time_increment
+                labels = labels.loc[labels['t_start'].between(0, time_increment)].copy()
+                labels['t_end'] = labels['t_end'].clip(upper=time_increment)
+                labels['filename'] = f'temp{k}'
+                if len(labels) == 0:
+                    labels = None
+            fp = File_Processor(f'temp{k}.{self.ext}', '', labels)
+            img_inc, annot_inc = fp.process_file(*settings[:4], device=settings[4], pad_mode=settings[5], data=(piece, sr))
+            img_db.append(img_inc)
+            if annot_inc is not None:
+                annotations.append(annot_inc)
+        return img_db, annotations
 
     def merge_and_filter_labels(self, img_db):
         """Annotations of this file (seconds / Hz) -> one row per window that holds at least one box:

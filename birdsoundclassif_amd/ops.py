@@ -251,6 +251,25 @@ def pcm16_to_wave(pcm, out_ld, lead, upsample, hq=None, reflect=False, first=0, 
     return out
 
 
+def resample_to_wave(x, out_ld, lead, L, M, taps, reflect=False, first=0, count=None, quant16=True):
+    """x f32 [batch, n] at any rate -> f32 [batch, out_ld] laid out like `pcm16_to_wave`: the piece [first, first+count)
+    of the 44.1 kHz signal = x itself (L = M = 1) or its rational L / M polyphase resampling with the float64 `taps`
+    [L, T] (rounded to the 16-bit grid when `quant16`)."""
+    _chk(x, torch.float32, 'x')
+    batch, n = x.shape
+    n_out = n if (L == 1 and M == 1) else -(-n * L // M)
+    if count is None:
+        count = n_out - first
+    if taps is not None:
+        _chk(taps, torch.float64, 'taps')
+        assert taps.shape[0] == L
+    out = torch.empty((batch, out_ld), device=x.device, dtype=torch.float32)
+    check(lib().nbm_resample_to_wave(_ptr(x), n, batch, n, L, M, _ptr(taps), taps.shape[1] if taps is not None else 0, first,
+                                     count, _ptr(out), out_ld, lead, int(bool(reflect)), int(bool(quant16)), _stream()),
+          'nbm_resample_to_wave')
+    return out
+
+
 def stft_db(wave, n_frames, hop, n_fft, basis, n_bins, floor_amp, db_ld=None, out=None, col0=0):
     """wave f32 [batch, wave_ld] (already centre-padded) -> (db [batch, n_bins, db_ld], minmax u32 [batch,2]).
     `basis`: float64 [bin tiles, k steps, 64, 2] in MFMA fragment order (prepare_dataset.dft_basis_f64).

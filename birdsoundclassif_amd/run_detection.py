@@ -83,6 +83,11 @@ def run_detection(model, config, wav_path, bird_dicts_path, min_score=0.5, bs=10
     img_db, _ = fp.process_file(device=device)
     if img_db is None:
         return {}
+    if len(img_db) > 0 and isinstance(img_db[0], list):
+        # recordings longer than 56 min: process_file returns one image list per split (reference process_long_file);
+        # the reference's own run_detection indexes that as a flat image list and fails (run_detection.py:44-55)
+        raise NotImplementedError('recordings longer than 1.5e8 samples come back as nested per-split image lists, which '
+                                  'the reference detection loop cannot consume either; split the recording first')
     imgs = fp.images_device                                   # [n_img, 375, 1024] on the GPU
     outputs = []
     for s in range(0, imgs.shape[0], bs):

@@ -116,6 +116,17 @@ int nbm_pcm16_to_wave(const int16_t* pcm, int64_t pcm_ld, int batch, int n, int 
                       const int32_t* hq, int64_t first, int64_t count, float* out, int64_t out_ld, int lead,
                       int pad_mode, void* stream);
 
+/* fp32 samples at any rate -> centre-padded fp32 waveform rows of one STFT chunk (same row layout and padding as
+ * nbm_pcm16_to_wave).  L = M = 1: the piece [first, first+count) of the samples themselves (float / 24- / 32-bit files at
+ * 44.1 kHz, librosa.load, prepare_dataset.py:162).  Otherwise the 44.1 kHz signal is the rational L / M polyphase
+ * resampling of x (44100 / sr = L / M reduced): y[m] = sum_k taps[(m M) mod L][k] x[floor(m M / L) - T/2 + 1 + k], taps
+ * float64 [L][T] (prepare_dataset.py:resample_taps), float64 accumulation in index order; quant16 = 1 rounds y to the
+ * 16-bit grid like the reference's `ffmpeg ... -acodec pcm_s16le -ar 44100` (prepare_dataset.py:175-178).  The signal has
+ * ceil(n L / M) samples. */
+int nbm_resample_to_wave(const float* x, int64_t x_ld, int batch, int64_t n, int L, int M, const double* taps, int T,
+                         int64_t first, int64_t count, float* out, int64_t out_ld, int lead, int pad_mode, int quant16,
+                         void* stream);
+
 /* STFT magnitude in dB for n_bins bins on the fp64 MFMA (librosa.stft + np.abs + amp_to_db + crop,
  * prepare_dataset.py:228-247):
  *   db[b][f][t] = 20 log10(max(floor, | sum_n w[n] wave[b][t*hop + n] exp(-2 pi i (low_bin + f) n / n_fft) |))

@@ -85,16 +85,111 @@ def upsample2x_pcm16(x):
     return out
 
 
+def read_wav(path):
+    """What `librosa.core.load(path, sr=None)` returns for a wav file (prepare_dataset.py:162): float32 mono in [-1, 1) --
+    PCM scaled by 2^-(bits-1) (8-bit is unsigned), IEEE float as stored, channels averaged -- and the sample rate.
+    Restated from the documented libsndfile / librosa behaviour (both absent here)."""
+    import struct
+    raw = open(path, 'rb').read()
+    assert raw[:4] == b'RIFF' and raw[8:12] == b'WAVE'
+    pos, fmt, data = 12, None, None
+    while pos + 8 <= len(raw):
+        cid, size = raw[pos:pos + 4], struct.unpack('<I', raw[pos + 4:pos + 8])[0]
+        if cid == b'fmt ':
+            fmt = raw[pos + 8:pos + 8 + size]
+        if cid == b'data':
+            data = raw[pos + 8:pos + 8 + size]
+        pos += 8 + size + (size & 1)
+    tag, nch, sr, _, _, bits = struct.unpack('<HHIIHH', fmt[:16])
+    if tag == 0xFFFE:
+        tag = struct.unpack('<H', fmt[24:26])[0]
+    if tag == 3:
+        y = np.frombuffer(data, dtype={32: '<f4', 64: '<f8'}[bits]).astype(np.float32)
+    elif bits == 8:
+        y = ((np.frombuffer(data, dtype=np.uint8).astype(np.float64) - 128) / 128).astype(np.float32)
+    elif bits == 24:
+        b = np.frombuffer(data, dtype=np.uint8).reshape(-1, 3).astype(np.int64)
+        v = b[:, 0] + (b[:, 1] << 8) + (b[:, 2] << 16)
+        y = ((v - ((v >> 23) << 24)) / 2.0 ** 23).astype(np.float32)
+    else:
+        y = (np.frombuffer(data, dtype={16: '<i2', 32: '<i4'}[bits]).astype(np.float64) / 2.0 ** (bits - 1)).astype(np.float32)
+    y = y.reshape(-1, nch)
+    return (y[:, 0] if nch == 1 else np.mean(y, axis=1, dtype=np.float32)), sr
+
+
+def resample_taps(sr, target=FREQ, zeros=16, rolloff=0.95, beta=8.0):
+    """The build's rational resampler (the reference shells out to `ffmpeg -ar 44100`, third-party and absent):
+    windowed-sinc interpolation y(t) = sum_n x[n] g(t - n), g(tau) = rho s sinc(rho s tau) kaiser_beta(tau s / zeros) for
+    |tau| < zeros / s, s = min(1, target / sr); returned as polyphase rows (L, M, taps [L, T]) with unit DC gain."""
+    from math import gcd
+    g = gcd(sr, target)
+    L, M = target // g, sr // g
+    s = min(1.0, L / M)
+    T = 2 * int(np.ceil(zeros / s))
+    taps = np.zeros((L, T))
+    for ph in range(L):
+        tau = ph / L + (T // 2 - 1) - np.arange(T)
+        u = tau * s / zeros
+        w = np.where(np.abs(u) < 1, np.i0(beta * np.sqrt(np.maximum(0.0, 1 - u * u))) / np.i0(beta), 0.0)
+        h = rolloff * s * np.sinc(rolloff * s * tau) * w
+        taps[ph] = h / h.sum()
+    return L, M, taps
+
+
+def resample_to_pcm16(x, sr, target=FREQ):
+    """float samples at `sr` -> int16 at 44.1 kHz: ceil(n L / M) outputs, y[m] = sum_k taps[(m M) % L][k] x[m M // L - T/2 +
+    1 + k] in float64, rounded to 16 bits (the `-acodec pcm_s16le` of the reference's ffmpeg call)."""
+    L, M, taps = resample_taps(sr, target)
+    T = taps.shape[1]
+    x = np.asarray(x, dtype=np.float64)
+    n = len(x)
+    n_out = -(-n * L // M)
+    m = np.arange(n_out, dtype=np.int64)
+    n0, ph = (m * M) // L, (m * M) % L
+    xp = np.concatenate([np.zeros(T, np.float64), x, np.zeros(T + 1, np.float64)])
+    acc = np.zeros(n_out)
+    for k in range(T):
+        acc += taps[ph, k] * xp[n0 - T // 2 + 1 + k + T]
+    return np.clip(np.rint(acc * 32768.0), -32768, 32767).astype(np.int16)
+
+
 def load(path):
     """File_Processor.load prepare_dataset.py:160-184 -> float32 in [-1,1) at 44.1 kHz."""
-    pcm, sr = read_wav_pcm16(path)
+    y, sr = read_wav(path)
     if sr == FREQ:
-        pass
-    elif sr * 2 == FREQ:
-        pcm = upsample2x_pcm16(pcm)
-    else:
-        raise NotImplementedError(f'sample rate {sr}: only 44100 and 22050 Hz are supported')
-    return pcm.astype(np.float32) / np.float32(32768.0)
+        return y
+    if sr * 2 == FREQ and np.array_equal(y * np.float32(32768), np.rint(y * np.float32(32768))):
+        # 16-bit material at 22.05 kHz: the exact-integer half-band interpolator
+        return upsample2x_pcm16((y * np.float32(32768)).astype(np.int16)).astype(np.float32) / np.float32(32768.0)
+    return resample_to_pcm16(y, sr).astype(np.float32) / np.float32(32768.0)
+
+
+def soundfile_round_trip(y):
+    """soundfile.write(..., float data) + librosa.load on a wav file (prepare_dataset.py:197-199, 217): libsndfile stores
+    float samples as 16-bit PCM = lrint(x * 32767); they come back as k / 32768."""
+    k = np.clip(np.rint(np.asarray(y, dtype=np.float64) * 32767.0), -32768, 32767)
+    return (k / 32768.0).astype(np.float32)
+
+
+def process_long_waveform(y, max_l, labels=None, filename=None, pad_mode='constant', chunk_l=int(5e7), **kw):
+    """File_Processor.process_long_file prepare_dataset.py:187-225 on a loaded 44.1 kHz waveform: None when len(y) <= max_l,
+    else (list of per-split image lists, list of (split index, label rows shifted into the split)).  `labels`: list of
+    (t_start, t_end, ...) tuples of this file."""
+    if len(y) <= max_l:
+        return None
+    inc = max_l / FREQ
+    out, kept = [], []
+    for k in range(int(len(y) / max_l) + 1):
+        piece = soundfile_round_trip(y[k * max_l:(k + 1) * max_l])
+        rows = None
+        if labels is not None:
+            rows = [(r[0] - k * inc, min(r[1] - k * inc, inc)) + tuple(r[2:]) for r in labels if 0 <= r[0] - k * inc <= inc]
+            rows = rows or None
+        t_end_max = max(r[1] for r in rows) if rows else None
+        imgs, _ = process_waveform(piece, pad_mode, chunk_l, t_end_max, **kw)
+        out.append(imgs)
+        kept.append(rows)
+    return out, kept
 
 
 # --------------------------------------------------------------------------- F3: spectrogram

@@ -315,6 +315,76 @@ def run_reference_frontend(PD, name, seed, n22, max_l, labels, tmpdir):
     return fp, imgs, annots
 
 
+LONG_CASE = dict(name='longfile', seed=7, n22=300000, max_file=250000)     # max_l = 250000 - 250000 % 44100 = 220500: 3 splits
+
+
+def long_case_labels():
+    """Annotations spread over the 13.6 s of the long-file case: some start in one split and end in the next."""
+    rows = [r for r in synth.label_rows(11, n=30, filename=LONG_CASE['name'], duration=13.0) if r[1] < 13.5]
+    rows.append((4.9, 5.6, 1500.0, 4000.0, 'sp3', LONG_CASE['name'], 3))          # straddles the first cut at 5.0 s
+    return rows
+
+
+def reference_long_file_processor(PD, max_file):
+    """File_Processor whose `process_long_file` is re-compiled from the reference's source with the hard-coded 15e7
+    (prepare_dataset.py:194) replaced, so that the split logic runs on a 14 s file."""
+    import ast
+    import inspect
+    import textwrap
+    tree = ast.parse(textwrap.dedent(inspect.getsource(PD.File_Processor.process_long_file)))
+    hits = [n for n in ast.walk(tree) if isinstance(n, ast.Constant) and n.value == 15e7]
+    assert len(hits) == 2
+    for h in hits:
+        h.value = max_file
+    ns = dict(PD.__dict__)
+    exec(compile(tree, f'prepare_dataset.py:process_long_file[15e7={max_file}]', 'exec'), ns)
+    return type('File_Processor_small_max', (PD.File_Processor,), {'process_long_file': ns['process_long_file']})
+
+
+def run_reference_long_file(PD, tmpdir):
+    """The real process_long_file on the long-file case.  `soundfile.write` is a stub that stores float data the way
+    libsndfile does by default (16-bit PCM, lrint(x * 32767)): that rule is this build's reading of the third-party
+    library, the split / label-shift / per-split normalisation logic is the reference's own code."""
+    import pandas as pd
+    import types
+    from . import frontend_ref as FR
+    sf = types.ModuleType('soundfile')
+
+    def write(path, data, sr):
+        k = np.clip(np.rint(np.asarray(data, dtype=np.float64) * 32767.0), -32768, 32767).astype(np.int16)
+        synth.write_wav(path, k, sr)
+    sf.write = write
+    sys.modules['soundfile'] = sf
+    PD.soundfile = sf
+    pcm44 = FR.upsample2x_pcm16(synth.clip_pcm16(LONG_CASE['seed'], LONG_CASE['n22']))
+    path = os.path.join(tmpdir, LONG_CASE['name'] + '.wav')
+    synth.write_wav(path, pcm44, 44100)
+    lab = pd.DataFrame(long_case_labels(), columns=['t_start', 't_end', 'f_start', 'f_end', 'species', 'filename', 'bird_id'])
+    cwd = os.getcwd()
+    os.chdir(tmpdir)                                  # the reference writes temp<k>.wav into the working directory
+    try:
+        fp = reference_long_file_processor(PD, LONG_CASE['max_file'])(path, '', lab)
+        out = fp.process_file()
+    finally:
+        os.chdir(cwd)
+    return out
+
+
+def frontend_long_golden(PD, g, tmpdir):
+    img_db, annots = run_reference_long_file(PD, tmpdir)
+    g['longfile.n_split'] = np.array(len(img_db))
+    for k, imgs in enumerate(img_db):
+        g[f'longfile.s{k}.n_img'] = np.array(len(imgs))
+        for i, im in enumerate(imgs):
+            pack(g, f'longfile.s{k}.img{i}', torch.from_numpy(np.asarray(im, dtype=np.float32)), full_limit=0)
+    g['longfile.n_annot'] = np.array(len(annots))
+    for k, a in enumerate(annots):
+        g[f'longfile.a{k}.index'] = np.asarray([int(i) for i in a['index']], dtype=np.int64)
+        g[f'longfile.a{k}.n_boxes'] = np.asarray([len(c) for c in a['coord']], dtype=np.int64)
+        g[f'longfile.a{k}.first_box'] = np.asarray([list(c[0]) for c in a['coord']], dtype=np.int64)
+    print('frontend longfile: splits', [len(x) for x in img_db], 'annotation frames', [len(a) for a in annots])
+
+
 def frontend_golden():
     """The REAL `File_Processor.process_file` (prepare_dataset.py:108-157, 228-294) on small wav files ->
     tests/golden/frontend.npz.  Pins the constants, amp_to_db, the crop, the per-file min/max over chunks, the chunk /
@@ -338,6 +408,7 @@ def frontend_golden():
                 g[f'{name}.annot_index'] = np.asarray([int(i) for i in annots['index']], dtype=np.int64)
                 g[f'{name}.t_end_max'] = np.array(max(r[1] for r in frontend_case_inputs(name, seed, n22, True)[1]))
             print('frontend', name, 'L', int(fp.spectrogram_length), 'windows', len(imgs))
+        frontend_long_golden(PD, g, d)
     np.savez_compressed(os.path.join(OUT, 'frontend.npz'), **g)
 
 

@@ -69,3 +69,25 @@ def test_every_pixel_live_against_the_reference(tmp_path):
         assert len(imgs) == len(ref_imgs)
         for a, b in zip(imgs, ref_imgs):
             assert np.array_equal(a, np.asarray(b, dtype=np.float32))
+
+
+def long_case_oracle(g):
+    c = MG.LONG_CASE
+    pcm44 = FR.upsample2x_pcm16(__import__('birdsoundclassif_amd.synth', fromlist=['x']).clip_pcm16(c['seed'], c['n22']))
+    y = pcm44.astype(np.float32) / np.float32(32768.0)
+    max_l = c['max_file'] - c['max_file'] % FR.FREQ
+    return FR.process_long_waveform(y, max_l, labels=[r[:2] for r in MG.long_case_labels()])
+
+
+def test_oracle_long_file_matches_reference_process_long_file():
+    """prepare_dataset.py:187-225 with the 15e7 limit scaled down: three splits, each normalised and windowed on its own,
+    annotations shifted into the split they START in, their end clipped to the split (which moves the padding of a split's
+    last window, :283-287)."""
+    g = load_golden('frontend.npz')
+    out, kept = long_case_oracle(g)
+    assert len(out) == int(g['longfile.n_split']) == 3
+    for k, imgs in enumerate(out):
+        assert len(imgs) == int(g[f'longfile.s{k}.n_img'])
+        for i, im in enumerate(imgs):
+            assert check_packed(g, f'longfile.s{k}.img{i}', torch.from_numpy(im), atol=0.0) == 0.0
+    assert int(g['longfile.n_annot']) == sum(r is not None for r in kept)

@@ -108,6 +108,68 @@ def test_reflect_pad_mode_matches_the_oracle_switch():
     assert (imgs[:, 0, :, :6] != zero[:, 0, :, :6]).any()
 
 
+def test_other_rates_and_sample_formats(tmp_path):
+    """F1 beyond 16-bit / 22.05 kHz: any rate through the rational polyphase resampler (device result == the oracle's int16
+    signal), 24-bit / float / stereo files as float32 like librosa.load -- whole front end vs the oracle."""
+    import struct
+    from birdsoundclassif_amd import ops
+    from birdsoundclassif_amd.nbm_datasets.prepare_dataset import SpectrogramFrontEnd, File_Processor
+    from test_frontend_oracle import _write_wav
+    fe = SpectrogramFrontEnd('cuda')
+    for sr in (48000, 16000, 32000):
+        pcm = synth.clip_pcm16(30, sr * 2, sr)                      # 2 s at the file's rate
+        x = torch.from_numpy(pcm.astype(np.float32) / np.float32(32768))[None].cuda()
+        kind, n44, (L, M, taps) = fe._source(torch.float32, len(pcm), sr)
+        w = ops.resample_to_wave(x, n44 + 8 - n44 % 4, 0, L, M, taps)[0, :n44].cpu().numpy()
+        ref = FR.resample_to_pcm16(pcm.astype(np.float64) / 32768.0, sr)
+        d = np.abs(np.rint(w * 32768).astype(np.int64) - ref)
+        assert len(ref) == n44 == 88200 and d.max() <= 1 and (d != 0).mean() < 1e-5, (sr, d.max(), (d != 0).mean())
+        p = str(tmp_path / f'r{sr}.wav')
+        synth.write_wav(p, pcm, sr)
+        got, _ = File_Processor(p).process_file()
+        ref_imgs, _ = FR.process_file(p)
+        assert len(got) == len(ref_imgs) == 1 and np.abs(got[0] - ref_imgs[0]).max() < IMG_TOL, sr
+    # 24-bit mono at 44.1 kHz, float32 stereo at 22.05 kHz (averaged, then resampled 1:2 by the generic filter)
+    base = FR.upsample2x_pcm16(synth.clip_pcm16(31))
+    p24 = str(tmp_path / 'a24.wav')
+    _write_wav(p24, 1, 24, 44100, [[int(v) * 256 + 77 for v in base]])
+    pf = str(tmp_path / 'af.wav')
+    a, b = synth.clip_pcm16(32), synth.clip_pcm16(33)
+    _write_wav(pf, 3, 32, 22050, [[float(v) / 32768 for v in a], [float(v) / 32768 * 0.5 for v in b]])
+    for p in (p24, pf):
+        got, _ = File_Processor(p).process_file()
+        ref_imgs, _ = FR.process_file(p)
+        assert len(got) == len(ref_imgs) == 1 and np.abs(got[0] - ref_imgs[0]).max() < IMG_TOL, p
+
+
+def test_long_file_splits_against_the_reference(tmp_path, monkeypatch):
+    """Recordings longer than 1.5e8 samples (here scaled to 250 000): nested per-split outputs of the REAL
+    process_long_file (tests/golden/frontend.npz, 'longfile'), incl. the annotations moved into their split."""
+    import pandas as pd
+    from birdsoundclassif_amd.nbm_datasets.prepare_dataset import SpectrogramFrontEnd, File_Processor
+    from oracle import make_golden as MG
+    g = load_golden('frontend.npz')
+    c = MG.LONG_CASE
+    monkeypatch.setattr(SpectrogramFrontEnd, 'MAX_FILE', c['max_file'])
+    path = str(tmp_path / (c['name'] + '.wav'))
+    synth.write_wav(path, FR.upsample2x_pcm16(synth.clip_pcm16(c['seed'], c['n22'])), 44100)
+    lab = pd.DataFrame(MG.long_case_labels(), columns=['t_start', 't_end', 'f_start', 'f_end', 'species', 'filename', 'bird_id'])
+    img_db, annots = File_Processor(path, '', lab).process_file()
+    assert len(img_db) == int(g['longfile.n_split']) and len(annots) == int(g['longfile.n_annot'])
+    for k, imgs in enumerate(img_db):
+        assert len(imgs) == int(g[f'longfile.s{k}.n_img'])
+        for i, im in enumerate(imgs):
+            check_packed(g, f'longfile.s{k}.img{i}', torch.from_numpy(im), atol=IMG_TOL)
+    for k, a in enumerate(annots):
+        assert [int(i) for i in a['index']] == g[f'longfile.a{k}.index'].tolist()
+        assert [len(cc) for cc in a['coord']] == g[f'longfile.a{k}.n_boxes'].tolist()
+        assert [list(cc[0]) for cc in a['coord']] == g[f'longfile.a{k}.first_box'].tolist()
+    # the detection driver refuses the nested result instead of mis-indexing it
+    from birdsoundclassif_amd import run_detection as RD
+    with pytest.raises(NotImplementedError):
+        RD.run_detection(None, None, path, 'unused')
+
+
 def test_silent_file_is_nan_like_reference():
     from birdsoundclassif_amd.nbm_datasets.prepare_dataset import SpectrogramFrontEnd
     fe = SpectrogramFrontEnd('cuda')
