@@ -101,6 +101,8 @@ SIGNATURES = {
     'nbm_wino_input': [_P, _I, _I, _I, _I, _P, _I, _P],
     'nbm_wino_output': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P],
     'nbm_wino_outgrad': [_P, _I, _I, _I, _I, _P, _P, _I, _P],
+    'nbm_wino_weight': [_P, _P, _I, _I, _I, _I, _P, _P],
+    'nbm_wino_weight_grad': [_P, _P, _I, _I, _I, _P, _P],
     'nbm_wino23_rows': [_P, _I, _I, _I, _I, _P, _P],
     'nbm_wino23_conv_fused': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     'nbm_weighted_sum': [_P, _P, _P, _P, _P, _L, _P],

@@ -329,6 +329,91 @@ __global__ __launch_bounds__(256) void wino43_outgrad_kernel(const float* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Weight-side transforms (once per parameter version in inference, once per optimisation step in training).
+// G [(m+2) x 3]: F(2x2,3x3) with points 0, 1, -1, inf (rows scaled by 1/2 as usual); F(4x4,3x3) with 0, 1, -1, 1/2, -2, inf.
+__constant__ double WG2[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+__constant__ double WG4[6][3] = {{1.0, 0.0, 0.0}, {1.0, 1.0, 1.0}, {1.0, -1.0, 1.0}, {1.0, 0.5, 0.25}, {1.0, -2.0, 4.0},
+                                 {0.0, 0.0, 1.0}};
+
+// g [N][C][3][3] (checkpoint layout) -> U [(m+2)^2][N'][C'] = (G g' G^T)[i][j], float64 arithmetic, one rounding.
+// transposed = 0: g' = g, N' = N, C' = C.  transposed = 1 (weights of the data-gradient convolution): g'[c][n][a][b] =
+// scale[n] g[n][c][2-a][2-b], N' = C, C' = N.
+template <int M>
+__global__ void wino_weight_kernel(const float* __restrict__ g, const float* __restrict__ scale, int N, int C,
+                                   int transposed, float* __restrict__ U) {
+  constexpr int A = M + 2;
+  const long long total = (long long)N * C;
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int n = (int)(idx / C), c = (int)(idx - (long long)n * C);
+    double w[3][3];
+    const double sc = scale ? (double)scale[n] : 1.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const int ia = transposed ? 2 - a : a, ib = transposed ? 2 - b : b;
+        w[a][b] = (double)g[idx * 9 + ia * 3 + ib] * sc;
+      }
+    const int no = transposed ? c : n, co = transposed ? n : c;
+    const int No = transposed ? C : N, Co = transposed ? N : C;
+    double t[A][3];                                     // t = G w
+#pragma unroll
+    for (int i = 0; i < A; ++i)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        double acc = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) acc += (M == 2 ? WG2[i][a] : WG4[i][a]) * w[a][b];
+        t[i][b] = acc;
+      }
+#pragma unroll
+    for (int i = 0; i < A; ++i)
+#pragma unroll
+      for (int j = 0; j < A; ++j) {
+        double acc = 0.0;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc += t[i][b] * (M == 2 ? WG2[j][b] : WG4[j][b]);
+        U[((long long)(i * A + j) * No + no) * Co + co] = (float)acc;
+      }
+  }
+}
+
+// dU [(m+2)^2][N][C] -> dW [N][C][3][3] = row_scale[n] * (G^T dU G)[a][b]   (fp32, fixed summation order)
+template <int M>
+__global__ void wino_weight_grad_kernel(const float* __restrict__ dU, const float* __restrict__ row_scale, int N, int C,
+                                        float* __restrict__ dW) {
+  constexpr int A = M + 2;
+  const long long total = (long long)N * C;
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int n = (int)(idx / C);
+    float u[A][A];
+#pragma unroll
+    for (int i = 0; i < A; ++i)
+#pragma unroll
+      for (int j = 0; j < A; ++j) u[i][j] = dU[(long long)(i * A + j) * total + idx];
+    const float sc = row_scale ? row_scale[n] : 1.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      float t[A];                                       // t[j] = sum_i G[i][a] u[i][j]
+#pragma unroll
+      for (int j = 0; j < A; ++j) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < A; ++i) acc += (float)(M == 2 ? WG2[i][a] : WG4[i][a]) * u[i][j];
+        t[j] = acc;
+      }
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < A; ++j) acc += t[j] * (float)(M == 2 ? WG2[j][b] : WG4[j][b]);
+        dW[idx * 9 + a * 3 + b] = acc * sc;
+      }
+    }
+  }
+}
+
 inline int grid_for(long long n) {
   long long g = (n + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
@@ -376,5 +461,27 @@ extern "C" int nbm_wino_output(const float* M, const float* scale, const float* 
   else
     hipLaunchKernelGGL(wino43_output_kernel, dim3(grid_for(tiles * (N / 2))), dim3(256), 0, (hipStream_t)stream, M, scale, shift,
                        mask, relu, B, H, W, N / 2, y);
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_wino_weight(const float* g, const float* scale, int N, int C, int transposed, int m, float* U, void* stream) {
+  if (!g || !U || N <= 0 || C <= 0 || (m != 2 && m != 4)) return NBM_EINVAL;
+  if (m == 2)
+    hipLaunchKernelGGL(wino_weight_kernel<2>, dim3(grid_for((long long)N * C)), dim3(256), 0, (hipStream_t)stream, g, scale, N, C,
+                       transposed, U);
+  else
+    hipLaunchKernelGGL(wino_weight_kernel<4>, dim3(grid_for((long long)N * C)), dim3(256), 0, (hipStream_t)stream, g, scale, N, C,
+                       transposed, U);
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_wino_weight_grad(const float* dU, const float* row_scale, int N, int C, int m, float* dW, void* stream) {
+  if (!dU || !dW || N <= 0 || C <= 0 || (m != 2 && m != 4)) return NBM_EINVAL;
+  if (m == 2)
+    hipLaunchKernelGGL(wino_weight_grad_kernel<2>, dim3(grid_for((long long)N * C)), dim3(256), 0, (hipStream_t)stream, dU,
+                       row_scale, N, C, dW);
+  else
+    hipLaunchKernelGGL(wino_weight_grad_kernel<4>, dim3(grid_for((long long)N * C)), dim3(256), 0, (hipStream_t)stream, dU,
+                       row_scale, N, C, dW);
   return nbm_launch_status();
 }

@@ -53,45 +53,23 @@ def krsc(weight):
     return _cached(weight, 'krsc', make)
 
 
-# weight-side Winograd matrices G [(m+2) x 3]: F(2x2,3x3) (points 0, 1, -1, inf, rows scaled by 1/2 as usual) and
-# F(4x4,3x3) with points 0, 1, -1, 1/2, -2, inf (the transforms in csrc/winograd.hip are built for the same points)
-_WINO_G = {2: ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0)),
-           4: ((1.0, 0.0, 0.0), (1.0, 1.0, 1.0), (1.0, -1.0, 1.0), (1.0, 0.5, 0.25), (1.0, -2.0, 4.0), (0.0, 0.0, 1.0))}
-_WINO_G_DEV = {}
-
-
-def _wino_g(device, dtype, m=2):
-    """G on the device, uploaded once: a `torch.tensor(..., device=cuda)` per call is a pageable H2D copy, i.e. a stream
-    synchronisation in the middle of the step (the weights change every optimisation step, so the transform reruns)."""
-    key = (str(device), dtype, m)
-    if key not in _WINO_G_DEV:
-        _WINO_G_DEV[key] = torch.tensor(_WINO_G[m], dtype=dtype, device=device)
-    return _WINO_G_DEV[key]
-
-
 def wino23(weight, transposed=False, m=2, scale=None):
-    """Winograd F(m x m, 3x3) weights U[(m+2)^2][N][C] = (G g G^T)[i][j] of a [Cout, Cin, 3, 3] convolution, computed in
-    float64 on the device and rounded once.  `transposed`: the weights of the DATA-GRADIENT convolution (kernel rotated by
-    180 degrees, channel roles swapped): U[..][Cin][Cout]; `scale` [Cout] (transposed only): the FrozenBN scale that
-    multiplies the incoming gradient per output channel, folded into the weights."""
+    """Winograd F(m x m, 3x3) weights U[(m+2)^2][N][C] = (G g G^T)[i][j] of a [Cout, Cin, 3, 3] convolution (`nbm_wino_weight`:
+    float64 arithmetic on the device, rounded once).  `transposed`: the weights of the DATA-GRADIENT convolution (kernel
+    rotated by 180 degrees, channel roles swapped): U[..][Cin][Cout]; `scale` [Cout] (transposed only): the FrozenBN scale
+    that multiplies the incoming gradient per output channel, folded into the weights."""
+    from .. import ops
+
     def make():
-        g = weight.detach().double()
-        if scale is not None:
-            g = g * scale.detach().double().view(-1, 1, 1, 1)
-        if transposed:
-            g = g.flip(2, 3).transpose(0, 1)
-        G = _wino_g(g.device, torch.float64, m)
-        u = torch.einsum('ia,ncab,jb->ijnc', G, g, G)
-        return u.reshape((m + 2) ** 2, g.shape[0], g.shape[1]).float().contiguous()
+        return ops.wino_weight(weight.detach().contiguous(), transposed, m, None if scale is None else scale.detach().contiguous())
     tag = ('wino', m, transposed) if scale is None else ('wino', m, transposed, scale.data_ptr(), scale._version)
     return _cached(weight, tag, make)
 
 
-def wino23_weight_grad(dU, m=2):
-    """dU [(m+2)^2, N, C] (gradient wrt the transformed weights) -> dW [N, C, 3, 3] = G^T dU G."""
-    G = _wino_g(dU.device, torch.float32, m)
-    n, c = dU.shape[1:]
-    return torch.einsum('ia,ijnc,jb->ncab', G, dU.view(m + 2, m + 2, n, c), G)
+def wino23_weight_grad(dU, m=2, row_scale=None):
+    """dU [(m+2)^2, N, C] (gradient wrt the transformed weights) -> dW [N, C, 3, 3] = row_scale[n] G^T dU G."""
+    from .. import ops
+    return ops.wino_weight_grad(dU, m, row_scale)
 
 
 def bn_affine(weight, bias, mean, var, eps, conv_bias=None):

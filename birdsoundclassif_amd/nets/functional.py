@@ -158,7 +158,7 @@ class Bottleneck(Function):
             gw2 = None
             if need[2]:
                 dU, _ = ops.conv3x3_winograd_wgrad(a1, g2, m=m)
-                gw2 = _prep.wino23_weight_grad(dU, m) * s2.view(-1, 1, 1, 1)
+                gw2 = _prep.wino23_weight_grad(dU, m, row_scale=s2)
             g1 = ops.conv3x3_winograd(g2, _prep.wino23(w2, transposed=True, m=m, scale=s2), None, m=m, mask=a1)
         else:
             gw2 = wgrad(g2r, a1, k2, w2, s2, **geom2) if need[2] else None

@@ -183,6 +183,28 @@ def conv3x3_winograd(x, U, bias=None, m=2, scale=None, relu=False, mask=None):
     return y
 
 
+def wino_weight(weight, transposed=False, m=2, scale=None):
+    """[N,C,3,3] -> U [(m+2)^2, N', C'] = G g' G^T (float64 arithmetic on the device, rounded once); `transposed`: the
+    data-gradient convolution's weights (rotated kernel, swapped channel roles, optional per-output-channel `scale`)."""
+    _chk(weight, name='weight')
+    N, C_ = weight.shape[:2]
+    assert tuple(weight.shape[2:]) == (3, 3)
+    No, Co = (C_, N) if transposed else (N, C_)
+    U = torch.empty(((m + 2) ** 2, No, Co), device=weight.device, dtype=torch.float32)
+    check(lib().nbm_wino_weight(_ptr(weight), _ptr(scale), N, C_, int(bool(transposed)), m, _ptr(U), _stream()),
+          'nbm_wino_weight')
+    return U
+
+
+def wino_weight_grad(dU, m=2, row_scale=None):
+    """dU [(m+2)^2, N, C] -> dW [N, C, 3, 3] = row_scale[n] * G^T dU G."""
+    _chk(dU, name='dU')
+    _, N, C_ = dU.shape
+    dW = torch.empty((N, C_, 3, 3), device=dU.device, dtype=torch.float32)
+    check(lib().nbm_wino_weight_grad(_ptr(dU), _ptr(row_scale), N, C_, m, _ptr(dW), _stream()), 'nbm_wino_weight_grad')
+    return dW
+
+
 def conv3x3_winograd_wgrad(x, g, want_bias=False, m=2):
     """Weight gradient of a 3x3 / s1 / p1 convolution in the Winograd domain: x [B,H,W,C] (forward input), g [B,H,W,N]
     (gradient wrt the output) -> (dU [(m+2)^2,N,C] with dU[xi] = dM[xi]^T V[xi], bias gradient [N] or None).  The caller

@@ -89,6 +89,15 @@ int nbm_wino_output(const float* M, const float* scale, const float* shift, cons
  * nbm_conv_wgrad (groups = (m+2)^2) and dW = G^T dU G on the host.  bias_grad [N] (may be NULL): += sum over pixels of g. */
 int nbm_wino_outgrad(const float* g, int B, int H, int W, int N, float* dM, float* bias_grad, int m, void* stream);
 
+/* Weight side of the Winograd convolutions (csrc/winograd.hip).
+ *   nbm_wino_weight:      g [N][C][3][3] (checkpoint layout) -> U [(m+2)^2][N'][C'] = G g' G^T in float64, rounded once.
+ *                         transposed = 0: g' = g.  transposed = 1: the data-gradient convolution's weights, g'[c][n][a][b] =
+ *                         scale[n] g[n][c][2-a][2-b] (kernel rotated by 180 degrees, channel roles swapped, optional
+ *                         per-output-channel FrozenBN scale folded in), N' = C, C' = N.
+ *   nbm_wino_weight_grad: dU [(m+2)^2][N][C] -> dW [N][C][3][3] = row_scale[n] G^T dU G (row_scale optional). */
+int nbm_wino_weight(const float* g, const float* scale, int N, int C, int transposed, int m, float* U, void* stream);
+int nbm_wino_weight_grad(const float* dU, const float* row_scale, int N, int C, int m, float* dW, void* stream);
+
 /* Winograd F(2x2,3x3) forward convolution in two launches (csrc/wino_fused.hip):
  *   nbm_wino23_rows:       x [B][H][W][C] -> R [4][B][TH][WP][C], TH = ceil(H/2), WP = 2 ceil(W/2) + 2: the four row
  *                          combinations (B^T d)_i of every tile row as zero-bordered image rows (2x the input);

@@ -276,3 +276,26 @@ def test_c_abi_from_plain_c(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert 'max |err|' in out.stdout
+
+
+def test_winograd_weight_transform_kernels():
+    """nbm_wino_weight / nbm_wino_weight_grad vs the float64 definition U = G g G^T, dW = G^T dU G (both tile sizes, the
+    rotated / channel-swapped / scaled form of the data-gradient weights, the row scale of the gradient)."""
+    from birdsoundclassif_amd import ops
+    G = {2: torch.tensor([[1.0, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1.0]], dtype=torch.float64),
+         4: torch.tensor([[1.0, 0, 0], [1, 1, 1], [1, -1, 1], [1, 0.5, 0.25], [1, -2, 4], [0, 0, 1.0]], dtype=torch.float64)}
+    w = rnd(('wwt', 1), 96, 160, 3, 3)
+    sc = rnd(('wsc', 1), 96).abs() + 0.5
+    for m in (2, 4):
+        a = m + 2
+        u = ops.wino_weight(w.cuda(), m=m).cpu()
+        ref = torch.einsum('ia,ncab,jb->ijnc', G[m], w.double(), G[m]).reshape(a * a, 96, 160)
+        assert u.shape == ref.shape and torch.equal(u, ref.float())
+        ut = ops.wino_weight(w.cuda(), transposed=True, m=m, scale=sc.cuda()).cpu()
+        gt = (w.double() * sc.double().view(-1, 1, 1, 1)).flip(2, 3).transpose(0, 1)
+        reft = torch.einsum('ia,ncab,jb->ijnc', G[m], gt, G[m]).reshape(a * a, 160, 96)
+        assert (ut.double() - reft).abs().max() <= 1.2e-7 * reft.abs().max()
+        dU = rnd(('wdu', m), a * a, 96, 160)
+        dw = ops.wino_weight_grad(dU.cuda(), m, row_scale=sc.cuda()).cpu()
+        refw = torch.einsum('ia,ijnc,jb->ncab', G[m], dU.double().view(a, a, 96, 160), G[m]) * sc.double().view(-1, 1, 1, 1)
+        assert (dw.double() - refw).abs().max() <= 2e-6 * refw.abs().max()
