@@ -272,3 +272,13 @@ def fill_state_dict(shapes, seed=0):
             v = np.sqrt(gain / fan_in) * normal(name, n, seed)
         out[name] = torch.from_numpy(np.asarray(v, dtype=np.float32).reshape(shape))
     return out
+
+
+def tame_bifpn(sd, factor=0.6):
+    """The filler weights drive a 2-layer BiFPN to O(50) activations: the box regression saturates and the proposal order
+    becomes one big tie.  Scaling every point-wise BiFPN weight by 0.6 keeps the maps O(1..10) (fixtures and tests of the
+    `--fpn bifpn` variant use this)."""
+    for k in sd:
+        if k.startswith('fpn.') and k.endswith('pt_wise.weight'):
+            sd[k] = sd[k] * factor
+    return sd

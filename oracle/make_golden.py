@@ -88,6 +88,8 @@ def variants_golden():
         args = ref_import.default_args(**kw)
         model, _ = ref_import.build_reference_model(args, train=False)
         sd = synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+        if tag == 'bifpn':
+            sd = synth.tame_bifpn(sd)
         model.load_state_dict(sd)
         model.eval()
         x = torch.from_numpy(synth.image_batch(0, 2))[:, None]

@@ -68,4 +68,5 @@ def state_dict_shapes(**overrides):
 
 
 def filler_state_dict(seed=0, **overrides):
-    return synth.fill_state_dict(state_dict_shapes(**overrides), seed)
+    sd = synth.fill_state_dict(state_dict_shapes(**overrides), seed)
+    return synth.tame_bifpn(sd) if overrides.get('fpn') == 'bifpn' else sd

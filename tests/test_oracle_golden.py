@@ -142,10 +142,8 @@ def test_composition_flags_vs_golden(tag, kw):
         o = O.forward_first_stage(sd, cfg, x)
     for i, t in enumerate(o['fpn_out']):
         check_packed(g, f'{tag}.fpn{i}', t, atol=5e-5, rtol=5e-5)
-    check_packed(g, f'{tag}.rpn_cls_scores', o['rpn_cls_scores'], atol=1e-4 if tag == 'bifpn' else 2e-5)
+    check_packed(g, f'{tag}.rpn_cls_scores', o['rpn_cls_scores'], atol=2e-5)
     ref_rois = g[f'{tag}.rois.full'].reshape(g[f'{tag}.rois.shape'])
-    # exact score ties come out of the reference's unstable argsort in an implementation-defined order;
-    # with the filler weights the BiFPN maps are O(50), its regression outputs saturate the box decoder and nearly every
-    # proposal is clipped to the image border: the proposal order is then all ties, so only the tensors are compared
-    if tag != 'bifpn':
-        assert (o['rois'].numpy() != ref_rois).any(-1).mean() <= 0.03
+    # exact score ties come out of the reference's unstable argsort in an implementation-defined order; the
+    # BiFPN variant runs with tamed filler weights (synth.tame_bifpn) so that its proposals are not one big tie
+    assert (o['rois'].numpy() != ref_rois).any(-1).mean() <= 0.03
