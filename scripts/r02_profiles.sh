@@ -17,6 +17,11 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $O/pmc_train_$c -- python3 $R/scripts/trainbench.py 128 2 > $O/pmc_train_$c.log 2>&1
 done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_train_MFMA -- python3 $R/scripts/trainbench.py 128 2 > $O/pmc_train_MFMA.log 2>&1
+# dominant launches: forward = the fused Winograd kernel of fpn.out_convs.4 at B = 64 (2 * 16 * 1540096 * 384 * 256 FLOP),
+# backward = the weight-gradient kernel's largest launch
+python3 $R/scripts/pmc_dominant.py $O/pmc_dominant.json "wino23_fused_kernel" 4844.723 $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_MFMA "fpn.out_convs.4 fused Winograd kernel, one launch = 64 images" > /dev/null
+python3 $R/scripts/pmc_dominant.py $O/pmc_rows.json "wino23_rows_kernel" 0 $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_MFMA "row half of the Winograd input transform of fpn.out_convs.4, 64 images" > /dev/null
+python3 $R/scripts/pmc_dominant.py $O/pmc_wgrad.json "igemm_tn_kernel<128, 0, 0>" 1958.706 $O/pmc_train_FETCH_SIZE $O/pmc_train_WRITE_SIZE $O/pmc_train_MFMA "largest weight-gradient launch: 36 Winograd F(4x4,3x3)-domain TN GEMMs of fpn.out_convs.4, 46 images" > /dev/null
 # per-kernel means of the counters (small text files; the raw csv stays on the box)
 for d in pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_MFMA pmc_train_FETCH_SIZE pmc_train_WRITE_SIZE pmc_train_MFMA; do
   python3 $R/scripts/pmc_summarize.py $O/$d > $O/$d.summary.txt
