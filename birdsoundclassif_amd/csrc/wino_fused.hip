@@ -192,7 +192,8 @@ __global__ __launch_bounds__(256, BN == 128 ? 1 : 2) void wino23_fused_kernel(co
   // kept as loop-carried state instead of being re-derived every step (17.9 ms: the conditional update splits the step's
   // scheduling region); the same state kept per plane in an explicit plane loop with the last two steps of every plane
   // peeled (main loop 15.1 instead of 15.4 ms, but the five inlined step bodies push the allocator into 98-128 spilled
-  // registers around the flush: 17.2 ms).
+  // registers around the flush: 17.2 ms); the step barrier moved between G2 and G3 with the next step's first fragments
+  // fetched under G3's MFMAs (legal with two stages; main loop unchanged at 15.3 ms, 32 spilled registers: 16.6 ms).
   f32x4 fa[2][MT], fb[2][NT];
   auto read_frags = [&](const float* Ab, const float* Bb, int q, int s) {
 #pragma unroll
