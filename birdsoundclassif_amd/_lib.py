@@ -134,6 +134,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    import torch  # noqa: F401  -- first: libnbm_hip.so must bind to the HIP runtime torch has loaded, not to a second copy
     if not os.path.isfile(LIB_PATH):
         raise RuntimeError(f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                            '(the NBM hot path has no CPU / eager fallback)')

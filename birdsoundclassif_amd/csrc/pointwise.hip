@@ -353,7 +353,7 @@ __global__ void pair_softmax_kernel(const float* __restrict__ x, long long n_pix
 
 }  // namespace
 
-extern "C" const char* nbm_version(void) { return "nbm_hip 0.1 (gfx950)"; }
+extern "C" const char* nbm_version(void) { return "nbm_hip 0.2 (gfx950)"; }
 
 extern "C" int nbm_pcm16_to_wave(const int16_t* pcm, int64_t pcm_ld, int batch, int n, int upsample,
                                  const int32_t* hq, int64_t first, int64_t count, float* out, int64_t out_ld, int lead,
