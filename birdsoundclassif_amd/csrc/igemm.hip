@@ -47,8 +47,14 @@ struct IgemmParams {
 // STAGES = 2: the deep-K pipeline (double-buffered LDS, 2 workgroups per CU).  STAGES = 1: short-K layers (K <= 256: 1x1
 // convolutions whose time is output / residual traffic, not MFMA): single LDS buffer (36.8 KB) and an epilogue staged in
 // two halves, so THREE workgroups fit a CU and their load / compute / store phases overlap instead of serialising.
+// K = 64 layers still sit at ~76 TF/s whatever N is (SQ counters: every wave spends 19 % of its 44 k-cycle life in its own
+// MFMAs, 36 % waiting for the matrix pipe behind its two SIMD partners, 28 % in waitcnt / barriers).  Measured and dropped
+// for them (scripts/lateral_probe.py, 64 -> 384 @188x512 x 64: 4.04 ms standalone, 6.45 ms with the merge epilogue):
+// 64-wide tiles at four workgroups per CU (4.19 / 6.05 ms); a persistent workgroup that keeps the weight tile in LDS and
+// has the next pixel tile's loads in flight under the current epilogue (3.99 / 7.96 ms), with or without a start stagger
+// of the two co-resident workgroups (3.85-3.91 ms).
 template <int BM, int BN, int WM, int WN, int AMODE, int EPI, int STAGES = 2>
-__global__ __launch_bounds__(256, STAGES == 1 ? (BN == 64 ? 4 : 3) : 2) void igemm_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_kernel(const IgemmParams p) {
   constexpr int MT = WM / 32, NT = WN / 32;
   constexpr int WAVES_N = BN / WN;
   constexpr int AR = BM / 32, BR = BN / 32;  // rows per thread in the staging pass
@@ -395,12 +401,6 @@ int launch_s1(const IgemmParams& p, int groups, hipStream_t st) {
   return nbm_launch_status();
 }
 
-int launch_s1_n64(const IgemmParams& p, int groups, hipStream_t st) {
-  dim3 grid(p.m_tiles * p.n_tiles, 1, groups);
-  hipLaunchKernelGGL((igemm_kernel<128, 64, 64, 32, A_FAST, EPI_STD, 1>), grid, dim3(256), 0, st, p);
-  return nbm_launch_status();
-}
-
 }  // namespace
 
 extern "C" int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream) {
@@ -441,11 +441,6 @@ extern "C" int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream) {
     p.n_tiles = (d->N + 127) / 128;
     // short K and a 16-byte epilogue: the three-workgroups-per-CU variant (see the template comment)
     static const int shortk_max = getenv("NBM_SHORTK_MAX") ? atoi(getenv("NBM_SHORTK_MAX")) : 8;   // 0 disables
-    static const int shortk_n64 = getenv("NBM_SHORTK_N64") ? atoi(getenv("NBM_SHORTK_N64")) : 0;   // experiment: K-steps <= this use 64-wide tiles
-    if (fast && p.vec_epi && p.nk <= shortk_n64 && d->N % 64 == 0) {
-      p.n_tiles = d->N / 64;
-      return launch_s1_n64(p, d->groups, st);
-    }
     if (fast && p.vec_epi && p.nk <= shortk_max)
       return launch_s1(p, d->groups, st);
     return fast ? launch<128, 128, 64, 64, A_FAST, EPI_STD>(p, d->groups, st)
