@@ -1,0 +1,111 @@
+// Network stem: init_conv (1x1, 1 -> 3 channels, + bias; reference backbone.py:104-105,110-113) folded into torchvision's
+// conv1 (7x7 / stride 2 / pad 3, 3 -> 64) + FrozenBN + ReLU -- one kernel on the single-channel spectrogram image.
+//
+//   u_c = a_c x + b_c inside the image, 0 in conv1's zero padding
+//   z_o(p) = sum_{r,s} (sum_c W[o][c][r][s] a_c) x(p + (r,s)) + sum_{(r,s) inside} (sum_c W[o][c][r][s] b_c)
+//          = sum_k  weff[o][k] x_k(p)                           +  bias_o(p)
+//   y_o = relu(z_o scale_o + shift_o)
+//
+// The generic implicit-GEMM path ran this layer on the 3-channel map with K = 147 padded to 160 through per-element
+// gathers: 2.8 ms at B = 64 (42 TF/s), plus 0.13 ms for init_conv and 0.6 GB of 3-channel traffic.  Here K = 7 rows x 8
+// (7 taps + one zero) = 56: a workgroup owns 128 output pixels of one output row; their 7 x 261 input samples are ONE
+// 7.4 KB LDS image, and lane (pixel p, k-slot) reads its A operand of k-pair j straight from it at a compile-time offset
+// (r * pitch + s0) + 2 p + slot -- no im2col anywhere.  The folded weights [56][64] sit in LDS as the B operand.  bias_o(p)
+// is a per-channel constant for interior pixels and a masked 49-term sum on the three-pixel border.
+#include "nbm_common.h"
+
+namespace {
+
+constexpr int SP = 264;        // LDS pitch of an image row: 2 * 128 + 5 samples, padded
+constexpr int KR = 8;          // k slots per filter row (7 taps + 1 zero)
+constexpr int KK = 7 * KR;     // 56
+
+struct StemParams {
+  const float* img; const float* weff; const float* wb; const float* wb_full; const float* scale; const float* shift;
+  float* y;
+  int B, H, W, Ho, Wo;
+};
+
+__global__ __launch_bounds__(256) void stem7x7_kernel(const StemParams p) {
+  __shared__ __attribute__((aligned(16))) float img_s[7 * SP];
+  __shared__ __attribute__((aligned(16))) float w_s[KK * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ox0 = blockIdx.x * 128, oy = blockIdx.y, b = blockIdx.z;
+
+  // ---- stage: 7 input rows x 261 columns (zeros outside the image), folded weights
+  const int ix0 = 2 * ox0 - 3;
+  for (int i = tid; i < 7 * SP; i += 256) {
+    const int r = i / SP, c = i - r * SP;
+    const int iy = 2 * oy - 3 + r, ix = ix0 + c;
+    float v = 0.f;
+    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c < 261)
+      v = p.img[((long long)b * p.H + iy) * p.W + ix];
+    img_s[i] = v;
+  }
+  for (int i = tid; i < KK * 64 / 4; i += 256)
+    reinterpret_cast<f32x4*>(w_s)[i] = reinterpret_cast<const f32x4*>(p.weff)[i];
+  __syncthreads();
+
+  // ---- 28 k-pairs; wave tile = 32 pixels x 64 channels (two 32x32 accumulators)
+  const int pl = lane & 31, slot = lane >> 5;
+  const float* a_base = img_s + 2 * (wave * 32 + pl) + slot;
+  const float* b_base = w_s + slot * 64 + pl;
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+#pragma unroll
+  for (int j = 0; j < KK / 2; ++j) {
+    constexpr int dummy = 0; (void)dummy;
+    const int r = (2 * j) / KR, s0 = (2 * j) % KR;                  // compile-time after unrolling
+    const float a = a_base[r * SP + s0];                            // slot 1 of the zero column (s = 7) has weight 0
+    const float b0 = b_base[(2 * j) * 64], b1 = b_base[(2 * j) * 64 + 32];
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+  }
+
+  // ---- epilogue.  C/D layout: col (channel) = lane & 31, row (pixel) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+  // Row / column taps inside the image: bit r of rmask, bit s of cmask.
+  unsigned rmask = 0;
+#pragma unroll
+  for (int r = 0; r < 7; ++r)
+    if ((unsigned)(2 * oy - 3 + r) < (unsigned)p.H) rmask |= 1u << r;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int n = 32 * t + pl;
+    const float sc = p.scale[n], sh = p.shift[n], bfull = p.wb_full[n];
+    const f32x16& acc = t == 0 ? acc0 : acc1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int ox = ox0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * slot;
+      if (ox >= p.Wo) continue;
+      unsigned cmask = 0;
+#pragma unroll
+      for (int s = 0; s < 7; ++s)
+        if ((unsigned)(2 * ox - 3 + s) < (unsigned)p.W) cmask |= 1u << s;
+      float bias = bfull;
+      if (rmask != 0x7fu || cmask != 0x7fu) {                       // border pixel: only the taps inside the image
+        bias = 0.f;
+        for (int r = 0; r < 7; ++r)
+          for (int s = 0; s < 7; ++s)
+            if (((rmask >> r) & 1u) && ((cmask >> s) & 1u)) bias += p.wb[n * 49 + r * 7 + s];
+      }
+      const float z = acc[e] + bias;
+      p.y[(((long long)b * p.Ho + oy) * p.Wo + ox) * 64 + n] = fmaxf(z * sc + sh, 0.f);
+    }
+  }
+}
+
+}  // namespace
+
+// y = relu(bn(conv1(init_conv(img)))) -- see nbm_hip.h.
+extern "C" int nbm_stem7x7(const float* img, int B, int H, int W, const float* weff, const float* wb, const float* wb_full,
+                           const float* scale, const float* shift, float* y, void* stream) {
+  if (!img || !weff || !wb || !wb_full || !scale || !shift || !y || B <= 0 || H <= 0 || W <= 0) return NBM_EINVAL;
+  if (!nbm_aligned16(weff)) return NBM_EALIGN;
+  StemParams p{};
+  p.img = img; p.weff = weff; p.wb = wb; p.wb_full = wb_full; p.scale = scale; p.shift = shift; p.y = y;
+  p.B = B; p.H = H; p.W = W; p.Ho = (H + 6 - 7) / 2 + 1; p.Wo = (W + 6 - 7) / 2 + 1;
+  dim3 grid((p.Wo + 127) / 128, p.Ho, B);
+  hipLaunchKernelGGL(stem7x7_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+  return nbm_launch_status();
+}

@@ -25,13 +25,13 @@ def _evict(obj_id):
         _cache.pop(k, None)
 
 
-def _cached(key_t, tag, fn):
+def _cached(key_t, tag, fn, extra=()):
     """Prepared copy of `key_t`.  An entry belongs to ONE tensor object: it keeps a weak reference to it and is only
     valid while that referent is alive and is `key_t` itself -- CPython reuses ids and the caching allocator reuses
     device addresses, so (id, data_ptr, version) alone can match a different model's parameter after the first model was
     freed.  Entries are dropped when their tensor dies (the prepared copies would otherwise leak on the device)."""
     key = (id(key_t), tag)
-    ver = (key_t.data_ptr(), key_t._version, key_t.device, _epoch)
+    ver = (key_t.data_ptr(), key_t._version, key_t.device, _epoch) + tuple(extra)
     hit = _cache.get(key)
     if hit is not None and hit[0]() is key_t and hit[1] == ver:
         return hit[2]
@@ -70,6 +70,20 @@ def wino23_weight_grad(dU, m=2, row_scale=None):
     """dU [(m+2)^2, N, C] (gradient wrt the transformed weights) -> dW [N, C, 3, 3] = row_scale[n] G^T dU G."""
     from .. import ops
     return ops.wino_weight_grad(dU, m, row_scale)
+
+
+def stem_fold(w1, w_init, b_init):
+    """Operands of `nbm_stem7x7`: init_conv (1 -> 3 channels, weight a_c, bias b_c) folded into conv1 [64,3,7,7], in float64:
+    weff [56,64] (k = 8 r + s, the s = 7 column zero) = sum_c W1 a_c; wb [64,49] = sum_c W1 b_c; wb_full [64] = wb.sum(1)."""
+    def make():
+        w = w1.detach().double()
+        a, b = w_init.detach().double().view(3), b_init.detach().double().view(3)
+        we = (w * a.view(1, 3, 1, 1)).sum(1)                       # [64,7,7]
+        wb = (w * b.view(1, 3, 1, 1)).sum(1)
+        weff = torch.zeros((7, 8, 64), dtype=torch.float64, device=w.device)
+        weff[:, :7] = we.permute(1, 2, 0)
+        return (weff.view(56, 64).float().contiguous(), wb.reshape(64, 49).float().contiguous(), wb.sum((1, 2)).float().contiguous())
+    return _cached(w1, 'stem', make, extra=(w_init.data_ptr(), w_init._version, b_init.data_ptr(), b_init._version))
 
 
 def bn_affine(weight, bias, mean, var, eps, conv_bias=None):

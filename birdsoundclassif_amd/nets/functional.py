@@ -33,6 +33,7 @@ def _w_to_ref_layout(gw, weight):
     return gw[:, :kh * kw * c].view(n, kh, kw, c).permute(0, 3, 1, 2)
 
 
+STEM_FOLDED = True       # init_conv folded into conv1 (csrc/stem.hip); False: init_conv kernel + generic implicit GEMM
 WINOGRAD = True          # module switch for A/B tests (tests/test_gpu_e2e.py compares both convolution paths)
 WINO_BWD_TILE = 4        # F(4x4,3x3) for the two backward convolutions (gradients tolerate its 2e-5 error); 2 = F(2x2,3x3)
 
@@ -296,8 +297,11 @@ class Stem(Function):
 
     @staticmethod
     def forward(ctx, x, w_init, b_init, w1, scale, shift):
-        y0 = ops.init_conv(x, w_init.detach(), b_init.detach())
-        y = ops.conv2d(y0, _prep.krsc(w1), 7, 7, 2, 3, scale=scale, shift=shift, act=ACT_RELU)
+        if STEM_FOLDED and w1.shape[0] == 64 and x.shape[-1] == 1:
+            y = ops.stem7x7(x, *_prep.stem_fold(w1, w_init, b_init), scale, shift)      # one kernel on the 1-channel image
+        else:
+            y0 = ops.init_conv(x, w_init.detach(), b_init.detach())
+            y = ops.conv2d(y0, _prep.krsc(w1), 7, 7, 2, 3, scale=scale, shift=shift, act=ACT_RELU)
         ctx.save_for_backward(x, w_init, b_init, w1, scale, y)
         return y
 

@@ -337,6 +337,18 @@ def init_conv(x, w, b):
     return y
 
 
+def stem7x7(img, weff, wb, wb_full, scale, shift):
+    """img [B,H,W,1] (or [B,H,W]) -> relu(scale * conv7x7/s2/p3(init_conv(img)) + shift) [B,Ho,Wo,64]; the folded operands
+    come from `_prep.stem_fold`."""
+    _chk(img, name='img')
+    B, H, W = img.shape[:3]
+    assert img.numel() == B * H * W and tuple(weff.shape) == (56, 64)
+    y = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64), device=img.device, dtype=torch.float32)
+    check(lib().nbm_stem7x7(_ptr(img), B, H, W, _ptr(_chk(weff)), _ptr(_chk(wb)), _ptr(_chk(wb_full)), _ptr(_chk(scale)),
+                            _ptr(_chk(shift)), _ptr(y), _stream()), 'nbm_stem7x7')
+    return y
+
+
 def maxpool3x3s2(x, with_index=False):
     """-> y, or (y, idx uint8 [B,Ho,Wo,C]: window position of each maximum, for `maxpool3x3s2_bwd`)."""
     _chk(x, name='x')

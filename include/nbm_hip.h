@@ -166,6 +166,14 @@ int nbm_spec_windows(const float* db, int64_t db_bs, int db_ld, int batch, int n
 /* y[p][c] = x[p]*w[c] + b[c]  -- BackboneBase.init_conv (backbone.py:104-105,110-113), 1 -> C. */
 int nbm_init_conv(const float* x, int64_t n_pix, const float* w, const float* b, int C, float* y, void* stream);
 
+/* Network stem in one kernel (csrc/stem.hip): y [B][Ho][Wo][64] = relu(scale * conv7x7_s2_p3(init_conv(img)) + shift) on the
+ * single-channel image img [B][H][W]: BackboneBase.init_conv (1x1, 1 -> 3, + bias; backbone.py:104-105,110-113) folded into
+ * torchvision's conv1 + FrozenBN + ReLU (backbone.py:131).  weff [56][64]: k = 8 r + s (s = 7: zero), weff[k][o] =
+ * sum_c W1[o][c][r][s] w_init[c]; wb [64][49] = sum_c W1[o][c][r][s] b_init[c] (summed over the taps INSIDE the image for
+ * border pixels), wb_full [64] its sum over all 49 taps (prepared by nets/_prep.py:stem_fold). */
+int nbm_stem7x7(const float* img, int B, int H, int W, const float* weff, const float* wb, const float* wb_full,
+                const float* scale, const float* shift, float* y, void* stream);
+
 /* 3x3 / stride 2 / pad 1 max pooling -- torchvision ResNet `maxpool` (backbone.py:131).  idx (may be NULL; training):
  * one byte per output element = r*3+s of the first maximum in scan order, consumed by nbm_maxpool3x3s2_bwd. */
 int nbm_maxpool3x3s2(const float* x, int B, int H, int W, int C, float* y, int Ho, int Wo, uint8_t* idx, void* stream);

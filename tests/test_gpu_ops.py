@@ -142,6 +142,22 @@ def test_dwconv(cfg):
         assert_close(nchw(got2), ref2, 4e-6, 4e-6, f'dwconv film {cfg}')
 
 
+@pytest.mark.parametrize('shape', [(2, 9, 11), (1, 37, 300), (2, 375, 1024), (1, 8, 257)])
+def test_stem7x7_folded(shape):
+    """csrc/stem.hip: init_conv folded into conv1 + FrozenBN + ReLU vs torch on the 3-channel map (borders: the init_conv
+    bias is only present inside the image)."""
+    from birdsoundclassif_amd.nets import _prep
+    B, H, W = shape
+    x = rnd(('st', shape), B, 1, H, W)
+    wi, bi = rnd('stw', 3, 1, 1, 1), rnd('stb', 3)
+    w1 = rnd('stw1', 64, 3, 7, 7, scale=0.1)
+    sc, sh = rnd('stsc', 64).abs() + 0.5, rnd('stsh', 64, scale=0.2)
+    ref = F.relu(F.conv2d(F.conv2d(x.double(), wi.double(), bi.double()), w1.double(), None, 2, 3) * sc.double().view(1, -1, 1, 1)
+                 + sh.double().view(1, -1, 1, 1)).float()
+    got = ops.stem7x7(nhwc(x), *_prep.stem_fold(dev(w1), dev(wi), dev(bi)), dev(sc), dev(sh))
+    assert_close(nchw(got), ref, 2e-5, 2e-5, f'stem7x7 {shape}')
+
+
 def test_init_conv():
     x = rnd('ic', 2, 1, 9, 11)
     w = rnd('icw', 3, 1, 1, 1)
