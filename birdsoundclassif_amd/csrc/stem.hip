@@ -19,6 +19,8 @@ namespace {
 constexpr int SP = 264;        // LDS pitch of an image row: 2 * 128 + 5 samples, padded
 constexpr int KR = 8;          // k slots per filter row (7 taps + 1 zero)
 constexpr int KK = 7 * KR;     // 56
+constexpr int OP = 68;         // LDS pitch of an output pixel (64 channels + 4)
+static_assert(7 * SP + KK * 64 <= 128 * OP, "operands must fit the output tile");
 
 struct StemParams {
   const float* img; const float* weff; const float* wb; const float* wb_full; const float* scale; const float* shift;
@@ -27,8 +29,11 @@ struct StemParams {
 };
 
 __global__ __launch_bounds__(256) void stem7x7_kernel(const StemParams p) {
-  __shared__ __attribute__((aligned(16))) float img_s[7 * SP];
-  __shared__ __attribute__((aligned(16))) float w_s[KK * 64];
+  // one LDS block: image rows + folded weights during the MFMA loop, then the [128 pixels][64 channels] output tile
+  __shared__ __attribute__((aligned(16))) float smem[128 * OP];
+  float* img_s = smem;
+  float* w_s = smem + 7 * SP;
+  __shared__ float cb_s[64 * 8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ox0 = blockIdx.x * 128, oy = blockIdx.y, b = blockIdx.z;
 
@@ -44,6 +49,22 @@ __global__ __launch_bounds__(256) void stem7x7_kernel(const StemParams p) {
   }
   for (int i = tid; i < KK * 64 / 4; i += 256)
     reinterpret_cast<f32x4*>(w_s)[i] = reinterpret_cast<const f32x4*>(p.weff)[i];
+  // init_conv bias seen through the filter rows inside the image: cb_s[n][s] = sum_{r inside} wb[n][r][s] (only workgroups
+  // on the image border read it)
+  unsigned rmask = 0;
+#pragma unroll
+  for (int r = 0; r < 7; ++r)
+    if ((unsigned)(2 * oy - 3 + r) < (unsigned)p.H) rmask |= 1u << r;
+  const bool row_border = rmask != 0x7fu;
+  const bool col_border = ox0 < 2 || 2 * (ox0 + 127) + 3 >= p.W;
+  if (row_border || col_border)
+    for (int i = tid; i < 64 * 7; i += 256) {
+      const int n = i / 7, sx = i - n * 7;
+      float a = 0.f;
+      for (int r = 0; r < 7; ++r)
+        if ((rmask >> r) & 1u) a += p.wb[n * 49 + r * 7 + sx];
+      cb_s[n * 8 + sx] = a;
+    }
   __syncthreads();
 
   // ---- 28 k-pairs; wave tile = 32 pixels x 64 channels (two 32x32 accumulators)
@@ -64,34 +85,41 @@ __global__ __launch_bounds__(256) void stem7x7_kernel(const StemParams p) {
   }
 
   // ---- epilogue.  C/D layout: col (channel) = lane & 31, row (pixel) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
-  // Row / column taps inside the image: bit r of rmask, bit s of cmask.
-  unsigned rmask = 0;
-#pragma unroll
-  for (int r = 0; r < 7; ++r)
-    if ((unsigned)(2 * oy - 3 + r) < (unsigned)p.H) rmask |= 1u << r;
+  // Row / column taps inside the image: bit r of rmask, bit s of cmask.  Values go through LDS so that every lane stores
+  // 4 channels (16 bytes) and a wave-instruction covers 4 whole pixels = 1 KB contiguous.
+  __syncthreads();                                                  // every wave is done with img_s / w_s
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int n = 32 * t + pl;
-    const float sc = p.scale[n], sh = p.shift[n], bfull = p.wb_full[n];
+    const float sc = p.scale[n], sh = p.shift[n];
+    float bfull = p.wb_full[n];
+    if (row_border) {
+      bfull = 0.f;
+#pragma unroll
+      for (int s = 0; s < 7; ++s) bfull += cb_s[n * 8 + s];
+    }
     const f32x16& acc = t == 0 ? acc0 : acc1;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      const int ox = ox0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * slot;
-      if (ox >= p.Wo) continue;
-      unsigned cmask = 0;
-#pragma unroll
-      for (int s = 0; s < 7; ++s)
-        if ((unsigned)(2 * ox - 3 + s) < (unsigned)p.W) cmask |= 1u << s;
+      const int px = wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * slot;
+      const int ox = ox0 + px;
       float bias = bfull;
-      if (rmask != 0x7fu || cmask != 0x7fu) {                       // border pixel: only the taps inside the image
+      if (col_border && (ox < 2 || 2 * ox + 3 >= p.W)) {            // only the columns inside the image
         bias = 0.f;
-        for (int r = 0; r < 7; ++r)
-          for (int s = 0; s < 7; ++s)
-            if (((rmask >> r) & 1u) && ((cmask >> s) & 1u)) bias += p.wb[n * 49 + r * 7 + s];
+#pragma unroll
+        for (int s = 0; s < 7; ++s)
+          if ((unsigned)(2 * ox - 3 + s) < (unsigned)p.W) bias += cb_s[n * 8 + s];
       }
-      const float z = acc[e] + bias;
-      p.y[(((long long)b * p.Ho + oy) * p.Wo + ox) * 64 + n] = fmaxf(z * sc + sh, 0.f);
+      smem[px * OP + n] = fmaxf((acc[e] + bias) * sc + sh, 0.f);
     }
+  }
+  __syncthreads();
+  float* yrow = p.y + (((long long)b * p.Ho + oy) * p.Wo + ox0) * 64;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int px = it * 16 + (tid >> 4), c4 = (tid & 15) * 4;
+    if (ox0 + px < p.Wo)
+      *reinterpret_cast<f32x4*>(yrow + px * 64 + c4) = *reinterpret_cast<const f32x4*>(smem + px * OP + c4);
   }
 }
 

@@ -344,8 +344,16 @@ def stem7x7(img, weff, wb, wb_full, scale, shift):
     B, H, W = img.shape[:3]
     assert img.numel() == B * H * W and tuple(weff.shape) == (56, 64)
     y = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64), device=img.device, dtype=torch.float32)
+    if FLOPS is not None:
+        FLOPS[0] += 2.0 * y.numel() * 56
+    if PROFILE is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     check(lib().nbm_stem7x7(_ptr(img), B, H, W, _ptr(_chk(weff)), _ptr(_chk(wb)), _ptr(_chk(wb_full)), _ptr(_chk(scale)),
                             _ptr(_chk(shift)), _ptr(y), _stream()), 'nbm_stem7x7')
+    if PROFILE is not None:
+        ev[1].record()
+        PROFILE.append(((1, 64, 7, H, W, B, 1, 2, None), *ev))
     return y
 
 
