@@ -225,23 +225,31 @@ struct RoiParams {
   float* pool; float* pe; int* level;
 };
 
+// Pyramid level and feature-map window of one RoI, layers.py:408-417 (sizes WITHOUT the +1), :424-427 (round), :450-462
+// (y2 clamp, growth to at least 2 x 2).  The rows read are y1..y2, the columns x1..min(x2, W-1).
+__device__ __forceinline__ void roi_window(const float* roi, int n_levels, const int* fh, const int* fw, int& lvl, int& x1,
+                                           int& y1, int& x2, int& y2) {
+  const float size = sqrtf((roi[2] - roi[0]) * (roi[3] - roi[1]));
+  const float lf = logf(size * 0.1f) / 0.6931471805599453f;
+  lvl = (lf != lf) ? (int)0x80000000 : (lf <= -2147483648.f ? (int)0x80000000 : (lf >= 2147483648.f ? (int)0x80000000 : (int)lf));
+  lvl = min(max(lvl, 0), n_levels - 1);
+  const float stride = (float)(2 << lvl);
+  x1 = (int)rintf(roi[0] / stride); y1 = (int)rintf(roi[1] / stride);
+  x2 = (int)rintf(roi[2] / stride); y2 = (int)rintf(roi[3] / stride);
+  const int H = fh[lvl], W = fw[lvl];
+  y2 = min(y2, H - 1);
+  while (y2 - y1 + 1 < 2) { y1 = max(0, y1 - 1); y2 = min(H - 1, y2 + 1); }
+  while (x2 - x1 + 1 < 2) { x1 = max(0, x1 - 1); x2 = min(W - 1, x2 + 1); }
+}
+
 __global__ void roi_pool_kernel(const RoiParams p) {
   const int slot = blockIdx.x;                 // b * roi_cap + r
   const int b = slot / p.roi_cap, r = slot - b * p.roi_cap;
   if (r >= p.n_roi[0]) return;
   const float* roi = p.rois + (long long)slot * 4;
-  // level assignment, layers.py:408-417 (sizes WITHOUT the +1)
-  const float size = sqrtf((roi[2] - roi[0]) * (roi[3] - roi[1]));
-  const float lf = logf(size * 0.1f) / 0.6931471805599453f;
-  int lvl = (lf != lf) ? (int)0x80000000 : (lf <= -2147483648.f ? (int)0x80000000 : (lf >= 2147483648.f ? (int)0x80000000 : (int)lf));
-  lvl = min(max(lvl, 0), p.n_levels - 1);
-  const float stride = (float)(2 << lvl);
-  int x1 = (int)rintf(roi[0] / stride), y1 = (int)rintf(roi[1] / stride);
-  int x2 = (int)rintf(roi[2] / stride), y2 = (int)rintf(roi[3] / stride);
+  int lvl, x1, y1, x2, y2;
+  roi_window(roi, p.n_levels, p.fh, p.fw, lvl, x1, y1, x2, y2);
   const int H = p.fh[lvl], W = p.fw[lvl];
-  y2 = min(y2, H - 1);
-  while (y2 - y1 + 1 < 2) { y1 = max(0, y1 - 1); y2 = min(H - 1, y2 + 1); }
-  while (x2 - x1 + 1 < 2) { x1 = max(0, x1 - 1); x2 = min(W - 1, x2 + 1); }
   if (threadIdx.x == 0) p.level[slot] = lvl;
   const int C = p.C, half = C >> 1;
   const float* fm = p.fmap[lvl];
@@ -288,6 +296,72 @@ __global__ void roi_pool_kernel(const RoiParams p) {
       }
     }
   }
+}
+
+// ------------------------------------------------------------------ demand-driven pyramid level: tiles under the RoIs
+// The finest FPN output map is read by two consumers only: the RPN's stride-8 depthwise convolution (a fixed pixel pattern)
+// and the RoI pooling of the RoIs assigned to that level.  This kernel lists the 2 x 2 Winograd output tiles of level `level`
+// that the RoI windows touch (minus the tiles in `skip`, which the fixed pattern has computed already): one workgroup per
+// image, an LDS bitmap, then an ordered compaction into 128-entry blocks (entries = b * TH * TW + ty * TW + tx, ascending,
+// -1 padded, a block never mixes images); blocks are handed out by an atomic counter, so the filled blocks are the leading
+// *n_blocks ones of `tiles` (capacity B * ceil(TH * TW / 128) blocks: cannot overflow).
+struct RoiTilesParams {
+  const float* rois; const int* n_roi; int B, roi_cap, n_levels, level; int fh[5], fw[5];
+  const unsigned char* skip; int* tiles; int* n_blocks;
+};
+
+__global__ __launch_bounds__(256) void roi_tiles_kernel(const RoiTilesParams p) {
+  extern __shared__ unsigned bits[];
+  __shared__ int part[256];
+  __shared__ int base_s;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int H = p.fh[p.level], W = p.fw[p.level];
+  const int TH = (H + 1) >> 1, TW = (W + 1) >> 1, THW = TH * TW;
+  const int n_words = (THW + 31) >> 5;
+  for (int i = tid; i < n_words; i += 256) bits[i] = 0u;
+  __syncthreads();
+  const int n = min(p.n_roi[0], p.roi_cap);
+  for (int r = tid; r < n; r += 256) {
+    int lvl, x1, y1, x2, y2;
+    roi_window(p.rois + ((long long)b * p.roi_cap + r) * 4, p.n_levels, p.fh, p.fw, lvl, x1, y1, x2, y2);
+    if (lvl != p.level) continue;
+    const int ty0 = max(y1, 0) >> 1, ty1 = min(y2, H - 1) >> 1, tx0 = max(x1, 0) >> 1, tx1 = min(x2, W - 1) >> 1;
+    for (int ty = ty0; ty <= ty1; ++ty)
+      for (int tx = tx0; tx <= tx1; ++tx) {
+        const int id = ty * TW + tx;
+        if (p.skip && p.skip[id]) continue;
+        atomicOr(&bits[id >> 5], 1u << (id & 31));
+      }
+  }
+  __syncthreads();
+  // ordered compaction: thread t owns the words [t * wpt, (t + 1) * wpt)
+  const int wpt = (n_words + 255) / 256;
+  int cnt = 0;
+  for (int i = tid * wpt; i < min((tid + 1) * wpt, n_words); ++i) cnt += __popc(bits[i]);
+  part[tid] = cnt;
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int i = 0; i < 256; ++i) { const int c = part[i]; part[i] = run; run += c; }
+    base_s = run ? atomicAdd(p.n_blocks, (run + 127) >> 7) : 0;
+    part[0] = 0;
+    bits[n_words] = (unsigned)run;                               // total, one spare word
+  }
+  __syncthreads();
+  const int total = (int)bits[n_words];
+  if (!total) return;
+  int* out = p.tiles + (long long)base_s * 128;
+  int o = part[tid];
+  for (int i = tid * wpt; i < min((tid + 1) * wpt, n_words); ++i) {
+    unsigned wbits = bits[i];
+    while (wbits) {
+      const int bit = __ffs(wbits) - 1;
+      wbits &= wbits - 1;
+      out[o++] = b * THW + (i << 5) + bit;
+    }
+  }
+  const int padded = ((total + 127) >> 7) << 7;
+  for (int i = total + tid; i < padded; i += 256) out[i] = -1;
 }
 
 // ------------------------------------------------------------------ FastRCNN eval post-processing
@@ -450,6 +524,29 @@ extern "C" int nbm_roi_pool(const nbm_roi_desc* d, void* stream) {
   p.pe_f = d->pe_f; p.pe_t = d->pe_t; p.img_h = d->img_h; p.img_w = d->img_w;
   p.pool = d->pool; p.pe = d->pe; p.level = d->level;
   hipLaunchKernelGGL(roi_pool_kernel, dim3(d->B * d->roi_cap), dim3(256), 0, (hipStream_t)stream, p);
+  return nbm_launch_status();
+}
+
+// RoI windows of pyramid level `level` -> list of the 2 x 2 output tiles they touch -- see nbm_hip.h.
+extern "C" int nbm_roi_tiles(const float* rois, const int* n_roi, int B, int roi_cap, int n_levels, int level,
+                             const int* fh, const int* fw, const unsigned char* skip, int* tiles, int* n_blocks,
+                             void* stream) {
+  if (!rois || !n_roi || !fh || !fw || !tiles || !n_blocks || B <= 0 || roi_cap <= 0 || n_levels < 1 || n_levels > 5 ||
+      level < 0 || level >= n_levels)
+    return NBM_EINVAL;
+  RoiTilesParams p{};
+  for (int i = 0; i < n_levels; ++i) {
+    if (fh[i] < 2 || fw[i] < 2) return NBM_EINVAL;
+    p.fh[i] = fh[i]; p.fw[i] = fw[i];
+  }
+  p.rois = rois; p.n_roi = n_roi; p.B = B; p.roi_cap = roi_cap; p.n_levels = n_levels; p.level = level;
+  p.skip = skip; p.tiles = tiles; p.n_blocks = n_blocks;
+  const int thw = ((fh[level] + 1) >> 1) * ((fw[level] + 1) >> 1);
+  const size_t lds = (size_t)(((thw + 31) >> 5) + 1) * 4;
+  if (lds > 60000) return NBM_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(n_blocks, 0, sizeof(int), st) != hipSuccess) return (int)hipGetLastError();
+  hipLaunchKernelGGL(roi_tiles_kernel, dim3(B), dim3(256), lds, st, p);
   return nbm_launch_status();
 }
 

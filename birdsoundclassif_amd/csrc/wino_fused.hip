@@ -42,6 +42,10 @@ struct WinoFusedParams {
   int T, N, C, nk;
   int H, W, TH, TW, THW, WP;
   int m_tiles, n_tiles, relu;
+  // Optional tile list (demand-driven evaluation, see nbm_wino23_conv_fused_tiles): m_tiles * 128 entries, entry = linear
+  // tile id (b * THW + ty * TW + tx) ascending inside a 128-entry block, or -1 (only at the end of a block).  n_blocks
+  // (device, optional): number of leading blocks that are filled; the other workgroups exit at once.
+  const int* tiles; const int* n_blocks;
 };
 
 // x [B][H][W][C] -> R [4][B][TH][WP][C], WP = 2 TW + 2: R[i][b][ty][x + 1] = sum_a BT[i][a] x[b][2ty - 1 + a][x] with
@@ -73,6 +77,44 @@ __global__ __launch_bounds__(256) void wino23_rows_kernel(const float* __restric
   }
 }
 
+// The same row transform for listed tiles only: entry e of `tiles` (linear tile id or -1) gets the four columns
+// xp = 2 tx .. 2 tx + 3 of its tile row written in all four row-combination images.  Neighbouring listed tiles write their two
+// shared columns twice (same values).  n_blocks (device, optional) = number of leading 128-entry blocks that are filled.
+__global__ __launch_bounds__(256) void wino23_rows_tiles_kernel(const float* __restrict__ x, int B, int H, int W, int C4,
+                                                                int TH, int TW, int WP, const int* __restrict__ tiles,
+                                                                int n_entries, const int* __restrict__ n_blocks,
+                                                                float* __restrict__ R) {
+  const long long per_plane = (long long)B * TH * WP * C4;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  f32x4* r4 = reinterpret_cast<f32x4*>(R);
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  if (n_blocks) n_entries = min(n_entries, *n_blocks * BM);
+  const long long total = (long long)n_entries * 4 * C4;
+  for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % C4);
+    const long long t = idx / C4;
+    const int k = (int)(t & 3), e = (int)(t >> 2);
+    const int id = tiles[e];
+    if (id < 0) continue;
+    const int THW = TH * TW;
+    const int b = id / THW, rem = id - b * THW;
+    const int ty = rem / TW, tx = rem - ty * TW;
+    const int xp = 2 * tx + k, ix = xp - 1;
+    f32x4 d[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int iy = 2 * ty - 1 + a;
+      const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      d[a] = ok ? x4[(((long long)b * H + iy) * W + ix) * C4 + c] : zero;
+    }
+    const long long o = (((long long)b * TH + ty) * WP + xp) * C4 + c;
+    r4[o] = d[0] - d[2];
+    r4[o + per_plane] = d[1] + d[2];
+    r4[o + 2 * per_plane] = d[2] - d[1];
+    r4[o + 3 * per_plane] = d[1] - d[3];
+  }
+}
+
 // ABL: timing-only ablations for scripts/wino_fused_probe.py (results are wrong): 1 = no flush, 2 = no epilogue,
 // 4 = every workgroup reads the same L2-resident A tile
 template <int BN, int WN, int ABL = 0>
@@ -95,6 +137,12 @@ __global__ __launch_bounds__(256, BN == 128 ? 1 : 2) void wino23_fused_kernel(co
   const int tile_m = wg / p.n_tiles, tile_n = wg - tile_m * p.n_tiles;
   const int bm0 = tile_m * BM, bn0 = tile_n * BN;
 
+  if (p.tiles) {                                   // uniform per workgroup
+    if (p.n_blocks && tile_m >= *p.n_blocks) return;
+    if (p.tiles[bm0] < 0) return;
+  }
+  auto tile_of = [&](int t) { return p.tiles ? p.tiles[t] : t; };     // t < p.T checked by the callers
+
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
   const int lrow = lane & 31, lh = lane >> 5;
@@ -105,15 +153,15 @@ __global__ __launch_bounds__(256, BN == 128 ? 1 : 2) void wino23_fused_kernel(co
   unsigned a_rel[AR], b_rel[BR];
   long long blk_base;
   {
-    const int t = bm0 < p.T ? bm0 : 0;
+    const int t = bm0 < p.T ? tile_of(bm0) : 0;
     const int bi = t / p.THW, rem = t - bi * p.THW;
     const int ty = rem / p.TW, tx = rem - ty * p.TW;
     blk_base = (((long long)bi * p.TH + ty) * p.WP + 2 * tx) * p.C;
   }
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
-    const int t = bm0 + r0 + 32 * i;
-    if (t < p.T) {
+    const int t = bm0 + r0 + 32 * i < p.T ? tile_of(bm0 + r0 + 32 * i) : -1;
+    if (t >= 0) {
       const int bi = t / p.THW, rem = t - bi * p.THW;
       const int ty = rem / p.TW, tx = rem - ty * p.TW;
       const long long off = (((long long)bi * p.TH + ty) * p.WP + 2 * tx) * p.C - blk_base;   // rows ascend with t
@@ -326,9 +374,9 @@ __global__ __launch_bounds__(256, BN == 128 ? 1 : 2) void wino23_fused_kernel(co
   // (odd sizes: the last tile row / column is half outside) -- computed once, the four passes only look it up
   long long* row_pix = reinterpret_cast<long long*>(lds + BM * CP);          // [BM]; BM * CP * 4 is a multiple of 16
   if (tid < BM) {
-    const int t = bm0 + tid;
+    const int t = bm0 + tid < p.T ? tile_of(bm0 + tid) : -1;
     long long v = -1;
-    if (t < p.T) {
+    if (t >= 0) {
       const int bi = t / p.THW, rem = t - bi * p.THW;
       const int ty = rem / p.TW, tx = rem - ty * p.TW;
       const long long pix = ((long long)bi * p.H + 2 * ty) * p.W + 2 * tx;
@@ -398,10 +446,44 @@ extern "C" int nbm_wino23_rows(const float* x, int B, int H, int W, int C, float
   return nbm_launch_status();
 }
 
+// Row transform of the listed tiles only -- see nbm_hip.h.
+extern "C" int nbm_wino23_rows_tiles(const float* x, int B, int H, int W, int C, const int* tiles, int n_entries,
+                                     const int* n_blocks, float* R, void* stream) {
+  if (!x || !R || !tiles || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || n_entries < 0) return NBM_EINVAL;
+  if (!nbm_aligned16(x) || !nbm_aligned16(R)) return NBM_EALIGN;
+  if (n_entries == 0) return NBM_OK;
+  const int TH = (H + 1) >> 1, TW = (W + 1) >> 1, WP = 2 * TW + 2;
+  const long long n = (long long)n_entries * 4 * (C / 4);
+  long long g = (n + 255) / 256;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(wino23_rows_tiles_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, B, H, W, C / 4, TH, TW,
+                     WP, tiles, n_entries, n_blocks, R);
+  return nbm_launch_status();
+}
+
+static int wino23_conv_fused_launch(const float* R, const float* U, const float* scale, const float* shift,
+                                    const float* mask, int relu, int B, int H, int W, int C, int N, float* y,
+                                    const int* tiles, int n_entries, const int* n_blocks, int variant, void* stream);
+
 // y = epi(conv3x3(x)) from the row-transformed input R [4][B][TH][WP][C] and the weights U [16][N][C] -- see nbm_hip.h.
 extern "C" int nbm_wino23_conv_fused(const float* R, const float* U, const float* scale, const float* shift,
                                      const float* mask, int relu, int B, int H, int W, int C, int N, float* y,
                                      int variant, void* stream) {
+  return wino23_conv_fused_launch(R, U, scale, shift, mask, relu, B, H, W, C, N, y, nullptr, 0, nullptr, variant, stream);
+}
+
+// The same for the listed tiles only (pixels of y outside the listed tiles are not written) -- see nbm_hip.h.
+extern "C" int nbm_wino23_conv_fused_tiles(const float* R, const float* U, const float* scale, const float* shift,
+                                           const float* mask, int relu, int B, int H, int W, int C, int N, float* y,
+                                           const int* tiles, int n_entries, const int* n_blocks, void* stream) {
+  if (!tiles || n_entries < 0 || (n_entries % BM)) return NBM_EINVAL;
+  if (n_entries == 0) return NBM_OK;
+  return wino23_conv_fused_launch(R, U, scale, shift, mask, relu, B, H, W, C, N, y, tiles, n_entries, n_blocks, 0, stream);
+}
+
+static int wino23_conv_fused_launch(const float* R, const float* U, const float* scale, const float* shift,
+                                    const float* mask, int relu, int B, int H, int W, int C, int N, float* y,
+                                    const int* tiles, int n_entries, const int* n_blocks, int variant, void* stream) {
   if (!R || !U || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0) return NBM_EINVAL;
   if ((C % BK) || C / BK < 2 || (N & 3)) return NBM_EUNSUPPORTED;
   if (!nbm_aligned16(R) || !nbm_aligned16(U) || !nbm_aligned16(y) || (shift && !nbm_aligned16(shift)) ||
@@ -414,10 +496,15 @@ extern "C" int nbm_wino23_conv_fused(const float* R, const float* U, const float
   // combination of R behind the block base, and the whole of U
   if (T > 0x7fffff00ll || (long long)N * C * 16 * 4 > 0x7fffffffll) return NBM_EUNSUPPORTED;
   if ((130ll * p.WP + 4) * C * 4 > 0x7fffffffll) return NBM_EUNSUPPORTED;
+  // listed tiles: a 128-entry block may span up to min(B, 8) whole images of one row combination (the callers keep a block
+  // inside one image, or a fixed pattern of every image's tile rows)
+  if (tiles && (long long)(B < 8 ? B : 8) * p.TH * p.WP * C * 4 > 0x7fffffffll) return NBM_EUNSUPPORTED;
   p.R = R; p.U = U; p.y = y; p.scale = scale; p.shift = shift; p.mask = mask; p.relu = relu;
   p.T = (int)T; p.N = N; p.C = C; p.nk = C / BK; p.H = H; p.W = W;
   p.r_gs = (long long)B * p.TH * p.WP * C; p.u_gs = N * C;
   p.m_tiles = (int)((T + BM - 1) / BM);
+  p.tiles = tiles; p.n_blocks = n_blocks;
+  if (tiles) { p.T = n_entries; p.m_tiles = n_entries / BM; }
   hipStream_t st = (hipStream_t)stream;
   const int abl = variant / 1000;
   variant %= 1000;

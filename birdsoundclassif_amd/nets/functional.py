@@ -50,11 +50,16 @@ class Conv(Function):
     """y = act(alpha * conv(x, W) * scale + (bias | shift) + residual); also nn.Linear (x [1,M,1,K])."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, scale, shift, residual, kh, kw, stride, pad, act, alpha, up=None):
+    def forward(ctx, x, weight, bias, scale, shift, residual, kh, kw, stride, pad, act, alpha, up=None, lazy_stride=None):
         sh = bias.detach() if bias is not None else shift
         ctx.wino = _winograd_ok(x, weight, kh, kw, stride, pad) and scale is None and residual is None and \
             act == ACT_NONE and alpha == 1.0 and up is None
-        if ctx.wino:          # large 3x3 (FPN output convolutions): Winograd F(2x2,3x3), 2.25x fewer multiplies
+        if ctx.wino and lazy_stride:
+            # demand-driven map (ops.conv3x3_winograd_lazy): the tiles a 3x3 / lazy_stride consumer reads now, the tiles under
+            # the RoIs when the RoI pooling asks for them; the backward pass is the dense one (the incoming gradient is
+            # zero wherever nothing was read)
+            y = ops.conv3x3_winograd_lazy(x, _prep.wino23(weight), sh, lazy_stride)
+        elif ctx.wino:        # large 3x3 (FPN output convolutions): Winograd F(2x2,3x3), 2.25x fewer multiplies
             y = ops.conv3x3_winograd(x, _prep.wino23(weight), sh)
         else:
             wk = _prep.krsc(weight) if weight.dim() == 4 else weight.detach()
@@ -104,7 +109,7 @@ class Conv(Function):
         gup = None
         if ctx.up_hw is not None and ctx.needs_input_grad[12]:        # fused top-down merge: d/d(coarse map)
             gup = ops.upsample_bilinear_bwd(g, *ctx.up_hw)
-        return gx, gw, gb, None, None, gres, None, None, None, None, None, None, gup
+        return gx, gw, gb, None, None, gres, None, None, None, None, None, None, gup, None
 
 
 class Bottleneck(Function):
@@ -185,15 +190,19 @@ class Bottleneck(Function):
 
 
 def conv(x, weight, bias=None, scale=None, shift=None, residual=None, kh=1, kw=1, stride=1, pad=0, act=ACT_NONE, alpha=1.0,
-         up=None):
-    """`up` [B,h,w,N]: + bilinear_align_corners(up) in the GEMM epilogue (FPN top-down merge, act must be NONE)."""
-    return Conv.apply(x, weight, bias, scale, shift, residual, kh, kw, stride, pad, act, alpha, up)
+         up=None, lazy_stride=None):
+    """`up` [B,h,w,N]: + bilinear_align_corners(up) in the GEMM epilogue (FPN top-down merge, act must be NONE).
+    `lazy_stride`: the output has exactly two consumers, a 3x3 / lazy_stride / pad 1 convolution and the RoI pooling: only the
+    pixels they read are computed (3x3 Winograd layers only; ignored elsewhere)."""
+    if lazy_stride and not (ops.LAZY_FINEST and _winograd_ok(x, weight, kh, kw, stride, pad) and x.shape[-1] >= 64):
+        lazy_stride = None
+    return Conv.apply(x, weight, bias, scale, shift, residual, kh, kw, stride, pad, act, alpha, up, lazy_stride)
 
 
 def linear(x2d, weight, bias=None, act=ACT_NONE, residual=None):
     M, K = x2d.shape
     res = residual.view(1, M, 1, -1) if residual is not None else None
-    return Conv.apply(x2d.view(1, M, 1, K), weight, bias, None, None, res, 1, 1, 1, 0, act, 1.0, None).view(M, -1)
+    return Conv.apply(x2d.view(1, M, 1, K), weight, bias, None, None, res, 1, 1, 1, 0, act, 1.0, None, None).view(M, -1)
 
 
 class Add(Function):

@@ -25,7 +25,17 @@ class NbmModel(nn.Module):
         self.fpn = fpn
         self.head = head
 
-    def _fpn_nhwc(self, samples):
+    def _lazy_stride(self):
+        """Stride of the RPN's first-level depthwise 3x3 (layers.py:62-65) when the finest FPN map can be computed on demand:
+        default topology only (FPN output read by the RPN and the RoI pooling, nothing else), and a pattern that leaves most
+        tiles unread."""
+        a = self.args
+        if getattr(a, 'fpn_first', False) or getattr(a, 'sandwich_attn', False) or getattr(a, 'fpn', 'fpn') != 'fpn':
+            return None
+        st = int(a.anchor_stride / 2)
+        return st if st >= 6 else None
+
+    def _fpn_nhwc(self, samples, lazy=False):
         if samples.dim() != 4 or samples.shape[1] != self.args.inpt_channels:
             raise ValueError(f'expected [B,{self.args.inpt_channels},H,W], got {tuple(samples.shape)}')
         x = samples.permute(0, 2, 3, 1).contiguous()
@@ -37,13 +47,17 @@ class NbmModel(nn.Module):
             return materialize(self.attn(self.fpn(features)))
         if getattr(self.args, 'sandwich_attn', False):
             return materialize(self.attn[1](self.fpn(self.attn[0](features))))
+        if lazy and self._lazy_stride():
+            return self.fpn(self.attn(features), lazy_stride=self._lazy_stride())
         return self.fpn(self.attn(features))
 
-    def forward_first_stage(self, samples, host_work=None):
+    def forward_first_stage(self, samples, host_work=None, lazy=None):
         """samples [B,1,H,W] f32 on the GPU -> {'rois','rpn_cls_scores','rpn_bbox_reg','fpn_out'} (nbm_model.py:39-54).
         Tensors are NCHW-shaped views of NHWC storage.  `host_work` (optional callable) runs after every kernel of the
-        first stage has been queued and before the host waits for the RoI count, i.e. hidden behind the GPU work."""
-        fpn_out = self._fpn_nhwc(samples)
+        first stage has been queued and before the host waits for the RoI count, i.e. hidden behind the GPU work.
+        `lazy` (default: in training mode): 'fpn_out'[0] holds only the pixels its consumers read -- the RPN pattern now,
+        the RoI windows once forward_second_stage runs; pass lazy=False to inspect the whole map."""
+        fpn_out = self._fpn_nhwc(samples, lazy=self.training if lazy is None else lazy)
         rois, cls, reg = self.head.forward_first_stage([f.permute(0, 3, 1, 2) for f in fpn_out], host_work)
         return {'rois': rois, 'rpn_cls_scores': cls, 'rpn_bbox_reg': reg,
                 'fpn_out': [f.permute(0, 3, 1, 2) for f in fpn_out]}
@@ -64,7 +78,7 @@ class NbmModel(nn.Module):
     def detect(self, samples, nms_thresh=0.3, min_score=0.5):
         """Sync-free eval forward: -> (det [B,50,6] rows {class,x1,y1,x2,y2,score} sorted by (class, score desc),
         n_det int32 [B]), both on the device.  Used by bulk inference; `forward` wraps it."""
-        fpn_out = self._fpn_nhwc(samples)
+        fpn_out = self._fpn_nhwc(samples, lazy=True)
         rois, _, n_roi, _, _, _ = self.head.forward_first_stage_device(fpn_out)
         return self.head.fast_rcnn.detect_device(fpn_out, rois, n_roi, nms_thresh, min_score)
 

@@ -8,6 +8,8 @@ import ctypes as C
 import os
 import math
 
+import numpy as np
+
 import torch
 
 from . import _lib
@@ -203,6 +205,140 @@ def wino_weight_grad(dU, m=2, row_scale=None):
     dW = torch.empty((N, C_, 3, 3), device=dU.device, dtype=torch.float32)
     check(lib().nbm_wino_weight_grad(_ptr(dU), _ptr(row_scale), N, C_, m, _ptr(dW), _stream()), 'nbm_wino_weight_grad')
     return dW
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Demand-driven evaluation of the finest FPN output convolution (csrc/wino_fused.hip: *_tiles entry points).
+# The map has two consumers (reference layers.py:62-65,81 and :408-417,464-467): the RPN's depthwise 3x3 with stride
+# anchor_stride / 2 = 8 -- a fixed pixel pattern, 25 % of the 2 x 2 Winograd tiles -- and the RoI pooling of the RoIs
+# assigned to that level.  `conv3x3_winograd_lazy` computes the pattern tiles at once and remembers the operands;
+# `lazy_complete` (called by the RoI pooling) computes the tiles under the RoI windows.  Every other pixel of the map is never
+# read by anything and is left unwritten.  NBM_LAZY_FINEST=0 switches the whole mechanism off (dense map).
+LAZY_FINEST = os.environ.get('NBM_LAZY_FINEST', '1') != '0'
+LAZY_POISON = False                 # tests: fill the map with NaN first, so that a read of an unwritten pixel shows
+_LAZY = {}                          # data_ptr of the sparse map -> (x, U, bias, y, skip)
+_PATTERNS = {}
+_ROI_TILE_BUF = {}
+
+
+def wino23_pattern(B, H, W, stride, device):
+    """2 x 2 output tiles of a [B,H,W] map that hold a pixel read by a 3x3 / `stride` / pad 1 consumer ->
+    (tiles int32 [n_entries] on the device: linear ids, ascending, -1 padded to a multiple of 128;  skip uint8 [TH*TW]:
+    1 where the pattern covers the tile;  number of listed tiles;  covered fraction of all tiles)."""
+    key = (B, H, W, stride, str(device))
+    hit = _PATTERNS.get(key)
+    if hit is None:
+        TH, TW = (H + 1) // 2, (W + 1) // 2
+
+        def need(n, nt):
+            m = np.zeros(nt, dtype=bool)
+            for o in range((n + 2 - 3) // stride + 1):
+                for k in range(3):
+                    r = o * stride - 1 + k
+                    if 0 <= r < n:
+                        m[r >> 1] = True
+            return m
+        mask = need(H, TH)[:, None] & need(W, TW)[None, :]
+        ids = np.flatnonzero(mask.ravel()).astype(np.int64)
+        allt = (np.arange(B, dtype=np.int64)[:, None] * (TH * TW) + ids[None, :]).ravel()
+        n = allt.size
+        pad = (-n) % 128
+        arr = np.concatenate([allt, np.full(pad, -1, dtype=np.int64)]).astype(np.int32)
+        hit = _PATTERNS[key] = (torch.from_numpy(arr).to(device), torch.from_numpy(mask.ravel().astype(np.uint8)).to(device),
+                                n, float(mask.mean()))
+    return hit
+
+
+def _wino23_tiles_run(x, U, bias, y, tiles, n_blocks, n_listed, label):
+    """Rows transform + fused kernel for the listed tiles of x [B,H,W,C] -> pixels of y (in place)."""
+    B, H, W, C_ = x.shape
+    N = U.shape[1]
+    per_img = 4 * (-(-H // 2)) * (2 * (-(-W // 2)) + 2) * C_
+    R, _ = _wino_scratch(x.device, B * per_img, 0)
+    st = _stream()
+    nb_ptr = _ptr(n_blocks) if n_blocks is not None else None
+    if FLOPS is not None:
+        if n_listed is None:
+            n_listed = int(n_blocks.item()) * 128
+        FLOPS[0] += 2.0 * 16 * n_listed * C_ * N
+    if PROFILE is not None:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
+    check(lib().nbm_wino23_rows_tiles(_ptr(x), B, H, W, C_, _ptr(tiles), tiles.numel(), nb_ptr, _ptr(R), st),
+          'nbm_wino23_rows_tiles')
+    if PROFILE is not None:
+        ev[1].record()
+    check(lib().nbm_wino23_conv_fused_tiles(_ptr(R), _ptr(U), None, _ptr(bias), None, 0, B, H, W, C_, N, _ptr(y), _ptr(tiles),
+                                            tiles.numel(), nb_ptr, st), 'nbm_wino23_conv_fused_tiles')
+    if PROFILE is not None:
+        ev[2].record()
+        PROFILE.append(((C_, N, 1, n_listed if n_listed is not None else 0, 1, 1, 16, 1, (label, H, W)), ev[1], ev[2]))
+        PROFILE.append(((label, C_, N, H, W, B), ev[0], ev[2]))
+
+
+def lazy_chunk(x):
+    """Images per launch of the sparse path: the row-transform scratch keeps its dense layout (holes unwritten)."""
+    _, H, W, C_ = x.shape
+    per_img = 4 * (-(-H // 2)) * (2 * (-(-W // 2)) + 2) * C_ * 4
+    return max(1, min(x.shape[0], WINO_CHUNK_BYTES // per_img))
+
+
+def conv3x3_winograd_lazy(x, U, bias, stride):
+    """Finest-level output convolution, pattern tiles only (see above) -> y [B,H,W,N] with the other pixels unwritten."""
+    _chk(x, name='x'), _chk(U, name='U')
+    B, H, W, C_ = x.shape
+    N = U.shape[1]
+    assert U.shape == (16, N, C_) and C_ % 32 == 0 and C_ >= 64 and N % 4 == 0
+    y = torch.empty((B, H, W, N), device=x.device, dtype=torch.float32)
+    if LAZY_POISON:
+        y.fill_(float('nan'))
+    chunk = lazy_chunk(x)
+    skip = None
+    for b0 in range(0, B, chunk):
+        nb = min(chunk, B - b0)
+        tiles, skip, n, _ = wino23_pattern(nb, H, W, stride, x.device)
+        _wino23_tiles_run(x[b0:b0 + nb], U, bias, y[b0:b0 + nb], tiles, None, n, 'wino23')
+    _LAZY.clear()                                # one deferred map at a time (the previous forward's is stale by now)
+    _LAZY[y.data_ptr()] = (x, U, bias, y, skip)
+    return y
+
+
+def lazy_pending(fm):
+    return fm.data_ptr() in _LAZY
+
+
+def lazy_complete(fm, rois, n_roi, fmap_hw, level=0):
+    """Compute the tiles of the deferred map `fm` under the windows of the RoIs assigned to `level` (the windows
+    `roi_pool` reads).  rois [B,cap,4], n_roi device int32[1], fmap_hw: (h, w) of every pyramid level.  No-op for a map
+    that is not deferred."""
+    st = _LAZY.pop(fm.data_ptr(), None)
+    if st is None:
+        return
+    x, U, bias, y, skip = st
+    B, H, W, C_ = x.shape
+    cap = rois.shape[1]
+    _chk(rois, name='rois')
+    nl = len(fmap_hw)
+    fh = (C.c_int * nl)(*[int(h) for h, _ in fmap_hw])
+    fw = (C.c_int * nl)(*[int(w) for _, w in fmap_hw])
+    blocks_per_img = -(-((H + 1) // 2 * ((W + 1) // 2)) // 128)
+    chunk = lazy_chunk(x)
+    key = (str(x.device), chunk * blocks_per_img * 128)
+    buf = _ROI_TILE_BUF.get(key)
+    if buf is None:
+        buf = _ROI_TILE_BUF[key] = (torch.empty((key[1],), device=x.device, dtype=torch.int32),
+                                    torch.zeros((1,), device=x.device, dtype=torch.int32))
+    tiles, n_blocks = buf
+    for b0 in range(0, B, chunk):
+        nb = min(chunk, B - b0)
+        check(lib().nbm_roi_tiles(_ptr(rois[b0:b0 + nb]), _ptr(n_roi), nb, cap, nl, level, fh, fw, _ptr(skip), _ptr(tiles),
+                                  _ptr(n_blocks), _stream()), 'nbm_roi_tiles')
+        _wino23_tiles_run(x[b0:b0 + nb], U, bias, y[b0:b0 + nb], tiles[:nb * blocks_per_img * 128], n_blocks, None,
+                          'wino23-rois')
+
+
+def lazy_clear():
+    _LAZY.clear()
 
 
 def conv3x3_winograd_wgrad(x, g, want_bias=False, m=2):

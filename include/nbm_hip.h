@@ -109,6 +109,26 @@ int nbm_wino23_rows(const float* x, int B, int H, int W, int C, float* R, void* 
 int nbm_wino23_conv_fused(const float* R, const float* U, const float* scale, const float* shift, const float* mask,
                           int relu, int B, int H, int W, int C, int N, float* y, int variant, void* stream);
 
+/* Demand-driven evaluation of a 3x3 convolution: only the listed 2 x 2 output tiles are computed.  The finest FPN output map
+ * (fpn.py:145, level P1 at 188x512) has two consumers in the reference: the RPN's stride-8 depthwise convolution
+ * (layers.py:62-65,81: a fixed 3x3-every-8 pixel pattern) and the RoI pooling of the RoIs assigned to that level
+ * (layers.py:408-417,464-467); every other pixel of the map is computed by the reference and never read.
+ *   tiles:     n_entries int32 (n_entries % 128 == 0): linear tile id b * TH * TW + ty * TW + tx, ascending inside each
+ *              128-entry block, -1 = none (only at the end of a block); the tiles of a block lie within 8 consecutive images.
+ *   n_blocks:  optional device scalar: number of leading 128-entry blocks that are filled (the rest is not read).
+ *   nbm_wino23_rows_tiles:       row half of the input transform for the four columns of every listed tile;
+ *   nbm_wino23_conv_fused_tiles: as nbm_wino23_conv_fused, writes ONLY the pixels of the listed tiles;
+ *   nbm_roi_tiles:               builds such a list on the device from the RoI windows (exactly the windows nbm_roi_pool
+ *                                reads) of pyramid level `level`, without the tiles flagged in skip [TH * TW] (optional);
+ *                                tiles must hold B * ceil(TH * TW / 128) * 128 entries; writes *n_blocks. */
+int nbm_wino23_rows_tiles(const float* x, int B, int H, int W, int C, const int* tiles, int n_entries, const int* n_blocks,
+                          float* R, void* stream);
+int nbm_wino23_conv_fused_tiles(const float* R, const float* U, const float* scale, const float* shift, const float* mask,
+                                int relu, int B, int H, int W, int C, int N, float* y, const int* tiles, int n_entries,
+                                const int* n_blocks, void* stream);
+int nbm_roi_tiles(const float* rois, const int* n_roi, int B, int roi_cap, int n_levels, int level, const int* fh,
+                  const int* fw, const unsigned char* skip, int* tiles, int* n_blocks, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Spectrogram front end.  Replaces File_Processor.load/spectrogram/split_power_spec
  * (nbm_model/nbm_datasets/prepare_dataset.py:160-184, 228-252, 255-294) incl. librosa.stft and the
