@@ -30,15 +30,22 @@ print(f'detect forward, B = {B}, {"direct 3x3 everywhere" if not Fn.WINOGRAD els
 print('   ms    TF/s(exec)  GB/s(alg)  launch')
 tot = 0.0
 for tag, ms in rows:
-    if tag[0] == 'wino23':
+    if not isinstance(tag[0], str) and len(tag) != 9:
+        continue
+    if tag[0] in ('wino23', 'wino23-rois'):
         _, C, N, H, W, b = tag
-        print(f'{ms:8.3f}      -         -      = whole Winograd layer above: 3x3 {C}->{N} @{H}x{W} B={b} (row transform + fused kernel)')
+        print(f'{ms:8.3f}      -         -      = whole Winograd layer above: 3x3 {C}->{N} @{H}x{W} B={b} (row transform + fused kernel)'
+              + (' -- tiles under the RoIs only' if tag[0] == 'wino23-rois' else ''))
         continue
     Cin, N, k, H, W, Bb, G, st, label = tag
     Ho, Wo = -(-H // st), -(-W // st)
     fl = 2.0 * G * Bb * Ho * Wo * N * Cin * k * k / 1e9
     by = 4.0 * G * (Bb * H * W * Cin + Bb * Ho * Wo * N + N * Cin * k * k) / 1e9
     what = f'{k}x{k} s{st} {Cin}->{N} @{H}x{W} B={Bb}' + (f' groups={G}' if G > 1 else '')
+    if label is not None and label[0] == 'wino23-rois':
+        print(f'{ms:8.3f}      -         -      fused Winograd kernel of 3x3 {Cin}->{N} @{label[1]}x{label[2]}, tiles under the RoIs (device-side list)')
+        tot += ms
+        continue
     if label is not None:
         what = f'fused Winograd kernel of 3x3 {Cin}->{N} @{label[1]}x{label[2]} ({G} planes x {H} tiles)'
         by = 4.0 * (H * 4 * Cin * 0.5 + H * 4 * N + G * N * Cin) / 1e9          # R (2x input) + y + U

@@ -70,3 +70,26 @@ def state_dict_shapes(**overrides):
 def filler_state_dict(seed=0, **overrides):
     sd = synth.fill_state_dict(state_dict_shapes(**overrides), seed)
     return synth.tame_bifpn(sd) if overrides.get('fpn') == 'bifpn' else sd
+
+
+def assert_rois_equal_up_to_near_ties(got, ref, ref_scores, eps=2e-7, what='RoIs'):
+    """RoIs [B,R,4] come out ordered by objectness (layers.py:292, an argsort of fp32 softmax outputs).  Two proposals whose
+    scores differ by less than a couple of fp32 ulps of 1.0 have no defined order across implementations (the reference's
+    own order depends on its BLAS build), so a run of such near-ties may come out permuted; everything else -- the rows
+    themselves, their number, every other position -- must be bit-identical."""
+    got, ref, sc = got.cpu(), ref.cpu(), ref_scores.cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    for b in range(ref.shape[0]):
+        i, R = 0, ref.shape[1]
+        while i < R:
+            if torch.equal(got[b, i], ref[b, i]):
+                i += 1
+                continue
+            j = i
+            while j + 1 < R and abs(float(sc[b, j + 1]) - float(sc[b, j])) <= eps:
+                j += 1
+            assert j > i, f'{what}: image {b} rank {i}: {got[b, i].tolist()} != {ref[b, i].tolist()} (no score tie)'
+            g = sorted(map(tuple, got[b, i:j + 1].tolist()))
+            r = sorted(map(tuple, ref[b, i:j + 1].tolist()))
+            assert g == r, f'{what}: image {b} ranks {i}..{j} differ beyond a permutation of near-ties'
+            i = j + 1
