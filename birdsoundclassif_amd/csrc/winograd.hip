@@ -9,19 +9,29 @@
 namespace {
 
 // x [B][H][W][C] -> V [16][T][C], T = B * ceil(H/2) * ceil(W/2); tile (ty, tx) reads rows 2ty-1 .. 2ty+2, cols 2tx-1 .. 2tx+2.
+// With a tile list (tiles != NULL: n_list linear tile ids b * TH * TW + ty * TW + tx, or -1) V is compact: [16][n_list][C],
+// row t holds the listed tile t (zeros for -1) -- the weight gradient of a demand-driven map only sums over the tiles
+// whose output was ever read.
 __global__ __launch_bounds__(256) void wino23_input_kernel(const float* __restrict__ x, int B, int H, int W, int C4,
-                                                           float* __restrict__ V) {
+                                                           float* __restrict__ V, const int* __restrict__ tiles,
+                                                           int n_list) {
   const int TH = (H + 1) >> 1, TW = (W + 1) >> 1;
-  const long long T = (long long)B * TH * TW;
+  const long long T = tiles ? (long long)n_list : (long long)B * TH * TW;
   const long long total = T * C4;
   const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
   f32x4* v4 = reinterpret_cast<f32x4*>(V);
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int c = (int)(i % C4);
-    long long t = i / C4;
-    const int tx = (int)(t % TW);
-    long long r = t / TW;
+    const long long t = i / C4;
+    const long long id = tiles ? (long long)tiles[t] : t;
+    if (id < 0) {
+#pragma unroll
+      for (int a = 0; a < 16; ++a) v4[((long long)a * T + t) * C4 + c] = zero;
+      continue;
+    }
+    const int tx = (int)(id % TW);
+    const long long r = id / TW;
     const int ty = (int)(r % TH);
     const int b = (int)(r / TH);
     f32x4 d[4][4];
@@ -116,9 +126,10 @@ __global__ __launch_bounds__(256) void wino23_output_kernel(const float* __restr
 // weight-gradient GEMMs dU[xi] = dM[xi]^T V[xi].  Every thread also accumulates the plain sum of its pixels per channel
 // (bias gradient) over its grid-stride items -- its channel chunk is fixed because the stride is a multiple of N4.
 __global__ __launch_bounds__(256) void wino23_outgrad_kernel(const float* __restrict__ g, int B, int H, int W, int N4,
-                                                             float* __restrict__ dM, float* __restrict__ bias_grad) {
+                                                             float* __restrict__ dM, float* __restrict__ bias_grad,
+                                                             const int* __restrict__ tiles, int n_list) {
   const int TH = (H + 1) >> 1, TW = (W + 1) >> 1;
-  const long long T = (long long)B * TH * TW;
+  const long long T = tiles ? (long long)n_list : (long long)B * TH * TW;      // tile list: as in wino23_input_kernel
   const long long total = T * N4;
   const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
   f32x4* m4 = reinterpret_cast<f32x4*>(dM);
@@ -127,14 +138,20 @@ __global__ __launch_bounds__(256) void wino23_outgrad_kernel(const float* __rest
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
     const int c = (int)(i % N4);
     my_c = c;
-    long long t = i / N4;
-    const int tx = (int)(t % TW);
-    long long r = t / TW;
+    const long long t = i / N4;
+    const long long id = tiles ? (long long)tiles[t] : t;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    if (id < 0) {
+#pragma unroll
+      for (int a = 0; a < 16; ++a) m4[((long long)a * T + t) * N4 + c] = zero;
+      continue;
+    }
+    const int tx = (int)(id % TW);
+    const long long r = id / TW;
     const int ty = (int)(r % TH);
     const int b = (int)(r / TH);
     const long long row = ((long long)b * H + 2 * ty) * W + 2 * tx;
     const bool in_y = 2 * ty + 1 < H, in_x = 2 * tx + 1 < W;          // odd sizes: the last tile row / column is half outside
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     const f32x4 y00 = g4[row * N4 + c], y01 = in_x ? g4[(row + 1) * N4 + c] : zero;
     const f32x4 y10 = in_y ? g4[(row + W) * N4 + c] : zero, y11 = (in_y && in_x) ? g4[(row + W + 1) * N4 + c] : zero;
     bsum += (y00 + y01) + (y10 + y11);
@@ -426,7 +443,8 @@ extern "C" int nbm_wino_input(const float* x, int B, int H, int W, int C, float*
   if (!nbm_aligned16(x) || !nbm_aligned16(V)) return NBM_EALIGN;
   const long long tiles = (long long)B * ((H + m - 1) / m) * ((W + m - 1) / m);
   if (m == 2)
-    hipLaunchKernelGGL(wino23_input_kernel, dim3(grid_for(tiles * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, B, H, W, C / 4, V);
+    hipLaunchKernelGGL(wino23_input_kernel, dim3(grid_for(tiles * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, B, H, W, C / 4, V,
+                       (const int*)nullptr, 0);
   else
     hipLaunchKernelGGL(wino43_input_kernel, dim3(grid_for(tiles * (C / 2))), dim3(256), 0, (hipStream_t)stream, x, B, H, W, C / 2, V);
   return nbm_launch_status();
@@ -442,9 +460,35 @@ extern "C" int nbm_wino_outgrad(const float* g, int B, int H, int W, int N, floa
   if (blocks > 4096) blocks = 4096;
   while ((blocks * 256) % per) ++blocks;
   if (m == 2)
-    hipLaunchKernelGGL(wino23_outgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, B, H, W, per, dM, bias_grad);
+    hipLaunchKernelGGL(wino23_outgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, B, H, W, per, dM, bias_grad,
+                       (const int*)nullptr, 0);
   else
     hipLaunchKernelGGL(wino43_outgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, B, H, W, per, dM, bias_grad);
+  return nbm_launch_status();
+}
+
+// F(2x2,3x3) input / output-gradient transforms of the listed tiles only (compact operands) -- see nbm_hip.h.
+extern "C" int nbm_wino23_input_tiles(const float* x, int B, int H, int W, int C, const int* tiles, int n_list, float* V,
+                                      void* stream) {
+  if (!x || !V || !tiles || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || n_list < 0) return NBM_EINVAL;
+  if (!nbm_aligned16(x) || !nbm_aligned16(V)) return NBM_EALIGN;
+  if (n_list == 0) return NBM_OK;
+  hipLaunchKernelGGL(wino23_input_kernel, dim3(grid_for((long long)n_list * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, B, H,
+                     W, C / 4, V, tiles, n_list);
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_wino23_outgrad_tiles(const float* g, int B, int H, int W, int N, const int* tiles, int n_list, float* dM,
+                                        float* bias_grad, void* stream) {
+  if (!g || !dM || !tiles || B <= 0 || H <= 0 || W <= 0 || N <= 0 || (N & 3) || n_list < 0) return NBM_EINVAL;
+  if (!nbm_aligned16(g) || !nbm_aligned16(dM)) return NBM_EALIGN;
+  if (n_list == 0) return NBM_OK;
+  const int per = N / 4;
+  long long blocks = ((long long)n_list * per + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  while ((blocks * 256) % per) ++blocks;              // a thread keeps one channel chunk (bias-gradient accumulation)
+  hipLaunchKernelGGL(wino23_outgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, B, H, W, per, dM,
+                     bias_grad, tiles, n_list);
   return nbm_launch_status();
 }
 

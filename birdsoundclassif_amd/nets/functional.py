@@ -35,6 +35,7 @@ def _w_to_ref_layout(gw, weight):
 
 STEM_FOLDED = True       # init_conv folded into conv1 (csrc/stem.hip); False: init_conv kernel + generic implicit GEMM
 WINOGRAD = True          # module switch for A/B tests (tests/test_gpu_e2e.py compares both convolution paths)
+LAZY_WGRAD = True        # weight gradient of the demand-driven finest FPN map over its computed tiles only
 WINO_BWD_TILE = 4        # F(4x4,3x3) for the two backward convolutions (gradients tolerate its 2e-5 error); 2 = F(2x2,3x3)
 
 
@@ -54,11 +55,13 @@ class Conv(Function):
         sh = bias.detach() if bias is not None else shift
         ctx.wino = _winograd_ok(x, weight, kh, kw, stride, pad) and scale is None and residual is None and \
             act == ACT_NONE and alpha == 1.0 and up is None
+        ctx.lazy = None
         if ctx.wino and lazy_stride:
             # demand-driven map (ops.conv3x3_winograd_lazy): the tiles a 3x3 / lazy_stride consumer reads now, the tiles under
             # the RoIs when the RoI pooling asks for them; the backward pass is the dense one (the incoming gradient is
             # zero wherever nothing was read)
-            y = ops.conv3x3_winograd_lazy(x, _prep.wino23(weight), sh, lazy_stride)
+            y, ctx.lazy = ops.conv3x3_winograd_lazy(x, _prep.wino23(weight), sh, lazy_stride)
+            ctx.lazy.keep = bool(ctx.needs_input_grad[1]) and LAZY_WGRAD
         elif ctx.wino:        # large 3x3 (FPN output convolutions): Winograd F(2x2,3x3), 2.25x fewer multiplies
             y = ops.conv3x3_winograd(x, _prep.wino23(weight), sh)
         else:
@@ -92,7 +95,11 @@ class Conv(Function):
             ops.conv_dgrad(gp, wk, gx, B=B, H=H, W=W, Cin=Cin, N=N, kh=kh, kw=kw, stride=stride, pad=pad,
                            g_ld=gp.shape[1], w_ld=wk.shape[1], a_scale=scale, alpha=alpha)
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1] and ctx.wino and N % 32 == 0:
+        if ctx.needs_input_grad[1] and ctx.lazy is not None and LAZY_WGRAD:
+            # demand-driven map: the gradient is zero outside the tiles that were computed -> F(2x2,3x3) over those tiles only
+            dU, gb = ops.conv3x3_winograd_wgrad_tiles(ctx.lazy, x, g.view(B, H, W, N), want_bias=want_gb)
+            gw = _prep.wino23_weight_grad(dU, 2)
+        elif ctx.needs_input_grad[1] and ctx.wino and N % 32 == 0:
             # weight gradient in the Winograd domain: 16 TN GEMMs dU = dM^T V, mapped back with dW = G^T dU G
             dU, gb = ops.conv3x3_winograd_wgrad(x, g.view(B, H, W, N), want_bias=want_gb, m=WINO_BWD_TILE)
             gw = _prep.wino23_weight_grad(dU, WINO_BWD_TILE)

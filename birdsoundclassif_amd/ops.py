@@ -8,6 +8,8 @@ import ctypes as C
 import os
 import math
 
+import weakref
+
 import numpy as np
 
 import torch
@@ -216,7 +218,7 @@ def wino_weight_grad(dU, m=2, row_scale=None):
 # read by anything and is left unwritten.  NBM_LAZY_FINEST=0 switches the whole mechanism off (dense map).
 LAZY_FINEST = os.environ.get('NBM_LAZY_FINEST', '1') != '0'
 LAZY_POISON = False                 # tests: fill the map with NaN first, so that a read of an unwritten pixel shows
-_LAZY = {}                          # data_ptr of the sparse map -> (x, U, bias, y, skip)
+_LAZY = {}                          # data_ptr of the sparse map -> LazyMap
 _PATTERNS = {}
 _ROI_TILE_BUF = {}
 
@@ -249,8 +251,8 @@ def wino23_pattern(B, H, W, stride, device):
     return hit
 
 
-def _wino23_tiles_run(x, U, bias, y, tiles, n_blocks, n_listed, label):
-    """Rows transform + fused kernel for the listed tiles of x [B,H,W,C] -> pixels of y (in place)."""
+def _wino23_tiles_run(x, U, bias, y_ptr, tiles, n_blocks, n_listed, label):
+    """Rows transform + fused kernel for the listed tiles of x [B,H,W,C] -> pixels of the map at device address y_ptr."""
     B, H, W, C_ = x.shape
     N = U.shape[1]
     per_img = 4 * (-(-H // 2)) * (2 * (-(-W // 2)) + 2) * C_
@@ -268,7 +270,7 @@ def _wino23_tiles_run(x, U, bias, y, tiles, n_blocks, n_listed, label):
           'nbm_wino23_rows_tiles')
     if PROFILE is not None:
         ev[1].record()
-    check(lib().nbm_wino23_conv_fused_tiles(_ptr(R), _ptr(U), None, _ptr(bias), None, 0, B, H, W, C_, N, _ptr(y), _ptr(tiles),
+    check(lib().nbm_wino23_conv_fused_tiles(_ptr(R), _ptr(U), None, _ptr(bias), None, 0, B, H, W, C_, N, C.c_void_p(y_ptr), _ptr(tiles),
                                             tiles.numel(), nb_ptr, st), 'nbm_wino23_conv_fused_tiles')
     if PROFILE is not None:
         ev[2].record()
@@ -283,8 +285,34 @@ def lazy_chunk(x):
     return max(1, min(x.shape[0], WINO_CHUNK_BYTES // per_img))
 
 
+class LazyMap:
+    """Book-keeping of one demand-driven map: operands and, per batch chunk, the tile lists that were computed (pattern
+    list; RoI list + its block count on the way to the host) -- the weight gradient sums over them.  The map itself is
+    NOT referenced (an autograd node owns this object and the map owns the node: a cycle would keep 12 GB alive until the
+    garbage collector runs); its consumers keep it alive and hand it back to `lazy_complete`."""
+    __slots__ = ('x', 'U', 'bias', 'skip', 'stride', 'chunks', 'roi', 'keep')
+
+    def __init__(self, x, U, bias, stride):
+        self.x, self.U, self.bias, self.stride = x, U, bias, stride
+        self.skip, self.chunks, self.roi, self.keep = None, [], None, False
+
+
+_PINNED = []
+_PINNED_NEXT = [0]
+
+
+def _pinned_int():
+    """A pinned host int32 from a small ring (hipHostMalloc per step would stall the stream)."""
+    if len(_PINNED) < 16:
+        _PINNED.append(torch.empty((1,), dtype=torch.int32, pin_memory=True))
+        return _PINNED[-1]
+    _PINNED_NEXT[0] = (_PINNED_NEXT[0] + 1) % len(_PINNED)
+    return _PINNED[_PINNED_NEXT[0]]
+
+
 def conv3x3_winograd_lazy(x, U, bias, stride):
-    """Finest-level output convolution, pattern tiles only (see above) -> y [B,H,W,N] with the other pixels unwritten."""
+    """Finest-level output convolution, pattern tiles only (see above) -> (y [B,H,W,N] with the other pixels unwritten,
+    LazyMap)."""
     _chk(x, name='x'), _chk(U, name='U')
     B, H, W, C_ = x.shape
     N = U.shape[1]
@@ -292,53 +320,100 @@ def conv3x3_winograd_lazy(x, U, bias, stride):
     y = torch.empty((B, H, W, N), device=x.device, dtype=torch.float32)
     if LAZY_POISON:
         y.fill_(float('nan'))
+    st = LazyMap(x, U, bias, stride)
+    img_bytes = H * W * N * 4
     chunk = lazy_chunk(x)
-    skip = None
     for b0 in range(0, B, chunk):
         nb = min(chunk, B - b0)
-        tiles, skip, n, _ = wino23_pattern(nb, H, W, stride, x.device)
-        _wino23_tiles_run(x[b0:b0 + nb], U, bias, y[b0:b0 + nb], tiles, None, n, 'wino23')
+        tiles, st.skip, n, _ = wino23_pattern(nb, H, W, stride, x.device)
+        st.chunks.append((b0, nb, tiles))
+        _wino23_tiles_run(x[b0:b0 + nb], U, bias, y.data_ptr() + b0 * img_bytes, tiles, None, n, 'wino23')
     _LAZY.clear()                                # one deferred map at a time (the previous forward's is stale by now)
-    _LAZY[y.data_ptr()] = (x, U, bias, y, skip)
-    return y
+    _LAZY[y.data_ptr()] = (st, weakref.ref(y))      # valid while the map object itself (or a view of it) is alive
+    return y, st
 
 
 def lazy_pending(fm):
-    return fm.data_ptr() in _LAZY
+    hit = _LAZY.get(fm.data_ptr())
+    return hit is not None and hit[1]() is not None
 
 
 def lazy_complete(fm, rois, n_roi, fmap_hw, level=0):
     """Compute the tiles of the deferred map `fm` under the windows of the RoIs assigned to `level` (the windows
     `roi_pool` reads).  rois [B,cap,4], n_roi device int32[1], fmap_hw: (h, w) of every pyramid level.  No-op for a map
     that is not deferred."""
-    st = _LAZY.pop(fm.data_ptr(), None)
-    if st is None:
+    hit = _LAZY.pop(fm.data_ptr(), None)
+    if hit is None or hit[1]() is None:
         return
-    x, U, bias, y, skip = st
+    st = hit[0]
+    x, U, bias = st.x, st.U, st.bias
     B, H, W, C_ = x.shape
+    img_bytes = H * W * U.shape[1] * 4
     cap = rois.shape[1]
     _chk(rois, name='rois')
     nl = len(fmap_hw)
     fh = (C.c_int * nl)(*[int(h) for h, _ in fmap_hw])
     fw = (C.c_int * nl)(*[int(w) for _, w in fmap_hw])
     blocks_per_img = -(-((H + 1) // 2 * ((W + 1) // 2)) // 128)
-    chunk = lazy_chunk(x)
-    key = (str(x.device), chunk * blocks_per_img * 128)
-    buf = _ROI_TILE_BUF.get(key)
-    if buf is None:
-        buf = _ROI_TILE_BUF[key] = (torch.empty((key[1],), device=x.device, dtype=torch.int32),
-                                    torch.zeros((1,), device=x.device, dtype=torch.int32))
-    tiles, n_blocks = buf
-    for b0 in range(0, B, chunk):
-        nb = min(chunk, B - b0)
-        check(lib().nbm_roi_tiles(_ptr(rois[b0:b0 + nb]), _ptr(n_roi), nb, cap, nl, level, fh, fw, _ptr(skip), _ptr(tiles),
+    keep = st.keep                                # a backward pass will want the lists
+    st.roi = []
+    for b0, nb, _ in st.chunks:
+        key = (str(x.device), nb * blocks_per_img * 128)
+        if keep:                                  # the backward pass reads the list again: a buffer of its own
+            tiles = torch.empty((key[1],), device=x.device, dtype=torch.int32)
+            n_blocks = torch.zeros((1,), device=x.device, dtype=torch.int32)
+        else:
+            buf = _ROI_TILE_BUF.get(key)
+            if buf is None:
+                buf = _ROI_TILE_BUF[key] = (torch.empty((key[1],), device=x.device, dtype=torch.int32),
+                                            torch.zeros((1,), device=x.device, dtype=torch.int32))
+            tiles, n_blocks = buf
+        check(lib().nbm_roi_tiles(_ptr(rois[b0:b0 + nb]), _ptr(n_roi), nb, cap, nl, level, fh, fw, _ptr(st.skip), _ptr(tiles),
                                   _ptr(n_blocks), _stream()), 'nbm_roi_tiles')
-        _wino23_tiles_run(x[b0:b0 + nb], U, bias, y[b0:b0 + nb], tiles[:nb * blocks_per_img * 128], n_blocks, None,
-                          'wino23-rois')
+        _wino23_tiles_run(x[b0:b0 + nb], U, bias, fm.data_ptr() + b0 * img_bytes, tiles, n_blocks, None, 'wino23-rois')
+        if keep:
+            host = _pinned_int()
+            host.copy_(n_blocks, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            st.roi.append((tiles, host, ev))
+    st.x = st.U = st.bias = None                  # the backward pass gets x from the tape
 
 
 def lazy_clear():
     _LAZY.clear()
+
+
+def conv3x3_winograd_wgrad_tiles(st, x, g, want_bias=False):
+    """Weight gradient of a demand-driven convolution (LazyMap `st`): g [B,H,W,N] is zero outside the tiles that were
+    computed, so dU[xi] = dM[xi]^T V[xi] sums over those tiles only: F(2x2,3x3) transforms of the listed tiles into
+    compact operands, 16 TN GEMMs over the listed rows.  -> (dU [16,N,C], bias gradient [N] | None)."""
+    _chk(x, name='x'), _chk(g, name='g')
+    B, H, W, C_ = x.shape
+    N = g.shape[-1]
+    dU = torch.zeros((16, N, C_), device=x.device, dtype=torch.float32)
+    gb = torch.zeros((N,), device=x.device, dtype=torch.float32) if want_bias else None
+    lmax = max(128, (WINO_CHUNK_BYTES // (16 * (C_ + N) * 4)) // 128 * 128)
+    stream = _stream()
+    for ci, (b0, nb, pattern) in enumerate(st.chunks):
+        lists = [pattern]
+        if st.roi:
+            tiles, host, ev = st.roi[ci]
+            ev.synchronize()                        # recorded during the forward pass: long done
+            n = int(host.item()) * 128
+            if n:
+                lists.append(tiles[:n])
+        full = torch.cat(lists) if len(lists) > 1 else lists[0]
+        xs, gs = x[b0:b0 + nb], g[b0:b0 + nb]
+        for l0 in range(0, full.numel(), lmax):
+            lst = full[l0:l0 + lmax]
+            L = lst.numel()
+            V, dM = _wino_scratch(x.device, 16 * L * C_, 16 * L * N)
+            check(lib().nbm_wino23_input_tiles(_ptr(xs), nb, H, W, C_, _ptr(lst), L, _ptr(V), stream), 'nbm_wino23_input_tiles')
+            check(lib().nbm_wino23_outgrad_tiles(_ptr(gs), nb, H, W, N, _ptr(lst), L, _ptr(dM), _ptr(gb), stream),
+                  'nbm_wino23_outgrad_tiles')
+            conv_wgrad(dM, V, dU, B=1, H=L, W=1, Cin=C_, N=N, groups=16, g_gs=L * N, x_gs=L * C_, out_gs=N * C_)
+    return dU, gb
 
 
 def conv3x3_winograd_wgrad(x, g, want_bias=False, m=2):

@@ -128,6 +128,13 @@ int nbm_wino23_conv_fused_tiles(const float* R, const float* U, const float* sca
                                 const int* n_blocks, void* stream);
 int nbm_roi_tiles(const float* rois, const int* n_roi, int B, int roi_cap, int n_levels, int level, const int* fh,
                   const int* fw, const unsigned char* skip, int* tiles, int* n_blocks, void* stream);
+/* Weight gradient of such a demand-driven convolution: the gradient wrt its output is zero outside the tiles that were
+ * read, so only those tiles enter dU[xi] = dM[xi]^T V[xi].  F(2x2,3x3) transforms of the listed tiles (entry -1 = a zero
+ * row) into COMPACT operands V [16][n_list][C] and dM [16][n_list][N] (+ bias gradient [N], optional, accumulated); the 16
+ * TN GEMMs are nbm_conv_wgrad with groups = 16 over n_list rows. */
+int nbm_wino23_input_tiles(const float* x, int B, int H, int W, int C, const int* tiles, int n_list, float* V, void* stream);
+int nbm_wino23_outgrad_tiles(const float* g, int B, int H, int W, int N, const int* tiles, int n_list, float* dM,
+                             float* bias_grad, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Spectrogram front end.  Replaces File_Processor.load/spectrogram/split_power_spec

@@ -43,7 +43,7 @@ def test_listed_tiles_equal_the_dense_convolution(shape):
     dense = ops.conv3x3_winograd(x, U, b)
     ops.LAZY_POISON = True
     try:
-        y = ops.conv3x3_winograd_lazy(x, U, b, 8)
+        y, _ = ops.conv3x3_winograd_lazy(x, U, b, 8)
     finally:
         ops.LAZY_POISON = False
     tiles, skip, n, frac = ops.wino23_pattern(B, H, W, 8, x.device)
@@ -87,6 +87,41 @@ def test_listed_tiles_equal_the_dense_convolution(shape):
     want = want.cuda()
     assert torch.equal(y[want], dense[want]), 'RoI tiles differ from the dense convolution'
     assert bool(torch.isnan(y[~want]).all()), 'a pixel outside pattern + RoI tiles was written'
+
+
+def test_weight_gradient_over_the_listed_tiles_equals_the_dense_one():
+    """g zero outside the computed tiles: the listed-tile F(2x2,3x3) weight gradient == torch's conv weight gradient."""
+    import torch.nn.functional as F
+    B, H, W, C, N = 2, 47, 66, 128, 64
+    x = rnd('wx', B, H, W, C).cuda()
+    w = rnd('ww', N, C, 3, 3, scale=0.05).cuda()
+    b = rnd('wb', N).cuda()
+    y, st = ops.conv3x3_winograd_lazy(x, _prep.wino23(w), b, 8)
+    st.keep = True
+    fh = [H, (H + 1) // 2, (H + 3) // 4, (H + 7) // 8, (H + 15) // 16]
+    fw = [W, (W + 1) // 2, (W + 3) // 4, (W + 7) // 8, (W + 15) // 16]
+    rois = torch.tensor([[[10., 12., 25., 20.], [60., 40., 70., 66.], [0., 0., 8., 9.]]] * B).cuda()
+    ops.lazy_complete(y, rois, torch.tensor([3], dtype=torch.int32, device='cuda'), list(zip(fh, fw)))
+    # mask of computed pixels: pattern tiles + RoI tiles (re-derived from the lists the map kept)
+    TH, TW = (H + 1) // 2, (W + 1) // 2
+    mask = torch.zeros((B, TH, TW), dtype=torch.bool, device='cuda')
+    ids = [st.chunks[0][2]]
+    tiles, host, ev = st.roi[0]
+    ev.synchronize()
+    ids.append(tiles[:int(host.item()) * 128])
+    ids = torch.cat(ids)
+    mask.view(-1)[ids[ids >= 0].long()] = True
+    m = mask.repeat_interleave(2, 1).repeat_interleave(2, 2)[:, :H, :W]
+    g = rnd('wg', B, H, W, N).cuda() * m[..., None]
+    dU, gb = ops.conv3x3_winograd_wgrad_tiles(st, x, g.contiguous(), want_bias=True)
+    gw = _prep.wino23_weight_grad(dU, 2)
+    xr = x.permute(0, 3, 1, 2).double().cpu().requires_grad_(False)
+    wr = w.double().cpu().requires_grad_(True)
+    F.conv2d(xr, wr, None, 1, 1).backward(g.permute(0, 3, 1, 2).double().cpu())
+    ref = wr.grad.float()
+    err = (gw.cpu() - ref).abs().max().item()
+    assert err < 2e-4 * ref.abs().max().item() + 1e-5, (err, ref.abs().max().item())
+    assert torch.allclose(gb.cpu(), g.sum((0, 1, 2)).cpu(), rtol=1e-4, atol=1e-4)
 
 
 @pytest.fixture(scope='module')
