@@ -83,7 +83,7 @@ def train_bench(rank, world, dist, batch, steps, warmup, mix_steps=10):
     ops.FLOPS = [0.0]                      # executed MFMA FLOPs of every GEMM launch (Winograd-domain counts where that path runs)
     ops.PROFILE_BWD = []                   # live HIP events around every data- / weight-gradient launch
     dt, loss = timed([False] * steps)
-    exec_gflop_per_clip = ops.FLOPS[0] / (steps * batch) / 1e9
+    exec_gflop_per_clip = ops.flops_total() / (steps * batch) / 1e9
     prof, ops.PROFILE_BWD, ops.FLOPS = ops.PROFILE_BWD, None, None
     # dominant backward kernel: igemm_tn_kernel<128,0,0> (weight gradients); its largest launches are the 36
     # Winograd F(4x4,3x3)-domain TN GEMMs of fpn.out_convs.4 (groups = 36, one launch per batch chunk)
@@ -96,17 +96,19 @@ def train_bench(rank, world, dist, batch, steps, warmup, mix_steps=10):
         def gflop(t):
             _, b, H, W, Cin, N, k, stride, groups = t
             return 2.0 * b * ((H - 1) // stride + 1) * ((W - 1) // stride + 1) * N * Cin * k * k * groups / 1e9
-        top = max(wg, key=lambda t: sum(wg[t]))
-        ach = gflop(top) * len(wg[top]) / sum(wg[top])
         all_ms = sum(sum(v) for v in wg.values())
         all_gf = sum(gflop(t) * len(v) for t, v in wg.items())
-        bwd_roof = {'bound': 'mfma', 'kernel': 'igemm_tn_kernel<128,0,0>: weight-gradient GEMMs; largest = the launches of '
-                                                f'(B,H,W,Cin,N,k,stride,groups) = {top[1:]}',
-                    'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS,
-                    'avg_launch_ms': sum(wg[top]) / len(wg[top]), 'launches': len(wg[top]),
-                    'executed_GFLOP_per_launch': gflop(top),
-                    'all_wgrad_ms_per_step': all_ms / steps, 'all_wgrad_TFLOPs': all_gf / all_ms,
-                    'traffic': None, 'traffic_note': 'FETCH_SIZE / WRITE_SIZE / MFMA-busy of this kernel: profiles/r02_pmc_wgrad.txt'}
+        n_launch = sum(len(v) for v in wg.values())
+        top = sorted(wg, key=lambda t: -sum(wg[t]))[:3]
+        bwd_roof = {'bound': 'mfma', 'kernel': 'igemm_tn_kernel<BN,MODE,0>: every weight-gradient launch of a step (TN GEMMs, split-K over '
+                                                'pixels / Winograd tiles with fp32 atomics)',
+                    'achieved': all_gf / all_ms, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': all_gf / all_ms / FP32_MFMA_PEAK_TFLOPS,
+                    'avg_launch_ms': all_ms / n_launch, 'launches': n_launch, 'executed_GFLOP_per_launch': all_gf / n_launch,
+                    'all_wgrad_ms_per_step': all_ms / steps,
+                    'largest_launches': [{'B,H,W,Cin,N,k,stride,groups': list(t[1:]), 'ms': sum(wg[t]) / len(wg[t]),
+                                          'launches': len(wg[t]), 'executed_TFLOPs': gflop(t) * len(wg[t]) / sum(wg[t])} for t in top],
+                    'traffic': None, 'traffic_note': 'FETCH_SIZE / WRITE_SIZE / MFMA-busy of this kernel: profiles/r02_pmc_wgrad.json'}
     pos = {'ms_per_step': dt / steps * 1e3, 'clips_per_s': world * batch * steps / dt}
     # the reference's schedule: one negative step in ten
     mix = None
@@ -125,7 +127,8 @@ def train_bench(rank, world, dist, batch, steps, warmup, mix_steps=10):
             'direct_conv_equivalent_GFLOP_per_clip': TRAIN_GFLOP_PER_CLIP,
             'direct_conv_equivalent_TFLOPs_per_gpu': v / world * TRAIN_GFLOP_PER_CLIP / 1e3,
             'note': 'executed = MFMA FLOPs the launches really perform (Winograd-domain counts for the 3x3 / stride-1 layers: '
-                    'F(2x2,3x3) forward, F(4x4,3x3) data and weight gradients); direct_conv_equivalent = SURVEY 993.45 GFLOP/clip '
+                    'F(2x2,3x3) forward, F(4x4,3x3) data and weight gradients; the finest FPN output map is computed on demand: tiles '
+                    'with a reader, forward and weight gradient); direct_conv_equivalent = SURVEY 993.45 GFLOP/clip '
                     'and is NOT a roofline figure',
             'reference_schedule_9_positive_1_negative': mix,
             'roofline_backward': bwd_roof,
@@ -270,38 +273,51 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # roofline of the dominant kernel: wino23_fused_kernel<128,64> on fpn.out_convs.4 (3x3 384->256 @188x512): the 16
-    # Winograd-domain GEMMs + both fused transform halves, one launch per batch chunk.  `achieved` counts the MFMA FLOPs
-    # that launch EXECUTES (2 * 16 * tiles * 384 * 256 = 1/2.25 of the direct-convolution count SURVEY uses) over its HIP
-    # event time; the layer-level figure next to it is the whole layer (row transform + fused kernel).
-    dom = [(tag, s.elapsed_time(e)) for (tag, s, e) in prof
-           if len(tag) == 9 and tag[:3] == (384, 256, 1) and tag[6] == 16 and tag[8] == ('wino23', 188, 512)]
-    layer = [s.elapsed_time(e) for (tag, s, e) in prof if tag == ('wino23', 384, 256, 188, 512, B)]
-    all_ms = sum(s.elapsed_time(e) for (tag, s, e) in prof if tag[0] != 'wino23')
+    # roofline of the dominant kernel = wino23_fused_kernel<128,64> (csrc/wino_fused.hip): every launch of a step, i.e. the
+    # FPN output convolutions (level P1 at 188x512 on demand: the tiles the RPN pattern reads, then the tiles under the
+    # RoIs; levels P2.. dense) and the ResNet 3x3 / stride-1 layers.  `achieved` = MFMA FLOPs these launches EXECUTE
+    # (2 * 16 planes * tiles * Cin * Cout = 1/2.25 of the direct-convolution count per computed tile) over their HIP-event
+    # time on the launch stream; avg_launch_ms is what rocprofv3 --stats reports as the kernel's average duration.
+    def tiles_of(tag):
+        t = tag[3]
+        return int(t.item()) * 128 if torch.is_tensor(t) else int(t)
+    fused = [(tag, s.elapsed_time(e)) for (tag, s, e) in prof
+             if len(tag) == 9 and isinstance(tag[8], tuple) and tag[8][0] in ('wino23', 'wino23-rois')]
+    all_ms = sum(s.elapsed_time(e) for (tag, s, e) in prof if len(tag) == 9)
     roof = None
     traffic = None                      # HBM bytes per launch of the dominant kernel: PMC counters cannot be read live;
     try:                                # the value comes from the committed rocprofv3 --pmc passes of this same command
         pj = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_dominant.json')))
-        if B == 64:
+        if B == 64 and pj.get('lazy_finest') == bool(ops.LAZY_FINEST):
             traffic = pj['traffic_bytes_per_launch']
     except Exception:
         traffic = None
-    if dom:
-        gflop = sum(2.0 * 16 * tag[3] * 384 * 256 / 1e9 for tag, _ in dom)
-        ms = sum(t for _, t in dom)
+    if fused:
+        per = [(tag, ms, 2.0 * 16 * tiles_of(tag) * tag[0] * tag[1] / 1e9) for tag, ms in fused]
+        gflop, ms = sum(g for _, _, g in per), sum(m for _, m, _ in per)
         ach = gflop / ms                                       # GFLOP/ms == TFLOP/s
-        roof = {'bound': 'mfma', 'kernel': 'wino23_fused_kernel<128,64>: fpn.out_convs.4 (3x3 384->256 @188x512) = column half '
-                                           'of the Winograd input transform + 16 transformed-domain GEMMs + output transform',
+        big = {}
+        for tag, m, g in per:                                  # per distinct launch (layer): time and rate
+            k = f'{tag[8][0]} 3x3 {tag[0]}->{tag[1]} @{tag[8][1]}x{tag[8][2]}'
+            slot = big.setdefault(k, [0.0, 0.0, 0])
+            slot[0] += m
+            slot[1] += g
+            slot[2] += 1
+        top = sorted(big.items(), key=lambda kv: -kv[1][0])[:3]
+        roof = {'bound': 'mfma', 'kernel': 'wino23_fused_kernel<128,64>: Winograd F(2x2,3x3) convolution in one kernel (column half of '
+                                           'the input transform + 16 transformed-domain GEMMs + output transform + epilogue); all its '
+                                           'launches of a step (FPN output convolutions, ResNet 3x3/s1 layers)',
                 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS,
-                'traffic': traffic, 'traffic_unit': 'bytes/launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r02_pmc_dominant.json)',
-                'avg_launch_ms': ms / len(dom), 'launches': len(dom), 'executed_GFLOP_per_launch': gflop / len(dom),
+                'traffic': traffic, 'traffic_unit': 'bytes/launch (2*FETCH_SIZE + WRITE_SIZE, mean over the launches, '
+                                                    'profiles/r02_pmc_dominant.json)',
+                'avg_launch_ms': ms / len(per), 'launches': len(per), 'launches_per_step': len(per) / a.steps,
+                'executed_GFLOP_per_launch': gflop / len(per), 'ms_per_step': ms / a.steps,
+                'largest_launches': [{'what': k, 'ms': v[0] / v[2], 'executed_TFLOPs': v[1] / v[0],
+                                      'frac': v[1] / v[0] / FP32_MFMA_PEAK_TFLOPS} for k, v in top],
                 'all_igemm_ms_per_step': all_ms / a.steps,
-                'whole_step_direct_conv_equivalent_TFLOPs': FWD_GFLOP_PER_CLIP * B * a.steps / (dt * 1e3)}
-        if layer:
-            lms = sum(layer) / len(layer)
-            roof['layer'] = {'what': 'fpn.out_convs.4 as executed: row transform + fused Winograd kernel', 'ms': lms,
-                             'executed_frac_of_mfma_peak': gflop / len(layer) / lms / FP32_MFMA_PEAK_TFLOPS,
-                             'direct_conv_equivalent_TFLOPs': FPN0_GFLOP_PER_CLIP * B / lms}
+                'whole_step_direct_conv_equivalent_TFLOPs': FWD_GFLOP_PER_CLIP * B * a.steps / (dt * 1e3),
+                'finest_fpn_map': 'on demand (RPN pattern tiles + tiles under the RoIs; the other pixels have no reader)'
+                                  if ops.LAZY_FINEST else 'dense'}
     # front end alone (HBM-bound stage of the path): live HIP events around K replays
     fe_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
     for s0, e0 in fe_ev:

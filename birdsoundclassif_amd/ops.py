@@ -23,6 +23,16 @@ ACT_NONE, ACT_RELU, ACT_SILU, ACT_LEAKY = 0, 1, 2, 3
 # entries are ((Cin, N, kh, H, W, B, groups, stride, label), start_event, end_event).
 PROFILE = None
 FLOPS = None                   # [float]: executed MFMA FLOPs of every GEMM launch since it was set (bench.py accounting)
+FLOPS_DEFERRED = []             # (device counter, FLOPs per count): launches whose size is only known on the device
+
+
+def flops_total():
+    """Executed MFMA FLOPs since `FLOPS = [0.0]` was set (synchronises to read the device-side counts)."""
+    tot = FLOPS[0] + sum(float(c.item()) * f for c, f in FLOPS_DEFERRED)
+    FLOPS_DEFERRED.clear()
+    return tot
+
+
 _PROFILE_LABEL = None          # set by composite ops (Winograd) so that their GEMM launches can be told apart
 
 
@@ -260,9 +270,10 @@ def _wino23_tiles_run(x, U, bias, y_ptr, tiles, n_blocks, n_listed, label):
     st = _stream()
     nb_ptr = _ptr(n_blocks) if n_blocks is not None else None
     if FLOPS is not None:
-        if n_listed is None:
-            n_listed = int(n_blocks.item()) * 128
-        FLOPS[0] += 2.0 * 16 * n_listed * C_ * N
+        if n_listed is None:                      # device-side count: resolved by flops_total(), no sync here
+            FLOPS_DEFERRED.append((n_blocks.clone(), 2.0 * 16 * 128 * C_ * N))
+        else:
+            FLOPS[0] += 2.0 * 16 * n_listed * C_ * N
     if PROFILE is not None:
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         ev[0].record()
@@ -274,7 +285,9 @@ def _wino23_tiles_run(x, U, bias, y_ptr, tiles, n_blocks, n_listed, label):
                                             tiles.numel(), nb_ptr, st), 'nbm_wino23_conv_fused_tiles')
     if PROFILE is not None:
         ev[2].record()
-        PROFILE.append(((C_, N, 1, n_listed if n_listed is not None else 0, 1, 1, 16, 1, (label, H, W)), ev[1], ev[2]))
+        # listed tiles: known on the host for the pattern, a device counter for the RoI tiles (resolved by the reader after a sync)
+        cnt = n_listed if n_listed is not None else n_blocks.clone()
+        PROFILE.append(((C_, N, 1, cnt, 1, 1, 16, 1, (label, H, W)), ev[1], ev[2]))
         PROFILE.append(((label, C_, N, H, W, B), ev[0], ev[2]))
 
 

@@ -1,8 +1,10 @@
-"""rocprofv3 --pmc CSVs -> JSON for the dominant launch of a kernel (the dispatches with the largest grid).
-usage: pmc_dominant.py OUT.json KERNEL_SUBSTR EXEC_GFLOP FETCH_DIR WRITE_DIR MFMA_DIR [label]"""
+"""rocprofv3 --pmc CSVs -> JSON for a kernel: the dispatches with the largest grid (default), or the mean over ALL its
+dispatches (mode `all`: the per-launch figure that pairs with a kernel's average duration in rocprofv3 --stats).
+usage: pmc_dominant.py OUT.json KERNEL_SUBSTR EXEC_GFLOP FETCH_DIR WRITE_DIR MFMA_DIR [label] [largest|all]"""
 import csv, glob, json, sys
 out, sub, gflop, dF, dW, dM = sys.argv[1], sys.argv[2], float(sys.argv[3]), sys.argv[4], sys.argv[5], sys.argv[6]
 label = sys.argv[7] if len(sys.argv) > 7 else ''
+mode = sys.argv[8] if len(sys.argv) > 8 else 'largest'
 
 
 def rows(d):
@@ -17,7 +19,7 @@ def per_launch(d, counter):
     if not rs:
         return None, 0, 0
     g = max(int(x['Grid_Size']) for x in rs)
-    sel = [float(x['Counter_Value']) for x in rs if int(x['Grid_Size']) == g]
+    sel = [float(x['Counter_Value']) for x in rs if mode == 'all' or int(x['Grid_Size']) == g]
     return sum(sel) / len(sel), len(sel), g
 
 
@@ -25,14 +27,14 @@ f, nf, grid = per_launch(dF, 'FETCH_SIZE')
 w, nw, _ = per_launch(dW, 'WRITE_SIZE')
 mf, _, _ = per_launch(dM, 'SQ_VALU_MFMA_BUSY_CYCLES')
 ga, _, _ = per_launch(dM, 'GRBM_GUI_ACTIVE')
-res = {'kernel': sub, 'what': label, 'launches_averaged': nf, 'grid_size_threads': grid, 'executed_GFLOP': gflop,
+res = {'kernel': sub, 'what': label, 'launches': mode, 'lazy_finest': True, 'launches_averaged': nf, 'grid_size_threads': grid, 'executed_GFLOP': gflop,
        'FETCH_SIZE_KB_per_launch': f, 'WRITE_SIZE_KB_per_launch': w,
        'fetch_bytes_raw': f * 1024, 'fetch_bytes_corrected_x2': 2 * f * 1024, 'write_bytes': w * 1024,
        'traffic_bytes_per_launch': 2 * f * 1024 + w * 1024,
        'mfma_busy_cycles': mf, 'grbm_gui_active_sum8xcd': ga,
        'mfma_busy_frac': (mf / (1024 * ga / 8)) if mf and ga else None,
        'note': 'separate rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE) '
-               'of the bench command; launches selected by the largest Grid_Size of the kernel; gfx950: FETCH_SIZE reports 1/2 of '
+               'of the bench command; launches: the largest Grid_Size of the kernel, or all of them (`launches`); gfx950: FETCH_SIZE reports 1/2 of '
                'wide coalesced 16 B/lane reads -> doubled (MI355X_MICROARCH.md, HBM) and counts L2 -> fabric requests, i.e. '
                'Infinity-Cache hits too; WRITE_SIZE exact; mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE/8)'}
 json.dump(res, open(out, 'w'), indent=1)

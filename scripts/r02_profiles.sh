@@ -17,11 +17,14 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $O/pmc_train_$c -- python3 $R/scripts/trainbench.py 128 2 > $O/pmc_train_$c.log 2>&1
 done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_train_MFMA -- python3 $R/scripts/trainbench.py 128 2 > $O/pmc_train_MFMA.log 2>&1
-# dominant launches: forward = the fused Winograd kernel of fpn.out_convs.4 at B = 64 (2 * 16 * 1540096 * 384 * 256 FLOP),
-# backward = the weight-gradient kernel's largest launch
-python3 $R/scripts/pmc_dominant.py $O/pmc_dominant.json "wino23_fused_kernel" 4844.723 $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_MFMA "fpn.out_convs.4 fused Winograd kernel, one launch = 64 images" > /dev/null
-python3 $R/scripts/pmc_dominant.py $O/pmc_rows.json "wino23_rows_kernel" 0 $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_MFMA "row half of the Winograd input transform of fpn.out_convs.4, 64 images" > /dev/null
-python3 $R/scripts/pmc_dominant.py $O/pmc_wgrad.json "igemm_tn_kernel<128, 0, 0>" 1958.706 $O/pmc_train_FETCH_SIZE $O/pmc_train_WRITE_SIZE $O/pmc_train_MFMA "largest weight-gradient launch: 36 Winograd F(4x4,3x3)-domain TN GEMMs of fpn.out_convs.4, 46 images" > /dev/null
+# plain bench line (no profiler attached): the numbers DESIGN.md quotes
+python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
+GF=$(python3 -c "import json,sys; print(json.loads(open('$O/bench_default.json').read().strip().splitlines()[-1])['roofline']['executed_GFLOP_per_launch'])")
+# dominant kernels: forward = wino23_fused_kernel, mean over ALL its launches of a step (pairs with its average duration in
+# bench_kernel_stats.csv); backward = the weight-gradient kernel's largest launch
+python3 $R/scripts/pmc_dominant.py $O/pmc_dominant.json "wino23_fused_kernel" $GF $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_MFMA "wino23_fused_kernel<128,64>, mean over all launches of the B = 64 detect step (finest FPN map on demand)" all > /dev/null
+python3 $R/scripts/pmc_dominant.py $O/pmc_rows.json "wino23_rows_tiles_kernel" 0 $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_MFMA "row half of the Winograd input transform, listed tiles of fpn.out_convs.4, 64 images" > /dev/null
+python3 $R/scripts/pmc_dominant.py $O/pmc_wgrad.json "igemm_tn_kernel<128, 0, 0>" 0 $O/pmc_train_FETCH_SIZE $O/pmc_train_WRITE_SIZE $O/pmc_train_MFMA "largest weight-gradient launch of the B = 128 training step" > /dev/null
 # per-kernel means of the counters (small text files; the raw csv stays on the box)
 for d in pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_MFMA pmc_train_FETCH_SIZE pmc_train_WRITE_SIZE pmc_train_MFMA; do
   python3 $R/scripts/pmc_summarize.py $O/$d > $O/$d.summary.txt
