@@ -46,6 +46,12 @@ struct WinoFusedParams {
   // tile id (b * THW + ty * TW + tx) ascending inside a 128-entry block, or -1 (only at the end of a block).  n_blocks
   // (device, optional): number of leading blocks that are filled; the other workgroups exit at once.
   const int* tiles; const int* n_blocks;
+  // Optional per-block plane / store masks (tile lists only): blk_info[block] = plane mask (bit xi = 4 i + j: the plane is
+  // computed) | store mask << 16 (bit 2 p + q: output pixel (p, q) of every tile of the block is stored).  A block whose
+  // tiles only need output row p = 1 (A^T row [0 1 -1 -1]) skips the four planes i = 0, likewise for columns: 9 or 12 planes
+  // instead of 16.  The planes that are computed are accumulated in the same order as in a full block: a stored pixel is
+  // bit-identical either way.
+  const unsigned* blk_info;
 };
 
 // x [B][H][W][C] -> R [4][B][TH][WP][C], WP = 2 TW + 2: R[i][b][ty][x + 1] = sum_a BT[i][a] x[b][2ty - 1 + a][x] with
@@ -142,6 +148,8 @@ __global__ __launch_bounds__(256, BN == 128 ? 1 : 2) void wino23_fused_kernel(co
     if (p.tiles[bm0] < 0) return;
   }
   auto tile_of = [&](int t) { return p.tiles ? p.tiles[t] : t; };     // t < p.T checked by the callers
+  const unsigned info = (p.tiles && p.blk_info) ? p.blk_info[tile_m] : 0x000fffffu;
+  const unsigned plane_mask = info & 0xffffu, store_mask = (info >> 16) & 0xfu;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm0 = (wave / WAVES_N) * WM, wn0 = (wave % WAVES_N) * WN;
@@ -180,7 +188,8 @@ __global__ __launch_bounds__(256, BN == 128 ? 1 : 2) void wino23_fused_kernel(co
 
   f32x4 ra[AR], ra2[AR], rb[BR];
   float a_sign = 1.f;             // sign of the second column of the tile being staged
-  int ld_xi = 0, ld_c0 = 0;       // cursor of the NEXT tile to load: plane, first channel
+  unsigned ld_rem = plane_mask;   // planes still to load (lowest set bit = ld_xi), same for the LDS-store cursor below
+  int ld_xi = __builtin_ctz(ld_rem), ld_c0 = 0;       // cursor of the NEXT tile to load: plane, first channel
 
   // V[i][j] = R_i[k1] + s R_i[k2] with (k1, k2, s) = (0,2,-), (1,2,+), (2,1,-), (1,3,-) for j = 0..3 (rows of B^T)
   auto load_tiles = [&]() {
@@ -199,10 +208,11 @@ __global__ __launch_bounds__(256, BN == 128 ? 1 : 2) void wino23_fused_kernel(co
     for (int r = 0; r < BR; ++r)
       rb[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b_rel[r], b_soff, 0));
     ld_c0 += BK;
-    if (ld_c0 == p.C) { ld_c0 = 0; ++ld_xi; }
+    if (ld_c0 == p.C) { ld_c0 = 0; ld_rem &= ld_rem - 1; ld_xi = ld_rem ? __builtin_ctz(ld_rem) : 0; }
   };
   // sign of the tile that the NEXT store_lds writes; tiles are stored in load order, one step behind the loads
-  int st_xi = 0, st_c0 = 0;
+  unsigned st_rem = plane_mask;
+  int st_xi = __builtin_ctz(st_rem), st_c0 = 0;
   auto store_lds = [&](int buf) {
     const float sgn = (st_xi & 3) == 1 ? 1.f : -1.f;
 #pragma unroll
@@ -216,7 +226,7 @@ __global__ __launch_bounds__(256, BN == 128 ? 1 : 2) void wino23_fused_kernel(co
     for (int r = 0; r < BR; ++r)
       *reinterpret_cast<f32x4*>(Bs + (buf * BN + r0 + 32 * r) * PITCH + c4 * 4) = rb[r];
     st_c0 += BK;
-    if (st_c0 == p.C) { st_c0 = 0; ++st_xi; }
+    if (st_c0 == p.C) { st_c0 = 0; st_rem &= st_rem - 1; st_xi = st_rem ? __builtin_ctz(st_rem) : 0; }
   };
   (void)a_sign;
 
@@ -336,8 +346,10 @@ __global__ __launch_bounds__(256, BN == 128 ? 1 : 2) void wino23_fused_kernel(co
   load_tiles();
   store_lds(0);
   load_tiles();
-  for (int xi = 0; xi < 16; ++xi) {
-    if (xi < 15) {
+  for (unsigned rem = plane_mask; rem;) {
+    const int xi = __builtin_ctz(rem);
+    rem &= rem - 1;
+    if (rem) {
       for (int kt = 0; kt < p.nk; ++kt) k_step(TT{}, TT{});
     } else {
       for (int kt = 0; kt + 2 < p.nk; ++kt) k_step(TT{}, TT{});
@@ -397,7 +409,8 @@ __global__ __launch_bounds__(256, BN == 128 ? 1 : 2) void wino23_fused_kernel(co
   for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
     for (int qq = 0; qq < 2; ++qq) {
-      if (pp | qq) __syncthreads();
+      if (!((store_mask >> (2 * pp + qq)) & 1u)) continue;         // uniform: nobody reads this pixel of the block's tiles
+      __syncthreads();
 #pragma unroll
       for (int a = 0; a < MT; ++a)
 #pragma unroll
@@ -463,27 +476,31 @@ extern "C" int nbm_wino23_rows_tiles(const float* x, int B, int H, int W, int C,
 
 static int wino23_conv_fused_launch(const float* R, const float* U, const float* scale, const float* shift,
                                     const float* mask, int relu, int B, int H, int W, int C, int N, float* y,
-                                    const int* tiles, int n_entries, const int* n_blocks, int variant, void* stream);
+                                    const int* tiles, int n_entries, const int* n_blocks, const unsigned* blk_info,
+                                    int variant, void* stream);
 
 // y = epi(conv3x3(x)) from the row-transformed input R [4][B][TH][WP][C] and the weights U [16][N][C] -- see nbm_hip.h.
 extern "C" int nbm_wino23_conv_fused(const float* R, const float* U, const float* scale, const float* shift,
                                      const float* mask, int relu, int B, int H, int W, int C, int N, float* y,
                                      int variant, void* stream) {
-  return wino23_conv_fused_launch(R, U, scale, shift, mask, relu, B, H, W, C, N, y, nullptr, 0, nullptr, variant, stream);
+  return wino23_conv_fused_launch(R, U, scale, shift, mask, relu, B, H, W, C, N, y, nullptr, 0, nullptr, nullptr, variant, stream);
 }
 
 // The same for the listed tiles only (pixels of y outside the listed tiles are not written) -- see nbm_hip.h.
 extern "C" int nbm_wino23_conv_fused_tiles(const float* R, const float* U, const float* scale, const float* shift,
                                            const float* mask, int relu, int B, int H, int W, int C, int N, float* y,
-                                           const int* tiles, int n_entries, const int* n_blocks, void* stream) {
+                                           const int* tiles, int n_entries, const int* n_blocks, const unsigned* blk_info,
+                                           void* stream) {
   if (!tiles || n_entries < 0 || (n_entries % BM)) return NBM_EINVAL;
   if (n_entries == 0) return NBM_OK;
-  return wino23_conv_fused_launch(R, U, scale, shift, mask, relu, B, H, W, C, N, y, tiles, n_entries, n_blocks, 0, stream);
+  return wino23_conv_fused_launch(R, U, scale, shift, mask, relu, B, H, W, C, N, y, tiles, n_entries, n_blocks, blk_info, 0,
+                                  stream);
 }
 
 static int wino23_conv_fused_launch(const float* R, const float* U, const float* scale, const float* shift,
                                     const float* mask, int relu, int B, int H, int W, int C, int N, float* y,
-                                    const int* tiles, int n_entries, const int* n_blocks, int variant, void* stream) {
+                                    const int* tiles, int n_entries, const int* n_blocks, const unsigned* blk_info,
+                                    int variant, void* stream) {
   if (!R || !U || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0) return NBM_EINVAL;
   if ((C % BK) || C / BK < 2 || (N & 3)) return NBM_EUNSUPPORTED;
   if (!nbm_aligned16(R) || !nbm_aligned16(U) || !nbm_aligned16(y) || (shift && !nbm_aligned16(shift)) ||
@@ -503,7 +520,7 @@ static int wino23_conv_fused_launch(const float* R, const float* U, const float*
   p.T = (int)T; p.N = N; p.C = C; p.nk = C / BK; p.H = H; p.W = W;
   p.r_gs = (long long)B * p.TH * p.WP * C; p.u_gs = N * C;
   p.m_tiles = (int)((T + BM - 1) / BM);
-  p.tiles = tiles; p.n_blocks = n_blocks;
+  p.tiles = tiles; p.n_blocks = n_blocks; p.blk_info = blk_info;
   if (tiles) { p.T = n_entries; p.m_tiles = n_entries / BM; }
   hipStream_t st = (hipStream_t)stream;
   const int abl = variant / 1000;

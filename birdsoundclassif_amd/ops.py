@@ -233,36 +233,82 @@ _PATTERNS = {}
 _ROI_TILE_BUF = {}
 
 
+class TilePattern:
+    """Tiles of a [B,H,W] map that hold a pixel read by a 3x3 / stride / pad 1 consumer, grouped by WHICH of their 2 x 2
+    pixels are read (all four; the second row only; the second column only; the last pixel only -- with stride 8 the pattern
+    enters three tiles out of four through one row, one column or one pixel):
+      tiles     int32 [n_entries] on the device: per class the linear ids, ascending over the batch, -1 padded to 128
+      blk_info  uint32 [n_entries / 128]: planes to compute | pixels to store << 16 (nbm_hip.h) -- 16 / 12 / 12 / 9 planes
+      full      uint8 [TH*TW]: 1 where all four pixels of the tile are computed (the RoI phase skips those)
+      any       bool  [TH*TW]: 1 where the tile is in the pattern at all (its weight-gradient term comes from this list)
+      n         number of listed tiles;  n_eff = sum(planes x tiles) / 16: the executed-FLOP equivalent in 16-plane tiles
+      frac      covered fraction of all tiles"""
+    __slots__ = ('tiles', 'blk_info', 'full', 'any', 'n', 'n_eff', 'frac')
+
+
 def wino23_pattern(B, H, W, stride, device):
-    """2 x 2 output tiles of a [B,H,W] map that hold a pixel read by a 3x3 / `stride` / pad 1 consumer ->
-    (tiles int32 [n_entries] on the device: linear ids, ascending, -1 padded to a multiple of 128;  skip uint8 [TH*TW]:
-    1 where the pattern covers the tile;  number of listed tiles;  covered fraction of all tiles)."""
     key = (B, H, W, stride, str(device))
     hit = _PATTERNS.get(key)
     if hit is None:
         TH, TW = (H + 1) // 2, (W + 1) // 2
 
-        def need(n, nt):
-            m = np.zeros(nt, dtype=bool)
+        def need(n, nt):                          # per tile row: which of its two pixel rows are read (bit 0: first, bit 1: second)
+            m = np.zeros(nt, dtype=np.int64)
             for o in range((n + 2 - 3) // stride + 1):
                 for k in range(3):
                     r = o * stride - 1 + k
                     if 0 <= r < n:
-                        m[r >> 1] = True
+                        m[r >> 1] |= 1 << (r & 1)
             return m
-        mask = need(H, TH)[:, None] & need(W, TW)[None, :]
-        ids = np.flatnonzero(mask.ravel()).astype(np.int64)
-        allt = (np.arange(B, dtype=np.int64)[:, None] * (TH * TW) + ids[None, :]).ravel()
-        n = allt.size
-        pad = (-n) % 128
-        arr = np.concatenate([allt, np.full(pad, -1, dtype=np.int64)]).astype(np.int32)
-        hit = _PATTERNS[key] = (torch.from_numpy(arr).to(device), torch.from_numpy(mask.ravel().astype(np.uint8)).to(device),
-                                n, float(mask.mean()))
+        ry, rx = need(H, TH), need(W, TW)
+        # planes i (rows of A^T = [1 1 1 0; 0 1 -1 -1]) a tile row needs: first pixel row -> {0,1,2}, second -> {1,2,3}
+        planes_of = {0: 0, 1: 0b0111, 2: 0b1110, 3: 0b1111}
+        lists, infos, n, n_eff = [], [], 0, 0.0
+        for cy in (3, 2, 1):
+            for cx in (3, 2, 1):
+                m2 = (ry == cy)[:, None] & (rx == cx)[None, :]
+                ids = np.flatnonzero(m2.ravel()).astype(np.int64)
+                if ids.size == 0:
+                    continue
+                allt = (np.arange(B, dtype=np.int64)[:, None] * (TH * TW) + ids[None, :]).ravel()
+                pm = 0
+                for i in range(4):
+                    for j in range(4):
+                        if (planes_of[cy] >> i) & 1 and (planes_of[cx] >> j) & 1:
+                            pm |= 1 << (4 * i + j)
+                sm = 0
+                for pp in range(2):
+                    for qq in range(2):
+                        if (cy >> pp) & 1 and (cx >> qq) & 1:
+                            sm |= 1 << (2 * pp + qq)
+                pad = (-allt.size) % 128
+                lists.append(np.concatenate([allt, np.full(pad, -1, dtype=np.int64)]))
+                infos.append(np.full((allt.size + pad) // 128, pm | (sm << 16), dtype=np.int64))
+                n += allt.size
+                n_eff += allt.size * bin(pm).count('1') / 16.0
+        anym = (ry > 0)[:, None] & (rx > 0)[None, :]
+        full = (ry == 3)[:, None] & (rx == 3)[None, :]
+        hit = _PATTERNS[key] = TilePattern()
+        # interleave the classes' blocks by relative position: the fused kernel hands contiguous block ranges to the 8 XCDs, and a
+        # range made of 16-plane blocks only would finish long after a range of 9-plane blocks (measured: no gain without this)
+        blocks = np.concatenate(lists).reshape(-1, 128)
+        infos = np.concatenate(infos)
+        pos = np.concatenate([(np.arange(len(i)) + 0.5) / len(i) for i in [l.reshape(-1, 128) for l in lists]])
+        order = np.argsort(pos, kind='stable')
+        infos = infos[order]
+        hit.tiles = torch.from_numpy(blocks[order].ravel().astype(np.int32)).to(device)
+        if os.environ.get('NBM_DEBUG_BLKINFO'):          # timing experiments only (results are wrong)
+            infos[:] = int(os.environ['NBM_DEBUG_BLKINFO'], 16)
+        hit.blk_info = torch.from_numpy(infos.astype(np.uint32).view(np.int32)).to(device)
+        hit.full = torch.from_numpy(full.ravel().astype(np.uint8)).to(device)
+        hit.any = torch.from_numpy(anym.ravel()).to(device)
+        hit.n, hit.n_eff, hit.frac = n, n_eff, float(anym.mean())
     return hit
 
 
-def _wino23_tiles_run(x, U, bias, y_ptr, tiles, n_blocks, n_listed, label):
-    """Rows transform + fused kernel for the listed tiles of x [B,H,W,C] -> pixels of the map at device address y_ptr."""
+def _wino23_tiles_run(x, U, bias, y_ptr, tiles, n_blocks, n_listed, label, blk_info=None):
+    """Rows transform + fused kernel for the listed tiles of x [B,H,W,C] -> pixels of the map at device address y_ptr.
+    n_listed: executed work in 16-plane tile equivalents (None: device-side count in n_blocks)."""
     B, H, W, C_ = x.shape
     N = U.shape[1]
     per_img = 4 * (-(-H // 2)) * (2 * (-(-W // 2)) + 2) * C_
@@ -282,7 +328,7 @@ def _wino23_tiles_run(x, U, bias, y_ptr, tiles, n_blocks, n_listed, label):
     if PROFILE is not None:
         ev[1].record()
     check(lib().nbm_wino23_conv_fused_tiles(_ptr(R), _ptr(U), None, _ptr(bias), None, 0, B, H, W, C_, N, C.c_void_p(y_ptr), _ptr(tiles),
-                                            tiles.numel(), nb_ptr, st), 'nbm_wino23_conv_fused_tiles')
+                                            tiles.numel(), nb_ptr, _ptr(blk_info), st), 'nbm_wino23_conv_fused_tiles')
     if PROFILE is not None:
         ev[2].record()
         # listed tiles: known on the host for the pattern, a device counter for the RoI tiles (resolved by the reader after a sync)
@@ -338,9 +384,10 @@ def conv3x3_winograd_lazy(x, U, bias, stride):
     chunk = lazy_chunk(x)
     for b0 in range(0, B, chunk):
         nb = min(chunk, B - b0)
-        tiles, st.skip, n, _ = wino23_pattern(nb, H, W, stride, x.device)
-        st.chunks.append((b0, nb, tiles))
-        _wino23_tiles_run(x[b0:b0 + nb], U, bias, y.data_ptr() + b0 * img_bytes, tiles, None, n, 'wino23')
+        pat = wino23_pattern(nb, H, W, stride, x.device)
+        st.skip = pat.full
+        st.chunks.append((b0, nb, pat))
+        _wino23_tiles_run(x[b0:b0 + nb], U, bias, y.data_ptr() + b0 * img_bytes, pat.tiles, None, pat.n_eff, 'wino23', pat.blk_info)
     _LAZY.clear()                                # one deferred map at a time (the previous forward's is stale by now)
     _LAZY[y.data_ptr()] = (st, weakref.ref(y))      # valid while the map object itself (or a view of it) is alive
     return y, st
@@ -408,14 +455,19 @@ def conv3x3_winograd_wgrad_tiles(st, x, g, want_bias=False):
     gb = torch.zeros((N,), device=x.device, dtype=torch.float32) if want_bias else None
     lmax = max(128, (WINO_CHUNK_BYTES // (16 * (C_ + N) * 4)) // 128 * 128)
     stream = _stream()
-    for ci, (b0, nb, pattern) in enumerate(st.chunks):
-        lists = [pattern]
+    thw = ((H + 1) // 2) * ((W + 1) // 2)
+    for ci, (b0, nb, pat) in enumerate(st.chunks):
+        lists = [pat.tiles]
         if st.roi:
             tiles, host, ev = st.roi[ci]
             ev.synchronize()                        # recorded during the forward pass: long done
             n = int(host.item()) * 128
             if n:
-                lists.append(tiles[:n])
+                # the RoI phase recomputes pattern tiles of which only some pixels had been stored: their term of the
+                # sum already comes from the pattern list
+                roi = tiles[:n]
+                dup = (roi >= 0) & pat.any[roi.clamp(min=0) % thw]
+                lists.append(torch.where(dup, torch.full_like(roi, -1), roi))
         full = torch.cat(lists) if len(lists) > 1 else lists[0]
         xs, gs = x[b0:b0 + nb], g[b0:b0 + nb]
         for l0 in range(0, full.numel(), lmax):

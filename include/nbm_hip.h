@@ -116,6 +116,10 @@ int nbm_wino23_conv_fused(const float* R, const float* U, const float* scale, co
  *   tiles:     n_entries int32 (n_entries % 128 == 0): linear tile id b * TH * TW + ty * TW + tx, ascending inside each
  *              128-entry block, -1 = none (only at the end of a block); the tiles of a block lie within 8 consecutive images.
  *   n_blocks:  optional device scalar: number of leading 128-entry blocks that are filled (the rest is not read).
+ *   blk_info:  optional, one word per 128-entry block: bits 0-15 = the transformed-domain planes xi = 4 i + j to compute,
+ *              bits 16-19 = the output pixels 2 p + q of every tile of the block to store.  A tile of which the reader only
+ *              wants the second output row (the stride-8 pattern enters most tiles through one row or one pixel) needs the
+ *              planes i = 1..3 only: 12 or 9 GEMMs instead of 16; the pixels it does store are bit-identical.
  *   nbm_wino23_rows_tiles:       row half of the input transform for the four columns of every listed tile;
  *   nbm_wino23_conv_fused_tiles: as nbm_wino23_conv_fused, writes ONLY the pixels of the listed tiles;
  *   nbm_roi_tiles:               builds such a list on the device from the RoI windows (exactly the windows nbm_roi_pool
@@ -125,7 +129,7 @@ int nbm_wino23_rows_tiles(const float* x, int B, int H, int W, int C, const int*
                           float* R, void* stream);
 int nbm_wino23_conv_fused_tiles(const float* R, const float* U, const float* scale, const float* shift, const float* mask,
                                 int relu, int B, int H, int W, int C, int N, float* y, const int* tiles, int n_entries,
-                                const int* n_blocks, void* stream);
+                                const int* n_blocks, const unsigned* blk_info, void* stream);
 int nbm_roi_tiles(const float* rois, const int* n_roi, int B, int roi_cap, int n_levels, int level, const int* fh,
                   const int* fw, const unsigned char* skip, int* tiles, int* n_blocks, void* stream);
 /* Weight gradient of such a demand-driven convolution: the gradient wrt its output is zero outside the tiles that were

@@ -46,18 +46,23 @@ def test_listed_tiles_equal_the_dense_convolution(shape):
         y, _ = ops.conv3x3_winograd_lazy(x, U, b, 8)
     finally:
         ops.LAZY_POISON = False
-    tiles, skip, n, frac = ops.wino23_pattern(B, H, W, 8, x.device)
-    assert 0.15 < frac < 0.45 and n == int(skip.sum()) * B
+    pat = ops.wino23_pattern(B, H, W, 8, x.device)
+    assert 0.15 < pat.frac < 0.45 and pat.n == int(pat.any.sum()) * B and pat.n_eff <= 0.8 * pat.n
     TH, TW = (H + 1) // 2, (W + 1) // 2
-    m = skip.view(TH, TW).bool().repeat_interleave(2, 0).repeat_interleave(2, 1)[:H, :W]
-    # pattern: every pixel a 3x3 / stride 8 / pad 1 convolution reads is inside a listed tile
-    for o in range((H - 1) // 8 + 1):
-        for k in range(3):
-            r = 8 * o - 1 + k
-            if 0 <= r < H:
-                assert bool(m[r].any())
-    assert torch.equal(y[:, m], dense[:, m]), 'listed tiles differ from the dense convolution'
-    assert bool(torch.isnan(y[:, ~m]).all()), 'a pixel outside the listed tiles was written'
+    # the pixels a 3x3 / stride 8 / pad 1 convolution reads: rows {8o-1, 8o, 8o+1} x the same columns -- exactly these are
+    # stored (a tile entered through one row / column / pixel stores just that), bit-identical to the dense convolution
+    rows = torch.zeros(H, dtype=torch.bool)
+    cols = torch.zeros(W, dtype=torch.bool)
+    for n_, v in ((H, rows), (W, cols)):
+        for o in range((n_ - 1) // 8 + 1):
+            for k in range(3):
+                if 0 <= 8 * o - 1 + k < n_:
+                    v[8 * o - 1 + k] = True
+    m = (rows[:, None] & cols[None, :]).cuda()
+    tile_any = pat.any.view(TH, TW).repeat_interleave(2, 0).repeat_interleave(2, 1)[:H, :W]
+    assert bool((m <= tile_any).all())
+    assert torch.equal(y[:, m], dense[:, m]), 'stored pixels differ from the dense convolution'
+    assert bool(torch.isnan(y[:, ~m]).all()), 'a pixel outside the pattern was written'
     # RoI phase: random boxes, most of them small enough for level 0
     fh = [H, (H + 1) // 2, (H + 3) // 4, (H + 7) // 8, (H + 15) // 16]
     fw = [W, (W + 1) // 2, (W + 3) // 4, (W + 7) // 8, (W + 15) // 16]
@@ -86,7 +91,7 @@ def test_listed_tiles_equal_the_dense_convolution(shape):
     assert n_lvl0 > 0
     want = want.cuda()
     assert torch.equal(y[want], dense[want]), 'RoI tiles differ from the dense convolution'
-    assert bool(torch.isnan(y[~want]).all()), 'a pixel outside pattern + RoI tiles was written'
+    assert bool(torch.isnan(y[~want]).all()), 'a pixel outside pattern pixels + RoI tiles was written'
 
 
 def test_weight_gradient_over_the_listed_tiles_equals_the_dense_one():
@@ -105,7 +110,7 @@ def test_weight_gradient_over_the_listed_tiles_equals_the_dense_one():
     # mask of computed pixels: pattern tiles + RoI tiles (re-derived from the lists the map kept)
     TH, TW = (H + 1) // 2, (W + 1) // 2
     mask = torch.zeros((B, TH, TW), dtype=torch.bool, device='cuda')
-    ids = [st.chunks[0][2]]
+    ids = [st.chunks[0][2].tiles]
     tiles, host, ev = st.roi[0]
     ev.synchronize()
     ids.append(tiles[:int(host.item()) * 128])
