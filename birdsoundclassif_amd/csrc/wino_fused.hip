@@ -140,7 +140,16 @@ __global__ __launch_bounds__(256, BN == 128 ? 1 : 2) void wino23_fused_kernel(co
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int tile_m = wg / p.n_tiles, tile_n = wg - tile_m * p.n_tiles;
+  int tile_m = wg / p.n_tiles, tile_n = wg - tile_m * p.n_tiles;
+  if (p.n_blocks) {
+    // device-side block count: only the leading blocks are filled, and the contiguous ranges above would put all of them on
+    // one XCD (measured: the RoI launch ran on an eighth of the chip).  Round-robin the M blocks over the XCDs instead; the N
+    // tiles of a block stay on its XCD, back to back.  The grid is padded to a multiple of 8 * n_tiles.
+    const int j = bid >> 3;
+    tile_n = j % p.n_tiles;
+    tile_m = (j / p.n_tiles) * 8 + xcd;
+    if (tile_m >= p.m_tiles) return;
+  }
   const int bm0 = tile_m * BM, bn0 = tile_n * BN;
 
   if (p.tiles) {                                   // uniform per workgroup
@@ -527,7 +536,7 @@ static int wino23_conv_fused_launch(const float* R, const float* U, const float*
   variant %= 1000;
   const bool wide = variant == 128 || (variant == 0 && N % 128 == 0);
   p.n_tiles = wide ? (N + 127) / 128 : (N + 63) / 64;
-  const dim3 grid(p.m_tiles * p.n_tiles), block(256);
+  const dim3 grid((n_blocks ? (p.m_tiles + 7) / 8 * 8 : p.m_tiles) * p.n_tiles), block(256);
 #define NBM_WF(BN_, WN_, A_) hipLaunchKernelGGL((wino23_fused_kernel<BN_, WN_, A_>), grid, block, 0, st, p)
   if (wide) {
     switch (abl) { case 0: NBM_WF(128, 64, 0); break; case 1: NBM_WF(128, 64, 1); break; case 2: NBM_WF(128, 64, 2); break;

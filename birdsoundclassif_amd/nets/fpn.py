@@ -99,10 +99,10 @@ class FPN(nn.Module):
         self.pt_wise = nn.ModuleDict({str(i): nn.Conv2d(cn, p_cn, 1) for i, cn in enumerate(channels)})
         self.out_convs = nn.ModuleDict({str(i): nn.Conv2d(p_cn, out_cn, 3, padding=1) for i in range(len(channels))})
 
-    def forward(self, x, lazy_stride=None):
+    def forward(self, x, lazy_strides=None):
         """x: bottom-up list of NHWC maps (or Scaled(map, factor)) -> bottom-up list of NHWC [B,h,w,out_cn].
-        `lazy_stride`: the finest output map is only read by a 3x3 / lazy_stride convolution (the RPN's first level) and by
-        the RoI pooling: it is computed on demand (Fn.conv), pixels nobody reads stay unwritten."""
+        `lazy_strides` {level: stride}: that output map is only read by a 3x3 / stride convolution (the RPN's convolution of
+        the level) and by the RoI pooling: it is computed on demand (Fn.conv), pixels nobody reads stay unwritten."""
         # The top-down merge `bilinear(coarser) + lateral` (reference fpn.py:143-144) happens in the epilogue of the
         # lateral 1x1 GEMM, so the lateral maps are never written and re-read on their own.
         outs, merged = [], None
@@ -113,7 +113,7 @@ class FPN(nn.Module):
             merged = Fn.conv(t, c.weight, bias=c.bias, alpha=alpha, up=merged)
             oc = self.out_convs[str(len(x) - 1 - i)]
             outs.insert(0, Fn.conv(merged, oc.weight, bias=oc.bias, kh=3, kw=3, pad=1,
-                                   lazy_stride=lazy_stride if i == 0 else None))
+                                   lazy_stride=(lazy_strides or {}).get(i)))
         return outs
 
 def build_fpn(args, channels):

@@ -60,8 +60,8 @@ class Conv(Function):
             # demand-driven map (ops.conv3x3_winograd_lazy): the tiles a 3x3 / lazy_stride consumer reads now, the tiles under
             # the RoIs when the RoI pooling asks for them; the backward pass is the dense one (the incoming gradient is
             # zero wherever nothing was read)
-            y, ctx.lazy = ops.conv3x3_winograd_lazy(x, _prep.wino23(weight), sh, lazy_stride)
-            ctx.lazy.keep = bool(ctx.needs_input_grad[1]) and LAZY_WGRAD
+            y, ctx.lazy = ops.conv3x3_winograd_lazy(x, _prep.wino23(weight), sh, lazy_stride[0])
+            ctx.lazy.keep = lazy_stride[1]        # a backward pass will follow: keep the RoI tile lists for the weight gradient
         elif ctx.wino:        # large 3x3 (FPN output convolutions): Winograd F(2x2,3x3), 2.25x fewer multiplies
             y = ops.conv3x3_winograd(x, _prep.wino23(weight), sh)
         else:
@@ -95,7 +95,7 @@ class Conv(Function):
             ops.conv_dgrad(gp, wk, gx, B=B, H=H, W=W, Cin=Cin, N=N, kh=kh, kw=kw, stride=stride, pad=pad,
                            g_ld=gp.shape[1], w_ld=wk.shape[1], a_scale=scale, alpha=alpha)
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1] and ctx.lazy is not None and LAZY_WGRAD:
+        if ctx.needs_input_grad[1] and ctx.lazy is not None and ctx.lazy.sparse and LAZY_WGRAD:
             # demand-driven map: the gradient is zero outside the tiles that were computed -> F(2x2,3x3) over those tiles only
             dU, gb = ops.conv3x3_winograd_wgrad_tiles(ctx.lazy, x, g.view(B, H, W, N), want_bias=want_gb)
             gw = _prep.wino23_weight_grad(dU, 2)
@@ -203,6 +203,8 @@ def conv(x, weight, bias=None, scale=None, shift=None, residual=None, kh=1, kw=1
     pixels they read are computed (3x3 Winograd layers only; ignored elsewhere)."""
     if lazy_stride and not (ops.LAZY_FINEST and _winograd_ok(x, weight, kh, kw, stride, pad) and x.shape[-1] >= 64):
         lazy_stride = None
+    if lazy_stride:
+        lazy_stride = (int(lazy_stride), bool(torch.is_grad_enabled() and weight.requires_grad and LAZY_WGRAD))
     return Conv.apply(x, weight, bias, scale, shift, residual, kh, kw, stride, pad, act, alpha, up, lazy_stride)
 
 

@@ -196,9 +196,10 @@ class ROIPooling(nn.Module):
         if (cfg.roi_pool_h, cfg.roi_pool_w) != (2, 2):
             raise NotImplementedError('roi_pool 2x2 (reference default) only')
         pe_f, pe_t = self.pe_tables(rois.device)
-        if ops.lazy_pending(fmaps_nhwc[0]):          # demand-driven finest map: compute the tiles under these RoIs first
-            with torch.no_grad():
-                ops.lazy_complete(fmaps_nhwc[0], rois.detach(), n_roi, [tuple(f.shape[1:3]) for f in fmaps_nhwc], level=0)
+        for lvl, fm in enumerate(fmaps_nhwc):        # demand-driven maps: compute the tiles under these RoIs first
+            if ops.lazy_pending(fm):
+                with torch.no_grad():
+                    ops.lazy_complete(fm, rois.detach(), n_roi, [tuple(f.shape[1:3]) for f in fmaps_nhwc], level=lvl)
         return Fn.RoiPool.apply(rois, n_roi, pe_f, pe_t, cfg.img_height, cfg.img_width, *fmaps_nhwc)
 
     def forward(self, rois, conv_out):

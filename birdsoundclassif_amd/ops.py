@@ -34,6 +34,13 @@ def flops_total():
 
 
 _PROFILE_LABEL = None          # set by composite ops (Winograd) so that their GEMM launches can be told apart
+PROFILE_FUSED_ONLY = False      # record only the launches of the fused Winograd kernel (bench.py's timed loop: ~17 event pairs per
+                                # step instead of ~250, whose records cost the step 2.5 %)
+
+
+def _prof_all():
+    return PROFILE is not None and not PROFILE_FUSED_ONLY
+
 
 
 def _stream():
@@ -83,7 +90,7 @@ def gemm_conv(x, w, y, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, Ho=None,
         d.up, d.up_H, d.up_W = _chk(up, name='up').data_ptr(), up.shape[1], up.shape[2]
     if FLOPS is not None:
         FLOPS[0] += 2.0 * B * Ho * Wo * N * kh * kw * Cin * groups
-    if PROFILE is not None:
+    if _prof_all():
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         check(lib().nbm_gemm_conv(C.byref(d), _stream()), 'nbm_gemm_conv')
@@ -162,7 +169,7 @@ def conv3x3_winograd(x, U, bias=None, m=2, scale=None, relu=False, mask=None):
     else:
         V, M = _wino_scratch(x.device, nxi * chunk * tiles * C_, nxi * chunk * tiles * N)
     st = _stream()
-    if PROFILE is not None:                       # whole-op bracket (transforms + GEMMs) next to the per-GEMM entries
+    if _prof_all():                       # whole-op bracket (transforms + GEMMs) next to the per-GEMM entries
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
     for b0 in range(0, B, chunk):
@@ -191,7 +198,7 @@ def conv3x3_winograd(x, U, bias=None, m=2, scale=None, relu=False, mask=None):
             _PROFILE_LABEL = None
         check(lib().nbm_wino_output(_ptr(M), _ptr(scale), _ptr(bias), mk, int(relu), nb, H, W, N, _ptr(y[b0:b0 + nb]), m, st),
               'nbm_wino_output')
-    if PROFILE is not None:
+    if _prof_all():
         ev[1].record()
         PROFILE.append((('wino23', C_, N, H, W, B), *ev))
     return y
@@ -306,7 +313,7 @@ def wino23_pattern(B, H, W, stride, device):
     return hit
 
 
-def _wino23_tiles_run(x, U, bias, y_ptr, tiles, n_blocks, n_listed, label, blk_info=None):
+def _wino23_tiles_run(x, U, bias, y_ptr, tiles, n_blocks, n_listed, label, blk_info=None, dense_rows=False):
     """Rows transform + fused kernel for the listed tiles of x [B,H,W,C] -> pixels of the map at device address y_ptr.
     n_listed: executed work in 16-plane tile equivalents (None: device-side count in n_blocks)."""
     B, H, W, C_ = x.shape
@@ -322,9 +329,13 @@ def _wino23_tiles_run(x, U, bias, y_ptr, tiles, n_blocks, n_listed, label, blk_i
             FLOPS[0] += 2.0 * 16 * n_listed * C_ * N
     if PROFILE is not None:
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        ev[0].record()
-    check(lib().nbm_wino23_rows_tiles(_ptr(x), B, H, W, C_, _ptr(tiles), tiles.numel(), nb_ptr, _ptr(R), st),
-          'nbm_wino23_rows_tiles')
+        if _prof_all():
+            ev[0].record()
+    if dense_rows:                                # every tile is listed: the plain row transform writes half the bytes
+        check(lib().nbm_wino23_rows(_ptr(x), B, H, W, C_, _ptr(R), st), 'nbm_wino23_rows')
+    else:
+        check(lib().nbm_wino23_rows_tiles(_ptr(x), B, H, W, C_, _ptr(tiles), tiles.numel(), nb_ptr, _ptr(R), st),
+              'nbm_wino23_rows_tiles')
     if PROFILE is not None:
         ev[1].record()
     check(lib().nbm_wino23_conv_fused_tiles(_ptr(R), _ptr(U), None, _ptr(bias), None, 0, B, H, W, C_, N, C.c_void_p(y_ptr), _ptr(tiles),
@@ -334,7 +345,8 @@ def _wino23_tiles_run(x, U, bias, y_ptr, tiles, n_blocks, n_listed, label, blk_i
         # listed tiles: known on the host for the pattern, a device counter for the RoI tiles (resolved by the reader after a sync)
         cnt = n_listed if n_listed is not None else n_blocks.clone()
         PROFILE.append(((C_, N, 1, cnt, 1, 1, 16, 1, (label, H, W)), ev[1], ev[2]))
-        PROFILE.append(((label, C_, N, H, W, B), ev[0], ev[2]))
+        if _prof_all():
+            PROFILE.append(((label, C_, N, H, W, B), ev[0], ev[2]))
 
 
 def lazy_chunk(x):
@@ -349,11 +361,11 @@ class LazyMap:
     list; RoI list + its block count on the way to the host) -- the weight gradient sums over them.  The map itself is
     NOT referenced (an autograd node owns this object and the map owns the node: a cycle would keep 12 GB alive until the
     garbage collector runs); its consumers keep it alive and hand it back to `lazy_complete`."""
-    __slots__ = ('x', 'U', 'bias', 'skip', 'stride', 'chunks', 'roi', 'keep')
+    __slots__ = ('x', 'U', 'bias', 'skip', 'stride', 'chunks', 'roi', 'keep', 'sparse')
 
     def __init__(self, x, U, bias, stride):
         self.x, self.U, self.bias, self.stride = x, U, bias, stride
-        self.skip, self.chunks, self.roi, self.keep = None, [], None, False
+        self.skip, self.chunks, self.roi, self.keep, self.sparse = None, [], None, False, True
 
 
 _PINNED = []
@@ -387,8 +399,11 @@ def conv3x3_winograd_lazy(x, U, bias, stride):
         pat = wino23_pattern(nb, H, W, stride, x.device)
         st.skip = pat.full
         st.chunks.append((b0, nb, pat))
-        _wino23_tiles_run(x[b0:b0 + nb], U, bias, y.data_ptr() + b0 * img_bytes, pat.tiles, None, pat.n_eff, 'wino23', pat.blk_info)
-    _LAZY.clear()                                # one deferred map at a time (the previous forward's is stale by now)
+        st.sparse = pat.frac < 0.6               # the weight gradient over the listed tiles pays off when most are not listed
+        _wino23_tiles_run(x[b0:b0 + nb], U, bias, y.data_ptr() + b0 * img_bytes, pat.tiles, None, pat.n_eff, 'wino23', pat.blk_info,
+                          dense_rows=pat.frac == 1.0)
+    for k in [k for k, v in _LAZY.items() if v[1]() is None]:      # maps of earlier forwards that were never completed
+        del _LAZY[k]
     _LAZY[y.data_ptr()] = (st, weakref.ref(y))      # valid while the map object itself (or a view of it) is alive
     return y, st
 
@@ -415,7 +430,7 @@ def lazy_complete(fm, rois, n_roi, fmap_hw, level=0):
     fh = (C.c_int * nl)(*[int(h) for h, _ in fmap_hw])
     fw = (C.c_int * nl)(*[int(w) for _, w in fmap_hw])
     blocks_per_img = -(-((H + 1) // 2 * ((W + 1) // 2)) // 128)
-    keep = st.keep                                # a backward pass will want the lists
+    keep = st.keep and st.sparse                  # a backward pass will want the lists
     st.roi = []
     for b0, nb, _ in st.chunks:
         key = (str(x.device), nb * blocks_per_img * 128)
@@ -622,12 +637,12 @@ def stem7x7(img, weff, wb, wb_full, scale, shift):
     y = torch.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64), device=img.device, dtype=torch.float32)
     if FLOPS is not None:
         FLOPS[0] += 2.0 * y.numel() * 56
-    if PROFILE is not None:
+    if _prof_all():
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
     check(lib().nbm_stem7x7(_ptr(img), B, H, W, _ptr(_chk(weff)), _ptr(_chk(wb)), _ptr(_chk(wb_full)), _ptr(_chk(scale)),
                             _ptr(_chk(shift)), _ptr(y), _stream()), 'nbm_stem7x7')
-    if PROFILE is not None:
+    if _prof_all():
         ev[1].record()
         PROFILE.append(((1, 64, 7, H, W, B, 1, 2, None), *ev))
     return y
