@@ -26,7 +26,9 @@ class GemmDesc(C.Structure):
                 ('Ho', C.c_int), ('Wo', C.c_int),
                 ('x_ld', C.c_int), ('w_ld', C.c_int), ('y_ld', C.c_int), ('res_ld', C.c_int),
                 ('alpha', C.c_float), ('act', C.c_int), ('shift_per_row', C.c_int),
-                ('up', C.c_void_p), ('up_H', C.c_int), ('up_W', C.c_int)]
+                ('up', C.c_void_p), ('up_H', C.c_int), ('up_W', C.c_int),
+                ('rows', C.c_void_p), ('rows_blocks', C.c_void_p),
+                ('rows_mode', C.c_int), ('rows_count', C.c_int), ('rows_TH', C.c_int), ('rows_TW', C.c_int)]
 
 
 class RoiDesc(C.Structure):
@@ -109,8 +111,8 @@ SIGNATURES = {
     'nbm_wino23_rows_tiles': [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P],
     'nbm_wino23_conv_fused_tiles': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P],
     'nbm_roi_tiles': [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
-    'nbm_wino23_input_tiles': [_P, _I, _I, _I, _I, _P, _I, _P, _P],
-    'nbm_wino23_outgrad_tiles': [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P],
+    'nbm_wino23_input_tiles': [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P],
+    'nbm_wino23_outgrad_tiles': [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P],
     'nbm_weighted_sum': [_P, _P, _P, _P, _P, _L, _P],
     'nbm_weighted_sum_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P],
     'nbm_softmax_rows_bwd': [_P, _P, _P, _L, _I, _F, _P],

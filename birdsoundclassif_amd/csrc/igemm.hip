@@ -42,6 +42,14 @@ struct IgemmParams {
   int vec_epi;           // epilogue may use 16-byte accesses (N % 4 == 0, pitches % 4 == 0, 16-byte aligned bases)
   // fused top-down merge: y += bilinear_align_corners(up [B][up_H][up_W][N]) (vector epilogue only)
   const float* up; int up_H, up_W; float up_sh, up_sw;
+  // ROWS instantiation only (1x1 / stride 1 / pad 0, one group, vector epilogue): GEMM row m is pixel row_pixel(m) of the dense
+  // NHWC maps x / y / residual (and of the `up` geometry) instead of pixel m -- the lateral convolution of a demand-driven FPN
+  // level is only evaluated where its consumer will read (nbm_gemm_conv, `rows`).
+  //   rows_mode 1: rows[m] = pixel index b*H*W + y*W + x, ascending, -1 = none (only at the end);
+  //   rows_mode 2: rows[m >> 4] = linear 2x2-tile id b*TH*TW + ty*TW + tx (or -1), row m = pixel (m & 15) of the tile's 4x4
+  //                input patch (rows 2ty-1.., columns 2tx-1..; outside the image = none).
+  //   rows_blocks (device, optional): number of leading 128-entry list blocks that are filled.
+  const int* rows; const int* rows_blocks; int rows_mode, rows_TH, rows_TW;
 };
 
 // STAGES = 2: the deep-K pipeline (double-buffered LDS, 2 workgroups per CU).  STAGES = 1: short-K layers (K <= 256: 1x1
@@ -53,7 +61,7 @@ struct IgemmParams {
 // 64-wide tiles at four workgroups per CU (4.19 / 6.05 ms); a persistent workgroup that keeps the weight tile in LDS and
 // has the next pixel tile's loads in flight under the current epilogue (3.99 / 7.96 ms), with or without a start stagger
 // of the two co-resident workgroups (3.85-3.91 ms).
-template <int BM, int BN, int WM, int WN, int AMODE, int EPI, int STAGES = 2>
+template <int BM, int BN, int WM, int WN, int AMODE, int EPI, int STAGES = 2, bool ROWS = false>
 __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_kernel(const IgemmParams p) {
   constexpr int MT = WM / 32, NT = WN / 32;
   constexpr int WAVES_N = BN / WN;
@@ -69,7 +77,28 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_kernel(const I
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int tile_m = wg / p.n_tiles, tile_n = wg - tile_m * p.n_tiles;
+  int tile_m = wg / p.n_tiles, tile_n = wg - tile_m * p.n_tiles;
+  // dense pixel index of GEMM row m, or -1 (ROWS only)
+  auto row_pixel = [&](int m) -> long long {
+    if (p.rows_mode == 1) return p.rows[m];
+    const int t = p.rows[m >> 4];
+    if (t < 0) return -1;
+    const int thw = p.rows_TH * p.rows_TW, k = m & 15;
+    const int b = t / thw, rem = t - b * thw;
+    const int ty = rem / p.rows_TW, tx = rem - ty * p.rows_TW;
+    const int y = 2 * ty - 1 + (k >> 2), x = 2 * tx - 1 + (k & 3);
+    if ((unsigned)y >= (unsigned)p.H || (unsigned)x >= (unsigned)p.W) return -1;
+    return ((long long)b * p.H + y) * p.W + x;
+  };
+  if constexpr (ROWS) {
+    if (p.rows_blocks) {          // device-side count: the filled blocks lead; spread them over the XCDs (see wino_fused.hip)
+      const int j = bid >> 3;
+      tile_n = j % p.n_tiles;
+      tile_m = (j / p.n_tiles) * 8 + xcd;
+      if (tile_m >= p.m_tiles || tile_m * (BM / 128) >= *p.rows_blocks * (p.rows_mode == 2 ? 16 : 1)) return;
+    }
+    if (p.rows[p.rows_mode == 2 ? (tile_m * BM) >> 4 : tile_m * BM] < 0) return;       // an empty block (lists are -1 padded at the end)
+  }
   const int bm0 = tile_m * BM, bn0 = tile_n * BN;
   const int g = blockIdx.z;
 
@@ -91,7 +120,11 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_kernel(const I
   unsigned a_rel[AR];
   unsigned long long a_taps[AR];
   long long blk_base = 0;
-  {
+  if constexpr (ROWS) {           // base = start of the image of the block's first listed entry (a block spans <= 2 images)
+    const int e0 = p.rows[p.rows_mode == 2 ? bm0 >> 4 : bm0];
+    const int b = p.rows_mode == 2 ? e0 / (p.rows_TH * p.rows_TW) : e0 / p.HoWo;
+    blk_base = (long long)b * p.HoWo * p.x_ld;
+  } else {
     const int m0 = bm0 < p.M ? bm0 : 0;
     const int b = m0 / p.HoWo, rem = m0 - b * p.HoWo;
     const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
@@ -101,8 +134,12 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_kernel(const I
   for (int i = 0; i < AR; ++i) {
     const int m = bm0 + r0 + 32 * i;
     a_ok[i] = m < p.M;
-    const int mm = a_ok[i] ? m : 0;
-    const int b = mm / p.HoWo, rem = mm - b * p.HoWo;
+    long long mm = a_ok[i] ? m : 0;
+    if constexpr (ROWS) {
+      if (a_ok[i]) { mm = row_pixel(m); a_ok[i] = mm >= 0; }
+      if (!a_ok[i]) mm = blk_base / p.x_ld;
+    }
+    const int b = (int)(mm / p.HoWo), rem = (int)(mm - (long long)b * p.HoWo);
     const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
     a_iy0[i] = oy * p.stride - p.pad;
     a_ix0[i] = ox * p.stride - p.pad;
@@ -318,8 +355,12 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_kernel(const I
       if (n < p.N) {
 #pragma unroll 4
         for (int r = rr; r < HROWS; r += RPP) {
-          const int m = bm0 + half * HROWS + r;
+          long long m = bm0 + half * HROWS + r;
           if (m >= p.M) break;
+          if constexpr (ROWS) {
+            m = row_pixel((int)m);
+            if (m < 0) continue;
+          }
           f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CP + cc * 4);
           const float rs = (p.shift_per_row && p.shift) ? p.shift[m] : 0.f;
 #pragma unroll
@@ -329,7 +370,10 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_kernel(const I
             v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3];
           }
           if (p.up) {       // same arithmetic as upsample_add_kernel (pointwise.hip): interp first, then + lateral
-            const int b = m / p.HoWo, rem = m - b * p.HoWo;
+#pragma clang fp contract(off)   // like torch's CPU upsample_bilinear2d: no fused multiply-adds in the coordinates or the
+                                 // blend (the compiler fused `scale * o - floor` in one instantiation of this kernel and not in
+                                 // another: 5e-6 apart)
+            const int b = (int)(m / p.HoWo), rem = (int)(m - (long long)b * p.HoWo);
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
             const float fy = p.up_sh * oy, fx = p.up_sw * ox;
             const int y0 = (int)fy, x0 = (int)fx;
@@ -401,6 +445,13 @@ int launch_s1(const IgemmParams& p, int groups, hipStream_t st) {
   return nbm_launch_status();
 }
 
+int launch_s1_rows(const IgemmParams& p, hipStream_t st) {
+  const int mt = p.rows_blocks ? (p.m_tiles + 7) / 8 * 8 : p.m_tiles;
+  dim3 grid(mt * p.n_tiles, 1, 1);
+  hipLaunchKernelGGL((igemm_kernel<128, 128, 64, 64, A_FAST, EPI_STD, 1, true>), grid, dim3(256), 0, st, p);
+  return nbm_launch_status();
+}
+
 }  // namespace
 
 extern "C" int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream) {
@@ -437,6 +488,18 @@ extern "C" int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const int BM = 128;
   p.m_tiles = (p.M + BM - 1) / BM;
+  if (d->rows) {                  // listed rows: the short-K 1x1 variant only
+    if (d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0 || d->groups != 1 || !fast || !p.vec_epi || d->shift_per_row ||
+        p.nk > 8 || d->N <= 64 || (d->rows_mode != 1 && d->rows_mode != 2) || d->rows_count <= 0 || (d->rows_count % 128))
+      return NBM_EUNSUPPORTED;
+    if (d->rows_mode == 2 && (d->rows_TH != (d->H + 1) / 2 || d->rows_TW != (d->W + 1) / 2)) return NBM_EINVAL;
+    if (2ll * d->H * d->W * d->x_ld * 4 > 0x7fffffffll) return NBM_EUNSUPPORTED;
+    p.rows = d->rows; p.rows_blocks = d->rows_blocks; p.rows_mode = d->rows_mode; p.rows_TH = d->rows_TH; p.rows_TW = d->rows_TW;
+    p.M = d->rows_count;
+    p.m_tiles = p.M / BM;
+    p.n_tiles = (d->N + 127) / 128;
+    return launch_s1_rows(p, st);
+  }
   if (d->N > 64) {
     p.n_tiles = (d->N + 127) / 128;
     // short K and a 16-byte epilogue: the three-workgroups-per-CU variant (see the template comment)

@@ -181,6 +181,7 @@ __global__ void upsample_add_kernel(const float* __restrict__ src, int B, int Hi
   f32x4* y4 = reinterpret_cast<f32x4*>(y);
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
        i += (long long)gridDim.x * blockDim.x) {
+#pragma clang fp contract(off)   // see the merge epilogue of igemm.hip: the two must agree bit for bit
     const int c = (int)(i % C4);
     long long t = i / C4;
     const int ox = (int)(t % Wo); t /= Wo;

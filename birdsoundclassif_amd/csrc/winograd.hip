@@ -14,7 +14,7 @@ namespace {
 // whose output was ever read.
 __global__ __launch_bounds__(256) void wino23_input_kernel(const float* __restrict__ x, int B, int H, int W, int C4,
                                                            float* __restrict__ V, const int* __restrict__ tiles,
-                                                           int n_list) {
+                                                           int n_list, const unsigned* __restrict__ blk_info) {
   const int TH = (H + 1) >> 1, TW = (W + 1) >> 1;
   const long long T = tiles ? (long long)n_list : (long long)B * TH * TW;
   const long long total = T * C4;
@@ -54,13 +54,17 @@ __global__ __launch_bounds__(256) void wino23_input_kernel(const float* __restri
       u[2][q] = d[2][q] - d[1][q];
       u[3][q] = d[1][q] - d[3][q];
     }
+    // plane_mask (list mode, optional, one word per entry): planes that are not this entry's to contribute are written as
+    // zeros -- the forward pass skipped them for a tile entered through one row / column / pixel (the input pixels only they
+    // depend on may never have been computed: 0 x garbage must not reach dU), or another entry of the same tile carries them
+    const unsigned pm = blk_info ? blk_info[t] & 0xffffu : 0xffffu;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       const f32x4 o0 = u[a][0] - u[a][2], o1 = u[a][1] + u[a][2], o2 = u[a][2] - u[a][1], o3 = u[a][1] - u[a][3];
-      v4[((long long)(a * 4 + 0) * T + t) * C4 + c] = o0;
-      v4[((long long)(a * 4 + 1) * T + t) * C4 + c] = o1;
-      v4[((long long)(a * 4 + 2) * T + t) * C4 + c] = o2;
-      v4[((long long)(a * 4 + 3) * T + t) * C4 + c] = o3;
+      v4[((long long)(a * 4 + 0) * T + t) * C4 + c] = ((pm >> (a * 4 + 0)) & 1u) ? o0 : zero;
+      v4[((long long)(a * 4 + 1) * T + t) * C4 + c] = ((pm >> (a * 4 + 1)) & 1u) ? o1 : zero;
+      v4[((long long)(a * 4 + 2) * T + t) * C4 + c] = ((pm >> (a * 4 + 2)) & 1u) ? o2 : zero;
+      v4[((long long)(a * 4 + 3) * T + t) * C4 + c] = ((pm >> (a * 4 + 3)) & 1u) ? o3 : zero;
     }
   }
 }
@@ -127,7 +131,8 @@ __global__ __launch_bounds__(256) void wino23_output_kernel(const float* __restr
 // (bias gradient) over its grid-stride items -- its channel chunk is fixed because the stride is a multiple of N4.
 __global__ __launch_bounds__(256) void wino23_outgrad_kernel(const float* __restrict__ g, int B, int H, int W, int N4,
                                                              float* __restrict__ dM, float* __restrict__ bias_grad,
-                                                             const int* __restrict__ tiles, int n_list) {
+                                                             const int* __restrict__ tiles, int n_list,
+                                                             const unsigned* __restrict__ entry_info) {
   const int TH = (H + 1) >> 1, TW = (W + 1) >> 1;
   const long long T = tiles ? (long long)n_list : (long long)B * TH * TW;      // tile list: as in wino23_input_kernel
   const long long total = T * N4;
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(256) void wino23_outgrad_kernel(const float* __rest
     const bool in_y = 2 * ty + 1 < H, in_x = 2 * tx + 1 < W;          // odd sizes: the last tile row / column is half outside
     const f32x4 y00 = g4[row * N4 + c], y01 = in_x ? g4[(row + 1) * N4 + c] : zero;
     const f32x4 y10 = in_y ? g4[(row + W) * N4 + c] : zero, y11 = (in_y && in_x) ? g4[(row + W + 1) * N4 + c] : zero;
-    bsum += (y00 + y01) + (y10 + y11);
+    if (!entry_info || ((entry_info[t] >> 16) & 1u)) bsum += (y00 + y01) + (y10 + y11);   // a tile listed twice counts once
     // rows of A = [1 0; 1 1; 1 -1; 0 -1]
     const f32x4 r0[2] = {y00, y01}, r1[2] = {y00 + y10, y01 + y11}, r2[2] = {y00 - y10, y01 - y11}, r3[2] = {-y10, -y11};
     const f32x4* rows[4] = {r0, r1, r2, r3};
@@ -444,7 +449,7 @@ extern "C" int nbm_wino_input(const float* x, int B, int H, int W, int C, float*
   const long long tiles = (long long)B * ((H + m - 1) / m) * ((W + m - 1) / m);
   if (m == 2)
     hipLaunchKernelGGL(wino23_input_kernel, dim3(grid_for(tiles * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, B, H, W, C / 4, V,
-                       (const int*)nullptr, 0);
+                       (const int*)nullptr, 0, (const unsigned*)nullptr);
   else
     hipLaunchKernelGGL(wino43_input_kernel, dim3(grid_for(tiles * (C / 2))), dim3(256), 0, (hipStream_t)stream, x, B, H, W, C / 2, V);
   return nbm_launch_status();
@@ -461,25 +466,25 @@ extern "C" int nbm_wino_outgrad(const float* g, int B, int H, int W, int N, floa
   while ((blocks * 256) % per) ++blocks;
   if (m == 2)
     hipLaunchKernelGGL(wino23_outgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, B, H, W, per, dM, bias_grad,
-                       (const int*)nullptr, 0);
+                       (const int*)nullptr, 0, (const unsigned*)nullptr);
   else
     hipLaunchKernelGGL(wino43_outgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, B, H, W, per, dM, bias_grad);
   return nbm_launch_status();
 }
 
 // F(2x2,3x3) input / output-gradient transforms of the listed tiles only (compact operands) -- see nbm_hip.h.
-extern "C" int nbm_wino23_input_tiles(const float* x, int B, int H, int W, int C, const int* tiles, int n_list, float* V,
-                                      void* stream) {
+extern "C" int nbm_wino23_input_tiles(const float* x, int B, int H, int W, int C, const int* tiles, int n_list,
+                                      const unsigned* blk_info, float* V, void* stream) {
   if (!x || !V || !tiles || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || n_list < 0) return NBM_EINVAL;
   if (!nbm_aligned16(x) || !nbm_aligned16(V)) return NBM_EALIGN;
   if (n_list == 0) return NBM_OK;
   hipLaunchKernelGGL(wino23_input_kernel, dim3(grid_for((long long)n_list * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, B, H,
-                     W, C / 4, V, tiles, n_list);
+                     W, C / 4, V, tiles, n_list, blk_info);
   return nbm_launch_status();
 }
 
-extern "C" int nbm_wino23_outgrad_tiles(const float* g, int B, int H, int W, int N, const int* tiles, int n_list, float* dM,
-                                        float* bias_grad, void* stream) {
+extern "C" int nbm_wino23_outgrad_tiles(const float* g, int B, int H, int W, int N, const int* tiles, int n_list,
+                                        const unsigned* plane_mask, float* dM, float* bias_grad, void* stream) {
   if (!g || !dM || !tiles || B <= 0 || H <= 0 || W <= 0 || N <= 0 || (N & 3) || n_list < 0) return NBM_EINVAL;
   if (!nbm_aligned16(g) || !nbm_aligned16(dM)) return NBM_EALIGN;
   if (n_list == 0) return NBM_OK;
@@ -488,7 +493,7 @@ extern "C" int nbm_wino23_outgrad_tiles(const float* g, int B, int H, int W, int
   if (blocks > 4096) blocks = 4096;
   while ((blocks * 256) % per) ++blocks;              // a thread keeps one channel chunk (bias-gradient accumulation)
   hipLaunchKernelGGL(wino23_outgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, B, H, W, per, dM,
-                     bias_grad, tiles, n_list);
+                     bias_grad, tiles, n_list, plane_mask);
   return nbm_launch_status();
 }
 

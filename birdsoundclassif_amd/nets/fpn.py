@@ -110,8 +110,11 @@ class FPN(nn.Module):
             fm = x[i]
             t, alpha = (fm.tensor, fm.factor) if isinstance(fm, Scaled) else (fm, 1.0)
             c = self.pt_wise[str(i)]
-            merged = Fn.conv(t, c.weight, bias=c.bias, alpha=alpha, up=merged)
+            # the lateral of a demand-driven level is itself only evaluated where that level's output convolution reads it;
+            # the finest level has no finer level that would read `merged`
             oc = self.out_convs[str(len(x) - 1 - i)]
+            lz = (lazy_strides or {}).get(i) if i == 0 and Fn.lazy3x3_ok(t.shape[1], t.shape[2], c.weight.shape[0], oc.weight) else None
+            merged = Fn.conv(t, c.weight, bias=c.bias, alpha=alpha, up=merged, lazy_stride=lz)
             outs.insert(0, Fn.conv(merged, oc.weight, bias=oc.bias, kh=3, kw=3, pad=1,
                                    lazy_stride=(lazy_strides or {}).get(i)))
         return outs

@@ -47,6 +47,13 @@ def _winograd_ok(x, weight, kh, kw, stride, pad):
     return H >= 8 and W >= 8 and Cin % 32 == 0 and weight.shape[0] % 4 == 0 and Cin >= 128
 
 
+def lazy3x3_ok(H, W, Cin, weight):
+    """Would `conv(x [.,H,W,Cin], weight, kh=3, kw=3, pad=1, lazy_stride=...)` take the demand-driven path?  (The lateral in
+    front of it may only go sparse if it does.)"""
+    return bool(ops.LAZY_FINEST and WINOGRAD and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3) and H >= 8 and W >= 8 and
+                Cin % 32 == 0 and Cin >= 128 and weight.shape[0] % 4 == 0)
+
+
 class Conv(Function):
     """y = act(alpha * conv(x, W) * scale + (bias | shift) + residual); also nn.Linear (x [1,M,1,K])."""
 
@@ -62,6 +69,9 @@ class Conv(Function):
             # zero wherever nothing was read)
             y, ctx.lazy = ops.conv3x3_winograd_lazy(x, _prep.wino23(weight), sh, lazy_stride[0])
             ctx.lazy.keep = lazy_stride[1]        # a backward pass will follow: keep the RoI tile lists for the weight gradient
+        elif lazy_stride and kh == 1:
+            # the lateral 1x1 (+ top-down merge) in front of a demand-driven 3x3: only the pixels that convolution reads
+            y = ops.conv1x1_lazy(x, _prep.krsc(weight), sh, alpha, up, lazy_stride[0])
         elif ctx.wino:        # large 3x3 (FPN output convolutions): Winograd F(2x2,3x3), 2.25x fewer multiplies
             y = ops.conv3x3_winograd(x, _prep.wino23(weight), sh)
         else:
@@ -201,7 +211,12 @@ def conv(x, weight, bias=None, scale=None, shift=None, residual=None, kh=1, kw=1
     """`up` [B,h,w,N]: + bilinear_align_corners(up) in the GEMM epilogue (FPN top-down merge, act must be NONE).
     `lazy_stride`: the output has exactly two consumers, a 3x3 / lazy_stride / pad 1 convolution and the RoI pooling: only the
     pixels they read are computed (3x3 Winograd layers only; ignored elsewhere)."""
-    if lazy_stride and not (ops.LAZY_FINEST and _winograd_ok(x, weight, kh, kw, stride, pad) and x.shape[-1] >= 64):
+    if lazy_stride and kh == 1:       # lateral in front of the demand-driven convolution (ops.conv1x1_lazy)
+        Cin, N = x.shape[-1], weight.shape[0]
+        if not (ops.LAZY_FINEST and ops.LAZY_LATERAL and kw == 1 and stride == 1 and pad == 0 and weight.dim() == 4 and scale is None
+                and residual is None and act == ACT_NONE and Cin % 32 == 0 and Cin <= 256 and N > 64 and N % 4 == 0):
+            lazy_stride = None
+    elif lazy_stride and not (ops.LAZY_FINEST and _winograd_ok(x, weight, kh, kw, stride, pad) and x.shape[-1] >= 64):
         lazy_stride = None
     if lazy_stride:
         lazy_stride = (int(lazy_stride), bool(torch.is_grad_enabled() and weight.requires_grad and LAZY_WGRAD))

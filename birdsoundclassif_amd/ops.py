@@ -68,7 +68,8 @@ def lib():
 # --------------------------------------------------------------------------- implicit GEMM
 def gemm_conv(x, w, y, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, Ho=None, Wo=None,
               x_ld=None, w_ld=None, y_ld=None, scale=None, shift=None, residual=None, res_ld=None,
-              groups=1, x_gs=0, w_gs=0, y_gs=0, res_gs=0, alpha=1.0, act=ACT_NONE, shift_per_row=False, up=None):
+              groups=1, x_gs=0, w_gs=0, y_gs=0, res_gs=0, alpha=1.0, act=ACT_NONE, shift_per_row=False, up=None,
+              rows=None, rows_mode=0, rows_count=0, rows_blocks=None, rows_thw=(0, 0)):
     """Raw call of nbm_gemm_conv (see include/nbm_hip.h for the exact semantics)."""
     Ho = (H + 2 * pad - kh) // stride + 1 if Ho is None else Ho
     Wo = (W + 2 * pad - kw) // stride + 1 if Wo is None else Wo
@@ -88,14 +89,28 @@ def gemm_conv(x, w, y, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, Ho=None,
     d.alpha, d.act, d.shift_per_row = float(alpha), int(act), int(bool(shift_per_row))
     if up is not None:                       # [B, up_H, up_W, N] coarse map merged in the epilogue
         d.up, d.up_H, d.up_W = _chk(up, name='up').data_ptr(), up.shape[1], up.shape[2]
+    if rows is not None:                     # listed pixels only (the lateral of a demand-driven FPN level)
+        d.rows, d.rows_mode, d.rows_count = rows.data_ptr(), int(rows_mode), int(rows_count)
+        d.rows_blocks = rows_blocks.data_ptr() if rows_blocks is not None else None
+        d.rows_TH, d.rows_TW = rows_thw
     if FLOPS is not None:
-        FLOPS[0] += 2.0 * B * Ho * Wo * N * kh * kw * Cin * groups
+        if rows is None:
+            FLOPS[0] += 2.0 * B * Ho * Wo * N * kh * kw * Cin * groups
+        elif rows_blocks is None:
+            FLOPS[0] += 2.0 * rows_count * N * Cin
+        else:
+            FLOPS_DEFERRED.append((rows_blocks.clone(), 2.0 * 128 * (16 if rows_mode == 2 else 1) * N * Cin))
     if _prof_all():
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         check(lib().nbm_gemm_conv(C.byref(d), _stream()), 'nbm_gemm_conv')
         ev1.record()
-        PROFILE.append(((Cin, N, kh, H, W, B, groups, stride, _PROFILE_LABEL), ev0, ev1))
+        if rows is None:
+            PROFILE.append(((Cin, N, kh, H, W, B, groups, stride, _PROFILE_LABEL), ev0, ev1))
+        elif rows_blocks is None:                  # listed pixels: M = the list
+            PROFILE.append(((Cin, N, kh, rows_count, 1, 1, groups, stride, ('rows', H, W)), ev0, ev1))
+        else:                                      # device-side count
+            PROFILE.append(((Cin, N, kh, 0, 1, 1, groups, stride, ('rows-rois', H, W)), ev0, ev1))
         return y
     check(lib().nbm_gemm_conv(C.byref(d), _stream()), 'nbm_gemm_conv')
     return y
@@ -234,6 +249,7 @@ def wino_weight_grad(dU, m=2, row_scale=None):
 # `lazy_complete` (called by the RoI pooling) computes the tiles under the RoI windows.  Every other pixel of the map is never
 # read by anything and is left unwritten.  NBM_LAZY_FINEST=0 switches the whole mechanism off (dense map).
 LAZY_FINEST = os.environ.get('NBM_LAZY_FINEST', '1') != '0'
+LAZY_LATERAL = os.environ.get('NBM_LAZY_LATERAL', '1') != '0'      # also the lateral 1x1 + merge in front of the map
 LAZY_POISON = False                 # tests: fill the map with NaN first, so that a read of an unwritten pixel shows
 _LAZY = {}                          # data_ptr of the sparse map -> LazyMap
 _PATTERNS = {}
@@ -249,8 +265,13 @@ class TilePattern:
       full      uint8 [TH*TW]: 1 where all four pixels of the tile are computed (the RoI phase skips those)
       any       bool  [TH*TW]: 1 where the tile is in the pattern at all (its weight-gradient term comes from this list)
       n         number of listed tiles;  n_eff = sum(planes x tiles) / 16: the executed-FLOP equivalent in 16-plane tiles
-      frac      covered fraction of all tiles"""
-    __slots__ = ('tiles', 'blk_info', 'full', 'any', 'n', 'n_eff', 'frac')
+      frac      covered fraction of all tiles
+      entry_pm  int32 [n_entries]: the plane mask of every list entry;  tile_pm int32 [TH*TW]: the plane mask of the tile's
+                class (0 = not in the pattern) -- the weight gradient counts every plane of every tile once
+      px_rows   int32 [n_px padded to 128]: the INPUT pixels these tiles read through the planes they compute (b*H*W + y*W + x,
+                ascending, -1 padded): with stride 8 the 5 x 5 neighbourhoods of the pattern, 39 % of the map -- the rows of
+                the lateral 1x1 convolution that feeds the demand-driven convolution"""
+    __slots__ = ('tiles', 'blk_info', 'full', 'any', 'n', 'n_eff', 'frac', 'px_rows', 'n_px', 'entry_pm', 'tile_pm')
 
 
 def wino23_pattern(B, H, W, stride, device):
@@ -303,6 +324,14 @@ def wino23_pattern(B, H, W, stride, device):
         pos = np.concatenate([(np.arange(len(i)) + 0.5) / len(i) for i in [l.reshape(-1, 128) for l in lists]])
         order = np.argsort(pos, kind='stable')
         infos = infos[order]
+        hit.entry_pm = torch.from_numpy(np.repeat((infos & 0xffff) | 0x10000, 128).astype(np.int32)).to(device)   # bit 16: counts in the bias gradient
+        tpm = np.zeros(TH * TW, dtype=np.int64)
+        for cy in (3, 2, 1):
+            for cx in (3, 2, 1):
+                pmv = sum(1 << (4 * i + j) for i in range(4) for j in range(4)
+                          if (planes_of[cy] >> i) & 1 and (planes_of[cx] >> j) & 1)
+                tpm[((ry == cy)[:, None] & (rx == cx)[None, :]).ravel()] = pmv
+        hit.tile_pm = torch.from_numpy(tpm.astype(np.int32)).to(device)
         hit.tiles = torch.from_numpy(blocks[order].ravel().astype(np.int32)).to(device)
         if os.environ.get('NBM_DEBUG_BLKINFO'):          # timing experiments only (results are wrong)
             infos[:] = int(os.environ['NBM_DEBUG_BLKINFO'], 16)
@@ -310,6 +339,20 @@ def wino23_pattern(B, H, W, stride, device):
         hit.full = torch.from_numpy(full.ravel().astype(np.uint8)).to(device)
         hit.any = torch.from_numpy(anym.ravel()).to(device)
         hit.n, hit.n_eff, hit.frac = n, n_eff, float(anym.mean())
+        # input rows a tile row reads: both output rows -> 2ty-1 .. 2ty+2; second only (planes i = 1..3) -> 2ty .. 2ty+2; first
+        # only (i = 0..2) -> 2ty-1 .. 2ty+1; same for columns
+        def px_need(r, n_):
+            m = np.zeros(n_, dtype=bool)
+            for t, c in enumerate(r):
+                if c:
+                    lo, hi = (2 * t - 1 if c & 1 else 2 * t), (2 * t + 2 if c & 2 else 2 * t + 1)
+                    m[max(lo, 0):min(hi, n_ - 1) + 1] = True
+            return m
+        pm = (px_need(ry, H)[:, None] & px_need(rx, W)[None, :]).ravel()
+        ids = np.flatnonzero(pm).astype(np.int64)
+        allp = (np.arange(B, dtype=np.int64)[:, None] * (H * W) + ids[None, :]).ravel()
+        hit.n_px = allp.size
+        hit.px_rows = torch.from_numpy(np.concatenate([allp, np.full((-allp.size) % 128, -1, dtype=np.int64)]).astype(np.int32)).to(device)
     return hit
 
 
@@ -361,11 +404,11 @@ class LazyMap:
     list; RoI list + its block count on the way to the host) -- the weight gradient sums over them.  The map itself is
     NOT referenced (an autograd node owns this object and the map owns the node: a cycle would keep 12 GB alive until the
     garbage collector runs); its consumers keep it alive and hand it back to `lazy_complete`."""
-    __slots__ = ('x', 'U', 'bias', 'skip', 'stride', 'chunks', 'roi', 'keep', 'sparse')
+    __slots__ = ('x', 'U', 'bias', 'skip', 'stride', 'chunks', 'roi', 'keep', 'sparse', 'lateral')
 
     def __init__(self, x, U, bias, stride):
         self.x, self.U, self.bias, self.stride = x, U, bias, stride
-        self.skip, self.chunks, self.roi, self.keep, self.sparse = None, [], None, False, True
+        self.skip, self.chunks, self.roi, self.keep, self.sparse, self.lateral = None, [], None, False, True, None
 
 
 _PINNED = []
@@ -381,6 +424,41 @@ def _pinned_int():
     return _PINNED[_PINNED_NEXT[0]]
 
 
+_LAZY_LATERAL = {}                  # data_ptr of a sparse lateral map -> (LateralState, weakref to the map)
+
+
+class LateralState:
+    """Operands of a lateral 1x1 convolution (+ top-down merge) whose output only exists where its one consumer, a demand-driven
+    3x3 convolution, reads it; `conv3x3_winograd_lazy` picks the state up and `lazy_complete` finishes the pixels under the RoI
+    tiles before it convolves them."""
+    __slots__ = ('t', 'wk', 'bias', 'alpha', 'up')
+
+    def __init__(self, t, wk, bias, alpha, up):
+        self.t, self.wk, self.bias, self.alpha, self.up = t, wk, bias, alpha, up
+
+
+def conv1x1_lazy(t, wk, bias, alpha, up, stride):
+    """Lateral 1x1 convolution + bilinear top-down merge (fpn.py:143-144) on the pixels that the pattern tiles of the following
+    demand-driven 3x3 convolution read (`TilePattern.px_rows`): t [B,H,W,Cin] -> x [B,H,W,N], other pixels unwritten.  Same
+    kernel, same arithmetic per pixel as the dense call."""
+    _chk(t, name='t'), _chk(wk, name='w')
+    B, H, W, Cin = t.shape
+    N = wk.shape[0]
+    x = torch.empty((B, H, W, N), device=t.device, dtype=torch.float32)
+    if LAZY_POISON:
+        x.fill_(float('nan'))
+    chunk = lazy_chunk(x)                      # the same batch chunks as the convolution that follows
+    for b0 in range(0, B, chunk):
+        nb = min(chunk, B - b0)
+        pat = wino23_pattern(nb, H, W, stride, t.device)
+        gemm_conv(t[b0:b0 + nb], wk, x[b0:b0 + nb], B=nb, H=H, W=W, Cin=Cin, N=N, w_ld=wk.shape[1], shift=bias, alpha=alpha,
+                  up=up[b0:b0 + nb] if up is not None else None, rows=pat.px_rows, rows_mode=1, rows_count=pat.px_rows.numel())
+    for k in [k for k, v in _LAZY_LATERAL.items() if v[1]() is None]:
+        del _LAZY_LATERAL[k]
+    _LAZY_LATERAL[x.data_ptr()] = (LateralState(t, wk, bias, alpha, up), weakref.ref(x))
+    return x
+
+
 def conv3x3_winograd_lazy(x, U, bias, stride):
     """Finest-level output convolution, pattern tiles only (see above) -> (y [B,H,W,N] with the other pixels unwritten,
     LazyMap)."""
@@ -392,6 +470,9 @@ def conv3x3_winograd_lazy(x, U, bias, stride):
     if LAZY_POISON:
         y.fill_(float('nan'))
     st = LazyMap(x, U, bias, stride)
+    lat = _LAZY_LATERAL.pop(x.data_ptr(), None)      # x itself only exists where the pattern tiles read it
+    if lat is not None and lat[1]() is not None:
+        st.lateral = lat[0]
     img_bytes = H * W * N * 4
     chunk = lazy_chunk(x)
     for b0 in range(0, B, chunk):
@@ -445,6 +526,11 @@ def lazy_complete(fm, rois, n_roi, fmap_hw, level=0):
             tiles, n_blocks = buf
         check(lib().nbm_roi_tiles(_ptr(rois[b0:b0 + nb]), _ptr(n_roi), nb, cap, nl, level, fh, fw, _ptr(st.skip), _ptr(tiles),
                                   _ptr(n_blocks), _stream()), 'nbm_roi_tiles')
+        if st.lateral is not None:                # the input patches of these tiles first (16 pixels per listed tile)
+            lt = st.lateral
+            gemm_conv(lt.t[b0:b0 + nb], lt.wk, x[b0:b0 + nb], B=nb, H=H, W=W, Cin=lt.t.shape[-1], N=C_, w_ld=lt.wk.shape[1],
+                      shift=lt.bias, alpha=lt.alpha, up=lt.up[b0:b0 + nb] if lt.up is not None else None, rows=tiles, rows_mode=2,
+                      rows_count=tiles.numel() * 16, rows_blocks=n_blocks, rows_thw=((H + 1) // 2, (W + 1) // 2))
         _wino23_tiles_run(x[b0:b0 + nb], U, bias, fm.data_ptr() + b0 * img_bytes, tiles, n_blocks, None, 'wino23-rois')
         if keep:
             host = _pinned_int()
@@ -452,7 +538,7 @@ def lazy_complete(fm, rois, n_roi, fmap_hw, level=0):
             ev = torch.cuda.Event()
             ev.record()
             st.roi.append((tiles, host, ev))
-    st.x = st.U = st.bias = None                  # the backward pass gets x from the tape
+    st.x = st.U = st.bias = st.lateral = None     # the backward pass gets x from the tape
 
 
 def lazy_clear():
@@ -472,25 +558,28 @@ def conv3x3_winograd_wgrad_tiles(st, x, g, want_bias=False):
     stream = _stream()
     thw = ((H + 1) // 2) * ((W + 1) // 2)
     for ci, (b0, nb, pat) in enumerate(st.chunks):
-        lists = [pat.tiles]
+        lists, infos = [pat.tiles], [pat.entry_pm]
         if st.roi:
             tiles, host, ev = st.roi[ci]
             ev.synchronize()                        # recorded during the forward pass: long done
             n = int(host.item()) * 128
             if n:
-                # the RoI phase recomputes pattern tiles of which only some pixels had been stored: their term of the
-                # sum already comes from the pattern list
+                # the RoI phase recomputed pattern tiles of which only some pixels had been stored: the planes of their class
+                # come from the pattern list, this entry contributes the others
                 roi = tiles[:n]
-                dup = (roi >= 0) & pat.any[roi.clamp(min=0) % thw]
-                lists.append(torch.where(dup, torch.full_like(roi, -1), roi))
+                lists.append(roi)
+                tpm = pat.tile_pm[roi.clamp(min=0) % thw]
+                infos.append((0xffff & ~tpm) | ((tpm == 0).int() << 16))
         full = torch.cat(lists) if len(lists) > 1 else lists[0]
+        info = torch.cat(infos) if len(infos) > 1 else infos[0]
         xs, gs = x[b0:b0 + nb], g[b0:b0 + nb]
         for l0 in range(0, full.numel(), lmax):
             lst = full[l0:l0 + lmax]
             L = lst.numel()
             V, dM = _wino_scratch(x.device, 16 * L * C_, 16 * L * N)
-            check(lib().nbm_wino23_input_tiles(_ptr(xs), nb, H, W, C_, _ptr(lst), L, _ptr(V), stream), 'nbm_wino23_input_tiles')
-            check(lib().nbm_wino23_outgrad_tiles(_ptr(gs), nb, H, W, N, _ptr(lst), L, _ptr(dM), _ptr(gb), stream),
+            check(lib().nbm_wino23_input_tiles(_ptr(xs), nb, H, W, C_, _ptr(lst), L, _ptr(info[l0:]), _ptr(V), stream),
+                  'nbm_wino23_input_tiles')
+            check(lib().nbm_wino23_outgrad_tiles(_ptr(gs), nb, H, W, N, _ptr(lst), L, _ptr(info[l0:]), _ptr(dM), _ptr(gb), stream),
                   'nbm_wino23_outgrad_tiles')
             conv_wgrad(dM, V, dU, B=1, H=L, W=1, Cin=C_, N=N, groups=16, g_gs=L * N, x_gs=L * C_, out_gs=N * C_)
     return dU, gb

@@ -71,6 +71,17 @@ typedef struct nbm_gemm_desc {
                             shift/residual and before act -- the FPN top-down merge fused into the lateral 1x1
                             (fpn.py:143-144); needs the 16-byte epilogue (N % 4 == 0, aligned) and groups == 1  */
   int up_H, up_W;
+  /* Listed rows (optional; 1x1 / stride 1 / pad 0, one group, Cin % 32 == 0, Cin <= 256, N > 64, 16-byte epilogue): the GEMM
+   * runs over rows_count (% 128 == 0) listed pixels of the dense maps instead of all B*H*W of them; x, y, residual and `up`
+   * keep their dense addressing, pixels that are not listed are neither read nor written.  Used for the lateral 1x1 +
+   * top-down merge that feeds a demand-driven FPN output convolution (nbm_wino23_conv_fused_tiles).
+   *   rows_mode 1: rows[m] = pixel index b*H*W + y*W + x, ascending, -1 = none (only at the end of the list);
+   *   rows_mode 2: rows[m / 16] = linear 2x2-tile id b*TH*TW + ty*TW + tx (-1 = none), row m = pixel m % 16 of that tile's
+   *                4x4 input patch (the list nbm_roi_tiles builds; rows_count = 16 x its entries);
+   *   rows_blocks: optional device scalar, number of leading 128-entry blocks of `rows` that are filled. */
+  const int* rows;
+  const int* rows_blocks;
+  int rows_mode, rows_count, rows_TH, rows_TW;
 } nbm_gemm_desc;
 
 int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream);
@@ -135,10 +146,14 @@ int nbm_roi_tiles(const float* rois, const int* n_roi, int B, int roi_cap, int n
 /* Weight gradient of such a demand-driven convolution: the gradient wrt its output is zero outside the tiles that were
  * read, so only those tiles enter dU[xi] = dM[xi]^T V[xi].  F(2x2,3x3) transforms of the listed tiles (entry -1 = a zero
  * row) into COMPACT operands V [16][n_list][C] and dM [16][n_list][N] (+ bias gradient [N], optional, accumulated); the 16
- * TN GEMMs are nbm_conv_wgrad with groups = 16 over n_list rows. */
-int nbm_wino23_input_tiles(const float* x, int B, int H, int W, int C, const int* tiles, int n_list, float* V, void* stream);
-int nbm_wino23_outgrad_tiles(const float* g, int B, int H, int W, int N, const int* tiles, int n_list, float* dM,
-                             float* bias_grad, void* stream);
+ * TN GEMMs are nbm_conv_wgrad with groups = 16 over n_list rows.  plane_mask (optional, one word per ENTRY, bits 0-15 = planes
+ * xi): the other planes of that entry are written as zeros -- planes the forward pass skipped (their input pixels may never
+ * have been computed), or planes that a second entry of the same tile contributes; bit 16 = this entry's pixels enter the
+ * bias gradient (a tile that is listed twice sets it once). */
+int nbm_wino23_input_tiles(const float* x, int B, int H, int W, int C, const int* tiles, int n_list, const unsigned* plane_mask,
+                           float* V, void* stream);
+int nbm_wino23_outgrad_tiles(const float* g, int B, int H, int W, int N, const int* tiles, int n_list, const unsigned* plane_mask,
+                             float* dM, float* bias_grad, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Spectrogram front end.  Replaces File_Processor.load/spectrogram/split_power_spec

@@ -42,6 +42,17 @@ for tag, ms in rows:
     fl = 2.0 * G * Bb * Ho * Wo * N * Cin * k * k / 1e9
     by = 4.0 * G * (Bb * H * W * Cin + Bb * Ho * Wo * N + N * Cin * k * k) / 1e9
     what = f'{k}x{k} s{st} {Cin}->{N} @{H}x{W} B={Bb}' + (f' groups={G}' if G > 1 else '')
+    if label is not None and label[0] == 'rows-rois':
+        print(f'{ms:8.3f}      -         -      {k}x{k} {Cin}->{N} @{label[1]}x{label[2]}, input patches of the tiles under the RoIs (device-side list)')
+        tot += ms
+        continue
+    if label is not None and label[0] == 'rows':
+        what = f'{k}x{k} {Cin}->{N} @{label[1]}x{label[2]}, {H} listed pixels of {Bb}x... (pattern input patches)'
+        fl = 2.0 * H * N * Cin / 1e9
+        by = 4.0 * H * (Cin + N) / 1e9
+        tot += ms
+        print(f'{ms:8.3f}  {fl / ms:8.1f}  {by / ms * 1e3:9.0f}   {what}')
+        continue
     if label is not None and label[0] == 'wino23-rois':
         print(f'{ms:8.3f}      -         -      fused Winograd kernel of 3x3 {Cin}->{N} @{label[1]}x{label[2]}, tiles under the RoIs (device-side list)')
         tot += ms

@@ -102,22 +102,23 @@ def test_weight_gradient_over_the_listed_tiles_equals_the_dense_one():
     x = rnd('wx', B, H, W, C).cuda()
     w = rnd('ww', N, C, 3, 3, scale=0.05).cuda()
     b = rnd('wb', N).cuda()
-    y, st = ops.conv3x3_winograd_lazy(x, _prep.wino23(w), b, 8)
+    ops.LAZY_POISON = True
+    try:
+        y, st = ops.conv3x3_winograd_lazy(x, _prep.wino23(w), b, 8)
+    finally:
+        ops.LAZY_POISON = False
     st.keep = True
     fh = [H, (H + 1) // 2, (H + 3) // 4, (H + 7) // 8, (H + 15) // 16]
     fw = [W, (W + 1) // 2, (W + 3) // 4, (W + 7) // 8, (W + 15) // 16]
     rois = torch.tensor([[[10., 12., 25., 20.], [60., 40., 70., 66.], [0., 0., 8., 9.]]] * B).cuda()
     ops.lazy_complete(y, rois, torch.tensor([3], dtype=torch.int32, device='cuda'), list(zip(fh, fw)))
-    # mask of computed pixels: pattern tiles + RoI tiles (re-derived from the lists the map kept)
+    # pixels with a reader: the pattern pixels + every pixel of the tiles under the RoIs (re-derived from the kept RoI list)
     TH, TW = (H + 1) // 2, (W + 1) // 2
-    mask = torch.zeros((B, TH, TW), dtype=torch.bool, device='cuda')
-    ids = [st.chunks[0][2].tiles]
+    m = ~torch.isnan(y[..., 0])                      # the map was NaN-poisoned: written == has a reader
     tiles, host, ev = st.roi[0]
     ev.synchronize()
-    ids.append(tiles[:int(host.item()) * 128])
-    ids = torch.cat(ids)
-    mask.view(-1)[ids[ids >= 0].long()] = True
-    m = mask.repeat_interleave(2, 1).repeat_interleave(2, 2)[:, :H, :W]
+    ids = tiles[:int(host.item()) * 128]
+    assert int((ids >= 0).sum()) > 0
     g = rnd('wg', B, H, W, N).cuda() * m[..., None]
     dU, gb = ops.conv3x3_winograd_wgrad_tiles(st, x, g.contiguous(), want_bias=True)
     gw = _prep.wino23_weight_grad(dU, 2)
@@ -128,6 +129,51 @@ def test_weight_gradient_over_the_listed_tiles_equals_the_dense_one():
     err = (gw.cpu() - ref).abs().max().item()
     assert err < 2e-4 * ref.abs().max().item() + 1e-5, (err, ref.abs().max().item())
     assert torch.allclose(gb.cpu(), g.sum((0, 1, 2)).cpu(), rtol=1e-4, atol=1e-4)
+
+
+def test_lateral_on_listed_pixels_equals_the_dense_lateral():
+    """ops.conv1x1_lazy (igemm ROWS variant, pixel list) and the RoI-phase patches (tile list x 16): the written pixels equal
+    the dense lateral + merge bit for bit, nothing else is written."""
+    B, H, W, Cin, N = 2, 47, 66, 64, 384
+    t = rnd('lt', B, H, W, Cin).cuda()
+    w = rnd('lw1', N, Cin, 1, 1, scale=0.1).cuda()
+    b = rnd('lb1', N).cuda()
+    up = rnd('lu', B, 24, 33, N).cuda()
+    wk = _prep.krsc(w)
+    dense = ops.conv2d(t, wk, shift=b, alpha=2.0, up=up)
+    ops.LAZY_POISON = True
+    try:
+        x = ops.conv1x1_lazy(t, wk, b, 2.0, up, 8)
+    finally:
+        ops.LAZY_POISON = False
+    pat = ops.wino23_pattern(B, H, W, 8, t.device)
+    m = torch.zeros(B * H * W, dtype=torch.bool, device='cuda')
+    m[pat.px_rows[pat.px_rows >= 0].long()] = True
+    m = m.view(B, H, W)
+    assert 0.3 < float(m.float().mean()) < 0.5
+    assert torch.equal(x[m], dense[m]) and bool(torch.isnan(x[~m]).all())
+    # the consumer: pattern tiles of the 3x3 convolution read only pixels that now exist
+    w3 = rnd('lw3', 64, N, 3, 3, scale=0.05).cuda()
+    b3 = rnd('lb3', 64).cuda()
+    U = _prep.wino23(w3)
+    ref = ops.conv3x3_winograd(dense, U, b3)
+    ops.LAZY_POISON = True
+    try:
+        y, st = ops.conv3x3_winograd_lazy(x, U, b3, 8)
+    finally:
+        ops.LAZY_POISON = False
+    assert st.lateral is not None
+    written = ~torch.isnan(y[..., 0])
+    assert int(written.sum()) > 0 and torch.equal(y[written], ref[written])
+    # RoI phase: lateral patches of the RoI tiles, then the tiles
+    fh = [H, (H + 1) // 2, (H + 3) // 4, (H + 7) // 8, (H + 15) // 16]
+    fw = [W, (W + 1) // 2, (W + 3) // 4, (W + 7) // 8, (W + 15) // 16]
+    rois = torch.tensor([[[10., 12., 25., 20.], [60., 40., 70., 66.], [0., 0., 8., 9.], [120., 80., 131., 93.]]] * B).cuda()
+    ops.lazy_complete(y, rois, torch.tensor([4], dtype=torch.int32, device='cuda'), list(zip(fh, fw)))
+    written2 = ~torch.isnan(y[..., 0])
+    assert int(written2.sum()) > int(written.sum()) and torch.equal(y[written2], ref[written2])
+    xm = ~torch.isnan(x[..., 0])
+    assert torch.equal(x[xm], dense[xm]) and int(xm.sum()) > int(m.sum())
 
 
 @pytest.fixture(scope='module')
