@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void wino23_rows_kernel(const float* __restric
 __global__ __launch_bounds__(256) void wino23_rows_tiles_kernel(const float* __restrict__ x, int B, int H, int W, int C4,
                                                                 int TH, int TW, int WP, const int* __restrict__ tiles,
                                                                 int n_entries, const int* __restrict__ n_blocks,
-                                                                float* __restrict__ R) {
+                                                                const unsigned* __restrict__ blk_info, float* __restrict__ R) {
   const long long per_plane = (long long)B * TH * WP * C4;
   const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
   f32x4* r4 = reinterpret_cast<f32x4*>(R);
@@ -102,6 +102,10 @@ __global__ __launch_bounds__(256) void wino23_rows_tiles_kernel(const float* __r
     const int k = (int)(t & 3), e = (int)(t >> 2);
     const int id = tiles[e];
     if (id < 0) continue;
+    // planes of the block (blk_info, optional): a row combination i / a column k that no computed plane uses is skipped
+    // (k = 0 is only read by the planes j = 0, k = 3 only by j = 3; the input rows behind a skipped combination may not exist)
+    const unsigned pm = blk_info ? blk_info[e >> 7] & 0xffffu : 0xffffu;
+    if ((k == 0 && !(pm & 0x1111u)) || (k == 3 && !(pm & 0x8888u))) continue;
     const int THW = TH * TW;
     const int b = id / THW, rem = id - b * THW;
     const int ty = rem / TW, tx = rem - ty * TW;
@@ -110,14 +114,15 @@ __global__ __launch_bounds__(256) void wino23_rows_tiles_kernel(const float* __r
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       const int iy = 2 * ty - 1 + a;
-      const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W &&
+                      !(a == 0 && !(pm & 0x000fu)) && !(a == 3 && !(pm & 0xf000u));
       d[a] = ok ? x4[(((long long)b * H + iy) * W + ix) * C4 + c] : zero;
     }
     const long long o = (((long long)b * TH + ty) * WP + xp) * C4 + c;
-    r4[o] = d[0] - d[2];
+    if (pm & 0x000fu) r4[o] = d[0] - d[2];
     r4[o + per_plane] = d[1] + d[2];
     r4[o + 2 * per_plane] = d[2] - d[1];
-    r4[o + 3 * per_plane] = d[1] - d[3];
+    if (pm & 0xf000u) r4[o + 3 * per_plane] = d[1] - d[3];
   }
 }
 
@@ -470,7 +475,7 @@ extern "C" int nbm_wino23_rows(const float* x, int B, int H, int W, int C, float
 
 // Row transform of the listed tiles only -- see nbm_hip.h.
 extern "C" int nbm_wino23_rows_tiles(const float* x, int B, int H, int W, int C, const int* tiles, int n_entries,
-                                     const int* n_blocks, float* R, void* stream) {
+                                     const int* n_blocks, const unsigned* blk_info, float* R, void* stream) {
   if (!x || !R || !tiles || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || n_entries < 0) return NBM_EINVAL;
   if (!nbm_aligned16(x) || !nbm_aligned16(R)) return NBM_EALIGN;
   if (n_entries == 0) return NBM_OK;
@@ -479,7 +484,7 @@ extern "C" int nbm_wino23_rows_tiles(const float* x, int B, int H, int W, int C,
   long long g = (n + 255) / 256;
   if (g > 16384) g = 16384;
   hipLaunchKernelGGL(wino23_rows_tiles_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, B, H, W, C / 4, TH, TW,
-                     WP, tiles, n_entries, n_blocks, R);
+                     WP, tiles, n_entries, n_blocks, blk_info, R);
   return nbm_launch_status();
 }
 

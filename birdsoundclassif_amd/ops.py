@@ -377,7 +377,7 @@ def _wino23_tiles_run(x, U, bias, y_ptr, tiles, n_blocks, n_listed, label, blk_i
     if dense_rows:                                # every tile is listed: the plain row transform writes half the bytes
         check(lib().nbm_wino23_rows(_ptr(x), B, H, W, C_, _ptr(R), st), 'nbm_wino23_rows')
     else:
-        check(lib().nbm_wino23_rows_tiles(_ptr(x), B, H, W, C_, _ptr(tiles), tiles.numel(), nb_ptr, _ptr(R), st),
+        check(lib().nbm_wino23_rows_tiles(_ptr(x), B, H, W, C_, _ptr(tiles), tiles.numel(), nb_ptr, _ptr(blk_info), _ptr(R), st),
               'nbm_wino23_rows_tiles')
     if PROFILE is not None:
         ev[1].record()

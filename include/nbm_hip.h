@@ -137,7 +137,7 @@ int nbm_wino23_conv_fused(const float* R, const float* U, const float* scale, co
  *                                reads) of pyramid level `level`, without the tiles flagged in skip [TH * TW] (optional);
  *                                tiles must hold B * ceil(TH * TW / 128) * 128 entries; writes *n_blocks. */
 int nbm_wino23_rows_tiles(const float* x, int B, int H, int W, int C, const int* tiles, int n_entries, const int* n_blocks,
-                          float* R, void* stream);
+                          const unsigned* blk_info, float* R, void* stream);
 int nbm_wino23_conv_fused_tiles(const float* R, const float* U, const float* scale, const float* shift, const float* mask,
                                 int relu, int B, int H, int W, int C, int N, float* y, const int* tiles, int n_entries,
                                 const int* n_blocks, const unsigned* blk_info, void* stream);
