@@ -110,7 +110,7 @@ SIGNATURES = {
     'nbm_wino23_conv_fused': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     'nbm_wino23_rows_tiles': [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P],
     'nbm_wino23_conv_fused_tiles': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P],
-    'nbm_roi_tiles': [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    'nbm_roi_tiles': [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P],
     'nbm_wino23_input_tiles': [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P],
     'nbm_wino23_outgrad_tiles': [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P],
     'nbm_weighted_sum': [_P, _P, _P, _P, _P, _L, _P],

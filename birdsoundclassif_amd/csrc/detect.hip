@@ -307,7 +307,7 @@ __global__ void roi_pool_kernel(const RoiParams p) {
 // *n_blocks ones of `tiles` (capacity B * ceil(TH * TW / 128) blocks: cannot overflow).
 struct RoiTilesParams {
   const float* rois; const int* n_roi; int B, roi_cap, n_levels, level; int fh[5], fw[5];
-  const unsigned char* skip; int* tiles; int* n_blocks;
+  const unsigned char* skip; int* tiles; int* n_blocks; int dilate;
 };
 
 __global__ __launch_bounds__(256) void roi_tiles_kernel(const RoiTilesParams p) {
@@ -325,7 +325,8 @@ __global__ __launch_bounds__(256) void roi_tiles_kernel(const RoiTilesParams p) 
     int lvl, x1, y1, x2, y2;
     roi_window(p.rois + ((long long)b * p.roi_cap + r) * 4, p.n_levels, p.fh, p.fw, lvl, x1, y1, x2, y2);
     if (lvl != p.level) continue;
-    const int ty0 = max(y1, 0) >> 1, ty1 = min(y2, H - 1) >> 1, tx0 = max(x1, 0) >> 1, tx1 = min(x2, W - 1) >> 1;
+    const int dl = p.dilate;           // > 0: the tiles within `dilate` pixels of the window (support of a 3x3 data gradient)
+    const int ty0 = max(y1 - dl, 0) >> 1, ty1 = min(y2 + dl, H - 1) >> 1, tx0 = max(x1 - dl, 0) >> 1, tx1 = min(min(x2, W - 1) + dl, W - 1) >> 1;
     for (int ty = ty0; ty <= ty1; ++ty)
       for (int tx = tx0; tx <= tx1; ++tx) {
         const int id = ty * TW + tx;
@@ -529,12 +530,13 @@ extern "C" int nbm_roi_pool(const nbm_roi_desc* d, void* stream) {
 
 // RoI windows of pyramid level `level` -> list of the 2 x 2 output tiles they touch -- see nbm_hip.h.
 extern "C" int nbm_roi_tiles(const float* rois, const int* n_roi, int B, int roi_cap, int n_levels, int level,
-                             const int* fh, const int* fw, const unsigned char* skip, int* tiles, int* n_blocks,
+                             const int* fh, const int* fw, const unsigned char* skip, int dilate, int* tiles, int* n_blocks,
                              void* stream) {
   if (!rois || !n_roi || !fh || !fw || !tiles || !n_blocks || B <= 0 || roi_cap <= 0 || n_levels < 1 || n_levels > 5 ||
-      level < 0 || level >= n_levels)
+      level < 0 || level >= n_levels || dilate < 0 || dilate > 2)
     return NBM_EINVAL;
   RoiTilesParams p{};
+  p.dilate = dilate;
   for (int i = 0; i < n_levels; ++i) {
     if (fh[i] < 2 || fw[i] < 2) return NBM_EINVAL;
     p.fh[i] = fh[i]; p.fw[i] = fw[i];

@@ -35,6 +35,7 @@ def _w_to_ref_layout(gw, weight):
 
 STEM_FOLDED = True       # init_conv folded into conv1 (csrc/stem.hip); False: init_conv kernel + generic implicit GEMM
 WINOGRAD = True          # module switch for A/B tests (tests/test_gpu_e2e.py compares both convolution paths)
+LAZY_DGRAD = True        # data gradient of the demand-driven finest FPN map through the listed fused kernel
 LAZY_WGRAD = True        # weight gradient of the demand-driven finest FPN map over its computed tiles only
 WINO_BWD_TILE = 4        # F(4x4,3x3) for the two backward convolutions (gradients tolerate its 2e-5 error); 2 = F(2x2,3x3)
 
@@ -95,7 +96,11 @@ class Conv(Function):
         wk = _prep.krsc(weight) if weight.dim() == 4 else weight.detach()
         gp = _pad32_rows(g.view(-1, N), N)
         gx = gw = gb = None
-        if ctx.needs_input_grad[0] and ctx.wino and N % 32 == 0:
+        if ctx.needs_input_grad[0] and ctx.lazy is not None and ctx.lazy.sparse and LAZY_DGRAD and N % 32 == 0 and N >= 64:
+            # demand-driven map: the incoming gradient lives on the pattern pixels and in the RoI windows, the outgoing one
+            # within a pixel of them -> the listed fused kernel on the tiles around them (F(2x2,3x3), no transforms through HBM)
+            gx = ops.conv3x3_winograd_dgrad_tiles(ctx.lazy, g.view(B, H, W, N), _prep.wino23(weight, transposed=True, m=2))
+        elif ctx.needs_input_grad[0] and ctx.wino and N % 32 == 0:
             # data gradient of a 3x3 / stride 1 / pad 1 convolution = the same convolution with the kernel rotated by 180
             # degrees and the channel roles swapped: Winograd again
             gx = ops.conv3x3_winograd(g.view(B, H, W, N), _prep.wino23(weight, transposed=True, m=WINO_BWD_TILE), None,

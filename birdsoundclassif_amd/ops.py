@@ -274,8 +274,10 @@ class TilePattern:
     __slots__ = ('tiles', 'blk_info', 'full', 'any', 'n', 'n_eff', 'frac', 'px_rows', 'n_px', 'entry_pm', 'tile_pm')
 
 
-def wino23_pattern(B, H, W, stride, device):
-    key = (B, H, W, stride, str(device))
+def wino23_pattern(B, H, W, stride, device, dilate=0):
+    """`dilate` = 1: the tiles / pixels within one pixel of the pattern instead -- where the DATA gradient of the 3x3 convolution
+    that produced the pattern pixels is non-zero."""
+    key = (B, H, W, stride, str(device), dilate)
     hit = _PATTERNS.get(key)
     if hit is None:
         TH, TW = (H + 1) // 2, (W + 1) // 2
@@ -284,9 +286,9 @@ def wino23_pattern(B, H, W, stride, device):
             m = np.zeros(nt, dtype=np.int64)
             for o in range((n + 2 - 3) // stride + 1):
                 for k in range(3):
-                    r = o * stride - 1 + k
-                    if 0 <= r < n:
-                        m[r >> 1] |= 1 << (r & 1)
+                    for r in range(o * stride - 1 + k - dilate, o * stride - 1 + k + dilate + 1):
+                        if 0 <= r < n:
+                            m[r >> 1] |= 1 << (r & 1)
             return m
         ry, rx = need(H, TH), need(W, TW)
         # planes i (rows of A^T = [1 1 1 0; 0 1 -1 -1]) a tile row needs: first pixel row -> {0,1,2}, second -> {1,2,3}
@@ -404,11 +406,11 @@ class LazyMap:
     list; RoI list + its block count on the way to the host) -- the weight gradient sums over them.  The map itself is
     NOT referenced (an autograd node owns this object and the map owns the node: a cycle would keep 12 GB alive until the
     garbage collector runs); its consumers keep it alive and hand it back to `lazy_complete`."""
-    __slots__ = ('x', 'U', 'bias', 'skip', 'stride', 'chunks', 'roi', 'keep', 'sparse', 'lateral')
+    __slots__ = ('x', 'U', 'bias', 'skip', 'stride', 'chunks', 'roi', 'keep', 'sparse', 'lateral', 'rois')
 
     def __init__(self, x, U, bias, stride):
         self.x, self.U, self.bias, self.stride = x, U, bias, stride
-        self.skip, self.chunks, self.roi, self.keep, self.sparse, self.lateral = None, [], None, False, True, None
+        self.skip, self.chunks, self.roi, self.keep, self.sparse, self.lateral, self.rois = None, [], None, False, True, None, None
 
 
 _PINNED = []
@@ -524,7 +526,7 @@ def lazy_complete(fm, rois, n_roi, fmap_hw, level=0):
                 buf = _ROI_TILE_BUF[key] = (torch.empty((key[1],), device=x.device, dtype=torch.int32),
                                             torch.zeros((1,), device=x.device, dtype=torch.int32))
             tiles, n_blocks = buf
-        check(lib().nbm_roi_tiles(_ptr(rois[b0:b0 + nb]), _ptr(n_roi), nb, cap, nl, level, fh, fw, _ptr(st.skip), _ptr(tiles),
+        check(lib().nbm_roi_tiles(_ptr(rois[b0:b0 + nb]), _ptr(n_roi), nb, cap, nl, level, fh, fw, _ptr(st.skip), 0, _ptr(tiles),
                                   _ptr(n_blocks), _stream()), 'nbm_roi_tiles')
         if st.lateral is not None:                # the input patches of these tiles first (16 pixels per listed tile)
             lt = st.lateral
@@ -538,11 +540,43 @@ def lazy_complete(fm, rois, n_roi, fmap_hw, level=0):
             ev = torch.cuda.Event()
             ev.record()
             st.roi.append((tiles, host, ev))
+    if keep:                                      # the data gradient lists the tiles around these windows again
+        st.rois = (rois, n_roi, nl, level, fh, fw)
     st.x = st.U = st.bias = st.lateral = None     # the backward pass gets x from the tape
 
 
 def lazy_clear():
     _LAZY.clear()
+
+
+def conv3x3_winograd_dgrad_tiles(st, g, Ut):
+    """Data gradient of a demand-driven convolution (LazyMap `st`): g [B,H,W,N] is zero except on the pattern pixels and inside
+    the RoI windows, so the gradient wrt the input is zero except within one pixel of them: the same convolution operator
+    (Ut = weights rotated / channel-swapped, F(2x2,3x3)) through the listed fused kernel -- the static list of the tiles around
+    the pattern (56 % of the tiles, 16 / 12 / 9 planes), then the tiles around the RoI windows -- into a zero-filled map."""
+    _chk(g, name='g'), _chk(Ut, name='Ut')
+    B, H, W, N = g.shape
+    C_ = Ut.shape[1]
+    assert Ut.shape == (16, C_, N)
+    gx = torch.zeros((B, H, W, C_), device=g.device, dtype=torch.float32)
+    img_bytes = H * W * C_ * 4
+    blocks_per_img = -(-((H + 1) // 2 * ((W + 1) // 2)) // 128)
+    for b0, nb, _ in st.chunks:
+        pat = wino23_pattern(nb, H, W, st.stride, g.device, dilate=1)
+        _wino23_tiles_run(g[b0:b0 + nb], Ut, None, gx.data_ptr() + b0 * img_bytes, pat.tiles, None, pat.n_eff, 'wino23-dgrad',
+                          pat.blk_info)
+        if st.rois is not None:
+            rois, n_roi, nl, level, fh, fw = st.rois
+            key = (str(g.device), nb * blocks_per_img * 128)
+            buf = _ROI_TILE_BUF.get(key)
+            if buf is None:
+                buf = _ROI_TILE_BUF[key] = (torch.empty((key[1],), device=g.device, dtype=torch.int32),
+                                            torch.zeros((1,), device=g.device, dtype=torch.int32))
+            tiles, n_blocks = buf
+            check(lib().nbm_roi_tiles(_ptr(rois[b0:b0 + nb]), _ptr(n_roi), nb, rois.shape[1], nl, level, fh, fw, _ptr(pat.full), 1,
+                                      _ptr(tiles), _ptr(n_blocks), _stream()), 'nbm_roi_tiles')
+            _wino23_tiles_run(g[b0:b0 + nb], Ut, None, gx.data_ptr() + b0 * img_bytes, tiles, n_blocks, None, 'wino23-dgrad-rois')
+    return gx
 
 
 def conv3x3_winograd_wgrad_tiles(st, x, g, want_bias=False):

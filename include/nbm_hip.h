@@ -135,6 +135,8 @@ int nbm_wino23_conv_fused(const float* R, const float* U, const float* scale, co
  *   nbm_wino23_conv_fused_tiles: as nbm_wino23_conv_fused, writes ONLY the pixels of the listed tiles;
  *   nbm_roi_tiles:               builds such a list on the device from the RoI windows (exactly the windows nbm_roi_pool
  *                                reads) of pyramid level `level`, without the tiles flagged in skip [TH * TW] (optional);
+ *                                dilate > 0: the tiles within `dilate` pixels of a window instead (where the data gradient of
+ *                                a 3x3 convolution of those windows is non-zero);
  *                                tiles must hold B * ceil(TH * TW / 128) * 128 entries; writes *n_blocks. */
 int nbm_wino23_rows_tiles(const float* x, int B, int H, int W, int C, const int* tiles, int n_entries, const int* n_blocks,
                           const unsigned* blk_info, float* R, void* stream);
@@ -142,7 +144,7 @@ int nbm_wino23_conv_fused_tiles(const float* R, const float* U, const float* sca
                                 int relu, int B, int H, int W, int C, int N, float* y, const int* tiles, int n_entries,
                                 const int* n_blocks, const unsigned* blk_info, void* stream);
 int nbm_roi_tiles(const float* rois, const int* n_roi, int B, int roi_cap, int n_levels, int level, const int* fh,
-                  const int* fw, const unsigned char* skip, int* tiles, int* n_blocks, void* stream);
+                  const int* fw, const unsigned char* skip, int dilate, int* tiles, int* n_blocks, void* stream);
 /* Weight gradient of such a demand-driven convolution: the gradient wrt its output is zero outside the tiles that were
  * read, so only those tiles enter dU[xi] = dM[xi]^T V[xi].  F(2x2,3x3) transforms of the listed tiles (entry -1 = a zero
  * row) into COMPACT operands V [16][n_list][C] and dM [16][n_list][N] (+ bias gradient [N], optional, accumulated); the 16

@@ -131,6 +131,48 @@ def test_weight_gradient_over_the_listed_tiles_equals_the_dense_one():
     assert torch.allclose(gb.cpu(), g.sum((0, 1, 2)).cpu(), rtol=1e-4, atol=1e-4)
 
 
+def test_data_gradient_over_the_listed_tiles_equals_the_dense_one():
+    """g non-zero on the pattern pixels and inside the level-0 RoI windows only: the listed-tile F(2x2,3x3) data gradient ==
+    torch's conv2d input gradient everywhere (zeros included)."""
+    import torch.nn.functional as F
+    B, H, W, C, N = 2, 47, 66, 128, 64
+    x = rnd('gx', B, H, W, C).cuda()
+    w = rnd('gw', N, C, 3, 3, scale=0.05).cuda()
+    y, st = ops.conv3x3_winograd_lazy(x, _prep.wino23(w), None, 8)
+    st.keep = True
+    fh = [H, (H + 1) // 2, (H + 3) // 4, (H + 7) // 8, (H + 15) // 16]
+    fw = [W, (W + 1) // 2, (W + 3) // 4, (W + 7) // 8, (W + 15) // 16]
+    rois_np = np.array([[[10., 12., 25., 20.], [60., 40., 70., 66.], [0., 0., 8., 9.], [120., 86., 131., 93.], [40., 40., 90., 90.]]] * B,
+                       dtype=np.float32)
+    rois = torch.from_numpy(rois_np).cuda()
+    ops.lazy_complete(y, rois, torch.tensor([5], dtype=torch.int32, device='cuda'), list(zip(fh, fw)))
+    m = torch.zeros(B, H, W, dtype=torch.bool)
+    rows = torch.zeros(H, dtype=torch.bool)
+    cols = torch.zeros(W, dtype=torch.bool)
+    for n_, v in ((H, rows), (W, cols)):
+        for o in range((n_ - 1) // 8 + 1):
+            for k in range(3):
+                if 0 <= 8 * o - 1 + k < n_:
+                    v[8 * o - 1 + k] = True
+    m |= (rows[:, None] & cols[None, :])[None]
+    n0 = 0
+    for bi in range(B):
+        for r in range(5):
+            lvl, x1, y1, x2, y2 = window(rois_np[bi, r], fh, fw)
+            if lvl == 0:
+                n0 += 1
+                m[bi, y1:y2 + 1, x1:x2 + 1] = True
+    assert n0 >= 4 * B
+    g = (rnd('gg', B, H, W, N) * m[..., None]).cuda().contiguous()
+    got = ops.conv3x3_winograd_dgrad_tiles(st, g, _prep.wino23(w, transposed=True, m=2))
+    xr = x.permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
+    F.conv2d(xr, w.double().cpu(), None, 1, 1).backward(g.permute(0, 3, 1, 2).double().cpu())
+    ref = xr.grad.permute(0, 2, 3, 1).float()
+    err = (got.cpu() - ref).abs().max().item()
+    assert err < 2e-5 * ref.abs().max().item() + 1e-6, (err, ref.abs().max().item())
+    assert bool((got.cpu()[(ref == 0).all(-1)] == 0).all())          # exact zeros where no gradient can arrive
+
+
 def test_lateral_on_listed_pixels_equals_the_dense_lateral():
     """ops.conv1x1_lazy (igemm ROWS variant, pixel list) and the RoI-phase patches (tile list x 16): the written pixels equal
     the dense lateral + merge bit for bit, nothing else is written."""
