@@ -118,6 +118,7 @@ SIGNATURES = {
     'nbm_softmax_rows_bwd': [_P, _P, _P, _L, _I, _F, _P],
     'nbm_pair_softmax_bwd': [_P, _P, _P, _L, _P],
     'nbm_dwconv3x3_bwd': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _I, _I, _P],
+    'nbm_dwconv3x3_bwd_acc': [_P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     'nbm_film_fwd': [_P, _P, _P, _L, _I, _P],
     'nbm_film_bwd': [_P, _P, _P, _P, _P, _L, _I, _P],
     'nbm_bn_train_fwd': [_P, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P],

@@ -356,7 +356,9 @@ __global__ void pair_softmax_bwd_kernel(const float* __restrict__ y, const float
 // RPN's stride 8 most pixels find no tap and just write zeros.
 template <int MULT>
 __global__ void dwconv_bwd_data_kernel(const float* __restrict__ g, int B, int H, int W, int Cin, int mult_rt, int stride,
-                                       const float* __restrict__ w, float* __restrict__ gx, int Ho, int Wo) {
+                                       const float* __restrict__ w, float* __restrict__ gx, int Ho, int Wo, int accumulate) {
+  // accumulate != 0: gx already holds another consumer's gradient of the same map (the RoI pooling's, see
+  // nbm_dwconv3x3_bwd_acc): add this one's on the pixels a tap reaches, touch nothing else.
   // one image row per blockIdx.y (grid-strided): with the RPN's strides 8 / 4 most rows are reached by no tap at all and
   // are plain zero fills; the per-pixel work is one division (was six), 12.3 -> see DESIGN for the measured time
   const int mult = MULT > 0 ? MULT : mult_rt;
@@ -370,8 +372,10 @@ __global__ void dwconv_bwd_data_kernel(const float* __restrict__ g, int B, int H
     for (int r = r_first; r < 3 && r <= iy + 1; r += stride)
       if ((iy + 1 - r) / stride < Ho) row_has = true;
     f32x4* orow = o4 + (long long)row * row_items;
+    if (accumulate && !row_has) continue;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < row_items; j += gridDim.x * blockDim.x) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      bool any = false;
       if (row_has) {
         const int ix = j / C4, c0 = (j - ix * C4) * 4;
         for (int r = r_first; r < 3 && r <= iy + 1; r += stride) {      // r <= iy + 1: output row >= 0
@@ -382,13 +386,19 @@ __global__ void dwconv_bwd_data_kernel(const float* __restrict__ g, int B, int H
             if (ox >= Wo) continue;
             const float* gp = g + ((long long)(b * Ho + oy) * Wo + ox) * Cout + c0 * mult;
             const float* wp = w + (long long)c0 * mult * 9 + r * 3 + s;
+            any = true;
 #pragma unroll
             for (int k = 0; k < 4; ++k)
               for (int e = 0; e < mult; ++e) acc[k] += gp[k * mult + e] * wp[(k * mult + e) * 9];
           }
         }
       }
-      orow[j] = acc;
+      if (!accumulate) {
+        orow[j] = acc;
+      } else if (any) {
+        const f32x4 o = orow[j];
+        orow[j] = o + acc;
+      }
     }
   }
 }
@@ -718,9 +728,9 @@ extern "C" int nbm_dwconv3x3_bwd(const float* x, const float* g, const float* w,
     if ((Cin & 3) || !nbm_aligned16(gx)) return NBM_EALIGN;
     const int bx = (W * (Cin / 4) + TPB - 1) / TPB;
     const dim3 grid(bx < 64 ? bx : 64, (long long)B * H < 65535 ? B * H : 65535);
-    if (mult == 2) hipLaunchKernelGGL(dwconv_bwd_data_kernel<2>, grid, dim3(TPB), 0, ST, g, B, H, W, Cin, mult, stride, w, gx, Ho, Wo);
-    else if (mult == 4) hipLaunchKernelGGL(dwconv_bwd_data_kernel<4>, grid, dim3(TPB), 0, ST, g, B, H, W, Cin, mult, stride, w, gx, Ho, Wo);
-    else hipLaunchKernelGGL(dwconv_bwd_data_kernel<0>, grid, dim3(TPB), 0, ST, g, B, H, W, Cin, mult, stride, w, gx, Ho, Wo);
+    if (mult == 2) hipLaunchKernelGGL(dwconv_bwd_data_kernel<2>, grid, dim3(TPB), 0, ST, g, B, H, W, Cin, mult, stride, w, gx, Ho, Wo, 0);
+    else if (mult == 4) hipLaunchKernelGGL(dwconv_bwd_data_kernel<4>, grid, dim3(TPB), 0, ST, g, B, H, W, Cin, mult, stride, w, gx, Ho, Wo, 0);
+    else hipLaunchKernelGGL(dwconv_bwd_data_kernel<0>, grid, dim3(TPB), 0, ST, g, B, H, W, Cin, mult, stride, w, gx, Ho, Wo, 0);
   }
   if (gw) {
     hipError_t e = hipMemsetAsync(gw, 0, sizeof(float) * Cout * 9, ST);
@@ -729,6 +739,19 @@ extern "C" int nbm_dwconv3x3_bwd(const float* x, const float* g, const float* w,
     dim3 grid(grid_for((long long)B * Ho * Wo, 4, 512), (Cout + 63) / 64);
     hipLaunchKernelGGL(dwconv_bwd_weight_kernel, grid, dim3(256), 0, ST, x, g, B, H, W, Cin, mult, stride, gw, gb, Ho, Wo);
   }
+  return nbm_launch_status();
+}
+// Data gradient of the depthwise 3x3 ADDED into gx -- see nbm_hip.h.
+extern "C" int nbm_dwconv3x3_bwd_acc(const float* g, const float* w, int B, int H, int W, int Cin, int mult, int stride,
+                                     float* gx, int Ho, int Wo, void* stream) {
+  if (!g || !w || !gx || B <= 0 || Cin <= 0 || mult <= 0 || stride <= 0) return NBM_EINVAL;
+  if ((H + 2 - 3) / stride + 1 != Ho || (W + 2 - 3) / stride + 1 != Wo) return NBM_EINVAL;
+  if ((Cin & 3) || !nbm_aligned16(gx)) return NBM_EALIGN;
+  const int bx = (W * (Cin / 4) + TPB - 1) / TPB;
+  const dim3 grid(bx < 64 ? bx : 64, (long long)B * H < 65535 ? B * H : 65535);
+  if (mult == 2) hipLaunchKernelGGL(dwconv_bwd_data_kernel<2>, grid, dim3(TPB), 0, ST, g, B, H, W, Cin, mult, stride, w, gx, Ho, Wo, 1);
+  else if (mult == 4) hipLaunchKernelGGL(dwconv_bwd_data_kernel<4>, grid, dim3(TPB), 0, ST, g, B, H, W, Cin, mult, stride, w, gx, Ho, Wo, 1);
+  else hipLaunchKernelGGL(dwconv_bwd_data_kernel<0>, grid, dim3(TPB), 0, ST, g, B, H, W, Cin, mult, stride, w, gx, Ho, Wo, 1);
   return nbm_launch_status();
 }
 extern "C" int nbm_film_fwd(const float* z, const float* film, float* y, int64_t n_pix, int C, void* stream) {

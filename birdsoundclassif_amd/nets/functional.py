@@ -406,7 +406,17 @@ class DwConv(Function):
     def backward(ctx, gy):
         x, weight = ctx.saved_tensors
         mult, stride, has_bias = ctx.cfg
-        gx, gw, gb = ops.dwconv3x3_bwd(x, gy.contiguous(), weight.detach(), mult, stride,
+        gy = gy.contiguous()
+        # The RPN's first convolution of a level and the RoI pooling read the same FPN map.  The RoI pooling's backward pass runs
+        # first (later node) and leaves its scatter map in ops._GRAD_ACC: add this gradient into it on the few pixels a tap reaches
+        # and return nothing -- instead of a dense write here, and a dense add by autograd (12.6 GB maps at level 0).  The
+        # producer's backward pass waits for both consumers either way.
+        acc = ops._GRAD_ACC.pop(x.data_ptr(), None) if ctx.needs_input_grad[0] else None
+        if acc is not None and acc.shape == x.shape:
+            ops.dwconv3x3_bwd_acc(gy, weight.detach(), mult, stride, acc)
+            _, gw, gb = ops.dwconv3x3_bwd(x, gy, weight.detach(), mult, stride, need_gx=False, need_gw=True, has_bias=has_bias)
+            return None, gw, gb, None, None
+        gx, gw, gb = ops.dwconv3x3_bwd(x, gy, weight.detach(), mult, stride,
                                        need_gx=ctx.needs_input_grad[0], need_gw=True, has_bias=has_bias)
         return gx, gw, gb, None, None
 
@@ -494,6 +504,8 @@ class RoiPool(Function):
     def forward(ctx, rois, n_roi, pe_f, pe_t, img_h, img_w, *fmaps):
         pool, pe, level = ops.roi_pool(list(fmaps), rois, n_roi, pe_f, pe_t, img_h, img_w)
         ctx.shapes = [tuple(f.shape) for f in fmaps]
+        ctx.fm_ptrs = [f.data_ptr() for f in fmaps]
+        ops._GRAD_ACC.clear()                      # nothing of an earlier step may survive into this one's backward pass
         ctx.save_for_backward(rois, level)
         ctx.mark_non_differentiable(pe, level)
         return pool, pe, level
@@ -503,6 +515,10 @@ class RoiPool(Function):
     def backward(ctx, gpool, _gpe, _glvl):
         rois, level = ctx.saved_tensors
         gf = ops.roi_pool_bwd(gpool.contiguous(), rois, level, ctx.shapes)
+        ops._GRAD_ACC.clear()
+        if ops.GRAD_SHARE:                         # the other consumer of each map may add its gradient here (Fn.DwConv.backward)
+            for ptr, g in zip(ctx.fm_ptrs, gf):
+                ops._GRAD_ACC[ptr] = g
         return (None, None, None, None, None, None, *gf)
 
 

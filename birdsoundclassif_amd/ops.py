@@ -1125,6 +1125,17 @@ def dwconv3x3_bwd(x, g, w, mult, stride, need_gx=True, need_gw=True, has_bias=Tr
     return gx, gw, gb
 
 
+GRAD_SHARE = True                   # consumers of one FPN map accumulate their gradients into one buffer (Fn.RoiPool / Fn.DwConv)
+_GRAD_ACC = {}                      # data_ptr of an FPN map -> the gradient map the RoI pooling's backward pass filled
+
+
+def dwconv3x3_bwd_acc(g, w, mult, stride, gx):
+    """gx [B,H,W,Cin] += data gradient of the depthwise 3x3 (only the pixels a tap reaches are touched)."""
+    B, H, W, Cin = gx.shape
+    check(lib().nbm_dwconv3x3_bwd_acc(_ptr(_chk(g)), _ptr(_chk(w)), B, H, W, Cin, mult, stride, _ptr(_chk(gx)), g.shape[1], g.shape[2],
+                                      _stream()), 'nbm_dwconv3x3_bwd_acc')
+
+
 def film_fwd(z, film):
     y = torch.empty_like(z)
     C_ = z.shape[-1]

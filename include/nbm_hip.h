@@ -374,6 +374,11 @@ int nbm_pair_softmax_bwd(const float* y, const float* gy, float* gx, int64_t n_p
 /* depthwise 3x3 gradients: gx (may be NULL), gw [Cout][9] and gb [Cout] (gw NULL = skip both) */
 int nbm_dwconv3x3_bwd(const float* x, const float* g, const float* w, int B, int H, int W, int Cin, int mult, int stride,
                       float* gx, float* gw, float* gb, int Ho, int Wo, void* stream);
+/* the data gradient of the same depthwise convolution ADDED into gx, which already holds the gradient another consumer of the
+ * map sent (the RoI pooling's scatter map, nbm_roi_pool_bwd): only the pixels a tap reaches are touched -- replaces a dense
+ * write, a dense zero fill and autograd's dense add for an FPN map with these two consumers */
+int nbm_dwconv3x3_bwd_acc(const float* g, const float* w, int B, int H, int W, int Cin, int mult, int stride, float* gx, int Ho,
+                          int Wo, void* stream);
 int nbm_film_fwd(const float* z, const float* film, float* y, int64_t n_pix, int C, void* stream);
 int nbm_film_bwd(const float* gy, const float* z, const float* film, float* gz, float* gfilm, int64_t n_pix, int C,
                  void* stream);
