@@ -325,6 +325,13 @@ def wino23_pattern(B, H, W, stride, device, dilate=0):
         infos = np.concatenate(infos)
         pos = np.concatenate([(np.arange(len(i)) + 0.5) / len(i) for i in [l.reshape(-1, 128) for l in lists]])
         order = np.argsort(pos, kind='stable')
+        # ... and inside each XCD's range the blocks with the most planes first, so that the range ends on short blocks
+        nblk = len(order)
+        npl = np.array([bin(int(v) & 0xffff).count('1') for v in infos])
+        for x8 in range(8):
+            lo, hi = nblk * x8 // 8, nblk * (x8 + 1) // 8
+            seg = order[lo:hi]
+            order[lo:hi] = seg[np.argsort(-npl[seg], kind='stable')]
         infos = infos[order]
         hit.entry_pm = torch.from_numpy(np.repeat((infos & 0xffff) | 0x10000, 128).astype(np.int32)).to(device)   # bit 16: counts in the bias gradient
         tpm = np.zeros(TH * TW, dtype=np.int64)
