@@ -5,6 +5,8 @@ forward AND backward computation below is a HIP kernel of libnbm_hip.so.  Replac
 reference's `losses.backward()` (reference train.py:212).  Activations NHWC fp32; weights arrive in the checkpoint
 layout and their gradients are returned in the same layout.
 """
+import weakref
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -411,7 +413,8 @@ class DwConv(Function):
         # first (later node) and leaves its scatter map in ops._GRAD_ACC: add this gradient into it on the few pixels a tap reaches
         # and return nothing -- instead of a dense write here, and a dense add by autograd (12.6 GB maps at level 0).  The
         # producer's backward pass waits for both consumers either way.
-        acc = ops._GRAD_ACC.pop(x.data_ptr(), None) if ctx.needs_input_grad[0] else None
+        ref = ops._GRAD_ACC.pop(x.data_ptr(), None) if ctx.needs_input_grad[0] else None
+        acc = ref() if ref is not None else None          # weak: alive only while autograd still holds the RoI pooling's map
         if acc is not None and acc.shape == x.shape:
             ops.dwconv3x3_bwd_acc(gy, weight.detach(), mult, stride, acc)
             _, gw, gb = ops.dwconv3x3_bwd(x, gy, weight.detach(), mult, stride, need_gx=False, need_gw=True, has_bias=has_bias)
@@ -518,7 +521,7 @@ class RoiPool(Function):
         ops._GRAD_ACC.clear()
         if ops.GRAD_SHARE:                         # the other consumer of each map may add its gradient here (Fn.DwConv.backward)
             for ptr, g in zip(ctx.fm_ptrs, gf):
-                ops._GRAD_ACC[ptr] = g
+                ops._GRAD_ACC[ptr] = weakref.ref(g)
         return (None, None, None, None, None, None, *gf)
 
 
