@@ -36,6 +36,7 @@ def _w_to_ref_layout(gw, weight):
 
 
 STEM_FOLDED = True       # init_conv folded into conv1 (csrc/stem.hip); False: init_conv kernel + generic implicit GEMM
+WINO_MIN_CIN = int(__import__('os').environ.get('NBM_WINO_MIN_CIN', '128'))   # 64-channel 3x3 layers: measured, see DESIGN 5
 WINOGRAD = True          # module switch for A/B tests (tests/test_gpu_e2e.py compares both convolution paths)
 LAZY_DGRAD = True        # data gradient of the demand-driven finest FPN map through the listed fused kernel
 LAZY_WGRAD = True        # weight gradient of the demand-driven finest FPN map over its computed tiles only
@@ -47,7 +48,7 @@ def _winograd_ok(x, weight, kh, kw, stride, pad):
     if not (kh == 3 and kw == 3 and stride == 1 and pad == 1 and weight.dim() == 4 and x.dim() == 4) or not WINOGRAD:
         return False
     _, H, W, Cin = x.shape
-    return H >= 8 and W >= 8 and Cin % 32 == 0 and weight.shape[0] % 4 == 0 and Cin >= 128
+    return H >= 8 and W >= 8 and Cin % 32 == 0 and weight.shape[0] % 4 == 0 and Cin >= WINO_MIN_CIN
 
 
 def lazy3x3_ok(H, W, Cin, weight):
