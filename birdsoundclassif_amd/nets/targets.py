@@ -133,20 +133,30 @@ class ProposalTargetLayer(nn.Module):
         batched = all(gt_c[i0:i1].max() > -1 for i0, i1 in zip(idx[:-1], idx[1:]))
         if batched:
             all_pad = np.concatenate([rois_c, gt_pad], axis=1)                       # [B, R + gmax, 4]
-            # the same fp32 operations in the same order as the NumPy form below, on torch's multi-threaded CPU kernels
-            # (every op rounds once, no fusion: bit-identical; the GPU idles while this runs: 15 -> 5 ms per step at B = 128)
-            ta, tg = torch.from_numpy(all_pad), torch.from_numpy(gt_pad)
-            a0, a1, a2, a3 = (ta[:, :, None, k] for k in range(4))
-            g0, g1, g2, g3 = (tg[:, None, :, k] for k in range(4))
-            xi = (torch.minimum(a2, g2) - torch.maximum(a0, g0) + 1).clamp_(min=0)
-            yi = (torch.minimum(a3, g3) - torch.maximum(a1, g1) + 1).clamp_(min=0)
-            inter = xi * yi
-            area_a = (a2 - a0 + 1) * (a3 - a1 + 1)
-            area_g = (g2 - g0 + 1) * (g3 - g1 + 1)
-            ov_t = inter / ((area_a + area_g) - inter)
-            ov_t.masked_fill_(~torch.from_numpy(valid)[:, None, :], -1)
-            mx_t, asg_t = ov_t.max(dim=-1)                                            # first maximal index, like argmax
-            mx_all, asg_all = mx_t.numpy(), asg_t.numpy()
+            # [B, gmax, R + gmax] with the long axis innermost: the same fp32 operations per element as the reference's IoU
+            # (nets_utils.py:103-126), 3x faster in NumPy than the [.., R + gmax, gmax] broadcast (inner loops of length gmax);
+            # the GPU idles while this runs.  (torch's CPU kernels were tried: bit-identical too, but waking 32 threads for
+            # 1 M-element tensors made it 43 ms on the GPU box.)
+            a0, a1, a2, a3 = (np.ascontiguousarray(all_pad[:, None, :, k]) for k in range(4))
+            g0, g1, g2, g3 = (np.ascontiguousarray(gt_pad[:, :, None, k]) for k in range(4))
+            xi = np.minimum(a2, g2)
+            xi -= np.maximum(a0, g0)
+            xi += _F(1)
+            np.maximum(xi, _F(0), out=xi)
+            yi = np.minimum(a3, g3)
+            yi -= np.maximum(a1, g1)
+            yi += _F(1)
+            np.maximum(yi, _F(0), out=yi)
+            inter = xi
+            inter *= yi
+            area_a = (a2 - a0 + _F(1)) * (a3 - a1 + _F(1))
+            area_g = (g2 - g0 + _F(1)) * (g3 - g1 + _F(1))
+            den = area_a + area_g
+            den -= inter
+            with np.errstate(divide='ignore', invalid='ignore'):
+                ov_all = inter / den
+            ov_all[~np.broadcast_to(valid[:, :, None], ov_all.shape)] = -1
+            mx_all, asg_all = ov_all.max(axis=1), ov_all.argmax(axis=1)
         for b, (i0, i1) in enumerate(zip(idx[:-1], idx[1:])):
             gt = gt_c[i0:i1]
             if batched:
