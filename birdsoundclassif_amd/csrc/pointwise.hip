@@ -251,6 +251,76 @@ __global__ void dwconv3x3_kernel(const float* __restrict__ x, int B, int H, int 
   }
 }
 
+// The same depthwise convolution, four consecutive output channels per thread (MULT in {1, 2, 4}: 4 / MULT input channels, one
+// 16 / 8 / 4-byte load per tap; 16-byte bias / FiLM / output accesses).  The 36 weights of the thread's channels stay in
+// registers when the grid stride keeps its channel chunk fixed.  Per output element the arithmetic is the scalar kernel's:
+// acc += x * w over the taps in (r, s) order, + bias, * gamma + beta.
+template <int MULT>
+__global__ void dwconv3x3_vec_kernel(const float* __restrict__ x, int B, int H, int W, int Cin, int stride,
+                                     const float* __restrict__ w, const float* __restrict__ bias,
+                                     const float* __restrict__ film, long long film_ld, float* __restrict__ y,
+                                     int Ho, int Wo) {
+  constexpr int NIN = 4 / MULT;
+  const int Cout = Cin * MULT, C4 = Cout >> 2;
+  const long long total = (long long)B * Ho * Wo * C4;
+  const long long gstride = (long long)gridDim.x * blockDim.x;
+  const bool fixed_chunk = (gstride % C4) == 0;
+  float wr[4][9];
+  int w_chunk = -1;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += gstride) {
+    const int c4 = (int)(i % C4);
+    const long long pix = i / C4;
+    long long t = pix;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    const int o0 = c4 * 4, ci0 = o0 / MULT;
+    if (!fixed_chunk || w_chunk != c4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wr[j][k] = w[(o0 + j) * 9 + k];
+      w_chunk = c4;
+    }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int iy = oy * stride - 1 + r;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int ix = ox * stride - 1 + s;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const float* xp = x + ((long long)(b * H + iy) * W + ix) * Cin + ci0;
+        float xv[NIN];
+        if constexpr (NIN == 4) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(xp);
+          xv[0] = v[0]; xv[1] = v[1]; xv[2] = v[2]; xv[3] = v[3];
+        } else if constexpr (NIN == 2) {
+          const float2 v = *reinterpret_cast<const float2*>(xp);
+          xv[0] = v.x; xv[1] = v.y;
+        } else {
+          xv[0] = *xp;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += xv[j / MULT] * wr[j][r * 3 + s];
+      }
+    }
+    f32x4 out = {acc[0], acc[1], acc[2], acc[3]};
+    if (bias) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + o0);
+      out += bv;
+    }
+    if (film) {
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(film + pix * film_ld + o0);
+      const f32x4 be = *reinterpret_cast<const f32x4*>(film + pix * film_ld + Cout + o0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) out[j] = out[j] * ga[j] + be[j];
+    }
+    *reinterpret_cast<f32x4*>(y + i * 4) = out;
+  }
+}
+
 // one wave per row
 __global__ void layernorm_kernel(const float* __restrict__ x, long long rows, int E, const float* __restrict__ w,
                                  const float* __restrict__ b, float eps, float* __restrict__ y) {
@@ -452,6 +522,17 @@ extern "C" int nbm_dwconv3x3(const float* x, int B, int H, int W, int Cin, int m
   if (!x || !w || !y || B <= 0 || Cin <= 0 || mult <= 0 || stride <= 0) return NBM_EINVAL;
   if ((H + 2 - 3) / stride + 1 != Ho || (W + 2 - 3) / stride + 1 != Wo) return NBM_EINVAL;
   if (film && film_ld < 2ll * Cin * mult) return NBM_EINVAL;
+  const int Cout = Cin * mult;
+  const bool vec = (mult == 1 || mult == 2 || mult == 4) && (Cout & 3) == 0 && (Cin % (4 / mult)) == 0 && nbm_aligned16(y) &&
+                   nbm_aligned16(x) && (!bias || nbm_aligned16(bias)) && (!film || (nbm_aligned16(film) && (film_ld & 3) == 0));
+  if (vec) {
+    const dim3 grid(grid_for((long long)B * Ho * Wo * (Cout / 4))), blk(TPB);
+    hipStream_t st = (hipStream_t)stream;
+    if (mult == 1) hipLaunchKernelGGL(dwconv3x3_vec_kernel<1>, grid, blk, 0, st, x, B, H, W, Cin, stride, w, bias, film, (long long)film_ld, y, Ho, Wo);
+    else if (mult == 2) hipLaunchKernelGGL(dwconv3x3_vec_kernel<2>, grid, blk, 0, st, x, B, H, W, Cin, stride, w, bias, film, (long long)film_ld, y, Ho, Wo);
+    else hipLaunchKernelGGL(dwconv3x3_vec_kernel<4>, grid, blk, 0, st, x, B, H, W, Cin, stride, w, bias, film, (long long)film_ld, y, Ho, Wo);
+    return nbm_launch_status();
+  }
   hipLaunchKernelGGL(dwconv3x3_kernel, dim3(grid_for((long long)B * Ho * Wo * Cin * mult)), dim3(TPB), 0,
                      (hipStream_t)stream, x, B, H, W, Cin, mult, stride, w, bias, film, (long long)film_ld, y, Ho, Wo);
   return nbm_launch_status();
