@@ -343,7 +343,7 @@ def main():
         del model
         torch.cuda.empty_cache()
         try:
-            train = train_bench(rank, world, dist, a.train_batch, a.train_steps, 1)
+            train = train_bench(rank, world, dist, a.train_batch, a.train_steps, 2)     # 2 warm-up steps: allocator, lists, pinned ring
         except Exception as exc:                  # the detect line above is the contract metric: never lose it
             train = {'error': f'{type(exc).__name__}: {exc}'[:500]}
     if rank == 0:

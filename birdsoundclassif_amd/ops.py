@@ -426,9 +426,8 @@ _PINNED_NEXT = [0]
 
 def _pinned_int():
     """A pinned host int32 from a small ring (hipHostMalloc per step would stall the stream)."""
-    if len(_PINNED) < 16:
-        _PINNED.append(torch.empty((1,), dtype=torch.int32, pin_memory=True))
-        return _PINNED[-1]
+    if not _PINNED:                               # all at once, on the first (warm-up) call
+        _PINNED.extend(torch.empty((1,), dtype=torch.int32, pin_memory=True) for _ in range(16))
     _PINNED_NEXT[0] = (_PINNED_NEXT[0] + 1) % len(_PINNED)
     return _PINNED[_PINNED_NEXT[0]]
 
