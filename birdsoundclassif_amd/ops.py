@@ -342,8 +342,6 @@ def wino23_pattern(B, H, W, stride, device, dilate=0):
                 tpm[((ry == cy)[:, None] & (rx == cx)[None, :]).ravel()] = pmv
         hit.tile_pm = torch.from_numpy(tpm.astype(np.int32)).to(device)
         hit.tiles = torch.from_numpy(blocks[order].ravel().astype(np.int32)).to(device)
-        if os.environ.get('NBM_DEBUG_BLKINFO'):          # timing experiments only (results are wrong)
-            infos[:] = int(os.environ['NBM_DEBUG_BLKINFO'], 16)
         hit.blk_info = torch.from_numpy(infos.astype(np.uint32).view(np.int32)).to(device)
         hit.full = torch.from_numpy(full.ravel().astype(np.uint8)).to(device)
         hit.any = torch.from_numpy(anym.ravel()).to(device)
@@ -549,10 +547,6 @@ def lazy_complete(fm, rois, n_roi, fmap_hw, level=0):
     if keep:                                      # the data gradient lists the tiles around these windows again
         st.rois = (rois, n_roi, nl, level, fh, fw)
     st.x = st.U = st.bias = st.lateral = None     # the backward pass gets x from the tape
-
-
-def lazy_clear():
-    _LAZY.clear()
 
 
 def conv3x3_winograd_dgrad_tiles(st, g, Ut):
