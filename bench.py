@@ -179,6 +179,7 @@ def main():
     ap.add_argument('--train-batch', type=int, default=128)
     ap.add_argument('--train-steps', type=int, default=3)
     ap.add_argument('--no-train', action='store_true')
+    ap.add_argument('--no-dense-reference', dest='no_dense_reference', action='store_true')
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -274,6 +275,23 @@ def main():
     step()
     torch.cuda.synchronize()
     prof_all, ops.PROFILE = ops.PROFILE, None
+    # for the record: the same step with the finest FPN level computed densely, as the reference does -- untimed
+    # for the headline, 1 warm-up + 3 steps
+    dense_ref = None
+    if ops.LAZY_FINEST and not a.no_dense_reference:
+        ops.LAZY_FINEST = False
+        try:
+            step()
+            sync_all()
+            td = time.perf_counter()
+            for _ in range(3):
+                step()
+            sync_all()
+            td = (time.perf_counter() - td) / 3
+            dense_ref = {'ms_per_step': td * 1e3, 'clips_per_s_per_gpu': B / td,
+                         'note': 'NBM_LAZY_FINEST=0: every pixel of the finest FPN map and of its lateral is computed; identical detections'}
+        finally:
+            ops.LAZY_FINEST = True
     if dist is not None:
         t = torch.tensor([dt], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -354,7 +372,7 @@ def main():
                                        '(PCM16 @22.05 kHz resident in HBM) through the HIP STFT front end + detector '
                                        'forward + device post-processing, detections returned to the host',
                            'batch_per_gpu': B, 'min_score': a.min_score, 'detections_per_step': n_det / a.steps},
-                'roofline': roof, 'frontend': frontend, 'train_step': train}
+                'roofline': roof, 'frontend': frontend, 'dense_finest_map': dense_ref, 'train_step': train}
         if world == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -8,11 +8,11 @@ cd /tmp && export TMPDIR=/tmp
 python3 $R/scripts/fwdprofile.py 64 > $O/fwd_layers.txt 2>&1
 python3 $R/scripts/fwdprofile.py 64 direct > $O/fwd_layers_direct.txt 2>&1
 python3 $R/scripts/trainlayers.py 128 > $O/train_layers.txt 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-dense-reference > $O/bench_under_rocprof.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train > $O/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train --no-dense-reference > $O/pmc_$c.log 2>&1
 done
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_MFMA -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train > $O/pmc_MFMA.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_MFMA -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train --no-dense-reference > $O/pmc_MFMA.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $O/pmc_train_$c -- python3 $R/scripts/trainbench.py 128 2 > $O/pmc_train_$c.log 2>&1
 done
