@@ -71,6 +71,7 @@ SIGNATURES = {
     'nbm_spec_windows': [_P, _L, _I, _I, _I, _I, _P, _P, _I, _I, _I, _P, _P],
     'nbm_init_conv': [_P, _L, _P, _P, _I, _P, _P],
     'nbm_stem7x7': [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
+    'nbm_stem7x7_wgrad': [_P, _P, _I, _I, _I, _P, _P, _P],
     'nbm_maxpool3x3s2': [_P, _I, _I, _I, _I, _P, _I, _I, _P, _P],
     'nbm_upsample_bilinear_add': [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P],
     'nbm_softmax_rows': [_P, _L, _I, _L, _P],

@@ -352,12 +352,16 @@ class Stem(Function):
         x, w_init, b_init, w1, scale, y = ctx.saved_tensors
         g = ops.relu_bwd(gy.contiguous(), y)
         B, H, W, _ = x.shape
-        x2 = torch.ones((B, H, W, 2), device=x.device, dtype=torch.float32)
-        x2[..., 0] = x[..., 0]
-        uv = torch.zeros((64, 7 * 7 * 2), device=x.device, dtype=torch.float32)
-        ops.conv_wgrad(g.view(-1, 64), x2, uv, B=B, H=H, W=W, Cin=2, N=64, kh=7, kw=7, stride=2, pad=3, row_scale=scale)
-        uv = uv.view(64, 7, 7, 2)
-        U, V = uv[..., 0], uv[..., 1]                                     # [64,7,7]
+        if STEM_FOLDED and w1.shape[0] == 64 and x.shape[-1] == 1:
+            U, V = ops.stem7x7_wgrad(x, g)                                # one MFMA kernel over the 1-channel image (stem.hip)
+            U, V = U * scale.view(64, 1, 1), V * scale.view(64, 1, 1)
+        else:
+            x2 = torch.ones((B, H, W, 2), device=x.device, dtype=torch.float32)
+            x2[..., 0] = x[..., 0]
+            uv = torch.zeros((64, 7 * 7 * 2), device=x.device, dtype=torch.float32)
+            ops.conv_wgrad(g.view(-1, 64), x2, uv, B=B, H=H, W=W, Cin=2, N=64, kh=7, kw=7, stride=2, pad=3, row_scale=scale)
+            uv = uv.view(64, 7, 7, 2)
+            U, V = uv[..., 0], uv[..., 1]                                 # [64,7,7]
         wi, bi = w_init.detach().view(3), b_init.detach().view(3)
         gw1 = wi.view(1, 3, 1, 1) * U[:, None] + bi.view(1, 3, 1, 1) * V[:, None]
         w1d = w1.detach()

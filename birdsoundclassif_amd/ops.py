@@ -771,6 +771,20 @@ def stem7x7(img, weff, wb, wb_full, scale, shift):
     return y
 
 
+def stem7x7_wgrad(img, g):
+    """img [B,H,W,1], g [B,Ho,Wo,64] (ReLU-masked output gradient) -> (U [64,7,7], V [64,7,7]): sums of g times the image sample /
+    the inside-the-image indicator under every tap (csrc/stem.hip)."""
+    _chk(img, name='img'), _chk(g, name='g')
+    B, H, W = img.shape[:3]
+    assert g.shape == (B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64)
+    D = torch.empty((64, 64), device=img.device, dtype=torch.float32)
+    Cb = torch.empty((64, 49), device=img.device, dtype=torch.float32)
+    check(lib().nbm_stem7x7_wgrad(_ptr(img), _ptr(g), B, H, W, _ptr(D), _ptr(Cb), _stream()), 'nbm_stem7x7_wgrad')
+    U = D[:, :56].view(64, 7, 8)[:, :, :7]
+    V = D[:, 56].view(64, 1, 1) - Cb.view(64, 7, 7)
+    return U, V
+
+
 def maxpool3x3s2(x, with_index=False):
     """-> y, or (y, idx uint8 [B,Ho,Wo,C]: window position of each maximum, for `maxpool3x3s2_bwd`)."""
     _chk(x, name='x')

@@ -222,6 +222,13 @@ int nbm_init_conv(const float* x, int64_t n_pix, const float* w, const float* b,
 int nbm_stem7x7(const float* img, int B, int H, int W, const float* weff, const float* wb, const float* wb_full,
                 const float* scale, const float* shift, float* y, void* stream);
 
+/* Weight-side gradient of the same stem (csrc/stem.hip): g [B][Ho][Wo][64] = gradient wrt the stem output, already masked by the
+ * ReLU.  D [64][64] (zeroed here): D[n][8 r + s] = U[n][r][s] = sum_px g[px][n] img[pix(px) + (r, s)], D[n][56] = S[n] =
+ * sum_px g[px][n];  Cb [64][49] (zeroed here): Cb[n][7 r + s] = sum of g[px][n] over the pixels whose tap (r, s) lies outside
+ * the image, so that V[n][r][s] = S[n] - Cb[n][7 r + s] counts the init_conv bias only inside conv1's zero padding.  The
+ * caller forms dW1 = a U + b V, da = sum W1 U, db = sum W1 V (backbone.py:104-113,131). */
+int nbm_stem7x7_wgrad(const float* img, const float* g, int B, int H, int W, float* D, float* Cb, void* stream);
+
 /* 3x3 / stride 2 / pad 1 max pooling -- torchvision ResNet `maxpool` (backbone.py:131).  idx (may be NULL; training):
  * one byte per output element = r*3+s of the first maximum in scan order, consumed by nbm_maxpool3x3s2_bwd. */
 int nbm_maxpool3x3s2(const float* x, int B, int H, int W, int C, float* y, int Ho, int Wo, uint8_t* idx, void* stream);
