@@ -354,7 +354,7 @@ __global__ void pair_softmax_bwd_kernel(const float* __restrict__ y, const float
 // depthwise 3x3 (pad 1, multiplier mult, stride st): data gradient, gather form, 4 input channels per thread.
 // Only taps r with (iy + 1 - r) % st == 0 reach an output row: r starts at (iy + 1) % st and steps by st, so with the
 // RPN's stride 8 most pixels find no tap and just write zeros.
-template <int MULT>
+template <int MULT, bool HOIST = false>
 __global__ void dwconv_bwd_data_kernel(const float* __restrict__ g, int B, int H, int W, int Cin, int mult_rt, int stride,
                                        const float* __restrict__ w, float* __restrict__ gx, int Ho, int Wo, int accumulate) {
   // accumulate != 0: gx already holds another consumer's gradient of the same map (the RoI pooling's, see
@@ -365,6 +365,21 @@ __global__ void dwconv_bwd_data_kernel(const float* __restrict__ g, int B, int H
   const int Cout = Cin * mult, C4 = Cin >> 2;
   const int row_items = W * C4;
   f32x4* o4 = reinterpret_cast<f32x4*>(gx);
+  // MULT == 2: the 72 weights of this thread's 4 input channels in registers (its channel chunk is fixed when the item stride is
+  // a multiple of C4): the per-tap scalar weight loads were what this kernel spent its time on
+  // (HOIST is only instantiated for strides <= 2: with larger strides most pixels are reached by no tap at all and preloading 72
+  // weights per thread measured 1.8x slower; the register array also costs occupancy, hence a separate instantiation)
+  float wr[HOIST ? 8 : 1][9];
+  const bool w_fixed = HOIST && ((gridDim.x * blockDim.x) % C4) == 0;
+  if constexpr (HOIST) {
+    if (w_fixed) {
+      const int c0w = (int)((blockIdx.x * blockDim.x + threadIdx.x) % C4) * 4;
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wr[q][k] = w[((long long)c0w * 2 + q) * 9 + k];
+    }
+  }
   for (int row = blockIdx.y; row < B * H; row += gridDim.y) {
     const int iy = row % H, b = row / H;
     const int r_first = (iy + 1) % stride;
@@ -388,12 +403,28 @@ __global__ void dwconv_bwd_data_kernel(const float* __restrict__ g, int B, int H
               if (ox >= Wo) continue;
               const f32x4* gp = reinterpret_cast<const f32x4*>(g + ((long long)(b * Ho + oy) * Wo + ox) * Cout + c0 * 2);
               const f32x4 g0 = gp[0], g1 = gp[1];
-              const float* wp = w + (long long)c0 * 2 * 9 + r * 3 + s;
               any = true;
-              acc[0] += g0[0] * wp[0];  acc[0] += g0[1] * wp[9];        // same order as the generic loop below
-              acc[1] += g0[2] * wp[18]; acc[1] += g0[3] * wp[27];
-              acc[2] += g1[0] * wp[36]; acc[2] += g1[1] * wp[45];
-              acc[3] += g1[2] * wp[54]; acc[3] += g1[3] * wp[63];
+              if (HOIST && w_fixed) {
+                // r, s are not compile-time here (they start at (iy + 1) % stride): select the tap's weights with a small switch
+                float w8[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                  float v = wr[HOIST ? q : 0][0];
+#pragma unroll
+                  for (int k = 1; k < 9; ++k) v = (r * 3 + s == k) ? wr[HOIST ? q : 0][k] : v;
+                  w8[q] = v;
+                }
+                acc[0] += g0[0] * w8[0]; acc[0] += g0[1] * w8[1];
+                acc[1] += g0[2] * w8[2]; acc[1] += g0[3] * w8[3];
+                acc[2] += g1[0] * w8[4]; acc[2] += g1[1] * w8[5];
+                acc[3] += g1[2] * w8[6]; acc[3] += g1[3] * w8[7];
+              } else {
+                const float* wp = w + (long long)c0 * 2 * 9 + r * 3 + s;
+                acc[0] += g0[0] * wp[0];  acc[0] += g0[1] * wp[9];        // same order as the generic loop below
+                acc[1] += g0[2] * wp[18]; acc[1] += g0[3] * wp[27];
+                acc[2] += g1[0] * wp[36]; acc[2] += g1[1] * wp[45];
+                acc[3] += g1[2] * wp[54]; acc[3] += g1[3] * wp[63];
+              }
             }
           }
         } else
@@ -816,7 +847,8 @@ extern "C" int nbm_dwconv3x3_bwd(const float* x, const float* g, const float* w,
     if ((Cin & 3) || !nbm_aligned16(gx)) return NBM_EALIGN;
     const int bx = (W * (Cin / 4) + TPB - 1) / TPB;
     const dim3 grid(bx < 64 ? bx : 64, (long long)B * H < 65535 ? B * H : 65535);
-    if (mult == 2) hipLaunchKernelGGL(dwconv_bwd_data_kernel<2>, grid, dim3(TPB), 0, ST, g, B, H, W, Cin, mult, stride, w, gx, Ho, Wo, 0);
+    if (mult == 2 && stride <= 2) hipLaunchKernelGGL((dwconv_bwd_data_kernel<2, true>), grid, dim3(TPB), 0, ST, g, B, H, W, Cin, mult, stride, w, gx, Ho, Wo, 0);
+    else if (mult == 2) hipLaunchKernelGGL(dwconv_bwd_data_kernel<2>, grid, dim3(TPB), 0, ST, g, B, H, W, Cin, mult, stride, w, gx, Ho, Wo, 0);
     else if (mult == 4) hipLaunchKernelGGL(dwconv_bwd_data_kernel<4>, grid, dim3(TPB), 0, ST, g, B, H, W, Cin, mult, stride, w, gx, Ho, Wo, 0);
     else hipLaunchKernelGGL(dwconv_bwd_data_kernel<0>, grid, dim3(TPB), 0, ST, g, B, H, W, Cin, mult, stride, w, gx, Ho, Wo, 0);
   }
@@ -846,7 +878,8 @@ extern "C" int nbm_dwconv3x3_bwd_acc(const float* g, const float* w, int B, int 
   if ((Cin & 3) || !nbm_aligned16(gx)) return NBM_EALIGN;
   const int bx = (W * (Cin / 4) + TPB - 1) / TPB;
   const dim3 grid(bx < 64 ? bx : 64, (long long)B * H < 65535 ? B * H : 65535);
-  if (mult == 2) hipLaunchKernelGGL(dwconv_bwd_data_kernel<2>, grid, dim3(TPB), 0, ST, g, B, H, W, Cin, mult, stride, w, gx, Ho, Wo, 1);
+  if (mult == 2 && stride <= 2) hipLaunchKernelGGL((dwconv_bwd_data_kernel<2, true>), grid, dim3(TPB), 0, ST, g, B, H, W, Cin, mult, stride, w, gx, Ho, Wo, 1);
+  else if (mult == 2) hipLaunchKernelGGL(dwconv_bwd_data_kernel<2>, grid, dim3(TPB), 0, ST, g, B, H, W, Cin, mult, stride, w, gx, Ho, Wo, 1);
   else if (mult == 4) hipLaunchKernelGGL(dwconv_bwd_data_kernel<4>, grid, dim3(TPB), 0, ST, g, B, H, W, Cin, mult, stride, w, gx, Ho, Wo, 1);
   else hipLaunchKernelGGL(dwconv_bwd_data_kernel<0>, grid, dim3(TPB), 0, ST, g, B, H, W, Cin, mult, stride, w, gx, Ho, Wo, 1);
   return nbm_launch_status();
