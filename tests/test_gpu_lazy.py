@@ -95,6 +95,58 @@ def test_listed_tiles_equal_the_dense_convolution(shape):
     assert bool(torch.isnan(y[~want]).all()), 'a pixel outside pattern pixels + RoI tiles was written'
 
 
+def test_many_rois_at_the_real_geometry():
+    """1000 RoIs per image (the negative training step's load) on the 188x512 map: every pixel of every level-0 window equals the
+    dense convolution, nothing outside pattern pixels + window tiles is written, and the dilated list covers the data gradient."""
+    B, H, W, C, N = 2, 188, 512, 128, 64
+    x = rnd('mx', B, H, W, C).cuda()
+    w = rnd('mw', N, C, 3, 3, scale=0.05).cuda()
+    b = rnd('mb', N).cuda()
+    U = _prep.wino23(w)
+    dense = ops.conv3x3_winograd(x, U, b)
+    ops.LAZY_POISON = True
+    try:
+        y, st = ops.conv3x3_winograd_lazy(x, U, b, 8)
+    finally:
+        ops.LAZY_POISON = False
+    st.keep = True
+    fh = [188, 94, 47, 24, 12]
+    fw = [512, 256, 128, 64, 32]
+    rng = np.random.default_rng(5)
+    cap = 1000
+    x1 = rng.integers(0, 1000, (B, cap)); y1 = rng.integers(0, 360, (B, cap))
+    bw = rng.integers(1, 60, (B, cap)); bh = rng.integers(1, 40, (B, cap))
+    rois = np.stack([x1, y1, np.minimum(x1 + bw, 1023), np.minimum(y1 + bh, 374)], -1).astype(np.float32)
+    rois_d = torch.from_numpy(rois).cuda()
+    ops.lazy_complete(y, rois_d, torch.tensor([cap], dtype=torch.int32, device='cuda'), list(zip(fh, fw)))
+    pat = ops.wino23_pattern(B, H, W, 8, x.device)
+    rows = torch.zeros(H, dtype=torch.bool); cols = torch.zeros(W, dtype=torch.bool)
+    for n_, v in ((H, rows), (W, cols)):
+        for o in range((n_ - 1) // 8 + 1):
+            for k in range(3):
+                if 0 <= 8 * o - 1 + k < n_:
+                    v[8 * o - 1 + k] = True
+    want = (rows[:, None] & cols[None, :])[None].repeat(B, 1, 1).clone()
+    win = torch.zeros(B, H, W, dtype=torch.bool)
+    n0 = 0
+    for bi in range(B):
+        for r in range(cap):
+            lvl, a1, b1, a2, b2 = window(rois[bi, r], fh, fw)
+            if lvl == 0:
+                n0 += 1
+                want[bi, (b1 >> 1) * 2:(b2 >> 1) * 2 + 2, (a1 >> 1) * 2:(a2 >> 1) * 2 + 2] = True
+                win[bi, b1:b2 + 1, a1:a2 + 1] = True
+    assert n0 > 100
+    want = want[:, :H, :W].cuda()
+    assert torch.equal(y[want], dense[want]) and bool(torch.isnan(y[~want]).all())
+    # data gradient: g lives on the pattern pixels and inside the windows
+    m = ((rows[:, None] & cols[None, :])[None] | win).cuda()
+    g = (rnd('mg', B, H, W, N).cuda() * m[..., None]).contiguous()
+    got = ops.conv3x3_winograd_dgrad_tiles(st, g, _prep.wino23(w, transposed=True, m=2))
+    ref = ops.conv3x3_winograd(g, _prep.wino23(w, transposed=True, m=2), None)        # the dense operator, same F(2x2,3x3)
+    assert torch.equal(got, ref)
+
+
 def test_weight_gradient_over_the_listed_tiles_equals_the_dense_one():
     """g zero outside the computed tiles: the listed-tile F(2x2,3x3) weight gradient == torch's conv weight gradient."""
     import torch.nn.functional as F
