@@ -290,6 +290,8 @@ def main():
             td = (time.perf_counter() - td) / 3
             dense_ref = {'ms_per_step': td * 1e3, 'clips_per_s_per_gpu': B / td,
                          'note': 'NBM_LAZY_FINEST=0: every pixel of the finest FPN map and of its lateral is computed; identical detections'}
+        except Exception as exc:                  # informational leg: never lose the headline line over it
+            dense_ref = {'error': f'{type(exc).__name__}: {exc}'[:300]}
         finally:
             ops.LAZY_FINEST = True
     if dist is not None:
