@@ -202,7 +202,7 @@ def main():
             # a collective that cannot complete raises after 5 minutes instead of hanging the bench
             dist.init_process_group('nccl', device_id=torch.device('cuda', local), timeout=datetime.timedelta(minutes=5))
 
-    from birdsoundclassif_amd import ops, synth
+    from birdsoundclassif_amd import ondemand, ops, synth
     from birdsoundclassif_amd.nbm_datasets.prepare_dataset import SpectrogramFrontEnd
     from birdsoundclassif_amd.nets import build_model
     from birdsoundclassif_amd.train import default_args
@@ -278,8 +278,8 @@ def main():
     # for the record: the same step with the finest FPN level computed densely, as the reference does -- untimed
     # for the headline, 1 warm-up + 3 steps
     dense_ref = None
-    if ops.LAZY_FINEST and not a.no_dense_reference:
-        ops.LAZY_FINEST = False
+    if ondemand.LAZY_FINEST and not a.no_dense_reference:
+        ondemand.LAZY_FINEST = False
         try:
             step()
             sync_all()
@@ -293,7 +293,7 @@ def main():
         except Exception as exc:                  # informational leg: never lose the headline line over it
             dense_ref = {'error': f'{type(exc).__name__}: {exc}'[:300]}
         finally:
-            ops.LAZY_FINEST = True
+            ondemand.LAZY_FINEST = True
     if dist is not None:
         t = torch.tensor([dt], device='cuda', dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -314,7 +314,7 @@ def main():
     traffic = None                      # HBM bytes per launch of the dominant kernel: PMC counters cannot be read live;
     try:                                # the value comes from the committed rocprofv3 --pmc passes of this same command
         pj = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_dominant.json')))
-        if B == 64 and pj.get('lazy_finest') == bool(ops.LAZY_FINEST):
+        if B == 64 and pj.get('lazy_finest') == bool(ondemand.LAZY_FINEST):
             traffic = pj['traffic_bytes_per_launch']
     except Exception:
         traffic = None
@@ -343,7 +343,7 @@ def main():
                 'all_gemm_type_launches_ms_per_step': all_ms,
                 'whole_step_direct_conv_equivalent_TFLOPs': FWD_GFLOP_PER_CLIP * B * a.steps / (dt * 1e3),
                 'finest_fpn_map': 'on demand (RPN pattern tiles + tiles under the RoIs; the other pixels have no reader)'
-                                  if ops.LAZY_FINEST else 'dense'}
+                                  if ondemand.LAZY_FINEST else 'dense'}
     # front end alone (HBM-bound stage of the path): live HIP events around K replays
     fe_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
     for s0, e0 in fe_ev:

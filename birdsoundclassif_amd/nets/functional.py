@@ -11,7 +11,7 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from .. import ops
+from .. import ops, ondemand
 from . import _prep
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = ops.ACT_NONE, ops.ACT_RELU, ops.ACT_LEAKY
@@ -38,6 +38,8 @@ def _w_to_ref_layout(gw, weight):
 STEM_FOLDED = True       # init_conv folded into conv1 (csrc/stem.hip); False: init_conv kernel + generic implicit GEMM
 WINO_MIN_CIN = int(__import__('os').environ.get('NBM_WINO_MIN_CIN', '128'))   # 64-channel 3x3 layers: measured, see DESIGN 5
 WINOGRAD = True          # module switch for A/B tests (tests/test_gpu_e2e.py compares both convolution paths)
+GRAD_SHARE = True        # the two consumers of an FPN map accumulate their gradients into one buffer (RoiPool / DwConv)
+_GRAD_ACC = {}           # data_ptr of an FPN map -> weak reference to the gradient map the RoI pooling's backward pass filled
 LAZY_DGRAD = True        # data gradient of the demand-driven finest FPN map through the listed fused kernel
 LAZY_WGRAD = True        # weight gradient of the demand-driven finest FPN map over its computed tiles only
 WINO_BWD_TILE = 4        # F(4x4,3x3) for the two backward convolutions (gradients tolerate its 2e-5 error); 2 = F(2x2,3x3)
@@ -54,7 +56,7 @@ def _winograd_ok(x, weight, kh, kw, stride, pad):
 def lazy3x3_ok(H, W, Cin, weight):
     """Would `conv(x [.,H,W,Cin], weight, kh=3, kw=3, pad=1, lazy_stride=...)` take the demand-driven path?  (The lateral in
     front of it may only go sparse if it does.)"""
-    return bool(ops.LAZY_FINEST and WINOGRAD and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3) and H >= 8 and W >= 8 and
+    return bool(ondemand.LAZY_FINEST and WINOGRAD and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3) and H >= 8 and W >= 8 and
                 Cin % 32 == 0 and Cin >= 128 and weight.shape[0] % 4 == 0)
 
 
@@ -68,14 +70,14 @@ class Conv(Function):
             act == ACT_NONE and alpha == 1.0 and up is None
         ctx.lazy = None
         if ctx.wino and lazy_stride:
-            # demand-driven map (ops.conv3x3_winograd_lazy): the tiles a 3x3 / lazy_stride consumer reads now, the tiles under
+            # demand-driven map (ondemand.conv3x3_winograd_lazy): the tiles a 3x3 / lazy_stride consumer reads now, the tiles under
             # the RoIs when the RoI pooling asks for them; the backward pass is the dense one (the incoming gradient is
             # zero wherever nothing was read)
-            y, ctx.lazy = ops.conv3x3_winograd_lazy(x, _prep.wino23(weight), sh, lazy_stride[0])
+            y, ctx.lazy = ondemand.conv3x3_winograd_lazy(x, _prep.wino23(weight), sh, lazy_stride[0])
             ctx.lazy.keep = lazy_stride[1]        # a backward pass will follow: keep the RoI tile lists for the weight gradient
         elif lazy_stride and kh == 1:
             # the lateral 1x1 (+ top-down merge) in front of a demand-driven 3x3: only the pixels that convolution reads
-            y = ops.conv1x1_lazy(x, _prep.krsc(weight), sh, alpha, up, lazy_stride[0])
+            y = ondemand.conv1x1_lazy(x, _prep.krsc(weight), sh, alpha, up, lazy_stride[0])
         elif ctx.wino:        # large 3x3 (FPN output convolutions): Winograd F(2x2,3x3), 2.25x fewer multiplies
             y = ops.conv3x3_winograd(x, _prep.wino23(weight), sh)
         else:
@@ -102,7 +104,7 @@ class Conv(Function):
         if ctx.needs_input_grad[0] and ctx.lazy is not None and ctx.lazy.sparse and LAZY_DGRAD and N % 32 == 0 and N >= 64:
             # demand-driven map: the incoming gradient lives on the pattern pixels and in the RoI windows, the outgoing one
             # within a pixel of them -> the listed fused kernel on the tiles around them (F(2x2,3x3), no transforms through HBM)
-            gx = ops.conv3x3_winograd_dgrad_tiles(ctx.lazy, g.view(B, H, W, N), _prep.wino23(weight, transposed=True, m=2))
+            gx = ondemand.conv3x3_winograd_dgrad_tiles(ctx.lazy, g.view(B, H, W, N), _prep.wino23(weight, transposed=True, m=2))
         elif ctx.needs_input_grad[0] and ctx.wino and N % 32 == 0:
             # data gradient of a 3x3 / stride 1 / pad 1 convolution = the same convolution with the kernel rotated by 180
             # degrees and the channel roles swapped: Winograd again
@@ -115,7 +117,7 @@ class Conv(Function):
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] and ctx.lazy is not None and ctx.lazy.sparse and LAZY_WGRAD:
             # demand-driven map: the gradient is zero outside the tiles that were computed -> F(2x2,3x3) over those tiles only
-            dU, gb = ops.conv3x3_winograd_wgrad_tiles(ctx.lazy, x, g.view(B, H, W, N), want_bias=want_gb)
+            dU, gb = ondemand.conv3x3_winograd_wgrad_tiles(ctx.lazy, x, g.view(B, H, W, N), want_bias=want_gb)
             gw = _prep.wino23_weight_grad(dU, 2)
         elif ctx.needs_input_grad[1] and ctx.wino and N % 32 == 0:
             # weight gradient in the Winograd domain: 16 TN GEMMs dU = dM^T V, mapped back with dW = G^T dU G
@@ -219,12 +221,12 @@ def conv(x, weight, bias=None, scale=None, shift=None, residual=None, kh=1, kw=1
     """`up` [B,h,w,N]: + bilinear_align_corners(up) in the GEMM epilogue (FPN top-down merge, act must be NONE).
     `lazy_stride`: the output has exactly two consumers, a 3x3 / lazy_stride / pad 1 convolution and the RoI pooling: only the
     pixels they read are computed (3x3 Winograd layers only; ignored elsewhere)."""
-    if lazy_stride and kh == 1:       # lateral in front of the demand-driven convolution (ops.conv1x1_lazy)
+    if lazy_stride and kh == 1:       # lateral in front of the demand-driven convolution (ondemand.conv1x1_lazy)
         Cin, N = x.shape[-1], weight.shape[0]
-        if not (ops.LAZY_FINEST and ops.LAZY_LATERAL and kw == 1 and stride == 1 and pad == 0 and weight.dim() == 4 and scale is None
+        if not (ondemand.LAZY_FINEST and ondemand.LAZY_LATERAL and kw == 1 and stride == 1 and pad == 0 and weight.dim() == 4 and scale is None
                 and residual is None and act == ACT_NONE and Cin % 32 == 0 and Cin <= 256 and N > 64 and N % 4 == 0):
             lazy_stride = None
-    elif lazy_stride and not (ops.LAZY_FINEST and _winograd_ok(x, weight, kh, kw, stride, pad) and x.shape[-1] >= 64):
+    elif lazy_stride and not (ondemand.LAZY_FINEST and _winograd_ok(x, weight, kh, kw, stride, pad) and x.shape[-1] >= 64):
         lazy_stride = None
     if lazy_stride:
         lazy_stride = (int(lazy_stride), bool(torch.is_grad_enabled() and weight.requires_grad and LAZY_WGRAD))
@@ -415,10 +417,10 @@ class DwConv(Function):
         mult, stride, has_bias = ctx.cfg
         gy = gy.contiguous()
         # The RPN's first convolution of a level and the RoI pooling read the same FPN map.  The RoI pooling's backward pass runs
-        # first (later node) and leaves its scatter map in ops._GRAD_ACC: add this gradient into it on the few pixels a tap reaches
+        # first (later node) and leaves its scatter map in _GRAD_ACC: add this gradient into it on the few pixels a tap reaches
         # and return nothing -- instead of a dense write here, and a dense add by autograd (12.6 GB maps at level 0).  The
         # producer's backward pass waits for both consumers either way.
-        ref = ops._GRAD_ACC.pop(x.data_ptr(), None) if ctx.needs_input_grad[0] else None
+        ref = _GRAD_ACC.pop(x.data_ptr(), None) if ctx.needs_input_grad[0] else None
         acc = ref() if ref is not None else None          # weak: alive only while autograd still holds the RoI pooling's map
         if acc is not None and acc.shape == x.shape:
             ops.dwconv3x3_bwd_acc(gy, weight.detach(), mult, stride, acc)
@@ -513,7 +515,7 @@ class RoiPool(Function):
         pool, pe, level = ops.roi_pool(list(fmaps), rois, n_roi, pe_f, pe_t, img_h, img_w)
         ctx.shapes = [tuple(f.shape) for f in fmaps]
         ctx.fm_ptrs = [f.data_ptr() for f in fmaps]
-        ops._GRAD_ACC.clear()                      # nothing of an earlier step may survive into this one's backward pass
+        _GRAD_ACC.clear()                      # nothing of an earlier step may survive into this one's backward pass
         ctx.save_for_backward(rois, level)
         ctx.mark_non_differentiable(pe, level)
         return pool, pe, level
@@ -523,10 +525,10 @@ class RoiPool(Function):
     def backward(ctx, gpool, _gpe, _glvl):
         rois, level = ctx.saved_tensors
         gf = ops.roi_pool_bwd(gpool.contiguous(), rois, level, ctx.shapes)
-        ops._GRAD_ACC.clear()
-        if ops.GRAD_SHARE:                         # the other consumer of each map may add its gradient here (Fn.DwConv.backward)
+        _GRAD_ACC.clear()
+        if GRAD_SHARE:                         # the other consumer of each map may add its gradient here (Fn.DwConv.backward)
             for ptr, g in zip(ctx.fm_ptrs, gf):
-                ops._GRAD_ACC[ptr] = weakref.ref(g)
+                _GRAD_ACC[ptr] = weakref.ref(g)
         return (None, None, None, None, None, None, *gf)
 
 

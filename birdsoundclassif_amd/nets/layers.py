@@ -9,7 +9,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import ops, ondemand
 from . import _prep, functional as Fn
 from .position_encoding import one_dimension_positional_encoding
 from .targets import AnchorTargetLayer, ProposalTargetLayer   # noqa: F401  (reference exports them from layers.py)
@@ -197,9 +197,9 @@ class ROIPooling(nn.Module):
             raise NotImplementedError('roi_pool 2x2 (reference default) only')
         pe_f, pe_t = self.pe_tables(rois.device)
         for lvl, fm in enumerate(fmaps_nhwc):        # demand-driven maps: compute the tiles under these RoIs first
-            if ops.lazy_pending(fm):
+            if ondemand.lazy_pending(fm):
                 with torch.no_grad():
-                    ops.lazy_complete(fm, rois.detach(), n_roi, [tuple(f.shape[1:3]) for f in fmaps_nhwc], level=lvl)
+                    ondemand.lazy_complete(fm, rois.detach(), n_roi, [tuple(f.shape[1:3]) for f in fmaps_nhwc], level=lvl)
         return Fn.RoiPool.apply(rois, n_roi, pe_f, pe_t, cfg.img_height, cfg.img_width, *fmaps_nhwc)
 
     def forward(self, rois, conv_out):

@@ -8,10 +8,6 @@ import ctypes as C
 import os
 import math
 
-import weakref
-
-import numpy as np
-
 import torch
 
 from . import _lib
@@ -239,384 +235,6 @@ def wino_weight_grad(dU, m=2, row_scale=None):
     dW = torch.empty((N, C_, 3, 3), device=dU.device, dtype=torch.float32)
     check(lib().nbm_wino_weight_grad(_ptr(dU), _ptr(row_scale), N, C_, m, _ptr(dW), _stream()), 'nbm_wino_weight_grad')
     return dW
-
-
-# ---------------------------------------------------------------------------------------------------------------------
-# Demand-driven evaluation of the finest FPN output convolution (csrc/wino_fused.hip: *_tiles entry points).
-# The map has two consumers (reference layers.py:62-65,81 and :408-417,464-467): the RPN's depthwise 3x3 with stride
-# anchor_stride / 2 = 8 -- a fixed pixel pattern, 25 % of the 2 x 2 Winograd tiles -- and the RoI pooling of the RoIs
-# assigned to that level.  `conv3x3_winograd_lazy` computes the pattern tiles at once and remembers the operands;
-# `lazy_complete` (called by the RoI pooling) computes the tiles under the RoI windows.  Every other pixel of the map is never
-# read by anything and is left unwritten.  NBM_LAZY_FINEST=0 switches the whole mechanism off (dense map).
-LAZY_FINEST = os.environ.get('NBM_LAZY_FINEST', '1') != '0'
-LAZY_LATERAL = os.environ.get('NBM_LAZY_LATERAL', '1') != '0'      # also the lateral 1x1 + merge in front of the map
-LAZY_POISON = False                 # tests: fill the map with NaN first, so that a read of an unwritten pixel shows
-_LAZY = {}                          # data_ptr of the sparse map -> LazyMap
-_PATTERNS = {}
-_ROI_TILE_BUF = {}
-
-
-class TilePattern:
-    """Tiles of a [B,H,W] map that hold a pixel read by a 3x3 / stride / pad 1 consumer, grouped by WHICH of their 2 x 2
-    pixels are read (all four; the second row only; the second column only; the last pixel only -- with stride 8 the pattern
-    enters three tiles out of four through one row, one column or one pixel):
-      tiles     int32 [n_entries] on the device: per class the linear ids, ascending over the batch, -1 padded to 128
-      blk_info  uint32 [n_entries / 128]: planes to compute | pixels to store << 16 (nbm_hip.h) -- 16 / 12 / 12 / 9 planes
-      full      uint8 [TH*TW]: 1 where all four pixels of the tile are computed (the RoI phase skips those)
-      any       bool  [TH*TW]: 1 where the tile is in the pattern at all (its weight-gradient term comes from this list)
-      n         number of listed tiles;  n_eff = sum(planes x tiles) / 16: the executed-FLOP equivalent in 16-plane tiles
-      frac      covered fraction of all tiles
-      entry_pm  int32 [n_entries]: the plane mask of every list entry;  tile_pm int32 [TH*TW]: the plane mask of the tile's
-                class (0 = not in the pattern) -- the weight gradient counts every plane of every tile once
-      px_rows   int32 [n_px padded to 128]: the INPUT pixels these tiles read through the planes they compute (b*H*W + y*W + x,
-                ascending, -1 padded): with stride 8 the 5 x 5 neighbourhoods of the pattern, 39 % of the map -- the rows of
-                the lateral 1x1 convolution that feeds the demand-driven convolution"""
-    __slots__ = ('tiles', 'blk_info', 'full', 'any', 'n', 'n_eff', 'frac', 'px_rows', 'n_px', 'entry_pm', 'tile_pm')
-
-
-def wino23_pattern(B, H, W, stride, device, dilate=0):
-    """`dilate` = 1: the tiles / pixels within one pixel of the pattern instead -- where the DATA gradient of the 3x3 convolution
-    that produced the pattern pixels is non-zero."""
-    key = (B, H, W, stride, str(device), dilate)
-    hit = _PATTERNS.get(key)
-    if hit is None:
-        TH, TW = (H + 1) // 2, (W + 1) // 2
-
-        def need(n, nt):                          # per tile row: which of its two pixel rows are read (bit 0: first, bit 1: second)
-            m = np.zeros(nt, dtype=np.int64)
-            for o in range((n + 2 - 3) // stride + 1):
-                for k in range(3):
-                    for r in range(o * stride - 1 + k - dilate, o * stride - 1 + k + dilate + 1):
-                        if 0 <= r < n:
-                            m[r >> 1] |= 1 << (r & 1)
-            return m
-        ry, rx = need(H, TH), need(W, TW)
-        # planes i (rows of A^T = [1 1 1 0; 0 1 -1 -1]) a tile row needs: first pixel row -> {0,1,2}, second -> {1,2,3}
-        planes_of = {0: 0, 1: 0b0111, 2: 0b1110, 3: 0b1111}
-        lists, infos, n, n_eff = [], [], 0, 0.0
-        for cy in (3, 2, 1):
-            for cx in (3, 2, 1):
-                m2 = (ry == cy)[:, None] & (rx == cx)[None, :]
-                ids = np.flatnonzero(m2.ravel()).astype(np.int64)
-                if ids.size == 0:
-                    continue
-                allt = (np.arange(B, dtype=np.int64)[:, None] * (TH * TW) + ids[None, :]).ravel()
-                pm = 0
-                for i in range(4):
-                    for j in range(4):
-                        if (planes_of[cy] >> i) & 1 and (planes_of[cx] >> j) & 1:
-                            pm |= 1 << (4 * i + j)
-                sm = 0
-                for pp in range(2):
-                    for qq in range(2):
-                        if (cy >> pp) & 1 and (cx >> qq) & 1:
-                            sm |= 1 << (2 * pp + qq)
-                pad = (-allt.size) % 128
-                lists.append(np.concatenate([allt, np.full(pad, -1, dtype=np.int64)]))
-                infos.append(np.full((allt.size + pad) // 128, pm | (sm << 16), dtype=np.int64))
-                n += allt.size
-                n_eff += allt.size * bin(pm).count('1') / 16.0
-        anym = (ry > 0)[:, None] & (rx > 0)[None, :]
-        full = (ry == 3)[:, None] & (rx == 3)[None, :]
-        hit = _PATTERNS[key] = TilePattern()
-        # interleave the classes' blocks by relative position: the fused kernel hands contiguous block ranges to the 8 XCDs, and a
-        # range made of 16-plane blocks only would finish long after a range of 9-plane blocks (measured: no gain without this)
-        blocks = np.concatenate(lists).reshape(-1, 128)
-        infos = np.concatenate(infos)
-        pos = np.concatenate([(np.arange(len(i)) + 0.5) / len(i) for i in [l.reshape(-1, 128) for l in lists]])
-        order = np.argsort(pos, kind='stable')
-        # ... and inside each XCD's range the blocks with the most planes first, so that the range ends on short blocks
-        nblk = len(order)
-        npl = np.array([bin(int(v) & 0xffff).count('1') for v in infos])
-        for x8 in range(8):
-            lo, hi = nblk * x8 // 8, nblk * (x8 + 1) // 8
-            seg = order[lo:hi]
-            order[lo:hi] = seg[np.argsort(-npl[seg], kind='stable')]
-        infos = infos[order]
-        hit.entry_pm = torch.from_numpy(np.repeat((infos & 0xffff) | 0x10000, 128).astype(np.int32)).to(device)   # bit 16: counts in the bias gradient
-        tpm = np.zeros(TH * TW, dtype=np.int64)
-        for cy in (3, 2, 1):
-            for cx in (3, 2, 1):
-                pmv = sum(1 << (4 * i + j) for i in range(4) for j in range(4)
-                          if (planes_of[cy] >> i) & 1 and (planes_of[cx] >> j) & 1)
-                tpm[((ry == cy)[:, None] & (rx == cx)[None, :]).ravel()] = pmv
-        hit.tile_pm = torch.from_numpy(tpm.astype(np.int32)).to(device)
-        hit.tiles = torch.from_numpy(blocks[order].ravel().astype(np.int32)).to(device)
-        hit.blk_info = torch.from_numpy(infos.astype(np.uint32).view(np.int32)).to(device)
-        hit.full = torch.from_numpy(full.ravel().astype(np.uint8)).to(device)
-        hit.any = torch.from_numpy(anym.ravel()).to(device)
-        hit.n, hit.n_eff, hit.frac = n, n_eff, float(anym.mean())
-        # input rows a tile row reads: both output rows -> 2ty-1 .. 2ty+2; second only (planes i = 1..3) -> 2ty .. 2ty+2; first
-        # only (i = 0..2) -> 2ty-1 .. 2ty+1; same for columns
-        def px_need(r, n_):
-            m = np.zeros(n_, dtype=bool)
-            for t, c in enumerate(r):
-                if c:
-                    lo, hi = (2 * t - 1 if c & 1 else 2 * t), (2 * t + 2 if c & 2 else 2 * t + 1)
-                    m[max(lo, 0):min(hi, n_ - 1) + 1] = True
-            return m
-        pm = (px_need(ry, H)[:, None] & px_need(rx, W)[None, :]).ravel()
-        ids = np.flatnonzero(pm).astype(np.int64)
-        allp = (np.arange(B, dtype=np.int64)[:, None] * (H * W) + ids[None, :]).ravel()
-        hit.n_px = allp.size
-        hit.px_rows = torch.from_numpy(np.concatenate([allp, np.full((-allp.size) % 128, -1, dtype=np.int64)]).astype(np.int32)).to(device)
-    return hit
-
-
-def _wino23_tiles_run(x, U, bias, y_ptr, tiles, n_blocks, n_listed, label, blk_info=None, dense_rows=False):
-    """Rows transform + fused kernel for the listed tiles of x [B,H,W,C] -> pixels of the map at device address y_ptr.
-    n_listed: executed work in 16-plane tile equivalents (None: device-side count in n_blocks)."""
-    B, H, W, C_ = x.shape
-    N = U.shape[1]
-    per_img = 4 * (-(-H // 2)) * (2 * (-(-W // 2)) + 2) * C_
-    R, _ = _wino_scratch(x.device, B * per_img, 0)
-    st = _stream()
-    nb_ptr = _ptr(n_blocks) if n_blocks is not None else None
-    if FLOPS is not None:
-        if n_listed is None:                      # device-side count: resolved by flops_total(), no sync here
-            FLOPS_DEFERRED.append((n_blocks.clone(), 2.0 * 16 * 128 * C_ * N))
-        else:
-            FLOPS[0] += 2.0 * 16 * n_listed * C_ * N
-    if PROFILE is not None:
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        if _prof_all():
-            ev[0].record()
-    if dense_rows:                                # every tile is listed: the plain row transform writes half the bytes
-        check(lib().nbm_wino23_rows(_ptr(x), B, H, W, C_, _ptr(R), st), 'nbm_wino23_rows')
-    else:
-        check(lib().nbm_wino23_rows_tiles(_ptr(x), B, H, W, C_, _ptr(tiles), tiles.numel(), nb_ptr, _ptr(blk_info), _ptr(R), st),
-              'nbm_wino23_rows_tiles')
-    if PROFILE is not None:
-        ev[1].record()
-    check(lib().nbm_wino23_conv_fused_tiles(_ptr(R), _ptr(U), None, _ptr(bias), None, 0, B, H, W, C_, N, C.c_void_p(y_ptr), _ptr(tiles),
-                                            tiles.numel(), nb_ptr, _ptr(blk_info), st), 'nbm_wino23_conv_fused_tiles')
-    if PROFILE is not None:
-        ev[2].record()
-        # listed tiles: known on the host for the pattern, a device counter for the RoI tiles (resolved by the reader after a sync)
-        cnt = n_listed if n_listed is not None else n_blocks.clone()
-        PROFILE.append(((C_, N, 1, cnt, 1, 1, 16, 1, (label, H, W)), ev[1], ev[2]))
-        if _prof_all():
-            PROFILE.append(((label, C_, N, H, W, B), ev[0], ev[2]))
-
-
-def lazy_chunk(x):
-    """Images per launch of the sparse path: the row-transform scratch keeps its dense layout (holes unwritten)."""
-    _, H, W, C_ = x.shape
-    per_img = 4 * (-(-H // 2)) * (2 * (-(-W // 2)) + 2) * C_ * 4
-    return max(1, min(x.shape[0], WINO_CHUNK_BYTES // per_img))
-
-
-class LazyMap:
-    """Book-keeping of one demand-driven map: operands and, per batch chunk, the tile lists that were computed (pattern
-    list; RoI list + its block count on the way to the host) -- the weight gradient sums over them.  The map itself is
-    NOT referenced (an autograd node owns this object and the map owns the node: a cycle would keep 12 GB alive until the
-    garbage collector runs); its consumers keep it alive and hand it back to `lazy_complete`."""
-    __slots__ = ('x', 'U', 'bias', 'skip', 'stride', 'chunks', 'roi', 'keep', 'sparse', 'lateral', 'rois')
-
-    def __init__(self, x, U, bias, stride):
-        self.x, self.U, self.bias, self.stride = x, U, bias, stride
-        self.skip, self.chunks, self.roi, self.keep, self.sparse, self.lateral, self.rois = None, [], None, False, True, None, None
-
-
-_PINNED = []
-_PINNED_NEXT = [0]
-
-
-def _pinned_int():
-    """A pinned host int32 from a small ring (hipHostMalloc per step would stall the stream)."""
-    if not _PINNED:                               # all at once, on the first (warm-up) call
-        _PINNED.extend(torch.empty((1,), dtype=torch.int32, pin_memory=True) for _ in range(16))
-    _PINNED_NEXT[0] = (_PINNED_NEXT[0] + 1) % len(_PINNED)
-    return _PINNED[_PINNED_NEXT[0]]
-
-
-_LAZY_LATERAL = {}                  # data_ptr of a sparse lateral map -> (LateralState, weakref to the map)
-
-
-class LateralState:
-    """Operands of a lateral 1x1 convolution (+ top-down merge) whose output only exists where its one consumer, a demand-driven
-    3x3 convolution, reads it; `conv3x3_winograd_lazy` picks the state up and `lazy_complete` finishes the pixels under the RoI
-    tiles before it convolves them."""
-    __slots__ = ('t', 'wk', 'bias', 'alpha', 'up')
-
-    def __init__(self, t, wk, bias, alpha, up):
-        self.t, self.wk, self.bias, self.alpha, self.up = t, wk, bias, alpha, up
-
-
-def conv1x1_lazy(t, wk, bias, alpha, up, stride):
-    """Lateral 1x1 convolution + bilinear top-down merge (fpn.py:143-144) on the pixels that the pattern tiles of the following
-    demand-driven 3x3 convolution read (`TilePattern.px_rows`): t [B,H,W,Cin] -> x [B,H,W,N], other pixels unwritten.  Same
-    kernel, same arithmetic per pixel as the dense call."""
-    _chk(t, name='t'), _chk(wk, name='w')
-    B, H, W, Cin = t.shape
-    N = wk.shape[0]
-    x = torch.empty((B, H, W, N), device=t.device, dtype=torch.float32)
-    if LAZY_POISON:
-        x.fill_(float('nan'))
-    chunk = lazy_chunk(x)                      # the same batch chunks as the convolution that follows
-    for b0 in range(0, B, chunk):
-        nb = min(chunk, B - b0)
-        pat = wino23_pattern(nb, H, W, stride, t.device)
-        gemm_conv(t[b0:b0 + nb], wk, x[b0:b0 + nb], B=nb, H=H, W=W, Cin=Cin, N=N, w_ld=wk.shape[1], shift=bias, alpha=alpha,
-                  up=up[b0:b0 + nb] if up is not None else None, rows=pat.px_rows, rows_mode=1, rows_count=pat.px_rows.numel())
-    for k in [k for k, v in _LAZY_LATERAL.items() if v[1]() is None]:
-        del _LAZY_LATERAL[k]
-    _LAZY_LATERAL[x.data_ptr()] = (LateralState(t, wk, bias, alpha, up), weakref.ref(x))
-    return x
-
-
-def conv3x3_winograd_lazy(x, U, bias, stride):
-    """Finest-level output convolution, pattern tiles only (see above) -> (y [B,H,W,N] with the other pixels unwritten,
-    LazyMap)."""
-    _chk(x, name='x'), _chk(U, name='U')
-    B, H, W, C_ = x.shape
-    N = U.shape[1]
-    assert U.shape == (16, N, C_) and C_ % 32 == 0 and C_ >= 64 and N % 4 == 0
-    y = torch.empty((B, H, W, N), device=x.device, dtype=torch.float32)
-    if LAZY_POISON:
-        y.fill_(float('nan'))
-    st = LazyMap(x, U, bias, stride)
-    lat = _LAZY_LATERAL.pop(x.data_ptr(), None)      # x itself only exists where the pattern tiles read it
-    if lat is not None and lat[1]() is not None:
-        st.lateral = lat[0]
-    img_bytes = H * W * N * 4
-    chunk = lazy_chunk(x)
-    for b0 in range(0, B, chunk):
-        nb = min(chunk, B - b0)
-        pat = wino23_pattern(nb, H, W, stride, x.device)
-        st.skip = pat.full
-        st.chunks.append((b0, nb, pat))
-        st.sparse = pat.frac < 0.6               # the weight gradient over the listed tiles pays off when most are not listed
-        _wino23_tiles_run(x[b0:b0 + nb], U, bias, y.data_ptr() + b0 * img_bytes, pat.tiles, None, pat.n_eff, 'wino23', pat.blk_info,
-                          dense_rows=pat.frac == 1.0)
-    for k in [k for k, v in _LAZY.items() if v[1]() is None]:      # maps of earlier forwards that were never completed
-        del _LAZY[k]
-    _LAZY[y.data_ptr()] = (st, weakref.ref(y))      # valid while the map object itself (or a view of it) is alive
-    return y, st
-
-
-def lazy_pending(fm):
-    hit = _LAZY.get(fm.data_ptr())
-    return hit is not None and hit[1]() is not None
-
-
-def lazy_complete(fm, rois, n_roi, fmap_hw, level=0):
-    """Compute the tiles of the deferred map `fm` under the windows of the RoIs assigned to `level` (the windows
-    `roi_pool` reads).  rois [B,cap,4], n_roi device int32[1], fmap_hw: (h, w) of every pyramid level.  No-op for a map
-    that is not deferred."""
-    hit = _LAZY.pop(fm.data_ptr(), None)
-    if hit is None or hit[1]() is None:
-        return
-    st = hit[0]
-    x, U, bias = st.x, st.U, st.bias
-    B, H, W, C_ = x.shape
-    img_bytes = H * W * U.shape[1] * 4
-    cap = rois.shape[1]
-    _chk(rois, name='rois')
-    nl = len(fmap_hw)
-    fh = (C.c_int * nl)(*[int(h) for h, _ in fmap_hw])
-    fw = (C.c_int * nl)(*[int(w) for _, w in fmap_hw])
-    blocks_per_img = -(-((H + 1) // 2 * ((W + 1) // 2)) // 128)
-    keep = st.keep and st.sparse                  # a backward pass will want the lists
-    st.roi = []
-    for b0, nb, _ in st.chunks:
-        key = (str(x.device), nb * blocks_per_img * 128)
-        if keep:                                  # the backward pass reads the list again: a buffer of its own
-            tiles = torch.empty((key[1],), device=x.device, dtype=torch.int32)
-            n_blocks = torch.zeros((1,), device=x.device, dtype=torch.int32)
-        else:
-            buf = _ROI_TILE_BUF.get(key)
-            if buf is None:
-                buf = _ROI_TILE_BUF[key] = (torch.empty((key[1],), device=x.device, dtype=torch.int32),
-                                            torch.zeros((1,), device=x.device, dtype=torch.int32))
-            tiles, n_blocks = buf
-        check(lib().nbm_roi_tiles(_ptr(rois[b0:b0 + nb]), _ptr(n_roi), nb, cap, nl, level, fh, fw, _ptr(st.skip), 0, _ptr(tiles),
-                                  _ptr(n_blocks), _stream()), 'nbm_roi_tiles')
-        if st.lateral is not None:                # the input patches of these tiles first (16 pixels per listed tile)
-            lt = st.lateral
-            gemm_conv(lt.t[b0:b0 + nb], lt.wk, x[b0:b0 + nb], B=nb, H=H, W=W, Cin=lt.t.shape[-1], N=C_, w_ld=lt.wk.shape[1],
-                      shift=lt.bias, alpha=lt.alpha, up=lt.up[b0:b0 + nb] if lt.up is not None else None, rows=tiles, rows_mode=2,
-                      rows_count=tiles.numel() * 16, rows_blocks=n_blocks, rows_thw=((H + 1) // 2, (W + 1) // 2))
-        _wino23_tiles_run(x[b0:b0 + nb], U, bias, fm.data_ptr() + b0 * img_bytes, tiles, n_blocks, None, 'wino23-rois')
-        if keep:
-            host = _pinned_int()
-            host.copy_(n_blocks, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            st.roi.append((tiles, host, ev))
-    if keep:                                      # the data gradient lists the tiles around these windows again
-        st.rois = (rois, n_roi, nl, level, fh, fw)
-    st.x = st.U = st.bias = st.lateral = None     # the backward pass gets x from the tape
-
-
-def conv3x3_winograd_dgrad_tiles(st, g, Ut):
-    """Data gradient of a demand-driven convolution (LazyMap `st`): g [B,H,W,N] is zero except on the pattern pixels and inside
-    the RoI windows, so the gradient wrt the input is zero except within one pixel of them: the same convolution operator
-    (Ut = weights rotated / channel-swapped, F(2x2,3x3)) through the listed fused kernel -- the static list of the tiles around
-    the pattern (56 % of the tiles, 16 / 12 / 9 planes), then the tiles around the RoI windows -- into a zero-filled map."""
-    _chk(g, name='g'), _chk(Ut, name='Ut')
-    B, H, W, N = g.shape
-    C_ = Ut.shape[1]
-    assert Ut.shape == (16, C_, N)
-    gx = torch.zeros((B, H, W, C_), device=g.device, dtype=torch.float32)
-    img_bytes = H * W * C_ * 4
-    blocks_per_img = -(-((H + 1) // 2 * ((W + 1) // 2)) // 128)
-    for b0, nb, _ in st.chunks:
-        pat = wino23_pattern(nb, H, W, st.stride, g.device, dilate=1)
-        _wino23_tiles_run(g[b0:b0 + nb], Ut, None, gx.data_ptr() + b0 * img_bytes, pat.tiles, None, pat.n_eff, 'wino23-dgrad',
-                          pat.blk_info)
-        if st.rois is not None:
-            rois, n_roi, nl, level, fh, fw = st.rois
-            key = (str(g.device), nb * blocks_per_img * 128)
-            buf = _ROI_TILE_BUF.get(key)
-            if buf is None:
-                buf = _ROI_TILE_BUF[key] = (torch.empty((key[1],), device=g.device, dtype=torch.int32),
-                                            torch.zeros((1,), device=g.device, dtype=torch.int32))
-            tiles, n_blocks = buf
-            check(lib().nbm_roi_tiles(_ptr(rois[b0:b0 + nb]), _ptr(n_roi), nb, rois.shape[1], nl, level, fh, fw, _ptr(pat.full), 1,
-                                      _ptr(tiles), _ptr(n_blocks), _stream()), 'nbm_roi_tiles')
-            _wino23_tiles_run(g[b0:b0 + nb], Ut, None, gx.data_ptr() + b0 * img_bytes, tiles, n_blocks, None, 'wino23-dgrad-rois')
-    return gx
-
-
-def conv3x3_winograd_wgrad_tiles(st, x, g, want_bias=False):
-    """Weight gradient of a demand-driven convolution (LazyMap `st`): g [B,H,W,N] is zero outside the tiles that were
-    computed, so dU[xi] = dM[xi]^T V[xi] sums over those tiles only: F(2x2,3x3) transforms of the listed tiles into
-    compact operands, 16 TN GEMMs over the listed rows.  -> (dU [16,N,C], bias gradient [N] | None)."""
-    _chk(x, name='x'), _chk(g, name='g')
-    B, H, W, C_ = x.shape
-    N = g.shape[-1]
-    dU = torch.zeros((16, N, C_), device=x.device, dtype=torch.float32)
-    gb = torch.zeros((N,), device=x.device, dtype=torch.float32) if want_bias else None
-    lmax = max(128, (WINO_CHUNK_BYTES // (16 * (C_ + N) * 4)) // 128 * 128)
-    stream = _stream()
-    thw = ((H + 1) // 2) * ((W + 1) // 2)
-    for ci, (b0, nb, pat) in enumerate(st.chunks):
-        lists, infos = [pat.tiles], [pat.entry_pm]
-        if st.roi:
-            tiles, host, ev = st.roi[ci]
-            ev.synchronize()                        # recorded during the forward pass: long done
-            n = int(host.item()) * 128
-            if n:
-                # the RoI phase recomputed pattern tiles of which only some pixels had been stored: the planes of their class
-                # come from the pattern list, this entry contributes the others
-                roi = tiles[:n]
-                lists.append(roi)
-                tpm = pat.tile_pm[roi.clamp(min=0) % thw]
-                infos.append((0xffff & ~tpm) | ((tpm == 0).int() << 16))
-        full = torch.cat(lists) if len(lists) > 1 else lists[0]
-        info = torch.cat(infos) if len(infos) > 1 else infos[0]
-        xs, gs = x[b0:b0 + nb], g[b0:b0 + nb]
-        for l0 in range(0, full.numel(), lmax):
-            lst = full[l0:l0 + lmax]
-            L = lst.numel()
-            V, dM = _wino_scratch(x.device, 16 * L * C_, 16 * L * N)
-            check(lib().nbm_wino23_input_tiles(_ptr(xs), nb, H, W, C_, _ptr(lst), L, _ptr(info[l0:]), _ptr(V), stream),
-                  'nbm_wino23_input_tiles')
-            check(lib().nbm_wino23_outgrad_tiles(_ptr(gs), nb, H, W, N, _ptr(lst), L, _ptr(info[l0:]), _ptr(dM), _ptr(gb), stream),
-                  'nbm_wino23_outgrad_tiles')
-            conv_wgrad(dM, V, dU, B=1, H=L, W=1, Cin=C_, N=N, groups=16, g_gs=L * N, x_gs=L * C_, out_gs=N * C_)
-    return dU, gb
 
 
 def conv3x3_winograd_wgrad(x, g, want_bias=False, m=2):
@@ -1137,10 +755,6 @@ def dwconv3x3_bwd(x, g, w, mult, stride, need_gx=True, need_gw=True, has_bias=Tr
     check(lib().nbm_dwconv3x3_bwd(_ptr(_chk(x)), _ptr(_chk(g)), _ptr(_chk(w)), B, H, W, Cin, mult, stride, _ptr(gx),
                                   _ptr(gw), _ptr(gb), Ho, Wo, _stream()), 'nbm_dwconv3x3_bwd')
     return gx, gw, gb
-
-
-GRAD_SHARE = True                   # consumers of one FPN map accumulate their gradients into one buffer (Fn.RoiPool / Fn.DwConv)
-_GRAD_ACC = {}                      # data_ptr of an FPN map -> the gradient map the RoI pooling's backward pass filled
 
 
 def dwconv3x3_bwd_acc(g, w, mult, stride, gx):

@@ -1,4 +1,4 @@
-"""GPU tests of the demand-driven finest FPN map (ops.conv3x3_winograd_lazy / lazy_complete, csrc/wino_fused.hip *_tiles,
+"""GPU tests of the demand-driven finest FPN map (ondemand.conv3x3_winograd_lazy / lazy_complete, csrc/wino_fused.hip *_tiles,
 csrc/detect.hip roi_tiles): the listed tiles are bit-identical to the dense convolution, the tile lists are exactly the
 tiles the consumers read, nothing reads an unwritten pixel (NaN poison), and detections / losses / gradients do not change."""
 import numpy as np
@@ -7,7 +7,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from birdsoundclassif_amd import ops, synth                                  # noqa: E402
+from birdsoundclassif_amd import ondemand, ops, synth                                  # noqa: E402
 from birdsoundclassif_amd.nets import _prep, functional as Fn                # noqa: E402
 from helpers import filler_state_dict                                        # noqa: E402
 
@@ -42,12 +42,12 @@ def test_listed_tiles_equal_the_dense_convolution(shape):
     b = rnd(('lb', shape), N).cuda()
     U = _prep.wino23(w)
     dense = ops.conv3x3_winograd(x, U, b)
-    ops.LAZY_POISON = True
+    ondemand.LAZY_POISON = True
     try:
-        y, _ = ops.conv3x3_winograd_lazy(x, U, b, S)
+        y, _ = ondemand.conv3x3_winograd_lazy(x, U, b, S)
     finally:
-        ops.LAZY_POISON = False
-    pat = ops.wino23_pattern(B, H, W, S, x.device)
+        ondemand.LAZY_POISON = False
+    pat = ondemand.wino23_pattern(B, H, W, S, x.device)
     assert (0.15 < pat.frac < 0.45 if S == 8 else pat.frac > 0.9) and pat.n == int(pat.any.sum()) * B and pat.n_eff <= 0.8 * pat.n
     TH, TW = (H + 1) // 2, (W + 1) // 2
     # the pixels a 3x3 / stride S / pad 1 convolution reads: rows {So-1, So, So+1} x the same columns -- exactly these are
@@ -78,9 +78,9 @@ def test_listed_tiles_equal_the_dense_convolution(shape):
     rois[0, 0] = (2 * W - 3, 0, 2 * W - 1, 5)                         # touches the right border
     rois_d = torch.from_numpy(rois).cuda()
     n_d = torch.tensor([n_roi], dtype=torch.int32, device='cuda')
-    assert ops.lazy_pending(y)
-    ops.lazy_complete(y, rois_d, n_d, list(zip(fh, fw)), level=0)
-    assert not ops.lazy_pending(y)
+    assert ondemand.lazy_pending(y)
+    ondemand.lazy_complete(y, rois_d, n_d, list(zip(fh, fw)), level=0)
+    assert not ondemand.lazy_pending(y)
     want = m[None].repeat(B, 1, 1).clone().cpu()
     n_lvl0 = 0
     for bi in range(B):
@@ -104,11 +104,11 @@ def test_many_rois_at_the_real_geometry():
     b = rnd('mb', N).cuda()
     U = _prep.wino23(w)
     dense = ops.conv3x3_winograd(x, U, b)
-    ops.LAZY_POISON = True
+    ondemand.LAZY_POISON = True
     try:
-        y, st = ops.conv3x3_winograd_lazy(x, U, b, 8)
+        y, st = ondemand.conv3x3_winograd_lazy(x, U, b, 8)
     finally:
-        ops.LAZY_POISON = False
+        ondemand.LAZY_POISON = False
     st.keep = True
     fh = [188, 94, 47, 24, 12]
     fw = [512, 256, 128, 64, 32]
@@ -118,8 +118,8 @@ def test_many_rois_at_the_real_geometry():
     bw = rng.integers(1, 60, (B, cap)); bh = rng.integers(1, 40, (B, cap))
     rois = np.stack([x1, y1, np.minimum(x1 + bw, 1023), np.minimum(y1 + bh, 374)], -1).astype(np.float32)
     rois_d = torch.from_numpy(rois).cuda()
-    ops.lazy_complete(y, rois_d, torch.tensor([cap], dtype=torch.int32, device='cuda'), list(zip(fh, fw)))
-    pat = ops.wino23_pattern(B, H, W, 8, x.device)
+    ondemand.lazy_complete(y, rois_d, torch.tensor([cap], dtype=torch.int32, device='cuda'), list(zip(fh, fw)))
+    pat = ondemand.wino23_pattern(B, H, W, 8, x.device)
     rows = torch.zeros(H, dtype=torch.bool); cols = torch.zeros(W, dtype=torch.bool)
     for n_, v in ((H, rows), (W, cols)):
         for o in range((n_ - 1) // 8 + 1):
@@ -142,7 +142,7 @@ def test_many_rois_at_the_real_geometry():
     # data gradient: g lives on the pattern pixels and inside the windows
     m = ((rows[:, None] & cols[None, :])[None] | win).cuda()
     g = (rnd('mg', B, H, W, N).cuda() * m[..., None]).contiguous()
-    got = ops.conv3x3_winograd_dgrad_tiles(st, g, _prep.wino23(w, transposed=True, m=2))
+    got = ondemand.conv3x3_winograd_dgrad_tiles(st, g, _prep.wino23(w, transposed=True, m=2))
     ref = ops.conv3x3_winograd(g, _prep.wino23(w, transposed=True, m=2), None)        # the dense operator, same F(2x2,3x3)
     assert torch.equal(got, ref)
 
@@ -154,16 +154,16 @@ def test_weight_gradient_over_the_listed_tiles_equals_the_dense_one():
     x = rnd('wx', B, H, W, C).cuda()
     w = rnd('ww', N, C, 3, 3, scale=0.05).cuda()
     b = rnd('wb', N).cuda()
-    ops.LAZY_POISON = True
+    ondemand.LAZY_POISON = True
     try:
-        y, st = ops.conv3x3_winograd_lazy(x, _prep.wino23(w), b, 8)
+        y, st = ondemand.conv3x3_winograd_lazy(x, _prep.wino23(w), b, 8)
     finally:
-        ops.LAZY_POISON = False
+        ondemand.LAZY_POISON = False
     st.keep = True
     fh = [H, (H + 1) // 2, (H + 3) // 4, (H + 7) // 8, (H + 15) // 16]
     fw = [W, (W + 1) // 2, (W + 3) // 4, (W + 7) // 8, (W + 15) // 16]
     rois = torch.tensor([[[10., 12., 25., 20.], [60., 40., 70., 66.], [0., 0., 8., 9.]]] * B).cuda()
-    ops.lazy_complete(y, rois, torch.tensor([3], dtype=torch.int32, device='cuda'), list(zip(fh, fw)))
+    ondemand.lazy_complete(y, rois, torch.tensor([3], dtype=torch.int32, device='cuda'), list(zip(fh, fw)))
     # pixels with a reader: the pattern pixels + every pixel of the tiles under the RoIs (re-derived from the kept RoI list)
     TH, TW = (H + 1) // 2, (W + 1) // 2
     m = ~torch.isnan(y[..., 0])                      # the map was NaN-poisoned: written == has a reader
@@ -172,7 +172,7 @@ def test_weight_gradient_over_the_listed_tiles_equals_the_dense_one():
     ids = tiles[:int(host.item()) * 128]
     assert int((ids >= 0).sum()) > 0
     g = rnd('wg', B, H, W, N).cuda() * m[..., None]
-    dU, gb = ops.conv3x3_winograd_wgrad_tiles(st, x, g.contiguous(), want_bias=True)
+    dU, gb = ondemand.conv3x3_winograd_wgrad_tiles(st, x, g.contiguous(), want_bias=True)
     gw = _prep.wino23_weight_grad(dU, 2)
     xr = x.permute(0, 3, 1, 2).double().cpu().requires_grad_(False)
     wr = w.double().cpu().requires_grad_(True)
@@ -190,14 +190,14 @@ def test_data_gradient_over_the_listed_tiles_equals_the_dense_one():
     B, H, W, C, N = 2, 47, 66, 128, 64
     x = rnd('gx', B, H, W, C).cuda()
     w = rnd('gw', N, C, 3, 3, scale=0.05).cuda()
-    y, st = ops.conv3x3_winograd_lazy(x, _prep.wino23(w), None, 8)
+    y, st = ondemand.conv3x3_winograd_lazy(x, _prep.wino23(w), None, 8)
     st.keep = True
     fh = [H, (H + 1) // 2, (H + 3) // 4, (H + 7) // 8, (H + 15) // 16]
     fw = [W, (W + 1) // 2, (W + 3) // 4, (W + 7) // 8, (W + 15) // 16]
     rois_np = np.array([[[10., 12., 25., 20.], [60., 40., 70., 66.], [0., 0., 8., 9.], [120., 86., 131., 93.], [40., 40., 90., 90.]]] * B,
                        dtype=np.float32)
     rois = torch.from_numpy(rois_np).cuda()
-    ops.lazy_complete(y, rois, torch.tensor([5], dtype=torch.int32, device='cuda'), list(zip(fh, fw)))
+    ondemand.lazy_complete(y, rois, torch.tensor([5], dtype=torch.int32, device='cuda'), list(zip(fh, fw)))
     m = torch.zeros(B, H, W, dtype=torch.bool)
     rows = torch.zeros(H, dtype=torch.bool)
     cols = torch.zeros(W, dtype=torch.bool)
@@ -216,7 +216,7 @@ def test_data_gradient_over_the_listed_tiles_equals_the_dense_one():
                 m[bi, y1:y2 + 1, x1:x2 + 1] = True
     assert n0 >= 4 * B
     g = (rnd('gg', B, H, W, N) * m[..., None]).cuda().contiguous()
-    got = ops.conv3x3_winograd_dgrad_tiles(st, g, _prep.wino23(w, transposed=True, m=2))
+    got = ondemand.conv3x3_winograd_dgrad_tiles(st, g, _prep.wino23(w, transposed=True, m=2))
     xr = x.permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
     F.conv2d(xr, w.double().cpu(), None, 1, 1).backward(g.permute(0, 3, 1, 2).double().cpu())
     ref = xr.grad.permute(0, 2, 3, 1).float()
@@ -226,7 +226,7 @@ def test_data_gradient_over_the_listed_tiles_equals_the_dense_one():
 
 
 def test_lateral_on_listed_pixels_equals_the_dense_lateral():
-    """ops.conv1x1_lazy (igemm ROWS variant, pixel list) and the RoI-phase patches (tile list x 16): the written pixels equal
+    """ondemand.conv1x1_lazy (igemm ROWS variant, pixel list) and the RoI-phase patches (tile list x 16): the written pixels equal
     the dense lateral + merge bit for bit, nothing else is written."""
     B, H, W, Cin, N = 2, 47, 66, 64, 384
     t = rnd('lt', B, H, W, Cin).cuda()
@@ -235,12 +235,12 @@ def test_lateral_on_listed_pixels_equals_the_dense_lateral():
     up = rnd('lu', B, 24, 33, N).cuda()
     wk = _prep.krsc(w)
     dense = ops.conv2d(t, wk, shift=b, alpha=2.0, up=up)
-    ops.LAZY_POISON = True
+    ondemand.LAZY_POISON = True
     try:
-        x = ops.conv1x1_lazy(t, wk, b, 2.0, up, 8)
+        x = ondemand.conv1x1_lazy(t, wk, b, 2.0, up, 8)
     finally:
-        ops.LAZY_POISON = False
-    pat = ops.wino23_pattern(B, H, W, 8, t.device)
+        ondemand.LAZY_POISON = False
+    pat = ondemand.wino23_pattern(B, H, W, 8, t.device)
     m = torch.zeros(B * H * W, dtype=torch.bool, device='cuda')
     m[pat.px_rows[pat.px_rows >= 0].long()] = True
     m = m.view(B, H, W)
@@ -251,11 +251,11 @@ def test_lateral_on_listed_pixels_equals_the_dense_lateral():
     b3 = rnd('lb3', 64).cuda()
     U = _prep.wino23(w3)
     ref = ops.conv3x3_winograd(dense, U, b3)
-    ops.LAZY_POISON = True
+    ondemand.LAZY_POISON = True
     try:
-        y, st = ops.conv3x3_winograd_lazy(x, U, b3, 8)
+        y, st = ondemand.conv3x3_winograd_lazy(x, U, b3, 8)
     finally:
-        ops.LAZY_POISON = False
+        ondemand.LAZY_POISON = False
     assert st.lateral is not None
     written = ~torch.isnan(y[..., 0])
     assert int(written.sum()) > 0 and torch.equal(y[written], ref[written])
@@ -263,7 +263,7 @@ def test_lateral_on_listed_pixels_equals_the_dense_lateral():
     fh = [H, (H + 1) // 2, (H + 3) // 4, (H + 7) // 8, (H + 15) // 16]
     fw = [W, (W + 1) // 2, (W + 3) // 4, (W + 7) // 8, (W + 15) // 16]
     rois = torch.tensor([[[10., 12., 25., 20.], [60., 40., 70., 66.], [0., 0., 8., 9.], [120., 80., 131., 93.]]] * B).cuda()
-    ops.lazy_complete(y, rois, torch.tensor([4], dtype=torch.int32, device='cuda'), list(zip(fh, fw)))
+    ondemand.lazy_complete(y, rois, torch.tensor([4], dtype=torch.int32, device='cuda'), list(zip(fh, fw)))
     written2 = ~torch.isnan(y[..., 0])
     assert int(written2.sum()) > int(written.sum()) and torch.equal(y[written2], ref[written2])
     xm = ~torch.isnan(x[..., 0])
@@ -283,16 +283,16 @@ def model():
 def test_detections_do_not_change_and_no_unwritten_pixel_is_read(model, B):
     x = torch.from_numpy(synth.image_batch(0, B))[:, None].cuda()
     with torch.no_grad():
-        ops.LAZY_FINEST = False
+        ondemand.LAZY_FINEST = False
         try:
             det0, n0 = model.detect(x, min_score=0.1)
         finally:
-            ops.LAZY_FINEST = True
-        ops.LAZY_POISON = True
+            ondemand.LAZY_FINEST = True
+        ondemand.LAZY_POISON = True
         try:
             det1, n1 = model.detect(x, min_score=0.1)
         finally:
-            ops.LAZY_POISON = False
+            ondemand.LAZY_POISON = False
     assert int(n0.sum()) > 0
     assert torch.equal(n0, n1) and torch.equal(det0, det1)        # NaN anywhere in the consumed pixels would break this
 
@@ -317,11 +317,11 @@ def test_train_step_losses_and_gradients_do_not_change(negative):
         opt, _ = T.build_optimizer(model, args)
         np.random.seed(5)
         # the baseline also runs without the shared gradient buffer of the two consumers of an FPN map (Fn.DwConv.backward)
-        ops.LAZY_FINEST, ops.LAZY_POISON, ops.GRAD_SHARE = lazy, lazy, lazy
+        ondemand.LAZY_FINEST, ondemand.LAZY_POISON, Fn.GRAD_SHARE = lazy, lazy, lazy
         try:
             loss = T.train_one_step(model, crit, opt, batch, args.clip_max_norm, 'cuda', negative_sample=negative)
         finally:
-            ops.LAZY_FINEST, ops.LAZY_POISON, ops.GRAD_SHARE = True, False, True
+            ondemand.LAZY_FINEST, ondemand.LAZY_POISON, Fn.GRAD_SHARE = True, False, True
         torch.cuda.synchronize()
         res[lazy] = ({k: float(v) for k, v in loss.items()}, float(opt.grad_norm()),
                      {k: v.detach().clone() for k, v in model.state_dict().items()})

@@ -1,4 +1,4 @@
-"""CPU: host logic of the demand-driven FPN level (ops.wino23_pattern): which tiles / planes / pixels the static lists hold, and
+"""CPU: host logic of the demand-driven FPN level (ondemand.wino23_pattern): which tiles / planes / pixels the static lists hold, and
 the contract fields of the committed bench line."""
 import json
 import os
@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from birdsoundclassif_amd import ops
+from birdsoundclassif_amd import ondemand
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -23,7 +23,7 @@ def pattern_rows(n, stride):
 @pytest.mark.parametrize('geom', [(2, 188, 512, 8), (3, 47, 66, 8), (1, 94, 256, 4), (2, 25, 33, 8)])
 def test_pattern_lists(geom):
     B, H, W, S = geom
-    pat = ops.wino23_pattern(B, H, W, S, 'cpu')
+    pat = ondemand.wino23_pattern(B, H, W, S, 'cpu')
     TH, TW = (H + 1) // 2, (W + 1) // 2
     tiles = pat.tiles.numpy().reshape(-1, 128)
     info = pat.blk_info.numpy().view(np.uint32)
