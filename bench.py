@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 import numpy as np   # noqa: E402
 import torch         # noqa: E402
 
+PMC_DOMINANT = 'r02_pmc_dominant.json'    # committed rocprofv3 --pmc passes of `python bench.py` (scripts/pmc_dominant.py)
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 FP64_MFMA_PEAK_TFLOPS = 78.6           # v_mfma_f64_16x16x4_f64: half the fp32 rate on this part (64 cycles / 2048 FLOP / SIMD)
 FPN0_GFLOP_PER_CLIP = 170.322          # fpn.out_convs.4, 3x3 384->256 @188x512
@@ -136,6 +137,60 @@ def train_bench(rank, world, dist, batch, steps, warmup, mix_steps=10):
             'workload': 'BASELINE.json configs[2]/[3]: positive training step (fwd + bwd + clip + AdamW), fp32'}
 
 
+def bulk_bench(model, rank, world, dist, n_files, batch, min_score, headline_clips_per_s_per_gpu):
+    """BASELINE.json configs[4] on this rank's shard, END TO END: `n_files` synthetic 3 s wav files on tmpfs -> `<wav>.txt` files
+    through `bulk.detect_files` (reader thread -> pinned batch -> H2D -> hipGraph replay of front end + detector + device
+    post-processing -> D2H of the compact rows -> writer thread: reference output dict -> txt).  Timed region = first file opened
+    to last txt file closed (model load and the one-time graph capture are outside, as they are for a 100k-file shard); one
+    untimed pass over two batches warms the page cache of nothing (tmpfs) but the threads / pinned slots."""
+    import shutil
+    import tempfile
+    from birdsoundclassif_amd import bulk, synth
+    root = tempfile.mkdtemp(prefix=f'nbm_bulk_r{rank}_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
+    try:
+        base = [synth.clip_pcm16(rank * 8 + i) for i in range(8)]
+        files = []
+        for i in range(n_files):
+            path = os.path.join(root, f'clip{i:06d}.wav')
+            synth.write_wav(path, base[i % 8], 22050)
+            files.append(path)
+        names = {f'Species {i}': i for i in range(1, 151)}
+        det = bulk.GraphedDetector(model, batch, 66150, 22050, min_score=min_score, independent=True)
+        kw = dict(batch=batch, min_score=min_score, bird_dict=names, write_txt=True, keep_results=False, detector=det)
+        bulk.detect_files(model, files[:2 * batch], **kw)
+        for f in files[:2 * batch]:
+            os.remove(bulk.txt_path(f))
+        stats = {}
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        bulk.detect_files(model, files, stats=stats, **kw)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], device='cuda', dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        n_txt = sum(1 for f in files if os.path.isfile(bulk.txt_path(f)))
+        import ast
+        n_det = sum(len(v['scores']) for f in files[:batch] for v in ast.literal_eval(open(bulk.txt_path(f)).read()).values())
+        del det
+        torch.cuda.empty_cache()
+        v = world * n_files / dt
+        return {'value': v, 'unit': 'clips/s', 'files_per_gpu': n_files, 'txt_files_written_rank0': n_txt, 'batch': batch,
+                'wall_s': dt, 'ratio_to_resident_hbm_headline': v / world / headline_clips_per_s_per_gpu,
+                'detections_in_first_batch': n_det,
+                'stages_rank0': {k: (round(x, 4) if isinstance(x, float) else x) for k, x in stats.items()},
+                'workload': 'BASELINE.json configs[4] on one shard per GPU: synthetic 3 s 22.05 kHz PCM16 wav files on tmpfs -> '
+                            'txt files (reference CLI output), hipGraph-captured detect loop, every clip an independent batch of '
+                            'one (= the reference\'s per-file loop), file reads / H2D / replay / D2H / txt writes overlapped'}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def cpu_baseline(n_clips=16, batch=4, threads=32):
     """Oracle port (numpy front end + pure-torch detector) on the host cores; bounded sample (~10-20 s).
     32 torch threads: measured fastest on the GPU box (8: 1.36, 16: 1.43, 32: 1.81, 64: 1.13, 128: 0.54 clips/s for
@@ -168,7 +223,7 @@ def cpu_baseline(n_clips=16, batch=4, threads=32):
                       f'oracle detector forward (torch CPU fp32, {threads} threads), {dt:.1f} s'}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
@@ -180,27 +235,141 @@ def main():
     ap.add_argument('--train-steps', type=int, default=3)
     ap.add_argument('--no-train', action='store_true')
     ap.add_argument('--no-dense-reference', dest='no_dense_reference', action='store_true')
-    a = ap.parse_args()
+    ap.add_argument('--bulk-files', type=int, default=2048,
+                    help='bulk_inference leg (configs[4] on this rank\'s shard): wav files on tmpfs -> txt files; 0 = skip')
+    return ap.parse_args(argv)
 
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv, script=None, timeout=None):
+    """`python bench.py --gpus N` without torchrun: start N rank processes of this script (one per GPU; RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment) BEFORE this process has made any GPU call -- it never makes one: it only
+    counts devices, waits, and relays rank 0's JSON line.  Nothing is re-exec'ed.  Returns the exit code: 0 only when every
+    rank exited 0 and rank 0 printed its line; the first failing rank takes the others down."""
+    import subprocess
+    script = script or os.path.abspath(__file__)
+    env = dict(os.environ)
+    env.update(WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()), NBM_BENCH_LAUNCHER='self')
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=e,
+                                      stdout=subprocess.PIPE if r == 0 else None, text=True if r == 0 else None))
+    out0, rc = '', 0
+    t_end = time.time() + timeout if timeout else None
+    try:
+        import threading
+        buf = []
+        rd = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+        rd.start()
+        alive = set(range(n))
+        while alive:
+            for r in sorted(alive):
+                c = procs[r].poll()
+                if c is None:
+                    continue
+                alive.discard(r)
+                if c != 0 and rc == 0:
+                    rc = c if c > 0 else 1
+                    print(f'bench launcher: rank {r} exited with code {c}; stopping the other ranks', file=sys.stderr, flush=True)
+                    for q in alive:
+                        procs[q].terminate()
+            if t_end and time.time() > t_end and alive:
+                rc = rc or 124
+                print('bench launcher: timeout; stopping the ranks', file=sys.stderr, flush=True)
+                for q in alive:
+                    procs[q].terminate()
+                t_end = None
+            time.sleep(0.05)
+        rd.join(5)
+        out0 = buf[0] if buf else ''
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    lines = [ln for ln in out0.splitlines() if ln.startswith('{')]
+    if rc == 0 and not lines:
+        print('bench launcher: rank 0 printed no JSON line', file=sys.stderr, flush=True)
+        rc = 1
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return rc
+
+
+def dist_setup(a):
+    """Rank environment -> (rank, world, local, dist | None, info).  `info` goes into the JSON line: backend, ranks_seen (an
+    all-reduce of ones: what the collective library really connected), the device index of every rank."""
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
-    if a.gpus != world and world > 1:
+    if a.gpus != world:
         raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}')
+    dry = os.environ.get('NBM_BENCH_DRY') == '1'       # tests/test_bench_launcher.py: rendezvous + collectives only, no GPU work
     # NBM_BENCH_SHARE_GPU=1 (functional rehearsal of the multi-rank path on a one-GPU box): every rank uses cuda:0 and
     # the collectives go through gloo, because RCCL refuses two ranks on one device.  Never set for measurements.
     share = os.environ.get('NBM_BENCH_SHARE_GPU') == '1'
-    torch.cuda.set_device(0 if share else local)
-    dist = None
+    dev = 0 if share else local
+    if not dry:
+        torch.cuda.set_device(dev)
+    dist, backend, seen, devices = None, None, 1, [dev]
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        if share:
-            dist.init_process_group('gloo')
+        if share or dry:
+            backend = 'gloo'
+            dist.init_process_group('gloo', timeout=datetime.timedelta(minutes=5))
         else:
-            import datetime
+            backend = 'nccl'                    # = RCCL on ROCm
             # a collective that cannot complete raises after 5 minutes instead of hanging the bench
             dist.init_process_group('nccl', device_id=torch.device('cuda', local), timeout=datetime.timedelta(minutes=5))
+        where = 'cpu' if dry else 'cuda'
+        one = torch.ones((1,), device=where, dtype=torch.float32)
+        dist.all_reduce(one)
+        seen = int(one.item())
+        idx = torch.zeros((world,), device=where, dtype=torch.int32)
+        idx[rank] = dev + 1
+        dist.all_reduce(idx)
+        devices = [int(v) - 1 for v in idx.tolist()]
+        if seen != world:
+            raise SystemExit(f'the {backend} all-reduce saw {seen} ranks, expected {world}')
+    info = {'backend': backend, 'ranks_seen': seen, 'rank_devices': devices,
+            'launcher': os.environ.get('NBM_BENCH_LAUNCHER', 'torchrun' if 'TORCHELASTIC_RUN_ID' in os.environ else 'external' if world > 1 else 'none')}
+    return rank, world, local, dist, info
+
+
+def main(argv=None):
+    a = parse_args(argv)
+    if 'WORLD_SIZE' not in os.environ and a.gpus > 1:
+        # launcher mode: no GPU call in this process (device_count() does not initialise the runtime)
+        dry = os.environ.get('NBM_BENCH_DRY') == '1'
+        share = os.environ.get('NBM_BENCH_SHARE_GPU') == '1'
+        have = torch.cuda.device_count()
+        if not (dry or share) and have < a.gpus:
+            print(f'bench: --gpus {a.gpus} but {have} GPU(s) visible; refusing to run a smaller job under that label',
+                  file=sys.stderr, flush=True)
+            raise SystemExit(2)
+        raise SystemExit(launch_ranks(a.gpus, sys.argv[1:] if argv is None else argv))
+
+    rank, world, local, dist, dist_info = dist_setup(a)
+    if os.environ.get('NBM_BENCH_DRY') == '1':
+        fail = os.environ.get('NBM_BENCH_DRY_FAIL_RANK')
+        if fail is not None and int(fail) == rank:
+            raise SystemExit(3)
+        if dist is not None:
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({'metric': 'dry run (launcher test)', 'n_gpus': world, **dist_info}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     from birdsoundclassif_amd import ondemand, ops, synth
     from birdsoundclassif_amd.nbm_datasets.prepare_dataset import SpectrogramFrontEnd
@@ -272,23 +441,32 @@ def main():
     prof, ops.PROFILE = ops.PROFILE, None
     ops.PROFILE_FUSED_ONLY = False
     ops.PROFILE = []                                           # one extra, untimed step with events around every GEMM-type launch
+    ops.FLOPS = [0.0]                                          # ... and the executed-MFMA-FLOP counter of every GEMM launch
     step()
     torch.cuda.synchronize()
-    prof_all, ops.PROFILE = ops.PROFILE, None
+    exec_gflop_per_clip = ops.flops_total() / B / 1e9 + 2.0 * 2 * 384 * 664 * 1024 / 1e9      # + the fp64 DFT GEMMs of the front end
+    prof_all, ops.PROFILE, ops.FLOPS = ops.PROFILE, None, None
     # for the record: the same step with the finest FPN level computed densely, as the reference does -- untimed
-    # for the headline, 1 warm-up + 3 steps
+    # for the headline, 2 warm-up + 10 steps; single-rank runs only (a failure of this optional leg on one rank must not leave
+    # the other ranks in a barrier)
     dense_ref = None
-    if ondemand.LAZY_FINEST and not a.no_dense_reference:
+    if ondemand.LAZY_FINEST and not a.no_dense_reference and world == 1:
         ondemand.LAZY_FINEST = False
         try:
             step()
-            sync_all()
+            step()
+            torch.cuda.synchronize()
             td = time.perf_counter()
-            for _ in range(3):
-                step()
-            sync_all()
-            td = (time.perf_counter() - td) / 3
-            dense_ref = {'ms_per_step': td * 1e3, 'clips_per_s_per_gpu': B / td,
+            pend = None
+            for _ in range(10):
+                cur = launch()
+                if pend is not None:
+                    finish(pend)
+                pend = cur
+            finish(pend)
+            torch.cuda.synchronize()
+            td = (time.perf_counter() - td) / 10
+            dense_ref = {'ms_per_step': td * 1e3, 'clips_per_s_per_gpu': B / td, 'steps': 10,
                          'note': 'NBM_LAZY_FINEST=0: every pixel of the finest FPN map and of its lateral is computed; identical detections'}
         except Exception as exc:                  # informational leg: never lose the headline line over it
             dense_ref = {'error': f'{type(exc).__name__}: {exc}'[:300]}
@@ -313,7 +491,7 @@ def main():
     roof = None
     traffic = None                      # HBM bytes per launch of the dominant kernel: PMC counters cannot be read live;
     try:                                # the value comes from the committed rocprofv3 --pmc passes of this same command
-        pj = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_dominant.json')))
+        pj = json.load(open(os.path.join(ROOT, 'profiles', PMC_DOMINANT)))
         if B == 64 and pj.get('lazy_finest') == bool(ondemand.LAZY_FINEST):
             traffic = pj['traffic_bytes_per_launch']
     except Exception:
@@ -334,14 +512,21 @@ def main():
                                            'the input transform + 16 transformed-domain GEMMs + output transform + epilogue); all its '
                                            'launches of a step (FPN output convolutions, ResNet 3x3/s1 layers)',
                 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS,
-                'traffic': traffic, 'traffic_unit': 'bytes/launch (2*FETCH_SIZE + WRITE_SIZE, mean over the launches, '
-                                                    'profiles/r02_pmc_dominant.json)',
+                'traffic': traffic, 'traffic_unit': 'bytes/launch (2*FETCH_SIZE + WRITE_SIZE, mean over the launches)',
+                'traffic_source': f'profiles/{PMC_DOMINANT}: separate rocprofv3 --pmc passes of this command, NOT measured in this run '
+                                  '(counters cannot be read live); null when batch / on-demand mode differ from that profile',
                 'avg_launch_ms': ms / len(per), 'launches': len(per), 'launches_per_step': len(per) / a.steps,
                 'executed_GFLOP_per_launch': gflop / len(per), 'ms_per_step': ms / a.steps,
                 'largest_launches': [{'what': k, 'ms': v[0] / v[2], 'executed_TFLOPs': v[1] / v[0],
                                       'frac': v[1] / v[0] / FP32_MFMA_PEAK_TFLOPS} for k, v in top],
                 'all_gemm_type_launches_ms_per_step': all_ms,
+                'whole_step_executed_GFLOP_per_clip': exec_gflop_per_clip,
+                'whole_step_executed_TFLOPs': exec_gflop_per_clip * B * a.steps / (dt * 1e3),
+                'whole_step_executed_frac_of_mfma_peak': exec_gflop_per_clip * B * a.steps / (dt * 1e3) / FP32_MFMA_PEAK_TFLOPS,
                 'whole_step_direct_conv_equivalent_TFLOPs': FWD_GFLOP_PER_CLIP * B * a.steps / (dt * 1e3),
+                'whole_step_note': 'executed = MFMA FLOPs the launches of a step really perform (Winograd-domain counts, listed tiles '
+                                   'only, fp64 DFT GEMMs counted at face value) over the wall time of the whole step incl. every '
+                                   'non-GEMM kernel; direct_conv_equivalent uses SURVEY 325.56 GFLOP/clip and is NOT a roofline figure',
                 'finest_fpn_map': 'on demand (RPN pattern tiles + tiles under the RoIs; the other pixels have no reader)'
                                   if ondemand.LAZY_FINEST else 'dense'}
     # front end alone (HBM-bound stage of the path): live HIP events around K replays
@@ -358,6 +543,14 @@ def main():
                 'dft_gemm_executed_TFLOPs_f64': B * fe_flop / (fe_ms * 1e-3) / 1e12, 'mfma_f64_peak_TFLOPs': FP64_MFMA_PEAK_TFLOPS,
                 'note': 'PCM16 -> 2x up-sample -> STFT-dB (folded real DFT on the fp64 MFMA, csrc/stft.hip) -> normalise/window; '
                         'algorithmic bytes 1.668 MB/clip (SURVEY 8d); the stage is bound by the DFT-GEMMs, not by HBM'}
+    bulk_leg = None
+    if a.bulk_files > 0:
+        try:
+            bulk_leg = bulk_bench(model, rank, world, dist, a.bulk_files, B, a.min_score, B * a.steps / dt)
+        except Exception as exc:                  # never lose the headline line over an extra leg
+            if dist is not None:
+                raise                             # ... but in a multi-rank run the other ranks sit in this leg's barrier
+            bulk_leg = {'error': f'{type(exc).__name__}: {exc}'[:500]}
     train = None
     if not a.no_train:
         del model
@@ -374,7 +567,8 @@ def main():
                                        '(PCM16 @22.05 kHz resident in HBM) through the HIP STFT front end + detector '
                                        'forward + device post-processing, detections returned to the host',
                            'batch_per_gpu': B, 'min_score': a.min_score, 'detections_per_step': n_det / a.steps},
-                'roofline': roof, 'frontend': frontend, 'dense_finest_map': dense_ref, 'train_step': train}
+                'roofline': roof, 'frontend': frontend, 'dense_finest_map': dense_ref, 'bulk_inference': bulk_leg,
+                'train_step': train, **dist_info}
         if world == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)

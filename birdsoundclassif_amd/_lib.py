@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libnbm_hip.so')
+# NBM_LIB: another build of the same ABI (scripts/wino_fused_probe.py uses the -DNBM_ABLATE build, `make -C csrc ablate`)
+LIB_PATH = os.environ.get('NBM_LIB') or os.path.join(_HERE, 'libnbm_hip.so')
 CSRC = os.path.join(_HERE, 'csrc')
 
 _lib = None
@@ -37,7 +38,7 @@ class RoiDesc(C.Structure):
                 ('n_levels', C.c_int), ('C', C.c_int),
                 ('rois', C.c_void_p), ('n_roi', C.c_void_p), ('B', C.c_int), ('roi_cap', C.c_int),
                 ('pe_f', C.c_void_p), ('pe_t', C.c_void_p), ('img_h', C.c_int), ('img_w', C.c_int),
-                ('pool', C.c_void_p), ('pe', C.c_void_p), ('level', C.c_void_p)]
+                ('pool', C.c_void_p), ('pe', C.c_void_p), ('level', C.c_void_p), ('n_roi_per_image', C.c_int)]
 
 
 class AugmentParams(C.Structure):
@@ -81,10 +82,10 @@ SIGNATURES = {
     'nbm_mha_small': [_P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _L, _L, _P, _F, _P],
     'nbm_pair_softmax': [_P, _L, _I, _I, _P, _I, _P],
     'nbm_rpn_decode': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P],
-    'nbm_rpn_select': [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P],
-    'nbm_nms_batched': [_P, _P, _P, _I, _I, _F, _I, _P, _P, _P, _P, _P, _P],
+    'nbm_rpn_select': [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _P],
+    'nbm_nms_batched': [_P, _P, _P, _I, _I, _F, _I, _P, _P, _P, _P, _P, _I, _P],
     'nbm_roi_pool': [C.POINTER(RoiDesc), _P],
-    'nbm_rcnn_post': [_P, _P, _I, _I, _P, _P, _I, _I, _I, _F, _F, _I, _P, _P, _P],
+    'nbm_rcnn_post': [_P, _P, _I, _I, _P, _P, _I, _I, _I, _F, _F, _I, _P, _P, _I, _P],
     # ---- training path
     'nbm_conv_dgrad': [C.POINTER(BwdDesc), _P],
     'nbm_conv_wgrad': [C.POINTER(BwdDesc), _P],
@@ -111,7 +112,7 @@ SIGNATURES = {
     'nbm_wino23_conv_fused': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
     'nbm_wino23_rows_tiles': [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P],
     'nbm_wino23_conv_fused_tiles': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P],
-    'nbm_roi_tiles': [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _P],
+    'nbm_roi_tiles': [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P],
     'nbm_wino23_input_tiles': [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P],
     'nbm_wino23_outgrad_tiles': [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P],
     'nbm_weighted_sum': [_P, _P, _P, _P, _P, _L, _P],

@@ -2,26 +2,45 @@
 (front end + detector + device post-processing) captured once in a hipGraph and replayed per batch.
 
 The graph is legal because `NbmModel.detect` never syncs with the host: every data-dependent size (kept anchors, NMS
-survivors, RoI count, detections per clip) lives in fixed-capacity device buffers with device-side counters.  Inputs
-are staged through a pinned host buffer into the graph's static input tensor.  Multi-GPU: one process per GPU, files
-sharded `files[rank::world]`, no data-path collective (`nbm_detect.py` does the sharding).
+survivors, RoI count, detections per clip) lives in fixed-capacity device buffers with device-side counters.
+
+`detect_files` is a three-stage software pipeline around the graph, so that the GPU never waits for a file or a dict:
+
+    reader thread   wav files -> rows of a pinned int16 batch buffer (a ring of `depth` slots)
+    main thread     H2D copy of the slot -> graph replay -> D2H copy of the compact [B,50,6] detection rows + counts into the
+                    slot's pinned result buffers, all on the graph's stream; batch i+1 is queued before the host waits for
+                    batch i
+    writer thread   rows -> the reference's per-file output dictionary (single-window `merge_images`) -> `<wav>.txt`
+
+The clips of a batch are INDEPENDENT (`NbmModel.detect(..., independent=True)`): the reference CLI runs one file per model call
+(nbm_detect.py:24-28 -> run_detection.py:49-55, a 3 s clip is a batch of one window), so the batch-coupled proposal counts of
+the reference's ProposalLayer / nms (min over the batch, layers.py:287, nets_utils.py:236) must not couple files that merely
+share a launch here: every clip keeps its own counts, exactly as if it had been run alone.
+
+Multi-GPU: one process per GPU, files sharded `files[rank::world]`, no data-path collective (`nbm_detect.py` does the sharding).
 """
 import os
+import queue
+import struct
+import threading
+import time
 
 import numpy as np
 import torch
 
 from .nbm_datasets.prepare_dataset import SpectrogramFrontEnd, read_wav_pcm16
-from .nets.layers import FastRCNN
 
 
 class GraphedDetector:
     """Captures `front end -> model.detect` for a fixed (batch, n_samples, sample rate) and replays it."""
 
-    def __init__(self, model, batch, n_samples, sr, min_score=0.2, nms_thresh=0.3, device='cuda'):
+    def __init__(self, model, batch, n_samples, sr, min_score=0.2, nms_thresh=0.3, device='cuda', independent=False):
         self.model, self.batch, self.sr = model.eval(), batch, sr
         self.fe = SpectrogramFrontEnd(device)
-        self.min_score, self.nms_thresh = min_score, nms_thresh
+        self.min_score, self.nms_thresh, self.independent = min_score, nms_thresh, independent
+        self.n_img = self.fe.n_images(self.fe.n_frames(n_samples * (2 if sr * 2 == self.fe.FREQ else 1)))
+        if self.n_img != 1:
+            raise NotImplementedError('GraphedDetector handles clips that fit one 1024-column window (<= 3.06 s)')
         self.pcm = torch.zeros((batch, n_samples), dtype=torch.int16, device=device)        # static graph input
         self.stream = torch.cuda.Stream()
         with torch.no_grad(), torch.cuda.stream(self.stream):
@@ -31,13 +50,10 @@ class GraphedDetector:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=self.stream):
                 self.det, self.n_det = self._run()                # static graph outputs
-        self.n_img = self.fe.n_images(self.fe.n_frames(n_samples * (2 if sr * 2 == self.fe.FREQ else 1)))
-        if self.n_img != 1:
-            raise NotImplementedError('GraphedDetector handles clips that fit one 1024-column window (<= 3.06 s)')
 
     def _run(self):
         imgs, _ = self.fe(self.pcm, self.sr)
-        return self.model.detect(imgs[:, 0][:, None].contiguous(), self.nms_thresh, self.min_score)
+        return self.model.detect(imgs[:, 0][:, None].contiguous(), self.nms_thresh, self.min_score, independent=self.independent)
 
     def replay(self):
         """Runs the captured step on the current content of `self.pcm`; results land in `self.det`, `self.n_det`."""
@@ -45,57 +61,210 @@ class GraphedDetector:
 
     def __call__(self, pcm):
         """pcm int16 [batch, n] (host or device) -> list[batch] of the reference's per-clip dictionaries."""
+        from .nets.layers import FastRCNN
         self.pcm.copy_(pcm, non_blocking=True)
         self.replay()
         return FastRCNN.dets_to_dicts(self.det, self.n_det, self.model.args.num_classes)
 
 
-def detect_files(model, files, batch=64, min_score=0.2, bird_dict=None, write_txt=True):
-    """Detects over equal-length 16-bit PCM wav files (3 s clips): -> list of per-file output dicts in `files` order.
-    The last, partial batch is padded with silence and its padding results are dropped."""
+def wav_header(path):
+    """(format tag, channels, sample rate, bits, n_samples per channel, byte offset of the samples) of a RIFF/WAVE file, reading
+    the chunk headers only."""
+    with open(path, 'rb') as f:
+        head = f.read(12)
+        if len(head) < 12 or head[:4] != b'RIFF' or head[8:12] != b'WAVE':
+            raise ValueError(f'{path}: not a RIFF/WAVE file')
+        fmt = None
+        while True:
+            ch = f.read(8)
+            if len(ch) < 8:
+                raise ValueError(f'{path}: wav file without fmt / data chunk')
+            cid, size = ch[:4], struct.unpack('<I', ch[4:])[0]
+            if cid == b'fmt ':
+                fmt = f.read(size + (size & 1))[:size]
+            elif cid == b'data':
+                if fmt is None:
+                    raise ValueError(f'{path}: data chunk in front of the fmt chunk')
+                tag, nch, sr, _, _, bits = struct.unpack('<HHIIHH', fmt[:16])
+                if tag == 0xFFFE and len(fmt) >= 26:
+                    tag = struct.unpack('<H', fmt[24:26])[0]
+                off = f.tell()
+                size = min(size, os.fstat(f.fileno()).st_size - off)
+                return tag, nch, sr, bits, size // max(1, nch * (bits // 8)), off
+            else:
+                f.seek(size + (size & 1), 1)
+
+
+def bulk_groups(files):
+    """Splits a file list into {(sample rate, n_samples): [files]} of the clips the graphed path takes -- mono 16-bit PCM at
+    22.05 or 44.1 kHz that fill exactly one spectrogram window -- and the rest (any other format, length or an unreadable
+    header), which goes through the per-file driver."""
+    groups, rest = {}, []
+    for f in files:
+        try:
+            tag, nch, sr, bits, n, _ = wav_header(f)
+        except (OSError, ValueError, struct.error):
+            rest.append(f)
+            continue
+        ok = tag == 1 and nch == 1 and bits == 16 and sr in (22050, 44100) and n > 0
+        # one window <=> 1 + n44 // HOP_LENGTH <= W_PIX frames (prepare_dataset.py:126,267 with the default dt / w_pix)
+        ok = ok and 1 + (n * (2 if sr == 22050 else 1)) // int(44100 * 0.003) <= 1024
+        if ok:
+            groups.setdefault((sr, n), []).append(f)
+        else:
+            rest.append(f)
+    return groups, rest
+
+
+def rows_to_result(rows, n, w_pix, hop, spectrogram_length, names=None):
+    """Detection rows of ONE single-window file -> the per-file output dictionary of run_detection (reference
+    run_detection.py:69-84 after `merge_images`, :163-249).  rows: float32 [>= n, 6] = {class, x1, y1, x2, y2, score} sorted by
+    (class, score desc).  For a file that is one window `merge_images` applies the first-window border rule (:195-196) and the
+    end-of-file rule (:213); its file-level NMS (:233) cannot suppress anything, because the detector's own class-agnostic NMS ran
+    at the same threshold on the same boxes (all surviving pairs have IoU < 0.3).
+    -> {species | class id: {'bbox_coord': [[x1,y1,x2,y2]...], 'scores': [...]}}, classes ascending."""
+    res = {}
+    if n <= 0:
+        return res
+    r = rows[:n]
+    keep = ~((r[:, 3] >= w_pix - 5) & ((r[:, 3] - r[:, 1]) < np.float32(0.9 * (w_pix - hop)))) & ~(r[:, 3] >= spectrogram_length)
+    r = r[keep]
+    if len(r) == 0:
+        return res
+    cls = r[:, 0].astype(np.int64)
+    starts = np.flatnonzero(np.r_[True, cls[1:] != cls[:-1]])
+    ends = np.r_[starts[1:], len(r)]
+    for s0, e0 in zip(starts.tolist(), ends.tolist()):
+        k = int(cls[s0])
+        res[names[k] if names else str(k)] = {'bbox_coord': r[s0:e0, 1:5].tolist(), 'scores': r[s0:e0, 5].tolist()}
+    return res
+
+
+def single_window_merge(d, w_pix, hop, spectrogram_length, names=None):
+    """`rows_to_result` for one entry of `FastRCNN.dets_to_dicts` (the reference's per-image dictionary)."""
+    rows = [np.concatenate([np.full((len(v['bbox_coord']), 1), float(k), dtype=np.float32), v['bbox_coord'].numpy(),
+                            v['scores'].reshape(-1, 1).numpy()], 1) for k, v in d.items() if len(v['bbox_coord'])]
+    if not rows:
+        return {}
+    rows = np.concatenate(rows).astype(np.float32)
+    return rows_to_result(rows, len(rows), w_pix, hop, spectrogram_length, names)
+
+
+def txt_path(wav_path):
+    return wav_path.replace('.wav', '.txt')          # like the reference CLI (nbm_detect.py:27)
+
+
+def detect_files(model, files, batch=64, min_score=0.2, bird_dict=None, write_txt=True, depth=5, keep_results=True,
+                 independent=True, stats=None, detector=None):
+    """Detects over equal-length mono 16-bit PCM wav files (single-window clips, see `bulk_groups`): -> list of per-file output
+    dicts in `files` order (None entries with keep_results=False); `<wav>.txt = str(dict)` written when `write_txt`.
+    The last, partial batch is padded with silence and its padding results are dropped.  `stats` (dict) receives the stage
+    times.  `detector`: a GraphedDetector to reuse (same batch / clip length / rate)."""
     if not files:
         return []
-    pcm0, sr = read_wav_pcm16(files[0])
-    n = len(pcm0)
-    det = GraphedDetector(model, batch, n, sr, min_score=min_score)
-    L = det.fe.n_frames(n * (2 if sr * 2 == det.fe.FREQ else 1))
-    host = torch.zeros((batch, n), dtype=torch.int16).pin_memory()
+    _, _, sr, _, n, _ = wav_header(files[0])
+    det = detector or GraphedDetector(model, batch, n, sr, min_score=min_score, independent=independent)
+    if (det.batch, det.pcm.shape[1], det.sr) != (batch, n, sr):
+        raise ValueError('the GraphedDetector handed in was captured for another batch / clip length / sample rate')
+    fe = det.fe
+    L = fe.n_frames(n * (2 if sr * 2 == fe.FREQ else 1))
     names = None
     if bird_dict is not None:
         names = {v: k for k, v in bird_dict.items()}
         names[0] = 'Non bird sound'
-    out = []
-    for s in range(0, len(files), batch):
-        chunk = files[s:s + batch]
-        host.zero_()
-        for i, f in enumerate(chunk):
-            p, sr_i = read_wav_pcm16(f)
-            if sr_i != sr or len(p) != n:
-                raise ValueError(f'{f}: bulk detection needs clips of identical length and rate')
-            host[i] = torch.from_numpy(p.copy())
-        dicts = det(host)[:len(chunk)]
-        for f, d in zip(chunk, dicts):
-            res = single_window_merge(d, det.fe.W_PIX, det.fe.HOP_SPECTRO, L, names)
-            out.append(res)
-            if write_txt:
-                with open(os.path.splitext(f)[0] + '.txt', 'w') as fh:
-                    fh.write(str(res))
+    n_batches = -(-len(files) // batch)
+    depth = max(3, depth)
+    cap = det.det.shape[1]
+    slots = [(torch.zeros((batch, n), dtype=torch.int16).pin_memory(), torch.zeros((batch, cap, 6), dtype=torch.float32).pin_memory(),
+              torch.zeros((batch,), dtype=torch.int32).pin_memory()) for _ in range(depth)]
+    free_q, ready_q, done_q = queue.Queue(), queue.Queue(), queue.Queue()
+    for s in range(depth):
+        free_q.put(s)
+    out = [None] * len(files)
+    err = []
+    t_read, t_write = [0.0], [0.0]
+
+    def reader():
+        try:
+            for i in range(n_batches):
+                s = free_q.get()
+                if s is None:
+                    return
+                t0 = time.perf_counter()
+                chunk = files[i * batch:(i + 1) * batch]
+                host = slots[s][0].numpy()
+                for j, f in enumerate(chunk):
+                    p, sr_i = read_wav_pcm16(f)
+                    if sr_i != sr or len(p) != n:
+                        raise ValueError(f'{f}: bulk detection needs clips of identical length and rate')
+                    host[j] = p
+                if len(chunk) < batch:
+                    host[len(chunk):] = 0
+                t_read[0] += time.perf_counter() - t0
+                ready_q.put((i, s, len(chunk)))
+        except BaseException as exc:                 # noqa: BLE001 -- handed to the main thread
+            err.append(exc)
+            ready_q.put(None)
+
+    def writer():
+        try:
+            while True:
+                item = done_q.get()
+                if item is None:
+                    return
+                i, s, cnt = item
+                t0 = time.perf_counter()
+                rows, nd = slots[s][1].numpy(), slots[s][2].numpy()
+                for j in range(cnt):
+                    res = rows_to_result(rows[j], int(nd[j]), fe.W_PIX, fe.HOP_SPECTRO, L, names)
+                    f = files[i * batch + j]
+                    if keep_results:
+                        out[i * batch + j] = res
+                    if write_txt:
+                        with open(txt_path(f), 'w') as fh:
+                            fh.write(str(res))
+                t_write[0] += time.perf_counter() - t0
+                free_q.put(s)
+        except BaseException as exc:                 # noqa: BLE001
+            err.append(exc)
+            free_q.put(None)
+
+    th_r, th_w = threading.Thread(target=reader, daemon=True), threading.Thread(target=writer, daemon=True)
+    t_start = time.perf_counter()
+    th_r.start(), th_w.start()
+    inflight = []
+    t_wait_in = 0.0
+    try:
+        with torch.no_grad(), torch.cuda.stream(det.stream):
+            for _ in range(n_batches):
+                t0 = time.perf_counter()
+                item = ready_q.get()
+                t_wait_in += time.perf_counter() - t0
+                if item is None or err:
+                    break
+                i, s, cnt = item
+                det.pcm.copy_(slots[s][0], non_blocking=True)
+                det.replay()
+                slots[s][1].copy_(det.det, non_blocking=True)
+                slots[s][2].copy_(det.n_det, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(det.stream)
+                inflight.append((i, s, cnt, ev))
+                if len(inflight) >= 2:             # the GPU has the next batch queued: now wait for the previous one
+                    i0, s0, c0, e0 = inflight.pop(0)
+                    e0.synchronize()
+                    done_q.put((i0, s0, c0))
+            for i0, s0, c0, e0 in inflight:
+                e0.synchronize()
+                done_q.put((i0, s0, c0))
+    finally:
+        done_q.put(None)
+        free_q.put(None)                            # unblocks a reader that waits for a slot after an error
+        th_w.join()
+        th_r.join(timeout=5)
+    if err:
+        raise err[0]
+    if stats is not None:
+        stats.update(wall_s=time.perf_counter() - t_start, reader_busy_s=t_read[0], writer_busy_s=t_write[0],
+                     gpu_loop_waited_for_input_s=t_wait_in, batches=n_batches, depth=depth)
     return out
-
-
-def single_window_merge(d, w_pix, hop, spectrogram_length, names=None):
-    """`merge_images` (reference run_detection.py:163-249) for a file that is ONE window: the first-window border rule
-    (:195-196), the end-of-file rule (:213), and the file-level NMS (:233) -- which cannot suppress anything here because
-    the detector's own class-agnostic NMS ran at the same threshold on the same boxes (all surviving pairs have
-    IoU < 0.3).  Returns {species | class id: {'bbox_coord': [[...]], 'scores': [...]}} like run_detection."""
-    min_border = 0.9 * (w_pix - hop)
-    res = {}
-    for k, v in d.items():
-        bb = v['bbox_coord']
-        if len(bb) == 0:
-            continue
-        sc = v['scores'].reshape(-1)
-        keep = ~((bb[:, 2] >= w_pix - 5) & ((bb[:, 2] - bb[:, 0]) < min_border)) & ~(bb[:, 2] >= spectrogram_length)
-        if keep.any():
-            res[names[int(k)] if names else k] = {'bbox_coord': bb[keep].numpy().tolist(), 'scores': sc[keep].numpy().tolist()}
-    return res

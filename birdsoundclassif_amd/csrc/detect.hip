@@ -65,7 +65,7 @@ constexpr int SEL_THREADS = 1024;
 __global__ __launch_bounds__(SEL_THREADS) void rpn_select_kernel(
     const float* __restrict__ boxes, const uint32_t* __restrict__ keys, const int* __restrict__ keep_count, int B,
     int KA, int top_n, int fail_below, int cap, float* __restrict__ sel_boxes, float* __restrict__ sel_scores,
-    int* __restrict__ n_sel) {
+    int* __restrict__ n_sel, int per_image) {
   extern __shared__ unsigned long long sm[];  // [cap] sort buffer, then 256 histogram counters + scalars
   unsigned long long* buf = sm;
   unsigned int* hist = reinterpret_cast<unsigned int*>(sm + cap);
@@ -75,12 +75,15 @@ __global__ __launch_bounds__(SEL_THREADS) void rpn_select_kernel(
   const uint32_t* kb = keys + (long long)b * KA;
 
   if (tid == 0) {
+    // layers.py:287: pre_nms_topN = min(topN, min over the BATCH of the kept-anchor counts).  per_image: every image is a
+    // batch of its own (bulk inference: the reference CLI runs one file per model call), n_sel[b]
     int mn = 0x7fffffff;
-    for (int i = 0; i < B; ++i) mn = min(mn, keep_count[i]);
+    if (per_image) mn = keep_count[b];
+    else for (int i = 0; i < B; ++i) mn = min(mn, keep_count[i]);
     int N = min(top_n, mn);
     if (N < fail_below) N = 0;
     s_N = N; s_need = N; s_prefix = 0ull; s_count = 0;
-    if (b == 0) n_sel[0] = N;
+    if (per_image) n_sel[b] = N; else if (b == 0) n_sel[0] = N;
   }
   __syncthreads();
   const int N = s_N;
@@ -143,10 +146,10 @@ __global__ __launch_bounds__(SEL_THREADS) void rpn_select_kernel(
 }
 
 // ------------------------------------------------------------------ NMS
-__global__ void nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ n_in, int cap, int words,
+__global__ void nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ n_in, int n_stride, int cap, int words,
                                 float thresh, unsigned long long* __restrict__ mask) {
-  const int n = n_in[0];
   const int b = blockIdx.z, rb = blockIdx.y, cb = blockIdx.x;
+  const int n = n_in[b * n_stride];
   if (rb * 64 >= n || cb * 64 >= n || cb < rb) return;
   __shared__ float cbox[64][4];
   const int t = threadIdx.x;
@@ -173,10 +176,10 @@ __global__ void nms_mask_kernel(const float* __restrict__ boxes, const int* __re
 
 // one wave per image: lane w owns removed-word w (cap <= 4096)
 __global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* __restrict__ mask,
-                                                      const int* __restrict__ n_in, int cap, int words,
+                                                      const int* __restrict__ n_in, int n_stride, int cap, int words,
                                                       int* __restrict__ keep_idx, int* __restrict__ keep_cnt) {
   const int b = blockIdx.x, lane = threadIdx.x;
-  const int n = n_in[0];
+  const int n = n_in[b * n_stride];
   const int nwords = (n + 63) >> 6;
   unsigned long long removed = 0ull;
   int cnt = 0;
@@ -197,12 +200,14 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const unsigned long long* 
 __global__ void nms_gather_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
                                   const int* __restrict__ keep_idx, const int* __restrict__ keep_cnt, int B, int cap,
                                   int post_n, float* __restrict__ rois, float* __restrict__ roi_scores,
-                                  int* __restrict__ n_out) {
+                                  int* __restrict__ n_out, int per_image) {
   const int b = blockIdx.x;
+  // nets_utils.py:236: post_nms_topN = min(topN, min over the BATCH of the survivor counts); per_image: n_out[b]
   int mn = 0x7fffffff;
-  for (int i = 0; i < B; ++i) mn = min(mn, keep_cnt[i]);
+  if (per_image) mn = keep_cnt[b];
+  else for (int i = 0; i < B; ++i) mn = min(mn, keep_cnt[i]);
   const int R = min(post_n, mn);
-  if (b == 0 && threadIdx.x == 0) n_out[0] = R;
+  if (threadIdx.x == 0) { if (per_image) n_out[b] = R; else if (b == 0) n_out[0] = R; }
   for (int r = threadIdx.x; r < post_n; r += blockDim.x) {
     float* o = rois + ((long long)b * post_n + r) * 4;
     if (r < R) {
@@ -220,7 +225,7 @@ __global__ void nms_gather_kernel(const float* __restrict__ boxes, const float* 
 // ------------------------------------------------------------------ RoI pooling (+ positional encoding)
 struct RoiParams {
   const float* fmap[5]; int fh[5], fw[5]; int n_levels, C;
-  const float* rois; const int* n_roi; int B, roi_cap;
+  const float* rois; const int* n_roi; int n_stride, B, roi_cap;
   const float* pe_f; const float* pe_t; int img_h, img_w;
   float* pool; float* pe; int* level;
 };
@@ -245,7 +250,7 @@ __device__ __forceinline__ void roi_window(const float* roi, int n_levels, const
 __global__ void roi_pool_kernel(const RoiParams p) {
   const int slot = blockIdx.x;                 // b * roi_cap + r
   const int b = slot / p.roi_cap, r = slot - b * p.roi_cap;
-  if (r >= p.n_roi[0]) return;
+  if (r >= p.n_roi[b * p.n_stride]) return;
   const float* roi = p.rois + (long long)slot * 4;
   int lvl, x1, y1, x2, y2;
   roi_window(roi, p.n_levels, p.fh, p.fw, lvl, x1, y1, x2, y2);
@@ -307,7 +312,7 @@ __global__ void roi_pool_kernel(const RoiParams p) {
 // *n_blocks ones of `tiles` (capacity B * ceil(TH * TW / 128) blocks: cannot overflow).
 struct RoiTilesParams {
   const float* rois; const int* n_roi; int B, roi_cap, n_levels, level; int fh[5], fw[5];
-  const unsigned char* skip; int* tiles; int* n_blocks; int dilate;
+  const unsigned char* skip; int* tiles; int* n_blocks; int dilate, n_stride;
 };
 
 __global__ __launch_bounds__(256) void roi_tiles_kernel(const RoiTilesParams p) {
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(256) void roi_tiles_kernel(const RoiTilesParams p) 
   const int n_words = (THW + 31) >> 5;
   for (int i = tid; i < n_words; i += 256) bits[i] = 0u;
   __syncthreads();
-  const int n = min(p.n_roi[0], p.roi_cap);
+  const int n = min(p.n_roi[b * p.n_stride], p.roi_cap);
   for (int r = tid; r < n; r += 256) {
     int lvl, x1, y1, x2, y2;
     roi_window(p.rois + ((long long)b * p.roi_cap + r) * 4, p.n_levels, p.fh, p.fw, lvl, x1, y1, x2, y2);
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(256) void rcnn_post_kernel(const float* __restrict_
                                                         const float* __restrict__ bbox_cls, int n_cls1, int img_w,
                                                         int img_h, float nms_thresh, float min_score,
                                                         int proposal_number, float* __restrict__ det,
-                                                        int* __restrict__ n_det) {
+                                                        int* __restrict__ n_det, int n_stride) {
   __shared__ unsigned long long skey[POST_MAX];
   __shared__ float sbox[POST_MAX][4];
   __shared__ float sscore[POST_MAX];
@@ -381,7 +386,7 @@ __global__ __launch_bounds__(256) void rcnn_post_kernel(const float* __restrict_
   __shared__ unsigned char alive[POST_MAX];
   __shared__ int s_cnt;
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int R = min(n_roi[0], roi_cap);
+  const int R = min(n_roi[b * n_stride], roi_cap);
   int P = 1;
   while (P < R) P <<= 1;
   // 1. class arg-max (first maximum), score
@@ -485,31 +490,32 @@ extern "C" int nbm_rpn_decode(const float* cls, const float* reg, const float* a
 }
 
 extern "C" int nbm_rpn_select(const float* boxes, const uint32_t* keys, const int* keep_count, int B, int KA,
-                              int top_n, int fail_below, int cap, float* sel_boxes, float* sel_scores, int* n_sel,
+                              int top_n, int fail_below, int cap, float* sel_boxes, float* sel_scores, int* n_sel, int per_image,
                               void* stream) {
   if (!boxes || !keys || !keep_count || !sel_boxes || !sel_scores || !n_sel || B <= 0 || KA <= 0) return NBM_EINVAL;
   if (cap < top_n || cap > 4096 || (cap & (cap - 1))) return NBM_EINVAL;
   const size_t shmem = (size_t)cap * 8 + 256 * 4;
   hipLaunchKernelGGL(rpn_select_kernel, dim3(B), dim3(SEL_THREADS), shmem, (hipStream_t)stream, boxes, keys,
-                     keep_count, B, KA, top_n, fail_below, cap, sel_boxes, sel_scores, n_sel);
+                     keep_count, B, KA, top_n, fail_below, cap, sel_boxes, sel_scores, n_sel, per_image ? 1 : 0);
   return nbm_launch_status();
 }
 
 extern "C" int nbm_nms_batched(const float* boxes, const float* scores, const int* n_in, int B, int cap,
                                float thresh, int post_n, uint64_t* mask_ws, int* keep_ws, float* rois,
-                               float* roi_scores, int* n_out, void* stream) {
+                               float* roi_scores, int* n_out, int per_image, void* stream) {
   if (!boxes || !scores || !n_in || !mask_ws || !keep_ws || !rois || !roi_scores || !n_out || B <= 0) return NBM_EINVAL;
   if (cap <= 0 || cap > 4096 || (cap & 63) || post_n <= 0 || post_n > cap) return NBM_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const int words = cap / 64;
   int* keep_idx = keep_ws;
   int* keep_cnt = keep_ws + (size_t)B * cap;
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words, B), dim3(64), 0, st, boxes, n_in, cap, words, thresh,
+  const int ns = per_image ? 1 : 0;
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(words, words, B), dim3(64), 0, st, boxes, n_in, ns, cap, words, thresh,
                      reinterpret_cast<unsigned long long*>(mask_ws));
   hipLaunchKernelGGL(nms_scan_kernel, dim3(B), dim3(64), 0, st, reinterpret_cast<const unsigned long long*>(mask_ws),
-                     n_in, cap, words, keep_idx, keep_cnt);
+                     n_in, ns, cap, words, keep_idx, keep_cnt);
   hipLaunchKernelGGL(nms_gather_kernel, dim3(B), dim3(256), 0, st, boxes, scores, keep_idx, keep_cnt, B, cap, post_n,
-                     rois, roi_scores, n_out);
+                     rois, roi_scores, n_out, ns);
   return nbm_launch_status();
 }
 
@@ -521,7 +527,7 @@ extern "C" int nbm_roi_pool(const nbm_roi_desc* d, void* stream) {
     p.fmap[i] = d->fmap[i]; p.fh[i] = d->fh[i]; p.fw[i] = d->fw[i];
     if (i < d->n_levels && (!d->fmap[i] || d->fh[i] < 2 || d->fw[i] < 2)) return NBM_EINVAL;
   }
-  p.n_levels = d->n_levels; p.C = d->C; p.rois = d->rois; p.n_roi = d->n_roi; p.B = d->B; p.roi_cap = d->roi_cap;
+  p.n_levels = d->n_levels; p.C = d->C; p.rois = d->rois; p.n_roi = d->n_roi; p.n_stride = d->n_roi_per_image ? 1 : 0; p.B = d->B; p.roi_cap = d->roi_cap;
   p.pe_f = d->pe_f; p.pe_t = d->pe_t; p.img_h = d->img_h; p.img_w = d->img_w;
   p.pool = d->pool; p.pe = d->pe; p.level = d->level;
   hipLaunchKernelGGL(roi_pool_kernel, dim3(d->B * d->roi_cap), dim3(256), 0, (hipStream_t)stream, p);
@@ -531,12 +537,13 @@ extern "C" int nbm_roi_pool(const nbm_roi_desc* d, void* stream) {
 // RoI windows of pyramid level `level` -> list of the 2 x 2 output tiles they touch -- see nbm_hip.h.
 extern "C" int nbm_roi_tiles(const float* rois, const int* n_roi, int B, int roi_cap, int n_levels, int level,
                              const int* fh, const int* fw, const unsigned char* skip, int dilate, int* tiles, int* n_blocks,
-                             void* stream) {
+                             int per_image, void* stream) {
   if (!rois || !n_roi || !fh || !fw || !tiles || !n_blocks || B <= 0 || roi_cap <= 0 || n_levels < 1 || n_levels > 5 ||
       level < 0 || level >= n_levels || dilate < 0 || dilate > 2)
     return NBM_EINVAL;
   RoiTilesParams p{};
   p.dilate = dilate;
+  p.n_stride = per_image ? 1 : 0;
   for (int i = 0; i < n_levels; ++i) {
     if (fh[i] < 2 || fw[i] < 2) return NBM_EINVAL;
     p.fh[i] = fh[i]; p.fw[i] = fw[i];
@@ -554,11 +561,11 @@ extern "C" int nbm_roi_tiles(const float* rois, const int* n_roi, int B, int roi
 
 extern "C" int nbm_rcnn_post(const float* rois, const int* n_roi, int B, int roi_cap, const float* bbox_reg,
                              const float* bbox_cls, int n_cls1, int img_w, int img_h, float nms_thresh,
-                             float min_score, int proposal_number, float* det, int* n_det, void* stream) {
+                             float min_score, int proposal_number, float* det, int* n_det, int per_image, void* stream) {
   if (!rois || !n_roi || !bbox_reg || !bbox_cls || !det || !n_det || B <= 0 || roi_cap <= 0 || roi_cap > POST_MAX ||
       n_cls1 < 2)
     return NBM_EINVAL;
   hipLaunchKernelGGL(rcnn_post_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, rois, n_roi, roi_cap, bbox_reg,
-                     bbox_cls, n_cls1, img_w, img_h, nms_thresh, min_score, proposal_number, det, n_det);
+                     bbox_cls, n_cls1, img_w, img_h, nms_thresh, min_score, proposal_number, det, n_det, per_image ? 1 : 0);
   return nbm_launch_status();
 }

@@ -537,12 +537,20 @@ static int wino23_conv_fused_launch(const float* R, const float* U, const float*
   p.tiles = tiles; p.n_blocks = n_blocks; p.blk_info = blk_info;
   if (tiles) { p.T = n_entries; p.m_tiles = n_entries / BM; }
   hipStream_t st = (hipStream_t)stream;
-  const int abl = variant / 1000;
+  // `variant`: 0 = automatic, 128 / 64 = channel-tile width; anything else is refused.  The timing-only ablations of
+  // scripts/wino_fused_probe.py (variant + 1000 * ABL: WRONG results by design) exist only in a -DNBM_ABLATE build
+  // (make ablate -> libnbm_hip_ablate.so), never in the shipped library.
+  int abl = 0;
+#ifdef NBM_ABLATE
+  abl = variant / 1000;
   variant %= 1000;
+#endif
+  if (variant != 0 && variant != 64 && variant != 128) return NBM_EINVAL;
   const bool wide = variant == 128 || (variant == 0 && N % 128 == 0);
   p.n_tiles = wide ? (N + 127) / 128 : (N + 63) / 64;
   const dim3 grid((n_blocks ? (p.m_tiles + 7) / 8 * 8 : p.m_tiles) * p.n_tiles), block(256);
 #define NBM_WF(BN_, WN_, A_) hipLaunchKernelGGL((wino23_fused_kernel<BN_, WN_, A_>), grid, block, 0, st, p)
+#ifdef NBM_ABLATE
   if (wide) {
     switch (abl) { case 0: NBM_WF(128, 64, 0); break; case 1: NBM_WF(128, 64, 1); break; case 2: NBM_WF(128, 64, 2); break;
                    case 3: NBM_WF(128, 64, 3); break; case 7: NBM_WF(128, 64, 7); break; default: return NBM_EINVAL; }
@@ -550,6 +558,10 @@ static int wino23_conv_fused_launch(const float* R, const float* U, const float*
     switch (abl) { case 0: NBM_WF(64, 32, 0); break; case 1: NBM_WF(64, 32, 1); break; case 2: NBM_WF(64, 32, 2); break;
                    case 3: NBM_WF(64, 32, 3); break; case 7: NBM_WF(64, 32, 7); break; default: return NBM_EINVAL; }
   }
+#else
+  (void)abl;
+  if (wide) NBM_WF(128, 64, 0); else NBM_WF(64, 32, 0);
+#endif
 #undef NBM_WF
   return nbm_launch_status();
 }

@@ -101,6 +101,9 @@ class Conv(Function):
         wk = _prep.krsc(weight) if weight.dim() == 4 else weight.detach()
         gp = _pad32_rows(g.view(-1, N), N)
         gx = gw = gb = None
+        if ctx.lazy is not None and ctx.lazy.sparse and ctx.lazy.done != len(ctx.lazy.rois):
+            raise RuntimeError('demand-driven FPN map: a RoI pooling ran on it without recording its tile lists (the map was '
+                               'produced under no_grad?) -- its gradient would be dropped')
         if ctx.needs_input_grad[0] and ctx.lazy is not None and ctx.lazy.sparse and LAZY_DGRAD and N % 32 == 0 and N >= 64:
             # demand-driven map: the incoming gradient lives on the pattern pixels and in the RoI windows, the outgoing one
             # within a pixel of them -> the listed fused kernel on the tiles around them (F(2x2,3x3), no transforms through HBM)
@@ -229,7 +232,11 @@ def conv(x, weight, bias=None, scale=None, shift=None, residual=None, kh=1, kw=1
     elif lazy_stride and not (ondemand.LAZY_FINEST and _winograd_ok(x, weight, kh, kw, stride, pad) and x.shape[-1] >= 64):
         lazy_stride = None
     if lazy_stride:
-        lazy_stride = (int(lazy_stride), bool(torch.is_grad_enabled() and weight.requires_grad and LAZY_WGRAD))
+        # `keep`: a backward pass can follow (gradient wrt the weight OR the input): the RoI poolings record their tile lists
+        lazy_stride = (int(lazy_stride), bool(torch.is_grad_enabled() and (weight.requires_grad or x.requires_grad)))
+        # with one of the listed backward passes switched off (A/B switches) a DENSE backward kernel multiplies the holes of the
+        # sparse maps by exact-zero gradients: the holes must then be zeros, not uninitialised memory
+        ondemand.ZERO_FILL = not (LAZY_WGRAD and LAZY_DGRAD)
     return Conv.apply(x, weight, bias, scale, shift, residual, kh, kw, stride, pad, act, alpha, up, lazy_stride)
 
 

@@ -21,11 +21,12 @@ class Faster_RCNN(nn.Module):
     def forward_second_stage(self, *args, **kwargs):
         return self.fast_rcnn(*args, **kwargs)
 
-    def forward_first_stage_device(self, fpn_nhwc):
-        """-> (rois [B,cap,4], roi_scores, n_roi device int, cls NHWC, reg NHWC, raw cls NHWC); no host sync."""
+    def forward_first_stage_device(self, fpn_nhwc, independent=False):
+        """-> (rois [B,cap,4], roi_scores, n_roi device int32 [1] (or [B] with `independent`: every image a batch of its own),
+        cls NHWC, reg NHWC, raw cls NHWC); no host sync."""
         cls, reg, cls_raw = self.rpn.forward_nhwc(fpn_nhwc)
         with torch.no_grad():
-            rois, scores, n_roi = self.prop_layer.forward_device(cls.detach(), reg.detach())
+            rois, scores, n_roi = self.prop_layer.forward_device(cls.detach(), reg.detach(), independent=independent)
         return rois, scores, n_roi, cls, reg, cls_raw
 
     def forward_first_stage(self, fpn_pyramid_out, host_work=None):

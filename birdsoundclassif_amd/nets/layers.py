@@ -151,8 +151,9 @@ class ProposalLayer(nn.Module):
             self._anchors[key] = torch.from_numpy((a + s).reshape(-1, 4).astype(np.float32)).to(device)
         return self._anchors[key]
 
-    def forward_device(self, cls_nhwc, reg_nhwc):
-        """-> (rois [B,post_n,4], scores [B,post_n], n_roi int32[1] on device); n_roi = 0 <=> "RPN failed"."""
+    def forward_device(self, cls_nhwc, reg_nhwc, independent=False):
+        """-> (rois [B,post_n,4], scores [B,post_n], n_roi int32[1] on device); n_roi = 0 <=> "RPN failed".
+        `independent`: n_roi int32 [B], the batch-coupled minima of layers.py:287 / nets_utils.py:236 taken per image."""
         cfg = self.config
         B, h, w, c2 = cls_nhwc.shape
         n_anchor = c2 // 2
@@ -162,7 +163,7 @@ class ProposalLayer(nn.Module):
         boxes, keys, cnt = ops.rpn_decode(cls_nhwc, reg_nhwc, anchors, n_anchor, cfg.img_width, cfg.img_height,
                                           cfg.min_threshold)
         cap = _pow2_cap(pre)
-        sb, ss, n_sel = ops.rpn_select(boxes, keys, cnt, pre, cfg.rcnn_batch_size, cap)
+        sb, ss, n_sel = ops.rpn_select(boxes, keys, cnt, pre, cfg.rcnn_batch_size, cap, per_image=independent)
         return ops.nms_batched(sb, ss, n_sel, cfg.nms_thresh, post)
 
     def forward(self, labels_pred, bbox_reg):
@@ -399,6 +400,8 @@ class FastRCNN(nn.Module):
 
     def _head(self, pool, pe, rois, n_roi):
         if self.config.tf_rcnn:
+            if n_roi.numel() != 1:
+                raise NotImplementedError('Transformer_RCNN with per-image RoI counts (independent detection)')
             return self.rcnn.forward_nhwc(pool, pe, rois.shape[0], rois.shape[1], n_roi)
         return self.rcnn.forward_nhwc(pool, pe)
 

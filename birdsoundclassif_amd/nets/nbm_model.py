@@ -60,13 +60,15 @@ class NbmModel(nn.Module):
             return self.fpn(self.attn(features), lazy_strides=self._lazy_strides())
         return self.fpn(self.attn(features))
 
-    def forward_first_stage(self, samples, host_work=None, lazy=None):
+    def forward_first_stage(self, samples, host_work=None, lazy=False):
         """samples [B,1,H,W] f32 on the GPU -> {'rois','rpn_cls_scores','rpn_bbox_reg','fpn_out'} (nbm_model.py:39-54).
         Tensors are NCHW-shaped views of NHWC storage.  `host_work` (optional callable) runs after every kernel of the
         first stage has been queued and before the host waits for the RoI count, i.e. hidden behind the GPU work.
-        `lazy` (default: in training mode): 'fpn_out'[0] holds only the pixels its consumers read -- the RPN pattern now,
-        the RoI windows once forward_second_stage runs; pass lazy=False to inspect the whole map."""
-        fpn_out = self._fpn_nhwc(samples, lazy=self.training if lazy is None else lazy)
+        `lazy=False` (default): every map of 'fpn_out' is dense, like the reference's.  `lazy=True` (what this package's own
+        `train.step` and `detect` pass): 'fpn_out'[0] holds only the pixels its consumers read -- the RPN pattern now, the tiles
+        under the RoI windows once a RoI pooling (`forward_second_stage`, any number of times, any RoIs) runs on THIS tensor or a
+        full view of it; every other pixel is unwritten memory, so a clone / slice / arithmetic on the map is meaningless."""
+        fpn_out = self._fpn_nhwc(samples, lazy=lazy)
         rois, cls, reg = self.head.forward_first_stage([f.permute(0, 3, 1, 2) for f in fpn_out], host_work)
         return {'rois': rois, 'rpn_cls_scores': cls, 'rpn_bbox_reg': reg,
                 'fpn_out': [f.permute(0, 3, 1, 2) for f in fpn_out]}
@@ -84,11 +86,15 @@ class NbmModel(nn.Module):
         return outputs
 
     @torch.no_grad()
-    def detect(self, samples, nms_thresh=0.3, min_score=0.5):
+    def detect(self, samples, nms_thresh=0.3, min_score=0.5, independent=False):
         """Sync-free eval forward: -> (det [B,50,6] rows {class,x1,y1,x2,y2,score} sorted by (class, score desc),
-        n_det int32 [B]), both on the device.  Used by bulk inference; `forward` wraps it."""
+        n_det int32 [B]), both on the device.  Used by bulk inference; `forward` wraps it.
+        `independent=False`: the reference's semantics for ONE model call on this batch -- the proposal counts are coupled over
+        the batch (pre / post-NMS top-N = min over the images, layers.py:287, nets_utils.py:236).  `independent=True`: every
+        image is a batch of its own, i.e. the result of B model calls with one image each (what the reference CLI does with B
+        single-window files); the counts live in int32 [B] device tensors."""
         fpn_out = self._fpn_nhwc(samples, lazy=True)
-        rois, _, n_roi, _, _, _ = self.head.forward_first_stage_device(fpn_out)
+        rois, _, n_roi, _, _, _ = self.head.forward_first_stage_device(fpn_out, independent=independent)
         return self.head.fast_rcnn.detect_device(fpn_out, rois, n_roi, nms_thresh, min_score)
 
     def forward(self, samples, nms_thresh=0.3, min_score=0.5):

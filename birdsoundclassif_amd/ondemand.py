@@ -178,26 +178,39 @@ def lazy_chunk(x):
 
 class LazyMap:
     """Book-keeping of one demand-driven map: operands and, per batch chunk, the tile lists that were computed (pattern
-    list; RoI list + its block count on the way to the host) -- the weight gradient sums over them.  The map itself is
-    NOT referenced (an autograd node owns this object and the map owns the node: a cycle would keep 12 GB alive until the
-    garbage collector runs); its consumers keep it alive and hand it back to `lazy_complete`."""
-    __slots__ = ('x', 'U', 'bias', 'skip', 'stride', 'chunks', 'roi', 'keep', 'sparse', 'lateral', 'rois')
+    list; per RoI pooling on the map a RoI list + its block count on the way to the host) -- the weight gradient sums over
+    them.  The map itself is NOT referenced (an autograd node owns this object and the map owns the node: a cycle would keep
+    12 GB alive until the garbage collector runs); its consumers keep it alive and hand it back to `lazy_complete`.
+    The operands stay here for as long as the map lives, so EVERY RoI pooling on the map -- not only the first -- finds the
+    tiles under its windows computed (`done` counts them); the state goes when the map does (`_forget`)."""
+    __slots__ = ('x', 'U', 'bias', 'skip', 'stride', 'chunks', 'roi', 'keep', 'sparse', 'lateral', 'rois', 'done', '__weakref__')
 
     def __init__(self, x, U, bias, stride):
         self.x, self.U, self.bias, self.stride = x, U, bias, stride
-        self.skip, self.chunks, self.roi, self.keep, self.sparse, self.lateral, self.rois = None, [], None, False, True, None, None
+        self.skip, self.chunks, self.keep, self.sparse, self.lateral = None, [], False, True, None
+        self.roi = []           # per RoI pooling: per chunk (tile list, pinned block count, event)
+        self.rois = []          # per RoI pooling: (rois, n_roi, n_levels, level, fh, fw)
+        self.done = 0
+
+    def __del__(self):          # the pinned counters go back to the pool
+        try:
+            for per_chunk in self.roi:
+                for _, host, _ in per_chunk:
+                    _PINNED_FREE.append(host)
+        except Exception:       # interpreter shutdown
+            pass
 
 
-_PINNED = []
-_PINNED_NEXT = [0]
+_PINNED_FREE = []
 
 
 def _pinned_int():
-    """A pinned host int32 from a small ring (hipHostMalloc per step would stall the stream)."""
-    if not _PINNED:                               # all at once, on the first (warm-up) call
-        _PINNED.extend(torch.empty((1,), dtype=torch.int32, pin_memory=True) for _ in range(16))
-    _PINNED_NEXT[0] = (_PINNED_NEXT[0] + 1) % len(_PINNED)
-    return _PINNED[_PINNED_NEXT[0]]
+    """A pinned host int32 of its own for one (LazyMap, RoI pooling, chunk): taken from a pool that grows on demand (during the
+    warm-up steps: hipHostMalloc stalls the stream) and refilled when the LazyMap dies -- never shared between two maps that are
+    both waiting for their backward pass."""
+    if not _PINNED_FREE:
+        _PINNED_FREE.extend(torch.empty((1,), dtype=torch.int32, pin_memory=True) for _ in range(16))
+    return _PINNED_FREE.pop()
 
 
 _LAZY_LATERAL = {}                  # data_ptr of a sparse lateral map -> (LateralState, weakref to the map)
@@ -213,6 +226,25 @@ class LateralState:
         self.t, self.wk, self.bias, self.alpha, self.up = t, wk, bias, alpha, up
 
 
+ZERO_FILL = False                   # functional.py sets it when a DENSE backward kernel may read a sparse map (A/B switches off)
+
+
+def _sparse_map(shape, device):
+    """Storage of a map of which only the pixels with a reader are ever written.  torch.empty by default; zeros when a dense
+    backward pass will multiply the holes by exact-zero gradients (0 x garbage could be NaN); NaN under LAZY_POISON (tests)."""
+    if LAZY_POISON:
+        return torch.full(shape, float('nan'), device=device, dtype=torch.float32)
+    if ZERO_FILL and torch.is_grad_enabled():
+        return torch.zeros(shape, device=device, dtype=torch.float32)
+    return torch.empty(shape, device=device, dtype=torch.float32)
+
+
+def _forget(table, key, ident):
+    hit = table.get(key)
+    if hit is not None and id(hit[0]) == ident:
+        del table[key]
+
+
 def conv1x1_lazy(t, wk, bias, alpha, up, stride):
     """Lateral 1x1 convolution + bilinear top-down merge (fpn.py:143-144) on the pixels that the pattern tiles of the following
     demand-driven 3x3 convolution read (`TilePattern.px_rows`): t [B,H,W,Cin] -> x [B,H,W,N], other pixels unwritten.  Same
@@ -220,9 +252,7 @@ def conv1x1_lazy(t, wk, bias, alpha, up, stride):
     _chk(t, name='t'), _chk(wk, name='w')
     B, H, W, Cin = t.shape
     N = wk.shape[0]
-    x = torch.empty((B, H, W, N), device=t.device, dtype=torch.float32)
-    if LAZY_POISON:
-        x.fill_(float('nan'))
+    x = _sparse_map((B, H, W, N), t.device)
     chunk = lazy_chunk(x)                      # the same batch chunks as the convolution that follows
     for b0 in range(0, B, chunk):
         nb = min(chunk, B - b0)
@@ -231,7 +261,9 @@ def conv1x1_lazy(t, wk, bias, alpha, up, stride):
                   up=up[b0:b0 + nb] if up is not None else None, rows=pat.px_rows, rows_mode=1, rows_count=pat.px_rows.numel())
     for k in [k for k, v in _LAZY_LATERAL.items() if v[1]() is None]:
         del _LAZY_LATERAL[k]
-    _LAZY_LATERAL[x.data_ptr()] = (LateralState(t, wk, bias, alpha, up), weakref.ref(x))
+    ls = LateralState(t, wk, bias, alpha, up)
+    _LAZY_LATERAL[x.data_ptr()] = (ls, weakref.ref(x))
+    weakref.finalize(x, _forget, _LAZY_LATERAL, x.data_ptr(), id(ls))
     return x
 
 
@@ -242,9 +274,7 @@ def conv3x3_winograd_lazy(x, U, bias, stride):
     B, H, W, C_ = x.shape
     N = U.shape[1]
     assert U.shape == (16, N, C_) and C_ % 32 == 0 and C_ >= 64 and N % 4 == 0
-    y = torch.empty((B, H, W, N), device=x.device, dtype=torch.float32)
-    if LAZY_POISON:
-        y.fill_(float('nan'))
+    y = _sparse_map((B, H, W, N), x.device)
     st = LazyMap(x, U, bias, stride)
     lat = _LAZY_LATERAL.pop(x.data_ptr(), None)      # x itself only exists where the pattern tiles read it
     if lat is not None and lat[1]() is not None:
@@ -262,6 +292,7 @@ def conv3x3_winograd_lazy(x, U, bias, stride):
     for k in [k for k, v in _LAZY.items() if v[1]() is None]:      # maps of earlier forwards that were never completed
         del _LAZY[k]
     _LAZY[y.data_ptr()] = (st, weakref.ref(y))      # valid while the map object itself (or a view of it) is alive
+    weakref.finalize(y, _forget, _LAZY, y.data_ptr(), id(st))     # ... and gone with it (operands included)
     return y, st
 
 
@@ -272,25 +303,30 @@ def lazy_pending(fm):
 
 def lazy_complete(fm, rois, n_roi, fmap_hw, level=0):
     """Compute the tiles of the deferred map `fm` under the windows of the RoIs assigned to `level` (the windows
-    `roi_pool` reads).  rois [B,cap,4], n_roi device int32[1], fmap_hw: (h, w) of every pyramid level.  No-op for a map
-    that is not deferred."""
-    hit = _LAZY.pop(fm.data_ptr(), None)
+    `roi_pool` reads).  rois [B,cap,4], n_roi device int32[1] (or [B]: per-image counts), fmap_hw: (h, w) of every pyramid
+    level.  No-op for a map that is not deferred.  May be called any number of times on the same map (each RoI pooling calls it
+    with its own RoIs): the operands live as long as the map."""
+    hit = _LAZY.get(fm.data_ptr())
     if hit is None or hit[1]() is None:
         return
     st = hit[0]
     x, U, bias = st.x, st.U, st.bias
     B, H, W, C_ = x.shape
+    if tuple(fm.shape[0:1]) != (B,) or rois.shape[0] != B:
+        raise ValueError('lazy_complete: the RoIs do not belong to this map (batch size differs)')
     img_bytes = H * W * U.shape[1] * 4
     cap = rois.shape[1]
     _chk(rois, name='rois')
+    per = ops.per_image_counts(n_roi, B)
     nl = len(fmap_hw)
     fh = (C.c_int * nl)(*[int(h) for h, _ in fmap_hw])
     fw = (C.c_int * nl)(*[int(w) for _, w in fmap_hw])
     blocks_per_img = -(-((H + 1) // 2 * ((W + 1) // 2)) // 128)
     keep = st.keep and st.sparse                  # a backward pass will want the lists
-    st.roi = []
+    per_chunk = []
     for b0, nb, _ in st.chunks:
         key = (str(x.device), nb * blocks_per_img * 128)
+        nr = n_roi[b0:b0 + nb] if per else n_roi
         if keep:                                  # the backward pass reads the list again: a buffer of its own
             tiles = torch.empty((key[1],), device=x.device, dtype=torch.int32)
             n_blocks = torch.zeros((1,), device=x.device, dtype=torch.int32)
@@ -300,8 +336,8 @@ def lazy_complete(fm, rois, n_roi, fmap_hw, level=0):
                 buf = _ROI_TILE_BUF[key] = (torch.empty((key[1],), device=x.device, dtype=torch.int32),
                                             torch.zeros((1,), device=x.device, dtype=torch.int32))
             tiles, n_blocks = buf
-        check(lib().nbm_roi_tiles(_ptr(rois[b0:b0 + nb]), _ptr(n_roi), nb, cap, nl, level, fh, fw, _ptr(st.skip), 0, _ptr(tiles),
-                                  _ptr(n_blocks), _stream()), 'nbm_roi_tiles')
+        check(lib().nbm_roi_tiles(_ptr(rois[b0:b0 + nb]), _ptr(nr), nb, cap, nl, level, fh, fw, _ptr(st.skip), 0, _ptr(tiles),
+                                  _ptr(n_blocks), per, _stream()), 'nbm_roi_tiles')
         if st.lateral is not None:                # the input patches of these tiles first (16 pixels per listed tile)
             lt = st.lateral
             gemm_conv(lt.t[b0:b0 + nb], lt.wk, x[b0:b0 + nb], B=nb, H=H, W=W, Cin=lt.t.shape[-1], N=C_, w_ld=lt.wk.shape[1],
@@ -313,10 +349,11 @@ def lazy_complete(fm, rois, n_roi, fmap_hw, level=0):
             host.copy_(n_blocks, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-            st.roi.append((tiles, host, ev))
+            per_chunk.append((tiles, host, ev))
     if keep:                                      # the data gradient lists the tiles around these windows again
-        st.rois = (rois, n_roi, nl, level, fh, fw)
-    st.x = st.U = st.bias = st.lateral = None     # the backward pass gets x from the tape
+        st.roi.append(per_chunk)
+        st.rois.append((rois, n_roi, nl, level, fh, fw))
+    st.done += 1
 
 
 def conv3x3_winograd_dgrad_tiles(st, g, Ut):
@@ -335,16 +372,16 @@ def conv3x3_winograd_dgrad_tiles(st, g, Ut):
         pat = wino23_pattern(nb, H, W, st.stride, g.device, dilate=1)
         _wino23_tiles_run(g[b0:b0 + nb], Ut, None, gx.data_ptr() + b0 * img_bytes, pat.tiles, None, pat.n_eff, 'wino23-dgrad',
                           pat.blk_info)
-        if st.rois is not None:
-            rois, n_roi, nl, level, fh, fw = st.rois
+        for rois, n_roi, nl, level, fh, fw in st.rois:          # one entry per RoI pooling that read the map
+            per = ops.per_image_counts(n_roi, B)
             key = (str(g.device), nb * blocks_per_img * 128)
             buf = _ROI_TILE_BUF.get(key)
             if buf is None:
                 buf = _ROI_TILE_BUF[key] = (torch.empty((key[1],), device=g.device, dtype=torch.int32),
                                             torch.zeros((1,), device=g.device, dtype=torch.int32))
             tiles, n_blocks = buf
-            check(lib().nbm_roi_tiles(_ptr(rois[b0:b0 + nb]), _ptr(n_roi), nb, rois.shape[1], nl, level, fh, fw, _ptr(pat.full), 1,
-                                      _ptr(tiles), _ptr(n_blocks), _stream()), 'nbm_roi_tiles')
+            check(lib().nbm_roi_tiles(_ptr(rois[b0:b0 + nb]), _ptr(n_roi[b0:b0 + nb] if per else n_roi), nb, rois.shape[1], nl, level,
+                                      fh, fw, _ptr(pat.full), 1, _ptr(tiles), _ptr(n_blocks), per, _stream()), 'nbm_roi_tiles')
             _wino23_tiles_run(g[b0:b0 + nb], Ut, None, gx.data_ptr() + b0 * img_bytes, tiles, n_blocks, None, 'wino23-dgrad-rois')
     return gx
 
@@ -363,17 +400,26 @@ def conv3x3_winograd_wgrad_tiles(st, x, g, want_bias=False):
     thw = ((H + 1) // 2) * ((W + 1) // 2)
     for ci, (b0, nb, pat) in enumerate(st.chunks):
         lists, infos = [pat.tiles], [pat.entry_pm]
-        if st.roi:
-            tiles, host, ev = st.roi[ci]
+        parts = []
+        for per_chunk in st.roi:                    # one entry per RoI pooling that read the map
+            tiles, host, ev = per_chunk[ci]
             ev.synchronize()                        # recorded during the forward pass: long done
             n = int(host.item()) * 128
             if n:
-                # the RoI phase recomputed pattern tiles of which only some pixels had been stored: the planes of their class
-                # come from the pattern list, this entry contributes the others
-                roi = tiles[:n]
-                lists.append(roi)
-                tpm = pat.tile_pm[roi.clamp(min=0) % thw]
-                infos.append((0xffff & ~tpm) | ((tpm == 0).int() << 16))
+                parts.append(tiles[:n])
+        if parts:
+            if len(parts) == 1:
+                roi = parts[0]
+            else:                                   # several RoI sets: every tile once (ascending ids, -1 padding at the end)
+                u = torch.unique(torch.cat(parts))
+                u = u[u >= 0]
+                roi = torch.full((-(-u.numel() // 128) * 128,), -1, device=u.device, dtype=torch.int32)
+                roi[:u.numel()] = u
+            # the RoI phase recomputed pattern tiles of which only some pixels had been stored: the planes of their class
+            # come from the pattern list, this entry contributes the others
+            lists.append(roi)
+            tpm = pat.tile_pm[roi.clamp(min=0) % thw]
+            infos.append((0xffff & ~tpm) | ((tpm == 0).int() << 16))
         full = torch.cat(lists) if len(lists) > 1 else lists[0]
         info = torch.cat(infos) if len(infos) > 1 else infos[0]
         xs, gs = x[b0:b0 + nb], g[b0:b0 + nb]

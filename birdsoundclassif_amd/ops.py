@@ -498,13 +498,23 @@ def rpn_decode(cls, reg, anchors, n_anchor, img_w, img_h, min_size):
     return boxes, keys, cnt
 
 
-def rpn_select(boxes, keys, keep_count, top_n, fail_below, cap):
+def per_image_counts(n, B):
+    """Count tensors are int32 [1] (one count for the whole batch: the reference's batch-coupled semantics) or int32 [B] (every
+    image a batch of its own, `independent` detection) -> the `per_image` flag of the C ABI."""
+    if n.numel() == 1:
+        return 0
+    if n.numel() != B:
+        raise ValueError(f'count tensor with {n.numel()} entries for a batch of {B}')
+    return 1
+
+
+def rpn_select(boxes, keys, keep_count, top_n, fail_below, cap, per_image=False):
     B, KA = keys.shape
     sel_boxes = torch.empty((B, cap, 4), device=boxes.device, dtype=torch.float32)
     sel_scores = torch.empty((B, cap), device=boxes.device, dtype=torch.float32)
-    n_sel = torch.empty((1,), device=boxes.device, dtype=torch.int32)
+    n_sel = torch.empty((B if per_image and B > 1 else 1,), device=boxes.device, dtype=torch.int32)
     check(lib().nbm_rpn_select(_ptr(boxes), _ptr(keys), _ptr(keep_count), B, KA, top_n, fail_below, cap,
-                               _ptr(sel_boxes), _ptr(sel_scores), _ptr(n_sel), _stream()), 'nbm_rpn_select')
+                               _ptr(sel_boxes), _ptr(sel_scores), _ptr(n_sel), per_image_counts(n_sel, B), _stream()), 'nbm_rpn_select')
     return sel_boxes, sel_scores, n_sel
 
 
@@ -517,9 +527,10 @@ def nms_batched(boxes, scores, n_in, thresh, post_n):
     keep_ws = torch.empty((B * (cap + 1),), device=boxes.device, dtype=torch.int32)
     rois = torch.empty((B, post_n, 4), device=boxes.device, dtype=torch.float32)
     rs = torch.empty((B, post_n), device=boxes.device, dtype=torch.float32)
-    n_out = torch.empty((1,), device=boxes.device, dtype=torch.int32)
+    per = per_image_counts(n_in, B)
+    n_out = torch.empty((B if per else 1,), device=boxes.device, dtype=torch.int32)
     check(lib().nbm_nms_batched(_ptr(boxes), _ptr(scores), _ptr(n_in), B, cap, float(thresh), post_n, _ptr(mask_ws),
-                                _ptr(keep_ws), _ptr(rois), _ptr(rs), _ptr(n_out), _stream()), 'nbm_nms_batched')
+                                _ptr(keep_ws), _ptr(rois), _ptr(rs), _ptr(n_out), per, _stream()), 'nbm_nms_batched')
     return rois, rs, n_out
 
 
@@ -534,6 +545,7 @@ def roi_pool(fmaps, rois, n_roi, pe_f, pe_t, img_h, img_w):
         d.fh[i], d.fw[i] = f.shape[1], f.shape[2]
     d.n_levels, d.C = len(fmaps), C_
     d.rois, d.n_roi, d.B, d.roi_cap = _chk(rois).data_ptr(), n_roi.data_ptr(), B, cap
+    d.n_roi_per_image = per_image_counts(n_roi, B)
     d.pe_f, d.pe_t, d.img_h, d.img_w = _chk(pe_f).data_ptr(), _chk(pe_t).data_ptr(), img_h, img_w
     pool = torch.zeros((B * cap, 2, 2, C_), device=rois.device, dtype=torch.float32)
     pe = torch.zeros((B * cap, 2, 2, C_), device=rois.device, dtype=torch.float32)
@@ -551,7 +563,7 @@ def rcnn_post(rois, n_roi, bbox_reg, bbox_cls, img_w, img_h, nms_thresh, min_sco
     n_det = torch.zeros((B,), device=rois.device, dtype=torch.int32)
     check(lib().nbm_rcnn_post(_ptr(_chk(rois)), _ptr(n_roi), B, cap, _ptr(_chk(bbox_reg)), _ptr(_chk(bbox_cls)),
                               n_cls1, img_w, img_h, float(nms_thresh), float(min_score), int(proposal_number),
-                              _ptr(det), _ptr(n_det), _stream()), 'nbm_rcnn_post')
+                              _ptr(det), _ptr(n_det), per_image_counts(n_roi, B), _stream()), 'nbm_rcnn_post')
     return det, n_det
 
 

@@ -236,7 +236,8 @@ def step(model, criterion, batch, device, negative_sample):
     if not negative_sample and hasattr(criterion, 'precompute_first_stage_targets'):
         # AnchorTargetLayer (host, NumPy RNG) runs while the GPU executes the first-stage forward queued before it
         host_work = lambda: criterion.precompute_first_stage_targets(bb_coord, lengths)
-    out_first_stage = model.forward_first_stage(inpt, host_work) if host_work else model.forward_first_stage(inpt)
+    # lazy=True: the finest FPN map is computed where it is read; it goes straight into forward_second_stage below
+    out_first_stage = model.forward_first_stage(inpt, host_work, lazy=True)
     loss.update(criterion.first_stage_loss(out_first_stage['rpn_cls_scores'], out_first_stage['rpn_bbox_reg'],
                                            bb_coord, lengths, negative_sample))
     if len(out_first_stage['rois']) == 0:            # "RPN failed": first-stage loss only

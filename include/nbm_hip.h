@@ -144,7 +144,8 @@ int nbm_wino23_conv_fused_tiles(const float* R, const float* U, const float* sca
                                 int relu, int B, int H, int W, int C, int N, float* y, const int* tiles, int n_entries,
                                 const int* n_blocks, const unsigned* blk_info, void* stream);
 int nbm_roi_tiles(const float* rois, const int* n_roi, int B, int roi_cap, int n_levels, int level, const int* fh,
-                  const int* fw, const unsigned char* skip, int dilate, int* tiles, int* n_blocks, void* stream);
+                  const int* fw, const unsigned char* skip, int dilate, int* tiles, int* n_blocks,
+                  int per_image /* n_roi[b] instead of n_roi[0]: see nbm_rpn_select */, void* stream);
 /* Weight gradient of such a demand-driven convolution: the gradient wrt its output is zero outside the tiles that were
  * read, so only those tiles enter dU[xi] = dM[xi]^T V[xi].  F(2x2,3x3) transforms of the listed tiles (entry -1 = a zero
  * row) into COMPACT operands V [16][n_list][C] and dM [16][n_list][N] (+ bias gradient [N], optional, accumulated); the 16
@@ -279,18 +280,23 @@ int nbm_rpn_decode(const float* cls, const float* reg, const float* anchors /*[K
 
 /* Top-N selection by (score desc, index asc) among kept anchors, N = min(top_n, min_b keep_count[b]);
  * writes sel_boxes[b][cap][4], sel_scores[b][cap], n_sel[0] = N (0 if N < fail_below: "RPN failed"
- * layers.py:287-290).  -- layers.py:292-297.  cap >= top_n, cap power of two <= 4096. */
+ * layers.py:287-290).  -- layers.py:292-297.  cap >= top_n, cap power of two <= 4096.
+ * per_image != 0: the B images are B independent batches of one (bulk inference over files that the reference CLI
+ * runs one per model call, nbm_detect.py:24-28): N_b = min(top_n, keep_count[b]), n_sel[b] = N_b -- no image's
+ * proposal count depends on its launch-mates.  The same flag on nbm_nms_batched / nbm_roi_pool (desc field) /
+ * nbm_roi_tiles / nbm_rcnn_post makes them read their count as n[b] instead of n[0]. */
 int nbm_rpn_select(const float* boxes, const uint32_t* keys, const int* keep_count, int B, int KA,
                    int top_n, int fail_below, int cap, float* sel_boxes, float* sel_scores, int* n_sel,
-                   void* stream);
+                   int per_image, void* stream);
 
 /* Greedy NMS in the given order (suppress IoU >= thresh, +1 pixel convention) then the batch-coupled
  * truncation R = min(post_n, min_b #keep_b) -- nets_utils.py:189-245.  n_in[0] boxes per image.
  * Workspaces: mask_ws B*cap*(cap/64) uint64, keep_ws B*(cap+1) int32.  Writes rois[b][post_n][4],
- * roi_scores[b][post_n], n_out[0] = R.  cap: multiple of 64, <= 4096. */
+ * roi_scores[b][post_n], n_out[0] = R.  cap: multiple of 64, <= 4096.
+ * per_image != 0: n_in[b] boxes in image b, R_b = min(post_n, #keep_b), n_out[b] = R_b. */
 int nbm_nms_batched(const float* boxes, const float* scores, const int* n_in, int B, int cap, float thresh,
                     int post_n, uint64_t* mask_ws, int* keep_ws, float* rois, float* roi_scores, int* n_out,
-                    void* stream);
+                    int per_image, void* stream);
 
 /* ROIPooling (layers.py:406-497): level assignment, window, 2x2 adaptive average of the FPN map and of
  * the separable positional encoding.  fmaps: 5 device pointers (NHWC, C channels); pe_f [img_h][C/2],
@@ -300,10 +306,11 @@ typedef struct nbm_roi_desc {
   int fh[5], fw[5];
   int n_levels, C;
   const float* rois;     /* [B][roi_cap][4] */
-  const int* n_roi;      /* device scalar   */
+  const int* n_roi;      /* device scalar, or [B] with n_roi_per_image */
   int B, roi_cap;
   const float* pe_f; const float* pe_t; int img_h, img_w;
   float* pool; float* pe; int* level;
+  int n_roi_per_image;   /* != 0: n_roi[b] RoIs in image b (see nbm_rpn_select) */
 } nbm_roi_desc;
 int nbm_roi_pool(const nbm_roi_desc* d, void* stream);
 
@@ -314,7 +321,7 @@ int nbm_roi_pool(const nbm_roi_desc* d, void* stream);
 int nbm_rcnn_post(const float* rois, const int* n_roi, int B, int roi_cap, const float* bbox_reg,
                   const float* bbox_cls, int n_cls1 /*1+num_classes*/, int img_w, int img_h,
                   float nms_thresh, float min_score, int proposal_number, float* det, int* n_det,
-                  void* stream);
+                  int per_image /* n_roi[b] */, void* stream);
 
 /* ================================================================================================
  * Training path: backward implicit GEMMs, point-wise gradients, train-mode BatchNorm, optimiser.

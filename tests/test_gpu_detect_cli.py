@@ -91,6 +91,44 @@ def test_nbm_detect_cli_on_8_wavs(tmp_path):
     assert n_total > 0
 
 
+def test_cli_bulk_route_writes_the_same_files_as_the_per_file_driver(tmp_path):
+    """nbm_detect routes equal-length single-window clips through the pipelined hipGraph loop (bulk.detect_files, every clip an
+    independent batch of one) and everything else through the per-file driver: the txt files are byte-identical to a run with
+    --no_bulk (per-file driver for every file = the reference's loop, nbm_detect.py:24-28)."""
+    import shutil
+    from birdsoundclassif_amd import bulk, nbm_detect
+    from birdsoundclassif_amd.train import default_args
+    ck = tmp_path / 'model_weights'
+    ck.mkdir()
+    args = default_args(device='cuda')
+    cfg = {k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in vars(args).items() if k not in ('scales',)}
+    (ck / 'args').write_text(json.dumps(cfg))
+    torch.save({'checkpoints': filler_state_dict(), 'steps': 0, 'epoch': 0, 'best_val_cls_loss': 99}, str(ck / 'model_chkpt.pt'))
+    (tmp_path / 'bird_dict.json').write_text(json.dumps({f'Species {i}': i for i in range(1, 151)}))
+    a, b = tmp_path / 'bulk', tmp_path / 'perfile'
+    a.mkdir()
+    for i in range(11):                              # 11 clips: a full batch of 8 + a padded one
+        synth.write_wav(str(a / f'clip{i:02d}.wav'), synth.clip_pcm16(400 + i), 22050)
+    synth.write_wav(str(a / 'quiet.wav'), (synth.clip_pcm16(420) // 64).astype(np.int16), 22050)    # same length, low level
+    long = np.concatenate([synth.clip_pcm16(430), synth.clip_pcm16(431)])
+    synth.write_wav(str(a / 'long.wav'), long, 22050)                                               # two windows: per-file route
+    synth.write_wav(str(a / 'short.wav'), synth.clip_pcm16(432)[:40000], 22050)                     # other length: alone in its group
+    shutil.copytree(str(a), str(b))
+    groups, rest = bulk.bulk_groups(sorted(str(p) for p in a.glob('*.wav')))
+    assert sorted(len(v) for v in groups.values()) == [1, 12] and [os.path.basename(f) for f in rest] == ['long.wav']
+    common = ['--ckpt', str(ck), '--min_score', '0.05', '--batch', '4', '--bird_dict', str(tmp_path / 'bird_dict.json')]
+    nbm_detect.main(common + ['--audio_dir', str(a), '--bulk_batch', '8'])
+    nbm_detect.main(common + ['--audio_dir', str(b), '--no_bulk'])
+    names = sorted(p.name for p in a.glob('*.txt'))
+    assert len(names) == 14 and names == sorted(p.name for p in b.glob('*.txt'))
+    n = 0
+    for name in names:
+        ta, tb = (a / name).read_text(), (b / name).read_text()
+        assert ta == tb, name
+        n += sum(len(v['scores']) for v in ast.literal_eval(ta).values())
+    assert n > 0
+
+
 def test_graphed_bulk_detection_matches_per_file_driver(tmp_path):
     """configs[4] in miniature: hipGraph-captured detect loop over a wav shard == the per-file run_detection driver."""
     from birdsoundclassif_amd import bulk

@@ -44,7 +44,7 @@ def test_listed_tiles_equal_the_dense_convolution(shape):
     dense = ops.conv3x3_winograd(x, U, b)
     ondemand.LAZY_POISON = True
     try:
-        y, _ = ondemand.conv3x3_winograd_lazy(x, U, b, S)
+        y, st = ondemand.conv3x3_winograd_lazy(x, U, b, S)
     finally:
         ondemand.LAZY_POISON = False
     pat = ondemand.wino23_pattern(B, H, W, S, x.device)
@@ -80,7 +80,7 @@ def test_listed_tiles_equal_the_dense_convolution(shape):
     n_d = torch.tensor([n_roi], dtype=torch.int32, device='cuda')
     assert ondemand.lazy_pending(y)
     ondemand.lazy_complete(y, rois_d, n_d, list(zip(fh, fw)), level=0)
-    assert not ondemand.lazy_pending(y)
+    assert ondemand.lazy_pending(y) and st.done == 1       # the state lives as long as the map: a later RoI set can be completed too
     want = m[None].repeat(B, 1, 1).clone().cpu()
     n_lvl0 = 0
     for bi in range(B):
@@ -167,7 +167,7 @@ def test_weight_gradient_over_the_listed_tiles_equals_the_dense_one():
     # pixels with a reader: the pattern pixels + every pixel of the tiles under the RoIs (re-derived from the kept RoI list)
     TH, TW = (H + 1) // 2, (W + 1) // 2
     m = ~torch.isnan(y[..., 0])                      # the map was NaN-poisoned: written == has a reader
-    tiles, host, ev = st.roi[0]
+    tiles, host, ev = st.roi[0][0]
     ev.synchronize()
     ids = tiles[:int(host.item()) * 128]
     assert int((ids >= 0).sum()) > 0
@@ -295,6 +295,112 @@ def test_detections_do_not_change_and_no_unwritten_pixel_is_read(model, B):
             ondemand.LAZY_POISON = False
     assert int(n0.sum()) > 0
     assert torch.equal(n0, n1) and torch.equal(det0, det1)        # NaN anywhere in the consumed pixels would break this
+
+
+def test_independent_detection_equals_one_image_per_call(model):
+    """detect(..., independent=True) on a batch == detect() on each image alone, bit for bit (bulk inference: the reference CLI
+    runs one file per model call).  Image 2 is blank: its proposal counts differ from its launch-mates'."""
+    x = torch.from_numpy(synth.image_batch(0, 5))[:, None].cuda()
+    x[2] = 0.0
+    with torch.no_grad():
+        det, n = model.detect(x, min_score=0.05, independent=True)
+        for b in range(5):
+            d1, n1 = model.detect(x[b:b + 1], min_score=0.05)
+            assert int(n[b]) == int(n1[0]), (b, int(n[b]), int(n1[0]))
+            assert torch.equal(det[b, :int(n1[0])], d1[0, :int(n1[0])]), b
+    assert int(n.sum()) > 0
+
+
+def _train_model():
+    from birdsoundclassif_amd import train as T
+    from birdsoundclassif_amd.nets import build_model
+    args = T.default_args(device='cuda')
+    m, _ = build_model(args)
+    m.load_state_dict(filler_state_dict())
+    return m.cuda().train()
+
+
+def test_a_second_roi_pooling_on_a_held_map_sees_its_tiles():
+    """The on-demand map stays completable for as long as it lives: two forward_second_stage calls with DIFFERENT RoIs on one
+    train-mode lazy `fpn_out` both equal the dense path (values and the gradients of both calls summed), and
+    forward_first_stage() hands out dense maps unless lazy=True is asked for (like the reference, nbm_model.py:39-54)."""
+    m = _train_model()
+    B = 2
+    x = torch.from_numpy(synth.image_batch(0, B))[:, None].cuda()
+    u = synth.uniform('rois2', 2 * B * 12 * 4).reshape(2, B, 12, 4)
+
+    def boxes(v, big):
+        x1, y1 = np.floor(v[..., 0] * 900), np.floor(v[..., 1] * 330)
+        w, h = np.floor(4 + v[..., 2] * (200 if big else 18)), np.floor(4 + v[..., 3] * (40 if big else 14))
+        return torch.tensor(np.stack([x1, y1, np.minimum(x1 + w, 1023), np.minimum(y1 + h, 374)], -1), dtype=torch.float32).cuda()
+    r1, r2 = boxes(u[0], False), boxes(u[1], True)
+    r2[:, :6] = boxes(u[1][:, :6] * 0.5 + 0.3, False)        # both sets hold level-0 RoIs, at different places
+    res = {}
+    for lazy in (False, True):
+        m.zero_grad(set_to_none=True)
+        ondemand.LAZY_POISON = lazy
+        try:
+            o = m.forward_first_stage(x, lazy=lazy)
+            if lazy:
+                assert bool(torch.isnan(o['fpn_out'][0]).any())              # holes: the map really is sparse here
+            s1 = m.forward_second_stage(o['fpn_out'], r1, training=True)
+            s2 = m.forward_second_stage(o['fpn_out'], r2, training=True)
+        finally:
+            ondemand.LAZY_POISON = False
+        loss = (s1['bbox_classes'][:, 1:8].sum() + s1['bbox_reg'][:, :40].sum() * 0.1 +
+                s2['bbox_classes'][:, 3:9].sum() * 2.0 + s2['bbox_reg'][:, 40:90].sum() * 0.05 + o['rpn_cls_scores'][:, :3].sum() * 0.01)
+        loss.backward()
+        torch.cuda.synchronize()
+        res[lazy] = ([v.detach().clone() for v in (s1['bbox_reg'], s1['bbox_classes'], s2['bbox_reg'], s2['bbox_classes'])],
+                     {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
+    dflt = m.forward_first_stage(x)['fpn_out'][0]
+    assert bool(torch.isfinite(dflt).all())                                   # default: dense
+    for a, b in zip(res[False][0], res[True][0]):
+        assert torch.isfinite(b).all() and torch.equal(a, b)
+    assert set(res[False][1]) == set(res[True][1])
+    for k, g in res[False][1].items():
+        g2 = res[True][1][k]
+        assert torch.isfinite(g2).all(), k
+        tol = 2e-3 * float(g.abs().max()) + 1e-7          # dense path: F(4x4,3x3) gradients of out_convs.4; listed path: F(2x2,3x3)
+        assert float((g - g2).abs().max()) <= tol, (k, float((g - g2).abs().max()), tol)
+
+
+@pytest.mark.parametrize('case', ['frozen_weight', 'wgrad_switch_off', 'dgrad_switch_off'])
+def test_listed_backward_with_a_frozen_weight_or_a_switch_off(case):
+    """the RoI tile lists must be recorded whenever ANY gradient can follow -- with fpn.out_convs.4.weight frozen the
+    data gradient under the RoI windows used to be dropped -- and with one of the listed backward passes switched off the dense
+    kernel that replaces it must not meet uninitialised memory in the holes of the sparse maps (0 x NaN)."""
+    m = _train_model()
+    B = 2
+    x = torch.from_numpy(synth.image_batch(0, B))[:, None].cuda()
+    u = synth.uniform('rois3', B * 12 * 4).reshape(B, 12, 4)
+    x1, y1 = np.floor(u[..., 0] * 900), np.floor(u[..., 1] * 330)
+    rois = torch.tensor(np.stack([x1, y1, np.minimum(x1 + np.floor(4 + u[..., 2] * 18), 1023),
+                                  np.minimum(y1 + np.floor(4 + u[..., 3] * 14), 374)], -1), dtype=torch.float32).cuda()
+    if case == 'frozen_weight':
+        m.fpn.out_convs['4'].weight.requires_grad_(False)
+    res = {}
+    for lazy in (False, True):
+        m.zero_grad(set_to_none=True)
+        if lazy and case == 'wgrad_switch_off':
+            Fn.LAZY_WGRAD = False
+        if lazy and case == 'dgrad_switch_off':
+            Fn.LAZY_DGRAD = False
+        try:
+            o = m.forward_first_stage(x, lazy=lazy)
+            s = m.forward_second_stage(o['fpn_out'], rois, training=True)
+            (s['bbox_classes'][:, 1:8].sum() + s['bbox_reg'][:, :40].sum() * 0.1).backward()
+        finally:
+            Fn.LAZY_WGRAD = Fn.LAZY_DGRAD = True
+        torch.cuda.synchronize()
+        res[lazy] = {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+    assert set(res[False]) == set(res[True]) and ('fpn.out_convs.4.weight' in res[True]) == (case != 'frozen_weight')
+    assert 'fpn.pt_wise.0.weight' in res[True] and float(res[False]['fpn.pt_wise.0.weight'].abs().max()) > 0
+    for k, g in res[False].items():
+        g2 = res[True][k]
+        assert torch.isfinite(g2).all(), k
+        tol = 2e-3 * float(g.abs().max()) + 1e-7
+        assert float((g - g2).abs().max()) <= tol, (k, float((g - g2).abs().max()), tol)
 
 
 @pytest.mark.parametrize('negative', [False, True])

@@ -205,6 +205,36 @@ def test_rpn_failed_path():
     assert rois.numel() == 0 and scores.numel() == 0
 
 
+def test_proposal_layer_independent_images_equal_one_image_per_call():
+    """`independent=True` (bulk inference): every image of the launch gets the RoIs the reference gives it when it is run ALONE
+    (one file per model call, reference nbm_detect.py:24-28) -- the batch-coupled minima of layers.py:287 / nets_utils.py:236 do
+    not leak between launch-mates.  Image 1 keeps few anchors, image 2 fails ("RPN failed"), images 0 and 3 fill the top-N."""
+    from birdsoundclassif_amd.nets.layers import ProposalLayer
+    from birdsoundclassif_amd.train import default_args
+    cfg, cls, reg = _rpn_inputs(4, 7)
+    few = reg[1, :, 5:6, 10:13].clone()             # image 1: all boxes collapse below min_threshold but those of 3 positions
+    reg[1] = -20.0
+    reg[1, :, 5:6, 10:13] = few
+    reg[2] = -20.0                                  # image 2: none survives
+    pl = ProposalLayer(default_args(), 5).eval()
+    rois, scores, n = pl.forward_device(cls.permute(0, 2, 3, 1).contiguous().cuda(), reg.permute(0, 2, 3, 1).contiguous().cuda(),
+                                        independent=True)
+    assert n.shape == (4,)
+    n = n.cpu().tolist()
+    coupled = pl.forward_device(cls.permute(0, 2, 3, 1).contiguous().cuda(), reg.permute(0, 2, 3, 1).contiguous().cuda())[2]
+    assert int(coupled.item()) == 0                 # one call on the whole batch: image 2 fails everybody (reference semantics)
+    seen = set()
+    for b in range(4):
+        ref_rois, ref_scores = O.proposal_layer(cfg, cls[b:b + 1], reg[b:b + 1], training=False)
+        nb = ref_rois.shape[1] if ref_rois.numel() else 0
+        assert n[b] == nb, (b, n[b], nb)
+        seen.add(nb)
+        if nb:
+            assert torch.equal(rois[b, :nb].cpu(), ref_rois[0]) and torch.equal(scores[b, :nb].cpu(), ref_scores[0])
+        assert not rois[b, nb:].any()
+    assert 0 in seen and 50 in seen and len(seen) >= 3, seen
+
+
 def test_nms_ties_and_order():
     # many identical boxes / scores: greedy NMS must walk in the given order
     boxes = torch.tensor([[10., 10, 50, 50], [10, 10, 50, 50], [12, 12, 52, 52], [200, 100, 260, 160],
