@@ -135,6 +135,11 @@ class Conv(Function):
             gw = _w_to_ref_layout(gwk, weight)
         elif want_gb:
             gb = ops.colsum(gp, N)
+        if ctx.lazy is not None:
+            # the map's gradient has been consumed: drop the operands the LazyMap kept for further RoI poolings, as the tape
+            # drops its saved tensors (19 GB of merged map + the lateral's inputs at B = 128 would otherwise stay allocated
+            # through the rest of the backward pass)
+            ctx.lazy.release()
         gres = g if (ctx.has_res and ctx.needs_input_grad[5]) else None
         gup = None
         if ctx.up_hw is not None and ctx.needs_input_grad[12]:        # fused top-down merge: d/d(coarse map)

@@ -192,6 +192,10 @@ class LazyMap:
         self.rois = []          # per RoI pooling: (rois, n_roi, n_levels, level, fh, fw)
         self.done = 0
 
+    def release(self):
+        """Called by the backward pass of the convolution: no RoI pooling can follow on a map whose gradient has been consumed."""
+        self.x = self.U = self.bias = self.lateral = None
+
     def __del__(self):          # the pinned counters go back to the pool
         try:
             for per_chunk in self.roi:
@@ -311,6 +315,10 @@ def lazy_complete(fm, rois, n_roi, fmap_hw, level=0):
         return
     st = hit[0]
     x, U, bias = st.x, st.U, st.bias
+    if x is None:
+        raise RuntimeError('this demand-driven FPN map has been through its backward pass: its operands are gone and the tiles '
+                           'under new RoIs cannot be computed any more (pool before calling backward, or ask '
+                           'forward_first_stage for dense maps: lazy=False)')
     B, H, W, C_ = x.shape
     if tuple(fm.shape[0:1]) != (B,) or rois.shape[0] != B:
         raise ValueError('lazy_complete: the RoIs do not belong to this map (batch size differs)')

@@ -281,15 +281,29 @@ def allreduce_grads(optimizer_or_model):
         else:
             dist.all_reduce(bits, op=dist.ReduceOp.MAX)
         optimizer_or_model.set_touched_bitmap(bits)
-    else:                                             # plain module: flatten once (used by the gloo CPU tests)
-        grads = [p.grad for p in optimizer_or_model.parameters() if p.grad is not None]
-        flat = torch.cat([g.reshape(-1) for g in grads])
+    else:
+        # plain module (torch optimiser; the gloo CPU tests): EVERY trainable parameter in module order, zeros where this rank
+        # has no gradient, plus one flag per parameter -- so that all ranks reduce buffers of the same length whatever soft
+        # failure one of them went through, and a parameter that got a gradient on ANY rank gets the average on every rank
+        params = [p for p in optimizer_or_model.parameters() if p.requires_grad]
+        if not params:
+            return
+        dev = params[0].device
+        flags = torch.tensor([0.0 if p.grad is None else 1.0 for p in params], device=dev)
+        flat = torch.cat([(torch.zeros_like(p) if p.grad is None else p.grad).reshape(-1).to(torch.float32) for p in params] + [flags])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        touched = flat[-len(params):] > 0
         flat.div_(world)
         off = 0
-        for g in grads:
-            g.copy_(flat[off:off + g.numel()].view_as(g))
-            off += g.numel()
+        for p, t in zip(params, touched.tolist()):
+            n = p.numel()
+            if t:
+                avg = flat[off:off + n].view_as(p).to(p.dtype)
+                if p.grad is None:
+                    p.grad = avg.clone()
+                else:
+                    p.grad.copy_(avg)
+            off += n
         return
     for b in bufs:
         if dist.get_backend() == 'nccl':

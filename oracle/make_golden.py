@@ -100,6 +100,9 @@ def variants_golden():
             pack(g, f'{tag}.rpn_cls_scores', o['rpn_cls_scores'], full_limit=10000)
             pack(g, f'{tag}.rpn_bbox_reg', o['rpn_bbox_reg'], full_limit=10000)
             pack(g, f'{tag}.rois', o['rois'])
+            rois2, roi_scores = model.head.prop_layer(o['rpn_cls_scores'], o['rpn_bbox_reg'])     # head.py:35 drops the scores
+            assert torch.equal(rois2, o['rois'])
+            pack(g, f'{tag}.roi_scores', roi_scores)
             pack_dets(g, f'{tag}.dets_min0.2', model(x, min_score=0.2))
         print('variant', tag, tuple(o['rois'].shape), len(g[f'{tag}.dets_min0.2']))
     np.savez_compressed(os.path.join(OUT, 'variants_b2.npz'), **g)

@@ -72,17 +72,29 @@ def filler_state_dict(seed=0, **overrides):
     return synth.tame_bifpn(sd) if overrides.get('fpn') == 'bifpn' else sd
 
 
-def assert_rois_equal_up_to_near_ties(got, ref, ref_scores, eps=2e-7, what='RoIs'):
+def assert_rois_equal_up_to_near_ties(got, ref, ref_scores, eps=2e-7, what='RoIs', max_pixel_flips=0):
     """RoIs [B,R,4] come out ordered by objectness (layers.py:292, an argsort of fp32 softmax outputs).  Two proposals whose
     scores differ by less than a couple of fp32 ulps of 1.0 have no defined order across implementations (the reference's
     own order depends on its BLAS build), so a run of such near-ties may come out permuted; everything else -- the rows
-    themselves, their number, every other position -- must be bit-identical."""
+    themselves, their number, every other position -- must be bit-identical.  A near-tie that straddles the top-N cut would
+    change the RoI SET, not just the order: that is never accepted (a permutation inside the list keeps the set).
+    `max_pixel_flips` (per image, default 0): rows that differ from the reference's in ONE coordinate by exactly ONE pixel -- a
+    box corner is `round()`-ed (nets_utils.py:186) and a pre-round value within fp32 noise of x.5 lands on either side,
+    in the reference itself from one BLAS build to the next.  Returns the list of such flips (image, rank, got row, ref row)."""
     got, ref, sc = got.cpu(), ref.cpu(), ref_scores.cpu()
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    flips = []
     for b in range(ref.shape[0]):
         i, R = 0, ref.shape[1]
+        n_flip = 0
         while i < R:
             if torch.equal(got[b, i], ref[b, i]):
+                i += 1
+                continue
+            d = (got[b, i] - ref[b, i]).abs()
+            if int((d != 0).sum()) == 1 and float(d.max()) == 1.0 and n_flip < max_pixel_flips:
+                n_flip += 1
+                flips.append((b, i, got[b, i].tolist(), ref[b, i].tolist()))
                 i += 1
                 continue
             j = i
@@ -93,3 +105,6 @@ def assert_rois_equal_up_to_near_ties(got, ref, ref_scores, eps=2e-7, what='RoIs
             r = sorted(map(tuple, ref[b, i:j + 1].tolist()))
             assert g == r, f'{what}: image {b} ranks {i}..{j} differ beyond a permutation of near-ties'
             i = j + 1
+    if flips:
+        print(f'{what}: {len(flips)} one-pixel rounding flip(s): {flips}')
+    return flips

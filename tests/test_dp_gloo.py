@@ -49,6 +49,41 @@ def test_allreduce_grads_world2():
         assert dict(out) == {0: True, 1: True}
 
 
+def _worker_partial(rank, world, port, out):
+    """The plain-module branch with a soft failure on rank 1 only: its second layer never runs (`grad is None`)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from birdsoundclassif_amd.train import allreduce_grads
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(8, 4), torch.nn.Linear(4, 2))
+    x = torch.full((3, 8), float(rank + 1))
+    h = m[0](x)
+    (h.sum() if rank == 1 else m[1](h).sum()).backward()
+    had = [p.grad is not None for p in m.parameters()]
+    local = [p.grad.clone() if p.grad is not None else torch.zeros_like(p) for p in m.parameters()]
+    allreduce_grads(m)
+    ok = all(p.grad is not None for p in m.parameters())
+    for p, g in zip(m.parameters(), local):
+        lst = [torch.zeros_like(g) for _ in range(world)]
+        dist.all_gather(lst, g)
+        ok = ok and torch.allclose(p.grad, sum(lst) / world, atol=1e-6)
+        lst2 = [torch.zeros_like(g) for _ in range(world)]
+        dist.all_gather(lst2, p.grad)
+        ok = ok and all(torch.equal(lst2[0], t) for t in lst2)
+    out[rank] = (bool(ok), had)
+    dist.destroy_process_group()
+
+
+def test_plain_module_branch_with_a_missing_gradient_on_one_rank():
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker_partial, args=(world, port, out), nprocs=world, join=True)
+        res = dict(out)
+    assert res[0] == (True, [True, True, True, True]) and res[1] == (True, [True, True, False, False])
+
+
 def test_allreduce_is_noop_without_process_group():
     from birdsoundclassif_amd.train import allreduce_grads
     m = torch.nn.Linear(3, 2)

@@ -9,7 +9,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from birdsoundclassif_amd import synth                                     # noqa: E402
-from helpers import check_packed, dets_to_rows, filler_state_dict, load_golden   # noqa: E402
+from helpers import assert_rois_equal_up_to_near_ties, check_packed, dets_to_rows, filler_state_dict, load_golden   # noqa: E402
 from oracle import frontend_ref as FR, nets_ref as O                       # noqa: E402
 
 
@@ -338,10 +338,20 @@ def test_composition_flags_vs_reference_golden(tag, kw):
             check_packed(g, f'{tag}.fpn{i}', f, atol=1e-4, rtol=1e-4)
         check_packed(g, f'{tag}.rpn_cls_scores', o['rpn_cls_scores'], atol=1e-4)
         check_packed(g, f'{tag}.rpn_bbox_reg', o['rpn_bbox_reg'], atol=1e-4)
-        ref_rois = g[f'{tag}.rois.full'].reshape(g[f'{tag}.rois.shape'])
-        assert (o['rois'].cpu().numpy() != ref_rois).any(-1).mean() <= 0.03        # unstable-argsort ties
-        rows, ref = dets_to_rows(m(x, min_score=0.2)), g[f'{tag}.dets_min0.2']
-        assert abs(len(rows) - len(ref)) <= 2
+        # RoIs: bit-identical to the reference's, up to permutations inside runs of proposals whose objectness differs by less
+        # than 2e-7 (the reference's argsort is unstable, layers.py:292) -- the RoI SET of every image is the reference's
+        ref_rois = torch.from_numpy(g[f'{tag}.rois.full'].reshape(g[f'{tag}.rois.shape']))
+        ref_scores = torch.from_numpy(g[f'{tag}.roi_scores.full'].reshape(g[f'{tag}.roi_scores.shape']))
+        # (and at most one corner per image that round() put on the other side of x.5 -- seen once in the suite: posenc, image 1,
+        # x2 = 226 vs 227; reported, and the second stage is then checked stage-wise on the reference's RoIs)
+        flips = assert_rois_equal_up_to_near_ties(o['rois'], ref_rois, ref_scores, what=f'{tag} RoIs', max_pixel_flips=1)
+        # detections: the same (image, class, box) rows as the reference, scores within 1e-4
+        dets = m.forward_second_stage(o['fpn_out'], ref_rois.cuda(), min_score=0.2, training=False) if flips else m(x, min_score=0.2)
+        rows, ref = dets_to_rows(dets), g[f'{tag}.dets_min0.2']
+        assert rows.shape == ref.shape, (rows.shape, ref.shape)
+        rows, ref = rows[np.lexsort(rows[:, :6].T[::-1])], ref[np.lexsort(ref[:, :6].T[::-1])]
+        assert np.array_equal(rows[:, :6], ref[:, :6]), f'{tag}: class / box assignments differ from the reference'
+        assert np.abs(rows[:, 6] - ref[:, 6]).max() < 1e-4
     m.train(), crit.train()
     opt, _ = build_optimizer(m, args)
     bb, ids, lengths = synth.label_batch(0, 2)
