@@ -1,0 +1,216 @@
+// Cell transforms of the BACKWARD pass of a demand-driven 3x3 / stride-1 / pad-1 convolution whose output is read through a
+// 3x3 / stride-S / pad-1 pattern (the finest FPN output map and the RPN's strided depthwise convolution, reference
+// fpn.py:145, layers.py:62-65,81).
+//
+// The gradient wrt that output is non-zero on the pattern pixels only (plus the RoI windows, which the listed-tile kernels
+// handle): one 3 x 3 block per S x S cell (rows S*oy-1 .. S*oy+1).  Per cell
+//   data gradient    gx[5x5 patch, rows S*oy-2 .. S*oy+2] = FULL linear convolution of the 3x3 block with the 3x3 kernel
+//   weight gradient  dW[3x3] = correlation of the 5x5 input patch with the 3x3 block
+// i.e. polynomial multiplication / its transpose: Toom-Cook with 5 points per axis, 25 multiplications per (cell, n, c)
+// instead of 81 -- and instead of the 16 / 12 / 9 planes of EVERY 2x2 Winograd tile within a pixel of the pattern (56 % of
+// the tiles) that the listed F(2x2,3x3) kernel spent on the same gradient.  Points {0, 1, -1, 2, -2}:
+//   E    [5 x 3]  evaluation of a 3-coefficient polynomial      (block and kernel side)
+//   Vinv [5 x 5]  inverse Vandermonde: interpolation of the 5 product values back to 5 coefficients
+//   block   ->  Vg = E g E^T                   nbm_cell_outgrad     [25][cells][N]     (shared by both gradients)
+//   kernel  ->  U  = E w E^T                   host (float64, once per step)
+//   M_xi = Vg_xi U_xi^T  (25 grouped GEMMs, nbm_gemm_conv)   ->   gx patch = Vinv M Vinv^T      nbm_cell_dgrad_output
+//   patch   ->  Vx = Vinv^T x Vinv             nbm_cell_input       [25][cells][C]
+//   dU_xi = Vg_xi^T Vx_xi (25 TN GEMMs, nbm_conv_wgrad)      ->   dW = E^T dU E                 host
+// fp32 error against float64: 3e-6 relative (the F(2x2,3x3) level), measured in scripts / tests.
+// All three kernels are HBM-bound streams: a thread owns (cell, 4 channels), 16-byte accesses, channels fastest.
+#include "nbm_common.h"
+
+namespace {
+
+constexpr int NP = 5;
+// compile-time matrices: every use below has constant indices after unrolling, so zeros and ones fold away
+__device__ constexpr float CE[5][3] = {{1.f, 0.f, 0.f}, {1.f, 1.f, 1.f}, {1.f, -1.f, 1.f}, {1.f, 2.f, 4.f}, {1.f, -2.f, 4.f}};
+__device__ constexpr float CV[5][5] = {{1.f, 0.f, 0.f, 0.f, 0.f},
+                                       {0.f, 2.f / 3, -2.f / 3, -1.f / 12, 1.f / 12},
+                                       {-5.f / 4, 2.f / 3, 2.f / 3, -1.f / 24, -1.f / 24},
+                                       {0.f, -1.f / 6, 1.f / 6, 1.f / 12, -1.f / 12},
+                                       {1.f / 4, -1.f / 6, -1.f / 6, 1.f / 24, 1.f / 24}};
+
+struct CellGeom { int B, H, W, C4, S, OH, OW; long long T; };
+
+__device__ __forceinline__ void cell_of(const CellGeom& q, long long cell, int& b, int& oy, int& ox) {
+  ox = (int)(cell % q.OW);
+  const long long r = cell / q.OW;
+  oy = (int)(r % q.OH);
+  b = (int)(r / q.OH);
+}
+
+// g [B][H][W][N] -> Vg [25][T][N] = E blk E^T per cell (pixels outside the image read as zeros); bias_grad (optional) +=
+// sum of the block pixels.  A thread keeps one channel quad over its grid-stride loop (the launch makes the stride a
+// multiple of N/4).
+__global__ __launch_bounds__(256) void cell_outgrad_kernel(const float* __restrict__ g, const CellGeom q, float* __restrict__ Vg,
+                                                           float* __restrict__ bias_grad) {
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+  f32x4* v4 = reinterpret_cast<f32x4*>(Vg);
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum = zero;
+  int my_c = -1;
+  const long long total = q.T * q.C4;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % q.C4);
+    const long long cell = i / q.C4;
+    my_c = c;
+    int b, oy, ox;
+    cell_of(q, cell, b, oy, ox);
+    f32x4 d[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int y = q.S * oy - 1 + a;
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const int x = q.S * ox - 1 + e;
+        const bool ok = (unsigned)y < (unsigned)q.H && (unsigned)x < (unsigned)q.W;
+        d[a][e] = ok ? g4[(((long long)b * q.H + y) * q.W + x) * q.C4 + c] : zero;
+        bsum += d[a][e];
+      }
+    }
+    f32x4 t[NP][3];                    // E d
+#pragma unroll
+    for (int a = 0; a < NP; ++a)
+#pragma unroll
+      for (int e = 0; e < 3; ++e) t[a][e] = CE[a][0] * d[0][e] + CE[a][1] * d[1][e] + CE[a][2] * d[2][e];
+#pragma unroll
+    for (int a = 0; a < NP; ++a)
+#pragma unroll
+      for (int e = 0; e < NP; ++e)
+        v4[((long long)(a * NP + e) * q.T + cell) * q.C4 + c] = CE[e][0] * t[a][0] + CE[e][1] * t[a][1] + CE[e][2] * t[a][2];
+  }
+  if (bias_grad && my_c >= 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(bias_grad + my_c * 4 + e, bsum[e]);
+  }
+}
+
+// x [B][H][W][C] -> Vx [25][T][C] = Vinv^T patch Vinv per cell (5x5 patch, rows S*oy-2 .. S*oy+2; outside the image = the
+// convolution's zero padding)
+__global__ __launch_bounds__(256) void cell_input_kernel(const float* __restrict__ x, const CellGeom q, float* __restrict__ Vx) {
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  f32x4* v4 = reinterpret_cast<f32x4*>(Vx);
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const long long total = q.T * q.C4;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % q.C4);
+    const long long cell = i / q.C4;
+    int b, oy, ox;
+    cell_of(q, cell, b, oy, ox);
+    f32x4 t[NP][NP];                   // t[a][l] = sum_j Vinv[j][a] patch[j][l], built row by row (25 live values, not 50)
+#pragma unroll
+    for (int a = 0; a < NP; ++a)
+#pragma unroll
+      for (int l = 0; l < NP; ++l) t[a][l] = zero;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int y = q.S * oy - 2 + j;
+#pragma unroll
+      for (int l = 0; l < NP; ++l) {
+        const int xx = q.S * ox - 2 + l;
+        const bool ok = (unsigned)y < (unsigned)q.H && (unsigned)xx < (unsigned)q.W;
+        const f32x4 v = ok ? x4[(((long long)b * q.H + y) * q.W + xx) * q.C4 + c] : zero;
+#pragma unroll
+        for (int a = 0; a < NP; ++a)
+          if (CV[j][a] != 0.f) t[a][l] += CV[j][a] * v;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < NP; ++a)
+#pragma unroll
+      for (int e = 0; e < NP; ++e) {
+        f32x4 o = zero;
+#pragma unroll
+        for (int l = 0; l < NP; ++l)
+          if (CV[l][e] != 0.f) o += CV[l][e] * t[a][l];
+        v4[((long long)(a * NP + e) * q.T + cell) * q.C4 + c] = o;
+      }
+  }
+}
+
+// M [25][T][C] -> gx [B][H][W][C]: patch = Vinv M Vinv^T written to the 5x5 pixels of the cell that lie inside the image
+// (S >= 5: patches of different cells do not overlap); the rest of gx is not touched
+__global__ __launch_bounds__(256) void cell_dgrad_output_kernel(const float* __restrict__ M, const CellGeom q, float* __restrict__ gx) {
+  const f32x4* m4 = reinterpret_cast<const f32x4*>(M);
+  f32x4* o4 = reinterpret_cast<f32x4*>(gx);
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const long long total = q.T * q.C4;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % q.C4);
+    const long long cell = i / q.C4;
+    int b, oy, ox;
+    cell_of(q, cell, b, oy, ox);
+    f32x4 t[NP][NP];                   // t[j][e] = sum_a Vinv[j][a] M[a][e]
+#pragma unroll
+    for (int j = 0; j < NP; ++j)
+#pragma unroll
+      for (int e = 0; e < NP; ++e) t[j][e] = zero;
+#pragma unroll
+    for (int a = 0; a < NP; ++a)
+#pragma unroll
+      for (int e = 0; e < NP; ++e) {
+        const f32x4 v = m4[((long long)(a * NP + e) * q.T + cell) * q.C4 + c];
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+          if (CV[j][a] != 0.f) t[j][e] += CV[j][a] * v;
+      }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int y = q.S * oy - 2 + j;
+      if ((unsigned)y >= (unsigned)q.H) continue;
+#pragma unroll
+      for (int l = 0; l < NP; ++l) {
+        const int xx = q.S * ox - 2 + l;
+        if ((unsigned)xx >= (unsigned)q.W) continue;
+        f32x4 o = zero;
+#pragma unroll
+        for (int e = 0; e < NP; ++e)
+          if (CV[l][e] != 0.f) o += CV[l][e] * t[j][e];
+        o4[(((long long)b * q.H + y) * q.W + xx) * q.C4 + c] = o;
+      }
+    }
+  }
+}
+
+inline bool cell_geom(int B, int H, int W, int C, int S, CellGeom& q) {
+  if (B <= 0 || H < 3 || W < 3 || C <= 0 || (C & 3) || S < 5) return false;
+  q.B = B; q.H = H; q.W = W; q.C4 = C / 4; q.S = S;
+  q.OH = (H + 2 - 3) / S + 1; q.OW = (W + 2 - 3) / S + 1;          // output size of the 3x3 / stride S / pad 1 reader
+  q.T = (long long)B * q.OH * q.OW;
+  return true;
+}
+
+inline unsigned stream_grid(long long total, int per) {
+  long long blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  while ((blocks * 256) % per) ++blocks;      // a thread keeps one channel quad over its grid-stride loop
+  return (unsigned)blocks;
+}
+
+}  // namespace
+
+extern "C" int nbm_cell_outgrad(const float* g, int B, int H, int W, int N, int stride, float* Vg, float* bias_grad, void* stream) {
+  CellGeom q;
+  if (!g || !Vg || !cell_geom(B, H, W, N, stride, q)) return NBM_EINVAL;
+  if (!nbm_aligned16(g) || !nbm_aligned16(Vg)) return NBM_EALIGN;
+  hipLaunchKernelGGL(cell_outgrad_kernel, dim3(stream_grid(q.T * q.C4, q.C4)), dim3(256), 0, (hipStream_t)stream, g, q, Vg, bias_grad);
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_cell_input(const float* x, int B, int H, int W, int C, int stride, float* Vx, void* stream) {
+  CellGeom q;
+  if (!x || !Vx || !cell_geom(B, H, W, C, stride, q)) return NBM_EINVAL;
+  if (!nbm_aligned16(x) || !nbm_aligned16(Vx)) return NBM_EALIGN;
+  hipLaunchKernelGGL(cell_input_kernel, dim3(stream_grid(q.T * q.C4, q.C4)), dim3(256), 0, (hipStream_t)stream, x, q, Vx);
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_cell_dgrad_output(const float* M, int B, int H, int W, int C, int stride, float* gx, void* stream) {
+  CellGeom q;
+  if (!M || !gx || !cell_geom(B, H, W, C, stride, q)) return NBM_EINVAL;
+  if (!nbm_aligned16(M) || !nbm_aligned16(gx)) return NBM_EALIGN;
+  hipLaunchKernelGGL(cell_dgrad_output_kernel, dim3(stream_grid(q.T * q.C4, q.C4)), dim3(256), 0, (hipStream_t)stream, M, q, gx);
+  return nbm_launch_status();
+}

@@ -132,9 +132,16 @@ __global__ __launch_bounds__(256) void wino23_output_kernel(const float* __restr
 __global__ __launch_bounds__(256) void wino23_outgrad_kernel(const float* __restrict__ g, int B, int H, int W, int N4,
                                                              float* __restrict__ dM, float* __restrict__ bias_grad,
                                                              const int* __restrict__ tiles, int n_list,
-                                                             const unsigned* __restrict__ entry_info) {
+                                                             const unsigned* __restrict__ entry_info, int pat_stride) {
   const int TH = (H + 1) >> 1, TW = (W + 1) >> 1;
   const long long T = tiles ? (long long)n_list : (long long)B * TH * TW;      // tile list: as in wino23_input_kernel
+  // pat_stride S > 0: the pixels of the 3x3 / stride-S / pad-1 pattern (rows S*o-1 .. S*o+1 of the cells that exist) read as
+  // zeros -- their share of the gradient is taken by the cell transforms (cellwino.hip), every pixel of g counts once
+  const int S = pat_stride, OHp = S > 0 ? (H + 2 - 3) / S + 1 : 0, OWp = S > 0 ? (W + 2 - 3) / S + 1 : 0;
+  auto in_pattern = [&](int y, int x) -> bool {
+    if (S <= 0) return false;
+    return (y + 1) % S < 3 && (y + 1) / S < OHp && (x + 1) % S < 3 && (x + 1) / S < OWp;
+  };
   const long long total = T * N4;
   const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
   f32x4* m4 = reinterpret_cast<f32x4*>(dM);
@@ -157,8 +164,10 @@ __global__ __launch_bounds__(256) void wino23_outgrad_kernel(const float* __rest
     const int b = (int)(r / TH);
     const long long row = ((long long)b * H + 2 * ty) * W + 2 * tx;
     const bool in_y = 2 * ty + 1 < H, in_x = 2 * tx + 1 < W;          // odd sizes: the last tile row / column is half outside
-    const f32x4 y00 = g4[row * N4 + c], y01 = in_x ? g4[(row + 1) * N4 + c] : zero;
-    const f32x4 y10 = in_y ? g4[(row + W) * N4 + c] : zero, y11 = (in_y && in_x) ? g4[(row + W + 1) * N4 + c] : zero;
+    const f32x4 y00 = in_pattern(2 * ty, 2 * tx) ? zero : g4[row * N4 + c];
+    const f32x4 y01 = (in_x && !in_pattern(2 * ty, 2 * tx + 1)) ? g4[(row + 1) * N4 + c] : zero;
+    const f32x4 y10 = (in_y && !in_pattern(2 * ty + 1, 2 * tx)) ? g4[(row + W) * N4 + c] : zero;
+    const f32x4 y11 = (in_y && in_x && !in_pattern(2 * ty + 1, 2 * tx + 1)) ? g4[(row + W + 1) * N4 + c] : zero;
     if (!entry_info || ((entry_info[t] >> 16) & 1u)) bsum += (y00 + y01) + (y10 + y11);   // a tile listed twice counts once
     // rows of A = [1 0; 1 1; 1 -1; 0 -1]
     const f32x4 r0[2] = {y00, y01}, r1[2] = {y00 + y10, y01 + y11}, r2[2] = {y00 - y10, y01 - y11}, r3[2] = {-y10, -y11};
@@ -466,7 +475,7 @@ extern "C" int nbm_wino_outgrad(const float* g, int B, int H, int W, int N, floa
   while ((blocks * 256) % per) ++blocks;
   if (m == 2)
     hipLaunchKernelGGL(wino23_outgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, B, H, W, per, dM, bias_grad,
-                       (const int*)nullptr, 0, (const unsigned*)nullptr);
+                       (const int*)nullptr, 0, (const unsigned*)nullptr, 0);
   else
     hipLaunchKernelGGL(wino43_outgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, B, H, W, per, dM, bias_grad);
   return nbm_launch_status();
@@ -484,8 +493,9 @@ extern "C" int nbm_wino23_input_tiles(const float* x, int B, int H, int W, int C
 }
 
 extern "C" int nbm_wino23_outgrad_tiles(const float* g, int B, int H, int W, int N, const int* tiles, int n_list,
-                                        const unsigned* plane_mask, float* dM, float* bias_grad, void* stream) {
-  if (!g || !dM || !tiles || B <= 0 || H <= 0 || W <= 0 || N <= 0 || (N & 3) || n_list < 0) return NBM_EINVAL;
+                                        const unsigned* plane_mask, float* dM, float* bias_grad, int skip_pattern_stride,
+                                        void* stream) {
+  if (!g || !dM || !tiles || B <= 0 || H <= 0 || W <= 0 || N <= 0 || (N & 3) || n_list < 0 || skip_pattern_stride < 0) return NBM_EINVAL;
   if (!nbm_aligned16(g) || !nbm_aligned16(dM)) return NBM_EALIGN;
   if (n_list == 0) return NBM_OK;
   const int per = N / 4;
@@ -493,7 +503,7 @@ extern "C" int nbm_wino23_outgrad_tiles(const float* g, int B, int H, int W, int
   if (blocks > 4096) blocks = 4096;
   while ((blocks * 256) % per) ++blocks;              // a thread keeps one channel chunk (bias-gradient accumulation)
   hipLaunchKernelGGL(wino23_outgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, B, H, W, per, dM,
-                     bias_grad, tiles, n_list, plane_mask);
+                     bias_grad, tiles, n_list, plane_mask, skip_pattern_stride);
   return nbm_launch_status();
 }
 

@@ -72,6 +72,30 @@ def wino23_weight_grad(dU, m=2, row_scale=None):
     return ops.wino_weight_grad(dU, m, row_scale)
 
 
+_CELL_E = [[1.0, 0.0, 0.0], [1.0, 1.0, 1.0], [1.0, -1.0, 1.0], [1.0, 2.0, 4.0], [1.0, -2.0, 4.0]]     # csrc/cellwino.hip: points 0, 1, -1, 2, -2
+
+
+def _cell_e(device):
+    return torch.tensor(_CELL_E, dtype=torch.float64, device=device)
+
+
+def cell_weight(weight):
+    """Kernel side of the cell transforms (csrc/cellwino.hip): [Cout, Cin, 3, 3] -> U [25][Cin][Cout] = (E w E^T)[a][b] -- the B
+    operand of the 25 data-gradient GEMMs M_xi = Vg_xi U_xi^T.  float64 on the device, rounded once; cached per weight version."""
+    def make():
+        E = _cell_e(weight.device)
+        u = torch.einsum('ar,bs,ncrs->abcn', E, E, weight.detach().double())
+        return u.reshape(25, weight.shape[1], weight.shape[0]).float().contiguous()
+    return _cached(weight, 'cell', make)
+
+
+def cell_weight_grad(dU):
+    """dU [25][N][C] (gradient wrt the transformed kernel) -> dW [N, C, 3, 3] = E^T dU E."""
+    E = _cell_e(dU.device)
+    N, C_ = dU.shape[1:]
+    return torch.einsum('at,bs,abnc->ncts', E, E, dU.double().view(5, 5, N, C_)).float()
+
+
 def stem_fold(w1, w_init, b_init):
     """Operands of `nbm_stem7x7`: init_conv (1 -> 3 channels, weight a_c, bias b_c) folded into conv1 [64,3,7,7], in float64:
     weff [56,64] (k = 8 r + s, the s = 7 column zero) = sum_c W1 a_c; wb [64,49] = sum_c W1 b_c; wb_full [64] = wb.sum(1)."""

@@ -107,7 +107,8 @@ class Conv(Function):
         if ctx.needs_input_grad[0] and ctx.lazy is not None and ctx.lazy.sparse and LAZY_DGRAD and N % 32 == 0 and N >= 64:
             # demand-driven map: the incoming gradient lives on the pattern pixels and in the RoI windows, the outgoing one
             # within a pixel of them -> the listed fused kernel on the tiles around them (F(2x2,3x3), no transforms through HBM)
-            gx = ondemand.conv3x3_winograd_dgrad_tiles(ctx.lazy, g.view(B, H, W, N), _prep.wino23(weight, transposed=True, m=2))
+            gx = ondemand.conv3x3_winograd_dgrad_tiles(ctx.lazy, g.view(B, H, W, N), _prep.wino23(weight, transposed=True, m=2),
+                                                       _prep.cell_weight(weight) if ondemand.CELL_BWD else None)
         elif ctx.needs_input_grad[0] and ctx.wino and N % 32 == 0:
             # data gradient of a 3x3 / stride 1 / pad 1 convolution = the same convolution with the kernel rotated by 180
             # degrees and the channel roles swapped: Winograd again
@@ -120,8 +121,10 @@ class Conv(Function):
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] and ctx.lazy is not None and ctx.lazy.sparse and LAZY_WGRAD:
             # demand-driven map: the gradient is zero outside the tiles that were computed -> F(2x2,3x3) over those tiles only
-            dU, gb = ondemand.conv3x3_winograd_wgrad_tiles(ctx.lazy, x, g.view(B, H, W, N), want_bias=want_gb)
+            dU, gb, dUc = ondemand.conv3x3_winograd_wgrad_tiles(ctx.lazy, x, g.view(B, H, W, N), want_bias=want_gb)
             gw = _prep.wino23_weight_grad(dU, 2)
+            if dUc is not None:                       # pattern share: cell transforms (csrc/cellwino.hip)
+                gw = gw + _prep.cell_weight_grad(dUc)
         elif ctx.needs_input_grad[1] and ctx.wino and N % 32 == 0:
             # weight gradient in the Winograd domain: 16 TN GEMMs dU = dM^T V, mapped back with dW = G^T dU G
             dU, gb = ops.conv3x3_winograd_wgrad(x, g.view(B, H, W, N), want_bias=want_gb, m=WINO_BWD_TILE)

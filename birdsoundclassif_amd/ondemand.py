@@ -183,7 +183,7 @@ class LazyMap:
     12 GB alive until the garbage collector runs); its consumers keep it alive and hand it back to `lazy_complete`.
     The operands stay here for as long as the map lives, so EVERY RoI pooling on the map -- not only the first -- finds the
     tiles under its windows computed (`done` counts them); the state goes when the map does (`_forget`)."""
-    __slots__ = ('x', 'U', 'bias', 'skip', 'stride', 'chunks', 'roi', 'keep', 'sparse', 'lateral', 'rois', 'done', '__weakref__')
+    __slots__ = ('x', 'U', 'bias', 'skip', 'stride', 'chunks', 'roi', 'keep', 'sparse', 'lateral', 'rois', 'done', 'vg', 'cell_gb', 'cell_gb_done', '__weakref__')
 
     def __init__(self, x, U, bias, stride):
         self.x, self.U, self.bias, self.stride = x, U, bias, stride
@@ -191,10 +191,13 @@ class LazyMap:
         self.roi = []           # per RoI pooling: per chunk (tile list, pinned block count, event)
         self.rois = []          # per RoI pooling: (rois, n_roi, n_levels, level, fh, fw)
         self.done = 0
+        self.vg = None          # backward pass: {chunk: Vg} of the cell transforms, shared by the data and the weight gradient
+        self.cell_gb = None     # ... and the bias gradient of the pattern pixels, summed by the same kernel
+        self.cell_gb_done = None    # chunks whose pattern pixels are in cell_gb already (a chunk's Vg may be computed twice)
 
     def release(self):
         """Called by the backward pass of the convolution: no RoI pooling can follow on a map whose gradient has been consumed."""
-        self.x = self.U = self.bias = self.lateral = None
+        self.x = self.U = self.bias = self.lateral = self.vg = self.cell_gb = self.cell_gb_done = None
 
     def __del__(self):          # the pinned counters go back to the pool
         try:
@@ -364,11 +367,46 @@ def lazy_complete(fm, rois, n_roi, fmap_hw, level=0):
     st.done += 1
 
 
-def conv3x3_winograd_dgrad_tiles(st, g, Ut):
+CELL_BWD = os.environ.get('NBM_CELL_BWD', '1') != '0'     # pattern share of both gradients through the cell transforms (cellwino.hip)
+
+
+def cell_count(B, H, W, stride):
+    return B * ((H + 2 - 3) // stride + 1) * ((W + 2 - 3) // stride + 1)
+
+
+def _cell_outgrad(st, g, ci, b0, nb):
+    """Vg [25][cells][N] of batch chunk `ci` (E blk E^T of the pattern blocks of g): the A operand of the data-gradient GEMMs and
+    the G operand of the weight-gradient GEMMs.  Computed once per backward pass (the sum of the block pixels = the pattern share
+    of the bias gradient rides along into st.cell_gb) and kept on the LazyMap until the weight gradient has used it."""
+    if st.vg is None:
+        st.vg = {}
+    hit = st.vg.get(ci)
+    if hit is not None:
+        return hit
+    B, H, W, N = g.shape
+    T = cell_count(nb, H, W, st.stride)
+    if st.cell_gb is None:
+        st.cell_gb, st.cell_gb_done = torch.zeros((N,), device=g.device, dtype=torch.float32), set()
+    vg = st.vg[ci] = torch.empty((25, T, N), device=g.device, dtype=torch.float32)
+    check(lib().nbm_cell_outgrad(_ptr(g[b0:b0 + nb]), nb, H, W, N, st.stride, _ptr(vg), None if ci in st.cell_gb_done else _ptr(st.cell_gb),
+                                 _stream()), 'nbm_cell_outgrad')
+    st.cell_gb_done.add(ci)
+    return vg
+
+
+def cell_usable(st, H, W, C_, N):
+    return CELL_BWD and st.stride >= 5 and C_ % 32 == 0 and N % 32 == 0 and H >= 3 and W >= 3
+
+
+def conv3x3_winograd_dgrad_tiles(st, g, Ut, Ucell=None):
     """Data gradient of a demand-driven convolution (LazyMap `st`): g [B,H,W,N] is zero except on the pattern pixels and inside
-    the RoI windows, so the gradient wrt the input is zero except within one pixel of them: the same convolution operator
-    (Ut = weights rotated / channel-swapped, F(2x2,3x3)) through the listed fused kernel -- the static list of the tiles around
-    the pattern (56 % of the tiles, 16 / 12 / 9 planes), then the tiles around the RoI windows -- into a zero-filled map."""
+    the RoI windows, so the gradient wrt the input is zero except within two pixels of the pattern blocks and one pixel of the
+    windows.  Pattern share (`Ucell` = _prep.cell_weight: [25][C][N]): per stride x stride cell the full convolution of the 3x3
+    gradient block with the kernel, Toom-Cook in 25 multiplications (cellwino.hip: block transform, 25 grouped GEMMs, patch
+    transform into a zero-filled map).  RoI share: the same convolution operator (Ut = weights rotated / channel-swapped,
+    F(2x2,3x3)) through the listed fused kernel on the tiles within a pixel of the RoI windows, which reads ALL of g there and
+    so overwrites those tiles with their complete values.  Without `Ucell` (or NBM_CELL_BWD=0) the pattern share also goes
+    through the listed fused kernel: the static list of the tiles around the pattern (56 % of the tiles, 16 / 12 / 9 planes)."""
     _chk(g, name='g'), _chk(Ut, name='Ut')
     B, H, W, N = g.shape
     C_ = Ut.shape[1]
@@ -376,10 +414,26 @@ def conv3x3_winograd_dgrad_tiles(st, g, Ut):
     gx = torch.zeros((B, H, W, C_), device=g.device, dtype=torch.float32)
     img_bytes = H * W * C_ * 4
     blocks_per_img = -(-((H + 1) // 2 * ((W + 1) // 2)) // 128)
-    for b0, nb, _ in st.chunks:
-        pat = wino23_pattern(nb, H, W, st.stride, g.device, dilate=1)
-        _wino23_tiles_run(g[b0:b0 + nb], Ut, None, gx.data_ptr() + b0 * img_bytes, pat.tiles, None, pat.n_eff, 'wino23-dgrad',
-                          pat.blk_info)
+    cell = Ucell is not None and cell_usable(st, H, W, C_, N)
+    if cell:
+        assert Ucell.shape == (25, C_, N)
+    for ci, (b0, nb, _) in enumerate(st.chunks):
+        if cell:
+            vg = _cell_outgrad(st, g, ci, b0, nb)
+            T = vg.shape[1]
+            M, _ = ops._wino_scratch(g.device, 25 * T * C_, 0)
+            global_label = ops._PROFILE_LABEL
+            ops._PROFILE_LABEL = ('cell-dgrad', H, W)
+            try:
+                gemm_conv(vg, Ucell, M, B=1, H=T, W=1, Cin=N, N=C_, groups=25, x_gs=T * N, w_gs=C_ * N, y_gs=T * C_)
+            finally:
+                ops._PROFILE_LABEL = global_label
+            check(lib().nbm_cell_dgrad_output(_ptr(M), nb, H, W, C_, st.stride, C.c_void_p(gx.data_ptr() + b0 * img_bytes), _stream()),
+                  'nbm_cell_dgrad_output')
+        else:
+            pat = wino23_pattern(nb, H, W, st.stride, g.device, dilate=1)
+            _wino23_tiles_run(g[b0:b0 + nb], Ut, None, gx.data_ptr() + b0 * img_bytes, pat.tiles, None, pat.n_eff, 'wino23-dgrad',
+                              pat.blk_info)
         for rois, n_roi, nl, level, fh, fw in st.rois:          # one entry per RoI pooling that read the map
             per = ops.per_image_counts(n_roi, B)
             key = (str(g.device), nb * blocks_per_img * 128)
@@ -389,25 +443,39 @@ def conv3x3_winograd_dgrad_tiles(st, g, Ut):
                                             torch.zeros((1,), device=g.device, dtype=torch.int32))
             tiles, n_blocks = buf
             check(lib().nbm_roi_tiles(_ptr(rois[b0:b0 + nb]), _ptr(n_roi[b0:b0 + nb] if per else n_roi), nb, rois.shape[1], nl, level,
-                                      fh, fw, _ptr(pat.full), 1, _ptr(tiles), _ptr(n_blocks), per, _stream()), 'nbm_roi_tiles')
+                                      fh, fw, None if cell else _ptr(pat.full), 1, _ptr(tiles), _ptr(n_blocks), per, _stream()), 'nbm_roi_tiles')
             _wino23_tiles_run(g[b0:b0 + nb], Ut, None, gx.data_ptr() + b0 * img_bytes, tiles, n_blocks, None, 'wino23-dgrad-rois')
     return gx
 
 
-def conv3x3_winograd_wgrad_tiles(st, x, g, want_bias=False):
-    """Weight gradient of a demand-driven convolution (LazyMap `st`): g [B,H,W,N] is zero outside the tiles that were
-    computed, so dU[xi] = dM[xi]^T V[xi] sums over those tiles only: F(2x2,3x3) transforms of the listed tiles into
-    compact operands, 16 TN GEMMs over the listed rows.  -> (dU [16,N,C], bias gradient [N] | None)."""
+def conv3x3_winograd_wgrad_tiles(st, x, g, want_bias=False, cell=None):
+    """Weight gradient of a demand-driven convolution (LazyMap `st`): g [B,H,W,N] is zero outside the pixels that were read.
+    `cell` (default: when usable): the PATTERN pixels of g through the cell transforms (cellwino.hip: per stride x stride cell the
+    correlation of the 5x5 input patch with the 3x3 gradient block, 25 TN GEMMs dUc[xi] = Vg[xi]^T Vx[xi] over the cells), the
+    other pixels of the tiles under the RoI windows through F(2x2,3x3) over the RoI lists (compact operands, 16 TN GEMMs, pattern
+    pixels read as zeros): every pixel of g counts once.  -> (dU [16,N,C], bias gradient [N] | None, dUc [25,N,C] | None); the
+    weight gradient is G^T dU G + E^T dUc E.  cell=False: everything through F(2x2,3x3) over the pattern + RoI tile lists with
+    their plane masks (round 2)."""
     _chk(x, name='x'), _chk(g, name='g')
     B, H, W, C_ = x.shape
     N = g.shape[-1]
+    if cell is None:
+        cell = cell_usable(st, H, W, C_, N)
     dU = torch.zeros((16, N, C_), device=x.device, dtype=torch.float32)
+    dUc = torch.zeros((25, N, C_), device=x.device, dtype=torch.float32) if cell else None
     gb = torch.zeros((N,), device=x.device, dtype=torch.float32) if want_bias else None
     lmax = max(128, (ops.WINO_CHUNK_BYTES // (16 * (C_ + N) * 4)) // 128 * 128)
     stream = _stream()
     thw = ((H + 1) // 2) * ((W + 1) // 2)
     for ci, (b0, nb, pat) in enumerate(st.chunks):
-        lists, infos = [pat.tiles], [pat.entry_pm]
+        lists, infos = ([], []) if cell else ([pat.tiles], [pat.entry_pm])
+        if cell:
+            vg = _cell_outgrad(st, g, ci, b0, nb)              # from the data gradient's pass when that ran first
+            T = vg.shape[1]
+            Vx, _ = ops._wino_scratch(x.device, 25 * T * C_, 0)
+            check(lib().nbm_cell_input(_ptr(x[b0:b0 + nb]), nb, H, W, C_, st.stride, _ptr(Vx), stream), 'nbm_cell_input')
+            conv_wgrad(vg, Vx, dUc, B=1, H=T, W=1, Cin=C_, N=N, groups=25, g_gs=T * N, x_gs=T * C_, out_gs=N * C_)
+            st.vg.pop(ci, None)
         parts = []
         for per_chunk in st.roi:                    # one entry per RoI pooling that read the map
             tiles, host, ev = per_chunk[ci]
@@ -423,11 +491,16 @@ def conv3x3_winograd_wgrad_tiles(st, x, g, want_bias=False):
                 u = u[u >= 0]
                 roi = torch.full((-(-u.numel() // 128) * 128,), -1, device=u.device, dtype=torch.int32)
                 roi[:u.numel()] = u
-            # the RoI phase recomputed pattern tiles of which only some pixels had been stored: the planes of their class
-            # come from the pattern list, this entry contributes the others
             lists.append(roi)
-            tpm = pat.tile_pm[roi.clamp(min=0) % thw]
-            infos.append((0xffff & ~tpm) | ((tpm == 0).int() << 16))
+            if cell:        # all planes of every RoI tile; the pattern pixels inside them are masked out of g instead
+                infos.append(torch.full_like(roi, 0x1ffff))
+            else:
+                # the RoI phase recomputed pattern tiles of which only some pixels had been stored: the planes of their class
+                # come from the pattern list, this entry contributes the others
+                tpm = pat.tile_pm[roi.clamp(min=0) % thw]
+                infos.append((0xffff & ~tpm) | ((tpm == 0).int() << 16))
+        if not lists:
+            continue
         full = torch.cat(lists) if len(lists) > 1 else lists[0]
         info = torch.cat(infos) if len(infos) > 1 else infos[0]
         xs, gs = x[b0:b0 + nb], g[b0:b0 + nb]
@@ -437,7 +510,11 @@ def conv3x3_winograd_wgrad_tiles(st, x, g, want_bias=False):
             V, dM = ops._wino_scratch(x.device, 16 * L * C_, 16 * L * N)
             check(lib().nbm_wino23_input_tiles(_ptr(xs), nb, H, W, C_, _ptr(lst), L, _ptr(info[l0:]), _ptr(V), stream),
                   'nbm_wino23_input_tiles')
-            check(lib().nbm_wino23_outgrad_tiles(_ptr(gs), nb, H, W, N, _ptr(lst), L, _ptr(info[l0:]), _ptr(dM), _ptr(gb), stream),
-                  'nbm_wino23_outgrad_tiles')
+            check(lib().nbm_wino23_outgrad_tiles(_ptr(gs), nb, H, W, N, _ptr(lst), L, _ptr(info[l0:]), _ptr(dM), _ptr(gb),
+                                                 st.stride if cell else 0, stream), 'nbm_wino23_outgrad_tiles')
             conv_wgrad(dM, V, dU, B=1, H=L, W=1, Cin=C_, N=N, groups=16, g_gs=L * N, x_gs=L * C_, out_gs=N * C_)
-    return dU, gb
+    if cell and gb is not None:
+        gb += st.cell_gb
+    if cell:
+        st.vg = st.cell_gb = st.cell_gb_done = None
+    return dU, gb, dUc

@@ -152,11 +152,26 @@ int nbm_roi_tiles(const float* rois, const int* n_roi, int B, int roi_cap, int n
  * TN GEMMs are nbm_conv_wgrad with groups = 16 over n_list rows.  plane_mask (optional, one word per ENTRY, bits 0-15 = planes
  * xi): the other planes of that entry are written as zeros -- planes the forward pass skipped (their input pixels may never
  * have been computed), or planes that a second entry of the same tile contributes; bit 16 = this entry's pixels enter the
- * bias gradient (a tile that is listed twice sets it once). */
+ * bias gradient (a tile that is listed twice sets it once).  skip_pattern_stride S > 0: the pixels of the 3x3 / stride-S /
+ * pad-1 reader pattern are read as zeros (their share of the gradient goes through the cell transforms below). */
 int nbm_wino23_input_tiles(const float* x, int B, int H, int W, int C, const int* tiles, int n_list, const unsigned* plane_mask,
                            float* V, void* stream);
 int nbm_wino23_outgrad_tiles(const float* g, int B, int H, int W, int N, const int* tiles, int n_list, const unsigned* plane_mask,
-                             float* dM, float* bias_grad, void* stream);
+                             float* dM, float* bias_grad, int skip_pattern_stride, void* stream);
+/* Backward pass of the same convolution over the PATTERN pixels of its output gradient (what autograd derives for
+ * fpn.py:145 from the RPN's stride-S depthwise convolution, layers.py:62-65,81): the gradient is one 3x3 block per S x S cell
+ * (rows S*oy-1 .. S*oy+1, cells = output pixels of the 3x3 / stride-S / pad-1 reader), so per cell the data gradient is the
+ * FULL convolution block * kernel (a 5x5 patch) and the weight gradient the correlation of the 5x5 input patch with the
+ * block: Toom-Cook with the points {0, 1, -1, 2, -2}, 25 multiplications per (cell, n, c) instead of 81 (csrc/cellwino.hip):
+ *   nbm_cell_outgrad       g [B][H][W][N] -> Vg [25][cells][N] = E blk E^T (+ bias_grad [N] += sum of the block pixels, optional)
+ *   nbm_cell_input         x [B][H][W][C] -> Vx [25][cells][C] = Vinv^T patch Vinv
+ *   nbm_cell_dgrad_output  M [25][cells][C] (= Vg_xi U_xi^T, nbm_gemm_conv with groups = 25, U = E w E^T from the host)
+ *                          -> the 5x5 pixels of every cell in gx [B][H][W][C] (patches do not overlap: S >= 5; other pixels
+ *                          are not written)
+ * the weight gradient's 25 TN GEMMs dU_xi = Vg_xi^T Vx_xi are nbm_conv_wgrad with groups = 25; dW = E^T dU E on the host. */
+int nbm_cell_outgrad(const float* g, int B, int H, int W, int N, int stride, float* Vg, float* bias_grad, void* stream);
+int nbm_cell_input(const float* x, int B, int H, int W, int C, int stride, float* Vx, void* stream);
+int nbm_cell_dgrad_output(const float* M, int B, int H, int W, int C, int stride, float* gx, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Spectrogram front end.  Replaces File_Processor.load/spectrogram/split_power_spec

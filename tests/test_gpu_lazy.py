@@ -142,13 +142,20 @@ def test_many_rois_at_the_real_geometry():
     # data gradient: g lives on the pattern pixels and inside the windows
     m = ((rows[:, None] & cols[None, :])[None] | win).cuda()
     g = (rnd('mg', B, H, W, N).cuda() * m[..., None]).contiguous()
-    got = ondemand.conv3x3_winograd_dgrad_tiles(st, g, _prep.wino23(w, transposed=True, m=2))
+    got = ondemand.conv3x3_winograd_dgrad_tiles(st, g, _prep.wino23(w, transposed=True, m=2))      # all through the listed F(2x2,3x3)
     ref = ops.conv3x3_winograd(g, _prep.wino23(w, transposed=True, m=2), None)        # the dense operator, same F(2x2,3x3)
     assert torch.equal(got, ref)
+    # pattern share through the cell transforms (Toom-Cook, other rounding): same support, values within fp32 noise
+    got2 = ondemand.conv3x3_winograd_dgrad_tiles(st, g, _prep.wino23(w, transposed=True, m=2), _prep.cell_weight(w))
+    assert torch.equal(got2 == 0, ref == 0) or bool(((got2 != 0) <= (ref != 0)).all())
+    assert float((got2 - ref).abs().max()) < 2e-5 * float(ref.abs().max())
 
 
-def test_weight_gradient_over_the_listed_tiles_equals_the_dense_one():
-    """g zero outside the computed tiles: the listed-tile F(2x2,3x3) weight gradient == torch's conv weight gradient."""
+@pytest.mark.parametrize('cell', [True, False])
+def test_weight_gradient_over_the_listed_tiles_equals_the_dense_one(cell):
+    """g zero outside the computed tiles: the weight gradient over the lists == torch's conv weight gradient.  cell: the pattern
+    pixels through the cell transforms (cellwino.hip), the rest of the RoI tiles through F(2x2,3x3) with the pattern pixels masked;
+    otherwise everything through the listed F(2x2,3x3) with plane masks."""
     import torch.nn.functional as F
     B, H, W, C, N = 2, 47, 66, 128, 64
     x = rnd('wx', B, H, W, C).cuda()
@@ -172,8 +179,9 @@ def test_weight_gradient_over_the_listed_tiles_equals_the_dense_one():
     ids = tiles[:int(host.item()) * 128]
     assert int((ids >= 0).sum()) > 0
     g = rnd('wg', B, H, W, N).cuda() * m[..., None]
-    dU, gb = ondemand.conv3x3_winograd_wgrad_tiles(st, x, g.contiguous(), want_bias=True)
-    gw = _prep.wino23_weight_grad(dU, 2)
+    dU, gb, dUc = ondemand.conv3x3_winograd_wgrad_tiles(st, x, g.contiguous(), want_bias=True, cell=cell)
+    assert (dUc is not None) == cell
+    gw = _prep.wino23_weight_grad(dU, 2) + (_prep.cell_weight_grad(dUc) if cell else 0)
     xr = x.permute(0, 3, 1, 2).double().cpu().requires_grad_(False)
     wr = w.double().cpu().requires_grad_(True)
     F.conv2d(xr, wr, None, 1, 1).backward(g.permute(0, 3, 1, 2).double().cpu())
@@ -183,9 +191,11 @@ def test_weight_gradient_over_the_listed_tiles_equals_the_dense_one():
     assert torch.allclose(gb.cpu(), g.sum((0, 1, 2)).cpu(), rtol=1e-4, atol=1e-4)
 
 
-def test_data_gradient_over_the_listed_tiles_equals_the_dense_one():
-    """g non-zero on the pattern pixels and inside the level-0 RoI windows only: the listed-tile F(2x2,3x3) data gradient ==
-    torch's conv2d input gradient everywhere (zeros included)."""
+@pytest.mark.parametrize('cell', [True, False])
+def test_data_gradient_over_the_listed_tiles_equals_the_dense_one(cell):
+    """g non-zero on the pattern pixels and inside the level-0 RoI windows only: the data gradient (cell: pattern share through
+    the cell transforms + listed F(2x2,3x3) around the RoI windows; otherwise all listed F(2x2,3x3)) == torch's conv2d input
+    gradient everywhere (zeros included)."""
     import torch.nn.functional as F
     B, H, W, C, N = 2, 47, 66, 128, 64
     x = rnd('gx', B, H, W, C).cuda()
@@ -216,7 +226,7 @@ def test_data_gradient_over_the_listed_tiles_equals_the_dense_one():
                 m[bi, y1:y2 + 1, x1:x2 + 1] = True
     assert n0 >= 4 * B
     g = (rnd('gg', B, H, W, N) * m[..., None]).cuda().contiguous()
-    got = ondemand.conv3x3_winograd_dgrad_tiles(st, g, _prep.wino23(w, transposed=True, m=2))
+    got = ondemand.conv3x3_winograd_dgrad_tiles(st, g, _prep.wino23(w, transposed=True, m=2), _prep.cell_weight(w) if cell else None)
     xr = x.permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
     F.conv2d(xr, w.double().cpu(), None, 1, 1).backward(g.permute(0, 3, 1, 2).double().cpu())
     ref = xr.grad.permute(0, 2, 3, 1).float()
