@@ -467,7 +467,7 @@ def main(argv=None):
             torch.cuda.synchronize()
             td = (time.perf_counter() - td) / 10
             dense_ref = {'ms_per_step': td * 1e3, 'clips_per_s_per_gpu': B / td, 'steps': 10,
-                         'note': 'NBM_LAZY_FINEST=0: every pixel of the finest FPN map and of its lateral is computed; identical detections'}
+                         'note': 'NBM_LAZY_FINEST=0: every pixel of the finest FPN map and of its lateral is computed; identical classes and boxes, scores within 1e-5 (tests/test_gpu_lazy.py)'}
         except Exception as exc:                  # informational leg: never lose the headline line over it
             dense_ref = {'error': f'{type(exc).__name__}: {exc}'[:300]}
         finally:

@@ -118,6 +118,7 @@ SIGNATURES = {
     'nbm_cell_outgrad': [_P, _I, _I, _I, _I, _I, _P, _P, _P],
     'nbm_cell_input': [_P, _I, _I, _I, _I, _I, _P, _P],
     'nbm_cell_dgrad_output': [_P, _I, _I, _I, _I, _I, _P, _P],
+    'nbm_cell_output': [_P, _P, _I, _I, _I, _I, _I, _P, _P],
     'nbm_weighted_sum': [_P, _P, _P, _P, _P, _L, _P],
     'nbm_weighted_sum_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P],
     'nbm_softmax_rows_bwd': [_P, _P, _P, _L, _I, _F, _P],

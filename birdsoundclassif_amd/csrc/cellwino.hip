@@ -173,6 +173,52 @@ __global__ __launch_bounds__(256) void cell_dgrad_output_kernel(const float* __r
   }
 }
 
+// M [25][T][N] (= Vx_xi U_xi^T) -> the 3x3 pattern block of every cell in y [B][H][W][N]: blk = E^T M E + bias (FORWARD: the
+// correlation form of the same 25-multiplication algorithm, F(3x3,3x3)); only the pattern pixels inside the image are written
+__global__ __launch_bounds__(256) void cell_output_kernel(const float* __restrict__ M, const float* __restrict__ bias, const CellGeom q,
+                                                          float* __restrict__ y) {
+  const f32x4* m4 = reinterpret_cast<const f32x4*>(M);
+  f32x4* o4 = reinterpret_cast<f32x4*>(y);
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const long long total = q.T * q.C4;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % q.C4);
+    const long long cell = i / q.C4;
+    int b, oy, ox;
+    cell_of(q, cell, b, oy, ox);
+    const f32x4 bv = bias ? reinterpret_cast<const f32x4*>(bias)[c] : zero;
+    f32x4 t[3][NP];                    // t[i][e] = sum_a E[a][i] M[a][e]
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int e = 0; e < NP; ++e) t[r][e] = zero;
+#pragma unroll
+    for (int a = 0; a < NP; ++a)
+#pragma unroll
+      for (int e = 0; e < NP; ++e) {
+        const f32x4 v = m4[((long long)(a * NP + e) * q.T + cell) * q.C4 + c];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+          if (CE[a][r] != 0.f) t[r][e] += CE[a][r] * v;
+      }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int yy = q.S * oy - 1 + r;
+      if ((unsigned)yy >= (unsigned)q.H) continue;
+#pragma unroll
+      for (int l = 0; l < 3; ++l) {
+        const int xx = q.S * ox - 1 + l;
+        if ((unsigned)xx >= (unsigned)q.W) continue;
+        f32x4 o = bv;
+#pragma unroll
+        for (int e = 0; e < NP; ++e)
+          if (CE[e][l] != 0.f) o += CE[e][l] * t[r][e];
+        o4[(((long long)b * q.H + yy) * q.W + xx) * q.C4 + c] = o;
+      }
+    }
+  }
+}
+
 inline bool cell_geom(int B, int H, int W, int C, int S, CellGeom& q) {
   if (B <= 0 || H < 3 || W < 3 || C <= 0 || (C & 3) || S < 5) return false;
   q.B = B; q.H = H; q.W = W; q.C4 = C / 4; q.S = S;
@@ -204,6 +250,14 @@ extern "C" int nbm_cell_input(const float* x, int B, int H, int W, int C, int st
   if (!x || !Vx || !cell_geom(B, H, W, C, stride, q)) return NBM_EINVAL;
   if (!nbm_aligned16(x) || !nbm_aligned16(Vx)) return NBM_EALIGN;
   hipLaunchKernelGGL(cell_input_kernel, dim3(stream_grid(q.T * q.C4, q.C4)), dim3(256), 0, (hipStream_t)stream, x, q, Vx);
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_cell_output(const float* M, const float* bias, int B, int H, int W, int N, int stride, float* y, void* stream) {
+  CellGeom q;
+  if (!M || !y || !cell_geom(B, H, W, N, stride, q)) return NBM_EINVAL;
+  if (!nbm_aligned16(M) || !nbm_aligned16(y) || (bias && !nbm_aligned16(bias))) return NBM_EALIGN;
+  hipLaunchKernelGGL(cell_output_kernel, dim3(stream_grid(q.T * q.C4, q.C4)), dim3(256), 0, (hipStream_t)stream, M, bias, q, y);
   return nbm_launch_status();
 }
 

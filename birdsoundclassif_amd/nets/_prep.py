@@ -75,18 +75,27 @@ def wino23_weight_grad(dU, m=2, row_scale=None):
 _CELL_E = [[1.0, 0.0, 0.0], [1.0, 1.0, 1.0], [1.0, -1.0, 1.0], [1.0, 2.0, 4.0], [1.0, -2.0, 4.0]]     # csrc/cellwino.hip: points 0, 1, -1, 2, -2
 
 
+_CELL_E_DEV = {}
+
+
 def _cell_e(device):
-    return torch.tensor(_CELL_E, dtype=torch.float64, device=device)
+    """Uploaded once per device: a per-call torch.tensor(..., device=cuda) is a pageable H2D copy = a stream sync in the middle of
+    a step (the host loses its run-ahead: 125 ms per training step when this sat in the forward pass)."""
+    key = str(device)
+    if key not in _CELL_E_DEV:
+        _CELL_E_DEV[key] = torch.tensor(_CELL_E, dtype=torch.float64, device=device)
+    return _CELL_E_DEV[key]
 
 
-def cell_weight(weight):
+def cell_weight(weight, forward=False):
     """Kernel side of the cell transforms (csrc/cellwino.hip): [Cout, Cin, 3, 3] -> U [25][Cin][Cout] = (E w E^T)[a][b] -- the B
-    operand of the 25 data-gradient GEMMs M_xi = Vg_xi U_xi^T.  float64 on the device, rounded once; cached per weight version."""
+    operand of the 25 data-gradient GEMMs M_xi = Vg_xi U_xi^T; `forward`: [25][Cout][Cin], the B operand of the forward GEMMs
+    M_xi = Vx_xi U_xi^T.  float64 on the device, rounded once; cached per weight version."""
     def make():
         E = _cell_e(weight.device)
-        u = torch.einsum('ar,bs,ncrs->abcn', E, E, weight.detach().double())
-        return u.reshape(25, weight.shape[1], weight.shape[0]).float().contiguous()
-    return _cached(weight, 'cell', make)
+        u = torch.einsum('ar,bs,ncrs->abnc' if forward else 'ar,bs,ncrs->abcn', E, E, weight.detach().double())
+        return u.reshape(25, *u.shape[2:]).float().contiguous()
+    return _cached(weight, ('cell', forward), make)
 
 
 def cell_weight_grad(dU):

@@ -73,7 +73,8 @@ class Conv(Function):
             # demand-driven map (ondemand.conv3x3_winograd_lazy): the tiles a 3x3 / lazy_stride consumer reads now, the tiles under
             # the RoIs when the RoI pooling asks for them; the backward pass is the dense one (the incoming gradient is
             # zero wherever nothing was read)
-            y, ctx.lazy = ondemand.conv3x3_winograd_lazy(x, _prep.wino23(weight), sh, lazy_stride[0])
+            y, ctx.lazy = ondemand.conv3x3_winograd_lazy(x, _prep.wino23(weight), sh, lazy_stride[0],
+                                                         _prep.cell_weight(weight, forward=True) if ondemand.CELL_FWD else None)
             ctx.lazy.keep = lazy_stride[1]        # a backward pass will follow: keep the RoI tile lists for the weight gradient
         elif lazy_stride and kh == 1:
             # the lateral 1x1 (+ top-down merge) in front of a demand-driven 3x3: only the pixels that convolution reads

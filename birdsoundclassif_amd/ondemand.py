@@ -274,9 +274,14 @@ def conv1x1_lazy(t, wk, bias, alpha, up, stride):
     return x
 
 
-def conv3x3_winograd_lazy(x, U, bias, stride):
+CELL_FWD = os.environ.get('NBM_CELL_FWD', '1') != '0'     # pattern pixels of the FORWARD pass through the cell transforms
+
+
+def conv3x3_winograd_lazy(x, U, bias, stride, Ucell=None):
     """Finest-level output convolution, pattern tiles only (see above) -> (y [B,H,W,N] with the other pixels unwritten,
-    LazyMap)."""
+    LazyMap).  `Ucell` (_prep.cell_weight(w, forward=True)): the pattern pixels through the cell transforms (F(3x3,3x3) per
+    stride x stride cell: 25 plane products per cell instead of the ~49 of the listed F(2x2,3x3) tiles) -- exactly the 9 / 64
+    pattern pixels are stored."""
     _chk(x, name='x'), _chk(U, name='U')
     B, H, W, C_ = x.shape
     N = U.shape[1]
@@ -294,6 +299,22 @@ def conv3x3_winograd_lazy(x, U, bias, stride):
         st.skip = pat.full
         st.chunks.append((b0, nb, pat))
         st.sparse = pat.frac < 0.6               # the weight gradient over the listed tiles pays off when most are not listed
+        if Ucell is not None and stride >= 5 and C_ % 32 == 0 and N % 4 == 0:
+            T = cell_count(nb, H, W, stride)
+            Vx, M = ops._wino_scratch(x.device, 25 * T * C_, 25 * T * N)
+            stream = _stream()
+            check(lib().nbm_cell_input(_ptr(x[b0:b0 + nb]), nb, H, W, C_, stride, _ptr(Vx), stream), 'nbm_cell_input')
+            keep_label, ops._PROFILE_LABEL = ops._PROFILE_LABEL, ('cell-fwd', H, W)
+            try:
+                gemm_conv(Vx, Ucell, M, B=1, H=T, W=1, Cin=C_, N=N, groups=25, x_gs=T * C_, w_gs=N * C_, y_gs=T * N)
+            finally:
+                ops._PROFILE_LABEL = keep_label
+            check(lib().nbm_cell_output(_ptr(M), _ptr(bias), nb, H, W, N, stride, C.c_void_p(y.data_ptr() + b0 * img_bytes), stream),
+                  'nbm_cell_output')
+            # the RoI phase skips nothing: every pixel the RoI pooling reads is then a value of the dense F(2x2,3x3) convolution, bit
+            # for bit; only the RPN's strided reader sees the cell values (1 tile in 16 is all pattern pixels: +6 % RoI-phase tiles)
+            st.skip = None
+            continue
         _wino23_tiles_run(x[b0:b0 + nb], U, bias, y.data_ptr() + b0 * img_bytes, pat.tiles, None, pat.n_eff, 'wino23', pat.blk_info,
                           dense_rows=pat.frac == 1.0)
     for k in [k for k, v in _LAZY.items() if v[1]() is None]:      # maps of earlier forwards that were never completed

@@ -172,6 +172,10 @@ int nbm_wino23_outgrad_tiles(const float* g, int B, int H, int W, int N, const i
 int nbm_cell_outgrad(const float* g, int B, int H, int W, int N, int stride, float* Vg, float* bias_grad, void* stream);
 int nbm_cell_input(const float* x, int B, int H, int W, int C, int stride, float* Vx, void* stream);
 int nbm_cell_dgrad_output(const float* M, int B, int H, int W, int C, int stride, float* gx, void* stream);
+/* FORWARD of the pattern pixels with the same 25 products per cell (the correlation form, F(3x3,3x3)): nbm_cell_input of the
+ * input, M_xi = Vx_xi U_xi^T (U = E w E^T as [25][N][C]), then blk = E^T M E + bias into the 3x3 pattern block of every cell of
+ * y [B][H][W][N] (other pixels are not written). */
+int nbm_cell_output(const float* M, const float* bias, int B, int H, int W, int N, int stride, float* y, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Spectrogram front end.  Replaces File_Processor.load/spectrogram/split_power_spec

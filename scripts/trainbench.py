@@ -21,4 +21,4 @@ for neg in (False,):
         torch.cuda.synchronize(); t = time.perf_counter()
         loss = train_one_step(model, crit, opt, batch, args.clip_max_norm, 'cuda', negative_sample=neg)
         torch.cuda.synchronize(); dt = time.perf_counter() - t
-        print(f'B={B} neg={neg} it={it} {dt*1e3:.1f} ms  {B/dt:.1f} clips/s  mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB', {k: round(float(v),4) for k,v in loss.items()}, flush=True)
+        print(f'B={B} neg={neg} it={it} {dt*1e3:.1f} ms  {B/dt:.1f} clips/s  mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB reserved {torch.cuda.memory_reserved()/2**30:.1f} retries {torch.cuda.memory_stats().get("num_alloc_retries", 0)}', {k: round(float(v),4) for k,v in loss.items()}, flush=True)

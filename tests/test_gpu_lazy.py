@@ -95,6 +95,47 @@ def test_listed_tiles_equal_the_dense_convolution(shape):
     assert bool(torch.isnan(y[~want]).all()), 'a pixel outside pattern pixels + RoI tiles was written'
 
 
+@pytest.mark.parametrize('shape', [(2, 24, 40, 128, 64, 8), (3, 47, 66, 128, 128, 8), (1, 188, 512, 384, 256, 8), (2, 45, 61, 64, 32, 6)])
+def test_cell_forward_stores_exactly_the_pattern_pixels(shape):
+    """Default forward of the pattern pixels: per stride x stride cell F(3x3,3x3) through the cell transforms (cellwino.hip,
+    25 plane products per cell).  Exactly the pattern pixels are written (NaN poison survives everywhere else), within fp32
+    rounding of the dense convolution (another summation order: not bit-identical, unlike the listed F(2x2,3x3) tiles above);
+    the RoI phase afterwards stores its tiles bit-identical to the dense F(2x2,3x3) convolution."""
+    B, H, W, C, N, S = shape
+    x = rnd(('cx', shape), B, H, W, C).cuda()
+    w = rnd(('cw', shape), N, C, 3, 3, scale=0.05).cuda()
+    b = rnd(('cb', shape), N).cuda()
+    U = _prep.wino23(w)
+    dense = ops.conv3x3_winograd(x, U, b) if C >= 64 else ops.conv2d(x, _prep.krsc(w), 3, 3, 1, 1, shift=b)
+    ondemand.LAZY_POISON = True
+    try:
+        y, st = ondemand.conv3x3_winograd_lazy(x, U, b, S, _prep.cell_weight(w, forward=True))
+    finally:
+        ondemand.LAZY_POISON = False
+    rows = torch.zeros(H, dtype=torch.bool)
+    cols = torch.zeros(W, dtype=torch.bool)
+    for n_, v in ((H, rows), (W, cols)):
+        for o in range((n_ - 1) // S + 1):
+            for k in range(3):
+                if 0 <= S * o - 1 + k < n_:
+                    v[S * o - 1 + k] = True
+    m = (rows[:, None] & cols[None, :]).cuda()
+    assert bool(torch.isnan(y[:, ~m]).all()), 'a pixel outside the pattern was written'
+    err = float((y[:, m] - dense[:, m]).abs().max())
+    assert err < 1e-5 * max(1.0, float(dense.abs().max())), (err, float(dense.abs().max()))
+    if C < 64:
+        return
+    fh = [H, (H + 1) // 2, (H + 3) // 4, (H + 7) // 8, (H + 15) // 16]
+    fw = [W, (W + 1) // 2, (W + 3) // 4, (W + 7) // 8, (W + 15) // 16]
+    rois = torch.tensor([[[10., 12., 25., 20.], [60., 40., 70., 66.], [0., 0., 8., 9.]]] * B).cuda()
+    before = y.clone()
+    ondemand.lazy_complete(y, rois, torch.tensor([3], dtype=torch.int32, device='cuda'), list(zip(fh, fw)))
+    new = ~torch.isnan(y[..., 0]) & torch.isnan(before[..., 0])
+    assert int(new.sum()) > 0 and torch.equal(y[new], dense[new])
+    changed = (y != before).any(-1) & ~torch.isnan(before[..., 0])            # pattern pixels inside RoI tiles: stored again, whole
+    assert torch.equal(y[changed], dense[changed])
+
+
 def test_many_rois_at_the_real_geometry():
     """1000 RoIs per image (the negative training step's load) on the 188x512 map: every pixel of every level-0 window equals the
     dense convolution, nothing outside pattern pixels + window tiles is written, and the dilated list covers the data gradient."""
@@ -304,7 +345,10 @@ def test_detections_do_not_change_and_no_unwritten_pixel_is_read(model, B):
         finally:
             ondemand.LAZY_POISON = False
     assert int(n0.sum()) > 0
-    assert torch.equal(n0, n1) and torch.equal(det0, det1)        # NaN anywhere in the consumed pixels would break this
+    # NaN anywhere in the consumed pixels would break this.  Classes and boxes identical; the scores see the pattern pixels of the
+    # finest map through another summation order (cell transforms vs the dense F(2x2,3x3) tiles)
+    assert torch.equal(n0, n1) and torch.equal(det0[..., :5], det1[..., :5])
+    assert float((det0[..., 5] - det1[..., 5]).abs().max()) < 1e-5
 
 
 def test_independent_detection_equals_one_image_per_call(model):
@@ -371,7 +415,7 @@ def test_a_second_roi_pooling_on_a_held_map_sees_its_tiles():
     for k, g in res[False][1].items():
         g2 = res[True][1][k]
         assert torch.isfinite(g2).all(), k
-        tol = 2e-3 * float(g.abs().max()) + 1e-7          # dense path: F(4x4,3x3) gradients of out_convs.4; listed path: F(2x2,3x3)
+        tol = 2e-3 * float(g.abs().max()) + 1e-6          # dense path: F(4x4,3x3) gradients of out_convs.4; on-demand path: cell transforms
         assert float((g - g2).abs().max()) <= tol, (k, float((g - g2).abs().max()), tol)
 
 
@@ -409,7 +453,7 @@ def test_listed_backward_with_a_frozen_weight_or_a_switch_off(case):
     for k, g in res[False].items():
         g2 = res[True][k]
         assert torch.isfinite(g2).all(), k
-        tol = 2e-3 * float(g.abs().max()) + 1e-7
+        tol = 2e-3 * float(g.abs().max()) + 1e-6
         assert float((g - g2).abs().max()) <= tol, (k, float((g - g2).abs().max()), tol)
 
 
@@ -441,8 +485,9 @@ def test_train_step_losses_and_gradients_do_not_change(negative):
         torch.cuda.synchronize()
         res[lazy] = ({k: float(v) for k, v in loss.items()}, float(opt.grad_norm()),
                      {k: v.detach().clone() for k, v in model.state_dict().items()})
-    assert res[False][0] == res[True][0], (res[False][0], res[True][0])
-    assert np.isfinite(res[True][1]) and abs(res[False][1] - res[True][1]) <= 1e-6 * res[False][1]
+    for k, v in res[False][0].items():          # the pattern pixels go through the cell transforms: same value up to fp32 rounding
+        assert abs(v - res[True][0][k]) <= 2e-6 * max(1.0, abs(v)), (k, v, res[True][0][k])
+    assert np.isfinite(res[True][1]) and abs(res[False][1] - res[True][1]) <= 1e-5 * res[False][1]
     # post-AdamW weights: the weight gradients are summed with float atomics (order varies from run to run), and the first
     # AdamW step turns a gradient into lr * g / (|g| + eps), which amplifies that noise where g is tiny
     for k, v in res[False][2].items():
