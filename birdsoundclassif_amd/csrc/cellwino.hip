@@ -219,8 +219,9 @@ __global__ __launch_bounds__(256) void cell_output_kernel(const float* __restric
   }
 }
 
-inline bool cell_geom(int B, int H, int W, int C, int S, CellGeom& q) {
-  if (B <= 0 || H < 3 || W < 3 || C <= 0 || (C & 3) || S < 5) return false;
+// S >= 3: the 3x3 blocks of different cells are disjoint; the 5x5 patches may overlap (read-only) unless they are written
+inline bool cell_geom(int B, int H, int W, int C, int S, CellGeom& q, int min_S = 3) {
+  if (B <= 0 || H < 3 || W < 3 || C <= 0 || (C & 3) || S < min_S) return false;
   q.B = B; q.H = H; q.W = W; q.C4 = C / 4; q.S = S;
   q.OH = (H + 2 - 3) / S + 1; q.OW = (W + 2 - 3) / S + 1;          // output size of the 3x3 / stride S / pad 1 reader
   q.T = (long long)B * q.OH * q.OW;
@@ -263,7 +264,7 @@ extern "C" int nbm_cell_output(const float* M, const float* bias, int B, int H, 
 
 extern "C" int nbm_cell_dgrad_output(const float* M, int B, int H, int W, int C, int stride, float* gx, void* stream) {
   CellGeom q;
-  if (!M || !gx || !cell_geom(B, H, W, C, stride, q)) return NBM_EINVAL;
+  if (!M || !gx || !cell_geom(B, H, W, C, stride, q, 5)) return NBM_EINVAL;      // 5x5 patches are WRITTEN: no overlap allowed
   if (!nbm_aligned16(M) || !nbm_aligned16(gx)) return NBM_EALIGN;
   hipLaunchKernelGGL(cell_dgrad_output_kernel, dim3(stream_grid(q.T * q.C4, q.C4)), dim3(256), 0, (hipStream_t)stream, M, q, gx);
   return nbm_launch_status();

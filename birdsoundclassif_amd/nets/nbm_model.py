@@ -29,10 +29,12 @@ class NbmModel(nn.Module):
 
     def _lazy_strides(self):
         """{pyramid level: stride of the RPN's depthwise 3x3 on that level (layers.py:62-65)} for the FPN output maps that are
-        computed on demand: default topology only (FPN outputs read by the RPN and the RoI pooling, nothing else), and level 0
-        only (stride 8: three tiles out of four are never read).  Level 1 (stride 4) was measured and left dense: every tile
-        holds a pattern pixel, so the gain is the 23 % of planes that partial tiles skip (10.1 -> 8.5 ms at B = 64), and the
-        RoI phase then recomputes the partial tiles under the level-1 RoIs -- 5.0 ms with 50 RoIs per image."""
+        computed on demand: default topology only (FPN outputs read by the RPN and the RoI pooling, nothing else).
+        Level 0 (stride 8): three 2x2 tiles out of four are never read.  Level 1 (stride 4): every tile holds a pattern pixel, so
+        the listed F(2x2,3x3) tiles gained nothing there (round 2: 10.1 -> 8.5 ms at B = 64, eaten by the RoI phase); with the
+        pattern pixels going through the cell transforms (csrc/cellwino.hip: 25 plane products per 4x4 cell instead of the 64 of
+        its four tiles) it pays: detect step 81.4 -> 75.6 ms at B = 64.  NBM_LAZY_LEVEL1=0 keeps level 1 dense."""
+        from .. import ondemand
         a = self.args
         if getattr(a, 'fpn_first', False) or getattr(a, 'sandwich_attn', False) or getattr(a, 'fpn', 'fpn') != 'fpn':
             return None
@@ -40,7 +42,7 @@ class NbmModel(nn.Module):
         if not (st >= 6 and st == int(st)):
             return None
         out = {0: int(st)}
-        if os.environ.get('NBM_LAZY_LEVEL1') == '1' and not self.training:
+        if ondemand.CELL_FWD and os.environ.get('NBM_LAZY_LEVEL1', '1') != '0' and int(st) % 2 == 0 and int(st) // 2 >= 3:
             out[1] = int(st) // 2
         return out
 

@@ -299,7 +299,7 @@ def conv3x3_winograd_lazy(x, U, bias, stride, Ucell=None):
         st.skip = pat.full
         st.chunks.append((b0, nb, pat))
         st.sparse = pat.frac < 0.6               # the weight gradient over the listed tiles pays off when most are not listed
-        if Ucell is not None and stride >= 5 and C_ % 32 == 0 and N % 4 == 0:
+        if Ucell is not None and stride >= 3 and C_ % 32 == 0 and N % 4 == 0:       # (3x3 blocks of different cells never overlap)
             T = cell_count(nb, H, W, stride)
             Vx, M = ops._wino_scratch(x.device, 25 * T * C_, 25 * T * N)
             stream = _stream()
