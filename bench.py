@@ -11,9 +11,10 @@ One "step" = one pass of the hot path over one batch of synthetic input per rank
 Workload = BASELINE.json configs[1] (batch 64 per GPU, fp32).  Multi-GPU: clips are independent, every rank
 runs its own batch (weak scaling, no data-path collective); value = all clips of all ranks / max-over-ranks time.
 
-Prints ONE JSON line on rank 0, carrying `roofline` (dominant kernel: the fused Winograd kernel of the FPN 3x3
-384->256 convolution at 188x512, timed live with HIP events on the launch stream) and `cpu_baseline` (the oracle port
-on the host cores, bounded sample, N=1 only).
+Prints ONE JSON line on rank 0, carrying `roofline` (dominant kernel: the deep-K instantiation of the fp32-MFMA implicit-GEMM
+kernel, all its launches of a step timed live with HIP events on the launch stream), `bulk_inference` (configs[4] on this
+rank's shard: wav files -> txt files end to end), `train_step` (configs[2] / [3]) and `cpu_baseline` (the oracle port on the
+host cores, bounded sample, N=1 only).  `python bench.py --gpus N` starts its N ranks itself (see launch_ranks).
 """
 import argparse
 import json
@@ -27,7 +28,7 @@ sys.path.insert(0, ROOT)
 import numpy as np   # noqa: E402
 import torch         # noqa: E402
 
-PMC_DOMINANT = 'r02_pmc_dominant.json'    # committed rocprofv3 --pmc passes of `python bench.py` (scripts/pmc_dominant.py)
+PMC_DOMINANT = 'r03_pmc_dominant.json'    # committed rocprofv3 --pmc passes of `python bench.py` (scripts/pmc_dominant.py)
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 FP64_MFMA_PEAK_TFLOPS = 78.6           # v_mfma_f64_16x16x4_f64: half the fp32 rate on this part (64 cycles / 2048 FLOP / SIMD)
 FPN0_GFLOP_PER_CLIP = 170.322          # fpn.out_convs.4, 3x3 384->256 @188x512
@@ -424,7 +425,7 @@ def main(argv=None):
         step()
     sync_all()
     ops.PROFILE = []                                           # live HIP-event timing of the dominant kernel's launches only:
-    ops.PROFILE_FUSED_ONLY = True                              # events around all ~250 launches cost the step 2.5 %
+    ops.PROFILE_ONLY = 'deepk'                                 # events around all ~250 launches cost the step 2.5 %
     t0 = time.perf_counter()
     n_det = 0
     pending = None
@@ -439,7 +440,7 @@ def main(argv=None):
     sync_all()
     dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
-    ops.PROFILE_FUSED_ONLY = False
+    ops.PROFILE_ONLY = None
     ops.PROFILE = []                                           # one extra, untimed step with events around every GEMM-type launch
     ops.FLOPS = [0.0]                                          # ... and the executed-MFMA-FLOP counter of every GEMM launch
     step()
@@ -477,58 +478,66 @@ def main(argv=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # roofline of the dominant kernel = wino23_fused_kernel<128,64> (csrc/wino_fused.hip): every launch of a step, i.e. the
-    # FPN output convolutions (level P1 at 188x512 on demand: the tiles the RPN pattern reads, then the tiles under the
-    # RoIs; levels P2.. dense) and the ResNet 3x3 / stride-1 layers.  `achieved` = MFMA FLOPs these launches EXECUTE
-    # (2 * 16 planes * tiles * Cin * Cout = 1/2.25 of the direct-convolution count per computed tile) over their HIP-event
-    # time on the launch stream; avg_launch_ms is what rocprofv3 --stats reports as the kernel's average duration.
-    def tiles_of(tag):
-        t = tag[3]
-        return int(t.item()) * 128 if torch.is_tensor(t) else int(t)
-    fused = [(tag, s.elapsed_time(e)) for (tag, s, e) in prof
-             if len(tag) == 9 and isinstance(tag[8], tuple) and tag[8][0] in ('wino23', 'wino23-rois')]
+    # roofline of the dominant kernel = igemm_kernel<128,128,64,64,A_FAST,EPI_STD,2> (csrc/igemm.hip), the deep-K instantiation of
+    # the implicit-GEMM kernel: every launch of a step that nbm_gemm_conv dispatches to it -- the ResNet 1x1 / strided 3x3 layers
+    # with K > 256, the attention GEMMs, the FPN laterals of levels 1-4 and the 25 grouped plane GEMMs of the cell transforms
+    # (FPN levels 0 and 1 on demand).  `achieved` = MFMA FLOPs these launches EXECUTE (2 * M * N * K * groups) over their HIP-event
+    # time on the launch stream inside the timed loop; avg_launch_ms is what rocprofv3 --stats reports as the kernel's average.
+    def gemm_gflop(tag):
+        Cin, N, k, H, W, Bn, groups, stride = tag[:8]
+        return 2.0 * Bn * ((H - 1) // stride + 1) * ((W - 1) // stride + 1) * N * Cin * k * k * groups / 1e9
+
+    def what(tag):
+        Cin, N, k, H, W, Bn, groups, stride, label = tag
+        g = f' x{groups} groups' if groups > 1 else ''
+        lab = f' [{label[0]} {label[1]}x{label[2]}]' if isinstance(label, tuple) else ''
+        return f'{k}x{k} s{stride} {Cin}->{N} @{H}x{W} B={Bn}{g}{lab}'
+    deep = [(tag, s.elapsed_time(e)) for (tag, s, e) in prof if len(tag) == 9 and ops.is_deepk(tag[0], tag[1], tag[2], tag[2])]
     all_ms = sum(s.elapsed_time(e) for (tag, s, e) in prof_all if len(tag) == 9)
+    fused_ms = sum(s.elapsed_time(e) for (tag, s, e) in prof_all
+                   if len(tag) == 9 and isinstance(tag[8], tuple) and tag[8][0] in ('wino23', 'wino23-rois'))
     roof = None
     traffic = None                      # HBM bytes per launch of the dominant kernel: PMC counters cannot be read live;
     try:                                # the value comes from the committed rocprofv3 --pmc passes of this same command
         pj = json.load(open(os.path.join(ROOT, 'profiles', PMC_DOMINANT)))
-        if B == 64 and pj.get('lazy_finest') == bool(ondemand.LAZY_FINEST):
+        if B == 64 and pj.get('lazy_finest') == bool(ondemand.LAZY_FINEST) and pj.get('kernel_family') == 'igemm deep-K':
             traffic = pj['traffic_bytes_per_launch']
     except Exception:
         traffic = None
-    if fused:
-        per = [(tag, ms, 2.0 * 16 * tiles_of(tag) * tag[0] * tag[1] / 1e9) for tag, ms in fused]
+    if deep:
+        per = [(tag, ms, gemm_gflop(tag)) for tag, ms in deep]
         gflop, ms = sum(g for _, _, g in per), sum(m for _, m, _ in per)
         ach = gflop / ms                                       # GFLOP/ms == TFLOP/s
         big = {}
         for tag, m, g in per:                                  # per distinct launch (layer): time and rate
-            k = f'{tag[8][0]} 3x3 {tag[0]}->{tag[1]} @{tag[8][1]}x{tag[8][2]}'
-            slot = big.setdefault(k, [0.0, 0.0, 0])
+            slot = big.setdefault(what(tag), [0.0, 0.0, 0])
             slot[0] += m
             slot[1] += g
             slot[2] += 1
-        top = sorted(big.items(), key=lambda kv: -kv[1][0])[:3]
-        roof = {'bound': 'mfma', 'kernel': 'wino23_fused_kernel<128,64>: Winograd F(2x2,3x3) convolution in one kernel (column half of '
-                                           'the input transform + 16 transformed-domain GEMMs + output transform + epilogue); all its '
-                                           'launches of a step (FPN output convolutions, ResNet 3x3/s1 layers)',
+        top = sorted(big.items(), key=lambda kv: -kv[1][0])[:4]
+        roof = {'bound': 'mfma', 'kernel': 'igemm_kernel<128,128,64,64,A_FAST,EPI_STD,STAGES=2>: fp32-MFMA implicit GEMM, deep-K '
+                                           'instantiation (128x128x32 tiles, double-buffered LDS, fused epilogue); all its launches of a '
+                                           'step: ResNet 1x1 / strided 3x3 layers with K > 256, attention, FPN laterals, the 25 grouped '
+                                           'plane GEMMs of the cell transforms of the on-demand FPN levels',
                 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS,
                 'traffic': traffic, 'traffic_unit': 'bytes/launch (2*FETCH_SIZE + WRITE_SIZE, mean over the launches)',
                 'traffic_source': f'profiles/{PMC_DOMINANT}: separate rocprofv3 --pmc passes of this command, NOT measured in this run '
                                   '(counters cannot be read live); null when batch / on-demand mode differ from that profile',
                 'avg_launch_ms': ms / len(per), 'launches': len(per), 'launches_per_step': len(per) / a.steps,
                 'executed_GFLOP_per_launch': gflop / len(per), 'ms_per_step': ms / a.steps,
-                'largest_launches': [{'what': k, 'ms': v[0] / v[2], 'executed_TFLOPs': v[1] / v[0],
+                'largest_launches': [{'what': k, 'ms': v[0] / v[2], 'launches_per_step': v[2] / a.steps, 'executed_TFLOPs': v[1] / v[0],
                                       'frac': v[1] / v[0] / FP32_MFMA_PEAK_TFLOPS} for k, v in top],
                 'all_gemm_type_launches_ms_per_step': all_ms,
+                'fused_winograd_kernel_ms_per_step': fused_ms,
                 'whole_step_executed_GFLOP_per_clip': exec_gflop_per_clip,
                 'whole_step_executed_TFLOPs': exec_gflop_per_clip * B * a.steps / (dt * 1e3),
                 'whole_step_executed_frac_of_mfma_peak': exec_gflop_per_clip * B * a.steps / (dt * 1e3) / FP32_MFMA_PEAK_TFLOPS,
                 'whole_step_direct_conv_equivalent_TFLOPs': FWD_GFLOP_PER_CLIP * B * a.steps / (dt * 1e3),
-                'whole_step_note': 'executed = MFMA FLOPs the launches of a step really perform (Winograd-domain counts, listed tiles '
-                                   'only, fp64 DFT GEMMs counted at face value) over the wall time of the whole step incl. every '
+                'whole_step_note': 'executed = MFMA FLOPs the launches of a step really perform (Winograd- / cell-domain counts, listed '
+                                   'tiles only, fp64 DFT GEMMs counted at face value) over the wall time of the whole step incl. every '
                                    'non-GEMM kernel; direct_conv_equivalent uses SURVEY 325.56 GFLOP/clip and is NOT a roofline figure',
-                'finest_fpn_map': 'on demand (RPN pattern tiles + tiles under the RoIs; the other pixels have no reader)'
-                                  if ondemand.LAZY_FINEST else 'dense'}
+                'fpn_levels_0_1': 'on demand (pattern pixels of the RPN readers through the cell transforms + tiles under the RoIs; the '
+                                  'other pixels have no reader)' if ondemand.LAZY_FINEST else 'dense'}
     # front end alone (HBM-bound stage of the path): live HIP events around K replays
     fe_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
     for s0, e0 in fe_ev:

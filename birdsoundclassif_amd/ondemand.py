@@ -147,7 +147,8 @@ def _wino23_tiles_run(x, U, bias, y_ptr, tiles, n_blocks, n_listed, label, blk_i
             ops.FLOPS_DEFERRED.append((n_blocks.clone(), 2.0 * 16 * 128 * C_ * N))
         else:
             ops.FLOPS[0] += 2.0 * 16 * n_listed * C_ * N
-    if ops.PROFILE is not None:
+    prof = ops._prof_fused()
+    if prof:
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         if ops._prof_all():
             ev[0].record()
@@ -156,11 +157,11 @@ def _wino23_tiles_run(x, U, bias, y_ptr, tiles, n_blocks, n_listed, label, blk_i
     else:
         check(lib().nbm_wino23_rows_tiles(_ptr(x), B, H, W, C_, _ptr(tiles), tiles.numel(), nb_ptr, _ptr(blk_info), _ptr(R), st),
               'nbm_wino23_rows_tiles')
-    if ops.PROFILE is not None:
+    if prof:
         ev[1].record()
     check(lib().nbm_wino23_conv_fused_tiles(_ptr(R), _ptr(U), None, _ptr(bias), None, 0, B, H, W, C_, N, C.c_void_p(y_ptr), _ptr(tiles),
                                             tiles.numel(), nb_ptr, _ptr(blk_info), st), 'nbm_wino23_conv_fused_tiles')
-    if ops.PROFILE is not None:
+    if prof:
         ev[2].record()
         # listed tiles: known on the host for the pattern, a device counter for the RoI tiles (resolved by the reader after a sync)
         cnt = n_listed if n_listed is not None else n_blocks.clone()

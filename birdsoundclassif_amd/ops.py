@@ -30,12 +30,23 @@ def flops_total():
 
 
 _PROFILE_LABEL = None          # set by composite ops (Winograd) so that their GEMM launches can be told apart
-PROFILE_FUSED_ONLY = False      # record only the launches of the fused Winograd kernel (bench.py's timed loop: ~17 event pairs per
-                                # step instead of ~250, whose records cost the step 2.5 %)
+PROFILE_ONLY = None             # None: every GEMM-type launch; 'fused': only the fused Winograd kernel; 'deepk': only the deep-K
+                                # instantiation of the implicit-GEMM kernel, igemm_kernel<128,128,64,64,A_FAST,EPI_STD,2> (bench.py's
+                                # timed loop: event pairs around all ~250 launches of a step cost it 2.5 %)
 
 
 def _prof_all():
-    return PROFILE is not None and not PROFILE_FUSED_ONLY
+    return PROFILE is not None and PROFILE_ONLY is None
+
+
+def _prof_fused():
+    return PROFILE is not None and PROFILE_ONLY in (None, 'fused')
+
+
+def is_deepk(Cin, N, kh, kw, rows=None):
+    """Does nbm_gemm_conv dispatch this launch to igemm_kernel<128,128,64,64,A_FAST,EPI_STD,STAGES=2> (csrc/igemm.hip: N > 64,
+    more than 8 K-steps of 32, channel count a multiple of 32, no row list)?"""
+    return rows is None and N > 64 and Cin % 32 == 0 and kh * kw * Cin > 256
 
 
 
@@ -96,7 +107,7 @@ def gemm_conv(x, w, y, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, Ho=None,
             FLOPS[0] += 2.0 * rows_count * N * Cin
         else:
             FLOPS_DEFERRED.append((rows_blocks.clone(), 2.0 * 128 * (16 if rows_mode == 2 else 1) * N * Cin))
-    if _prof_all():
+    if _prof_all() or (PROFILE is not None and PROFILE_ONLY == 'deepk' and is_deepk(Cin, N, kh, kw, rows)):
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         check(lib().nbm_gemm_conv(C.byref(d), _stream()), 'nbm_gemm_conv')
@@ -191,12 +202,12 @@ def conv3x3_winograd(x, U, bias=None, m=2, scale=None, relu=False, mask=None):
             check(lib().nbm_wino23_rows(_ptr(x[b0:b0 + nb]), nb, H, W, C_, _ptr(V), st), 'nbm_wino23_rows')
             if FLOPS is not None:
                 FLOPS[0] += 2.0 * nxi * T * C_ * N
-            if PROFILE is not None:
+            if _prof_fused():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             check(lib().nbm_wino23_conv_fused(_ptr(V), _ptr(U), _ptr(scale), _ptr(bias), mk, int(relu), nb, H, W, C_, N,
                                               _ptr(y[b0:b0 + nb]), WINO_FUSED_VARIANT, st), 'nbm_wino23_conv_fused')
-            if PROFILE is not None:
+            if _prof_fused():
                 e1.record()
                 PROFILE.append(((C_, N, 1, T, 1, 1, nxi, 1, ('wino23', H, W)), e0, e1))
             continue

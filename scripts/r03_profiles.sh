@@ -1,0 +1,29 @@
+#!/bin/bash
+# Round-3 profile collection on the GPU box (run through gpurun): writes the files that profiles/r03_* are copied from.
+set -e
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/r03
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+python3 $R/scripts/fwdprofile.py 64 > $O/fwd_layers.txt 2>&1
+python3 $R/scripts/trainlayers.py 128 > $O/train_layers.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-dense-reference --bulk-files 0 > $O/bench_under_rocprof.log 2>&1
+find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/bench_kernel_stats.csv \;
+rm -rf $O/stats
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/tstats -- python3 $R/scripts/trainbench.py 128 3 > $O/train_under_rocprof.log 2>&1
+find $O/tstats -name "*kernel_stats.csv" -exec cp {} $O/train_kernel_stats.csv \;
+rm -rf $O/tstats
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train --no-dense-reference --bulk-files 0 > $O/pmc_$c.log 2>&1
+done
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_MFMA -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-train --no-dense-reference --bulk-files 0 > $O/pmc_MFMA.log 2>&1
+# plain bench line (no profiler attached): the numbers DESIGN.md quotes
+python3 $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
+GF=$(python3 -c "import json,sys; print(json.loads(open('$O/bench_default.json').read().strip().splitlines()[-1])['roofline']['executed_GFLOP_per_launch'])")
+python3 $R/scripts/pmc_dominant.py $O/pmc_dominant.json "igemm_kernel<128, 128, 64, 64, 0, 0, 2, false>" $GF $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_MFMA "igemm_kernel<128,128,64,64,A_FAST,EPI_STD,2>, mean over all launches of the B = 64 detect step (FPN levels 0 and 1 on demand)" all > /dev/null
+python3 $R/scripts/pmc_dominant.py $O/pmc_fused.json "wino23_fused_kernel" 0 $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_MFMA "wino23_fused_kernel<128,64>, mean over all launches of the B = 64 detect step" all > /dev/null
+for d in pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_MFMA; do
+  python3 $R/scripts/pmc_summarize.py $O/$d > $O/$d.summary.txt
+  rm -rf $O/$d
+done
+ls -la $O
