@@ -328,9 +328,11 @@ __global__ __launch_bounds__(256, 2) void igemm_nn_kernel(const BwdParams p) {
 //   B_GENERIC unaligned or Cin % 4 != 0: scalar gather over the flattened (tap, c) axis
 enum { B_SAME = 0, B_STRIDED = 1, B_GENERIC = 2 };
 
-template <int BN, int BMODE, int SCHED = 0>
+// BM: rows of the dW tile = output channels n of the convolution.  128 by default; 64 for layers with N <= 64 (ResNet layer1:
+// with the 128-row tile half of every MFMA multiplied the zero padding of the G tile -- 59 TF/s "executed" on 3x3 64 -> 64).
+template <int BN, int BMODE, int SCHED = 0, int BM = 128>
 __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(const BwdParams p) {
-  constexpr int BM = 128, WM = 64, WN = BN / 2, MT = 2, NT = WN / 32;
+  constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;
   constexpr int AP = BM + 4, BP = BN + 4;
   __shared__ __attribute__((aligned(16))) float lds[2 * BK * AP + 2 * BK * BP];
   nbm_stagger_priority();
@@ -506,10 +508,11 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(const BwdParams p) {
     constexpr bool STORE = decltype(store_c)::value, LOAD = decltype(load_c)::value;
     const int cur = kt & 1;
     __syncthreads();
-    if (do_bias) {            // workgroup-uniform: column sums of the G tile (bias gradient), 16 pixels per thread
-      const float* Ar = As + (cur * BK + (tid >> 7) * 16) * AP + (tid & 127);
+    if (do_bias) {            // workgroup-uniform: column sums of the G tile (bias gradient), 32 * BM / 256 pixels per thread
+      constexpr int BT = 256 / BM, PX = BK / BT;
+      const float* Ar = As + (cur * BK + (tid / BM) * PX) * AP + (tid % BM);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) bsum += Ar[e * AP];
+      for (int e = 0; e < PX; ++e) bsum += Ar[e * AP];
     }
     const float* Ab = As + (cur * BK + lh * 16) * AP + wm0 + lrow;
     const float* Bb = Bs + (cur * BK + lh * 16) * BP + wn0 + lrow;
@@ -553,7 +556,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(const BwdParams p) {
   }
 
   if (do_bias) {
-    const int n = bm0 + (tid & 127);
+    const int n = bm0 + (tid % BM);
     if (n < p.N) atomicAdd(p.bias_grad + (long long)grp * p.N + n, bsum);
   }
   float* __restrict__ og = p.out + (long long)grp * p.out_gs;
@@ -652,7 +655,8 @@ extern "C" int nbm_conv_wgrad(const nbm_bwd_desc* d, void* stream) {
   const int taps = d->kh * d->kw;
   if (d->out_ld < taps * d->Cin) return NBM_EINVAL;
   p.M = d->B * d->Ho * d->Wo;
-  p.m_tiles = (d->N + 127) / 128;
+  const bool narrow_m = d->N <= 64 && !p.b_generic;            // 64-row dW tiles: no MFMA spent on the zero half of a 128-row G tile
+  p.m_tiles = narrow_m ? 1 : (d->N + 127) / 128;
   hipStream_t st = (hipStream_t)stream;
   const bool wide = !p.b_generic && d->Cin > 64;
   const int BN = wide ? 128 : 64;
@@ -679,6 +683,12 @@ extern "C" int nbm_conv_wgrad(const nbm_bwd_desc* d, void* stream) {
   const bool same = !p.b_generic && d->stride == 1 && d->Ho == d->H && d->Wo == d->W && (d->Wo >= BK || p.plain) &&
                     (long long)BK * d->x_ld * 4 < 0x40000000ll;
   if (p.b_generic) hipLaunchKernelGGL((igemm_tn_kernel<64, B_GENERIC>), grid, dim3(256), 0, st, p);
+  else if (narrow_m) {
+    if (wide && same) hipLaunchKernelGGL((igemm_tn_kernel<128, B_SAME, 0, 64>), grid, dim3(256), 0, st, p);
+    else if (wide) hipLaunchKernelGGL((igemm_tn_kernel<128, B_STRIDED, 0, 64>), grid, dim3(256), 0, st, p);
+    else if (same) hipLaunchKernelGGL((igemm_tn_kernel<64, B_SAME, 0, 64>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((igemm_tn_kernel<64, B_STRIDED, 0, 64>), grid, dim3(256), 0, st, p);
+  }
   else if (wide && same) {
     static const int sched = getenv("NBM_TN_SCHED") ? atoi(getenv("NBM_TN_SCHED")) : 0;
     if (sched == 1) hipLaunchKernelGGL((igemm_tn_kernel<128, B_SAME, 1>), grid, dim3(256), 0, st, p);
