@@ -46,8 +46,15 @@ class PositionEmbeddingSine(torch.nn.Module):
 
 
 def build_position_encoding(args):
+    if args.position_embedding in ('v3', 'learned'):
+        # reference position_encoding.py:59-83 + backbone.py:139-148: Joiner evaluates the embedding for EVERY pyramid level on every
+        # forward pass and PositionEmbeddingLearned indexes nn.Embedding(50, .) with arange(w) -- w = 512 ... 32 columns at the
+        # reference's own 375 x 1024 input, so its first forward pass dies with an IndexError.  Nothing to be faithful to.
+        raise IndexError('--position_embedding learned: the reference indexes nn.Embedding(50, .) with arange(width of every '
+                         'pyramid level) (position_encoding.py:63-80, backbone.py:146) and fails on its first forward pass at any '
+                         'input wider than 100 px; use the sine encoding')
     if args.position_embedding not in ('v2', 'sine'):
-        raise NotImplementedError(f'position_embedding={args.position_embedding}: only the sine encoding is implemented')
+        raise ValueError(f'not supported {args.position_embedding}')
     if getattr(args, 'add_posenc', False) and not getattr(args, 'one_dim_posenc', True):
         raise ValueError('--add_posenc needs the one-dimensional encoding: the 2-D variant has twice the channels of the map '
                          'it is added to and fails in the reference too (position_encoding.py:52)')

@@ -44,3 +44,17 @@ def test_anchors_match_reference():
     sh = get_anchor_shifts_frcnn(64, 24, 16)
     assert np.array_equal(sh, mine.get_anchor_shifts_frcnn(64, 24, 16))
     assert np.array_equal((ref + sh).reshape(-1, 4), O.all_anchors(cfg))
+
+
+def test_learned_position_embedding_cannot_run_in_the_reference():
+    """`--position_embedding learned` (position_encoding.py:59-83): the reference's Joiner evaluates the embedding for every
+    pyramid level (backbone.py:139-148) and the module indexes nn.Embedding(50, .) with arange(w) -- the narrowest level of a
+    375 x 1024 input is 32 columns wide, the next 64: its forward pass fails in the reference itself, so the build raises too."""
+    warnings.filterwarnings('ignore')
+    m, _ = R.build_reference_model(R.default_args(position_embedding='learned'))
+    with torch.no_grad(), pytest.raises(IndexError):
+        m.forward_first_stage(torch.zeros(1, 1, 375, 1024))
+    from birdsoundclassif_amd.nets import build_model
+    from birdsoundclassif_amd.train import default_args
+    with pytest.raises(IndexError):
+        build_model(default_args(device='cpu', position_embedding='learned'))
