@@ -254,7 +254,7 @@ __global__ void colsum_kernel(const float* __restrict__ g, long long M, int N, i
 // gradient of 3x3/s2/p1 max pooling, gather form over the arg-max positions the forward pass recorded (r*3+s, one byte
 // per output element): every input pixel looks at the <= 4 windows that contain it.  Reads idx + gy, writes gx once.
 __global__ void maxpool_bwd_kernel(const uint8_t* __restrict__ idx, const float* __restrict__ gy, float* __restrict__ gx,
-                                   int B, int H, int W, int C4, int Ho, int Wo) {
+                                   int B, int H, int W, int C4, int Ho, int Wo, const float* __restrict__ residual) {
   const long long total = (long long)B * H * W * C4;
   const uint32_t* idx4 = reinterpret_cast<const uint32_t*>(idx);
   const f32x4* g4 = reinterpret_cast<const f32x4*>(gy);
@@ -265,7 +265,7 @@ __global__ void maxpool_bwd_kernel(const uint8_t* __restrict__ idx, const float*
     const int ix = (int)(t % W); t /= W;
     const int iy = (int)(t % H);
     const int b = (int)(t / H);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc = residual ? reinterpret_cast<const f32x4*>(residual)[i] : f32x4{0.f, 0.f, 0.f, 0.f};   // other consumer's gradient
     for (int oy = (iy >> 1); oy <= ((iy + 1) >> 1); ++oy) {
       if (oy >= Ho) continue;
       const int r = iy - (oy * 2 - 1);
@@ -808,12 +808,13 @@ extern "C" int nbm_colsum(const float* g, int64_t M, int N, int ld, float* out, 
   return nbm_launch_status();
 }
 extern "C" int nbm_maxpool3x3s2_bwd(const uint8_t* idx, const float* gy, float* gx, int B, int H, int W, int C, int Ho,
-                                    int Wo, void* stream) {
+                                    int Wo, const float* residual, void* stream) {
   if (!idx || !gy || !gx || B <= 0 || C <= 0 || (C & 3)) return NBM_EINVAL;
+  if (residual && !nbm_aligned16(residual)) return NBM_EALIGN;
   if ((H + 2 - 3) / 2 + 1 != Ho || (W + 2 - 3) / 2 + 1 != Wo) return NBM_EINVAL;
   if (!nbm_aligned16(gy) || !nbm_aligned16(gx) || (((uintptr_t)idx) & 3u)) return NBM_EALIGN;
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((long long)B * H * W * (C / 4))), dim3(TPB), 0, ST, idx, gy, gx, B, H,
-                     W, C / 4, Ho, Wo);
+                     W, C / 4, Ho, Wo, residual);
   return nbm_launch_status();
 }
 extern "C" int nbm_upsample_bilinear_bwd(const float* gy, int B, int Hi, int Wi, int C, float* gsrc, int Ho, int Wo,

@@ -256,7 +256,8 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restri
 // M [36][T][N] (+ bias) -> y [B][H][W][N] = A^T m A per 4x4 tile (partial tiles at the bottom / right edge)
 __global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restrict__ M, const float* __restrict__ scale,
                                                             const float* __restrict__ bias, const float* __restrict__ mask,
-                                                            int relu, int B, int H, int W, int N2, float* __restrict__ y) {
+                                                            int relu, int B, int H, int W, int N2, float* __restrict__ y,
+                                                            const float* __restrict__ residual) {
   const int TH = (H + 3) >> 2, TW = (W + 3) >> 2;
   const long long T = (long long)B * TH * TW;
   const long long total = T * N2;
@@ -300,7 +301,9 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restr
 #pragma unroll
         for (int q = 0; q < 6; ++q) acc += s[p][q] * W43_AT[o][q];
         const long long idx = (((long long)b * H + oy) * W + ox) * N2 + c;
-        y2[idx] = wino_epilogue(acc, sv, bv, relu, mk, idx);
+        f32x2 v = wino_epilogue(acc, sv, bv, relu, mk, idx);
+        if (residual) v += reinterpret_cast<const f32x2*>(residual)[idx];      // gradient of another consumer of the same tensor
+        y2[idx] = v;
       }
     }
   }
@@ -508,7 +511,8 @@ extern "C" int nbm_wino23_outgrad_tiles(const float* g, int B, int H, int W, int
 }
 
 extern "C" int nbm_wino_output(const float* M, const float* scale, const float* shift, const float* mask, int relu, int B,
-                               int H, int W, int N, float* y, int m, void* stream) {
+                               int H, int W, int N, float* y, int m, const float* residual, void* stream) {
+  if (residual && (m != 4 || !nbm_aligned16(residual))) return NBM_EUNSUPPORTED;
   if (!M || !y || B <= 0 || H <= 0 || W <= 0 || N <= 0 || (N & 3) || (m != 2 && m != 4)) return NBM_EINVAL;
   if (!nbm_aligned16(M) || !nbm_aligned16(y) || (shift && !nbm_aligned16(shift)) || (scale && !nbm_aligned16(scale)) ||
       (mask && !nbm_aligned16(mask)))
@@ -516,10 +520,10 @@ extern "C" int nbm_wino_output(const float* M, const float* scale, const float* 
   const long long tiles = (long long)B * ((H + m - 1) / m) * ((W + m - 1) / m);
   if (m == 2)
     hipLaunchKernelGGL(wino23_output_kernel, dim3(grid_for(tiles * (N / 4))), dim3(256), 0, (hipStream_t)stream, M, scale, shift,
-                       mask, relu, B, H, W, N / 4, y);
+                       mask, relu, B, H, W, N / 4, y);      // (residual: F(4x4) only, checked above)
   else
     hipLaunchKernelGGL(wino43_output_kernel, dim3(grid_for(tiles * (N / 2))), dim3(256), 0, (hipStream_t)stream, M, scale, shift,
-                       mask, relu, B, H, W, N / 2, y);
+                       mask, relu, B, H, W, N / 2, y, residual);
   return nbm_launch_status();
 }
 

@@ -28,6 +28,29 @@ class SetCriterion(nn.Module):
         self.anchor_target_layer = AnchorTargetLayer(args)
         self.proposal_target_layer = ProposalTargetLayer(args)
         self._pre = None
+        self._pre_loss = None
+        self._pinned = {}
+
+    def _upload(self, name, arr, dev):
+        """Small host array -> device through a persistent pinned staging buffer, asynchronously: a pageable `.to(device)` is a
+        stream-ordered blocking copy, i.e. the host would wait for every kernel queued in front of it.  The buffer is reused
+        every step: the step's host sync on the RoI count lies between two uses."""
+        if dev.type != 'cuda':
+            return torch.from_numpy(arr).to(dev)
+        t = torch.from_numpy(np.ascontiguousarray(arr))
+        buf = self._pinned.get(name)
+        if buf is None or buf.numel() < t.numel() or buf.dtype != t.dtype:
+            buf = self._pinned[name] = torch.empty((max(t.numel(), 8192),), dtype=t.dtype).pin_memory()
+        view = buf[:t.numel()].view(t.shape)
+        view.copy_(t)
+        return view.to(dev, non_blocking=True)
+
+    def precompute_first_stage_loss(self, labels_pred, bbox_reg, gt_bbox, lengths):
+        """Positive step: anchor targets (host) AND the first-stage loss kernels, queued behind the first-stage forward while the
+        GPU is still executing it -- the host does not wait for anything here (pinned uploads), so when it blocks on the RoI count
+        afterwards the loss is already computed instead of costing 8 ms of idle GPU behind the sync.  `first_stage_loss` returns
+        the result."""
+        self._pre_loss = self.first_stage_loss(labels_pred, bbox_reg, gt_bbox, lengths, False)
 
     def precompute_first_stage_targets(self, gt_bbox, lengths):
         """Run the AnchorTargetLayer (host, NumPy RNG) ahead of the forward pass so that it overlaps with the GPU work
@@ -46,6 +69,9 @@ class SetCriterion(nn.Module):
             top = p[..., 1].argmax(dim=1)
             top_p = p[torch.arange(B, device=p.device), top]
             return {'first_neg_class_loss': (-torch.log(top_p)).mean()}
+        if self._pre_loss is not None:
+            out, self._pre_loss = self._pre_loss, None
+            return out
         assert gt_bbox is not None and lengths is not None
         dev = labels_pred.device
         if self._pre is not None:
@@ -56,9 +82,9 @@ class SetCriterion(nn.Module):
         keep_np = np.nonzero(lab_np != -1)[0]
         lab_k = lab_np[keep_np]
         n_keep, n_pos = len(keep_np), int((lab_k > 0).sum())
-        keep = torch.from_numpy(keep_np).to(dev)
-        lab = torch.from_numpy(lab_k).to(dev)
-        t = reg_targets.permute(0, 2, 3, 1).reshape(-1, 4)[torch.from_numpy(keep_np)].to(dev)
+        keep = self._upload('keep', keep_np, dev)
+        lab = self._upload('lab', lab_k, dev)
+        t = self._upload('t', reg_targets.permute(0, 2, 3, 1).reshape(-1, 4)[torch.from_numpy(keep_np)].numpy(), dev)
         p = labels_pred.permute(0, 2, 3, 1).reshape(-1, 2)[keep]
         class_loss = (-torch.log(p.gather(1, lab[:, None])[:, 0])).sum() * (1 / n_keep)
         r = bbox_reg.permute(0, 2, 3, 1).reshape(-1, 4)[keep]
@@ -70,6 +96,8 @@ class SetCriterion(nn.Module):
     @torch.no_grad()
     def generate_all_rois(self, *args, **kwargs):
         rois, bbox_targets, labels = self.proposal_target_layer(*args, **kwargs)
+        # the labels were built on the host: keep that copy for second_stage_loss (a .cpu() there is a device sync)
+        self._labels_host = (labels, self.proposal_target_layer.last_labels_host) if labels is not None else None
         return {'rois': rois, 'bbox_targets': bbox_targets, 'labels': labels}
 
     def second_stage_loss(self, bbox_reg, bbox_classes, bbox_targets=None, labels=None, neg_sample=False):
@@ -82,7 +110,11 @@ class SetCriterion(nn.Module):
         B, nb, nc = len(bbox_targets), cfg.rcnn_batch_size, cfg.num_classes
         dev = bbox_reg.device
         t = bbox_targets.view(B * nb, 4 * (nc + 1))
-        lab_np = labels.detach().flatten().cpu().numpy().astype(np.int64)        # 16 labels per image
+        held = getattr(self, '_labels_host', None)
+        if held is not None and held[0] is labels:
+            lab_np = held[1].reshape(-1).astype(np.int64)                        # 16 labels per image, still on the host
+        else:
+            lab_np = labels.detach().flatten().cpu().numpy().astype(np.int64)
         n_fg = int((lab_np > 0).sum())
         lab = torch.from_numpy(lab_np).to(dev)
         pg = bbox_classes.gather(1, lab[:, None])[:, 0]
@@ -99,4 +131,7 @@ class SetCriterion(nn.Module):
 
     @torch.no_grad()
     def loss_cardinality(self, outputs, targets):
-        return {'cardinality_error': (outputs.argmax(-1) != 0).sum().item() - (targets != 0).sum().item()}
+        """Logging only (reference nbm_model.py:219-226).  A 0-dim DEVICE tensor: `.item()` here would make the host wait for the
+        second-stage forward before it may queue the backward pass; whoever logs the value converts it (float() / int())."""
+        n_tgt = int((targets != 0).sum().item()) if not targets.is_cuda else (targets != 0).sum()
+        return {'cardinality_error': (outputs.argmax(-1) != 0).sum() - n_tgt}

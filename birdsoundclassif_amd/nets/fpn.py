@@ -115,8 +115,10 @@ class FPN(nn.Module):
             oc = self.out_convs[str(len(x) - 1 - i)]
             lz = (lazy_strides or {}).get(i) if i == 0 and Fn.lazy3x3_ok(t.shape[1], t.shape[2], c.weight.shape[0], oc.weight) else None
             merged = Fn.conv(t, c.weight, bias=c.bias, alpha=alpha, up=merged, lazy_stride=lz)
+            # (i > 0: `merged` is also the `up` of the next finer lateral, whose backward pass runs first and hands its share of the
+            # gradient over: Fn._STASH)
             outs.insert(0, Fn.conv(merged, oc.weight, bias=oc.bias, kh=3, kw=3, pad=1,
-                                   lazy_stride=(lazy_strides or {}).get(i)))
+                                   lazy_stride=(lazy_strides or {}).get(i), accept_stash=i > 0))
         return outs
 
 def build_fpn(args, channels):

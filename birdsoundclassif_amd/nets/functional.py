@@ -44,6 +44,43 @@ LAZY_DGRAD = True        # data gradient of the demand-driven finest FPN map thr
 LAZY_WGRAD = True        # weight gradient of the demand-driven finest FPN map over its computed tiles only
 WINO_BWD_TILE = 4        # F(4x4,3x3) for the two backward convolutions (gradients tolerate its 2e-5 error); 2 = F(2x2,3x3)
 
+# Gradient hand-over between the consumers of one tensor.  A tensor with two consumers (a merged FPN map: its output convolution and
+# the next finer level's top-down merge; a backbone tap: the next ResNet stage and the FPN lateral) gets its gradient from autograd
+# as a SUM of two dense tensors -- a pass of its own that reads both and writes a third (9 ms of a B = 128 step).  Instead the
+# consumer whose backward node runs FIRST (the one created later: autograd runs ready nodes by descending sequence number, and the
+# FPN nodes never wait for a backbone node) leaves its gradient here and returns None; the other consumer, which registered itself in
+# the forward pass (`stash_accept`), adds it in the epilogue of the kernel that produces its own gradient (`residual`).
+GRAD_STASH = True
+_STASH = {}              # data_ptr -> gradient left by the first consumer's backward pass
+_STASH_OK = {}           # data_ptr -> shape of the tensors whose OTHER consumer will pick a stashed gradient up (this forward pass)
+
+
+def stash_reset():
+    """Start of a forward pass: forget the registrations (and any gradient) of earlier passes."""
+    _STASH.clear()
+    _STASH_OK.clear()
+
+
+def stash_accept(t, needs_grad):
+    """Called from the forward pass of the consumer that will pick the stash up; `needs_grad` = ctx.needs_input_grad of `t`
+    (inside Function.forward grad mode is off, so torch.is_grad_enabled() says nothing)."""
+    if GRAD_STASH and needs_grad:
+        _STASH_OK[t.data_ptr()] = tuple(t.shape)
+        return True
+    return False
+
+
+def _stash_wanted(t):
+    return bool(GRAD_STASH and t is not None and _STASH_OK.get(t.data_ptr()) == tuple(t.shape))
+
+
+def stash_check_empty():
+    """After a backward pass: a gradient that nobody picked up would have been dropped silently."""
+    if _STASH:
+        n = len(_STASH)
+        _STASH.clear()
+        raise RuntimeError(f'{n} stashed gradient(s) were never picked up by their second consumer (functional._STASH)')
+
 
 def _winograd_ok(x, weight, kh, kw, stride, pad):
     """3x3 / stride 1 / pad 1 with MFMA-friendly channel counts (odd map sizes cost one zero-padded tile row / column)."""
@@ -64,7 +101,8 @@ class Conv(Function):
     """y = act(alpha * conv(x, W) * scale + (bias | shift) + residual); also nn.Linear (x [1,M,1,K])."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, scale, shift, residual, kh, kw, stride, pad, act, alpha, up=None, lazy_stride=None):
+    def forward(ctx, x, weight, bias, scale, shift, residual, kh, kw, stride, pad, act, alpha, up=None, lazy_stride=None,
+                accept_stash=False):
         sh = bias.detach() if bias is not None else shift
         ctx.wino = _winograd_ok(x, weight, kh, kw, stride, pad) and scale is None and residual is None and \
             act == ACT_NONE and alpha == 1.0 and up is None
@@ -87,6 +125,10 @@ class Conv(Function):
         ctx.geom = (kh, kw, stride, pad, act, alpha)
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         ctx.up_hw = tuple(up.shape[1:3]) if up is not None else None
+        # gradient hand-over (see _STASH): leave d/dx / d/d(up) for the tensor's other consumer, or pick up what it left
+        ctx.stash_x = kh == 1 and _stash_wanted(x)
+        ctx.stash_up, ctx.up_ptr = _stash_wanted(up), (up.data_ptr() if up is not None else 0)
+        ctx.take_x = bool(accept_stash) and (ctx.lazy is None or not ctx.lazy.sparse) and stash_accept(x, ctx.needs_input_grad[0])
         ctx.save_for_backward(x, weight, scale, y if act in (ACT_RELU, ACT_LEAKY) else None)
         return y
 
@@ -113,12 +155,20 @@ class Conv(Function):
         elif ctx.needs_input_grad[0] and ctx.wino and N % 32 == 0:
             # data gradient of a 3x3 / stride 1 / pad 1 convolution = the same convolution with the kernel rotated by 180
             # degrees and the channel roles swapped: Winograd again
+            other = _STASH.pop(x.data_ptr(), None) if ctx.take_x else None       # the other consumer's share of d/dx
+            fuse = other is not None and WINO_BWD_TILE == 4
             gx = ops.conv3x3_winograd(g.view(B, H, W, N), _prep.wino23(weight, transposed=True, m=WINO_BWD_TILE), None,
-                                      m=WINO_BWD_TILE)
+                                      m=WINO_BWD_TILE, residual=other if fuse else None)
+            if other is not None and not fuse:
+                gx = ops.axpby(gx, other)
         elif ctx.needs_input_grad[0]:
+            other = _STASH.pop(x.data_ptr(), None) if ctx.take_x else None
             gx = torch.empty_like(x)
             ops.conv_dgrad(gp, wk, gx, B=B, H=H, W=W, Cin=Cin, N=N, kh=kh, kw=kw, stride=stride, pad=pad,
-                           g_ld=gp.shape[1], w_ld=wk.shape[1], a_scale=scale, alpha=alpha)
+                           g_ld=gp.shape[1], w_ld=wk.shape[1], a_scale=scale, alpha=alpha, residual=other)
+            if ctx.stash_x:                           # the tensor's other consumer adds this in its own kernel
+                _STASH[x.data_ptr()] = gx
+                gx = None
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] and ctx.lazy is not None and ctx.lazy.sparse and LAZY_WGRAD:
             # demand-driven map: the gradient is zero outside the tiles that were computed -> F(2x2,3x3) over those tiles only
@@ -148,7 +198,10 @@ class Conv(Function):
         gup = None
         if ctx.up_hw is not None and ctx.needs_input_grad[12]:        # fused top-down merge: d/d(coarse map)
             gup = ops.upsample_bilinear_bwd(g, *ctx.up_hw)
-        return gx, gw, gb, None, None, gres, None, None, None, None, None, None, gup, None
+            if ctx.stash_up:                          # the coarse map's output convolution adds it in its data-gradient epilogue
+                _STASH[ctx.up_ptr] = gup
+                gup = None
+        return gx, gw, gb, None, None, gres, None, None, None, None, None, None, gup, None, None
 
 
 class Bottleneck(Function):
@@ -173,6 +226,9 @@ class Bottleneck(Function):
         y = ops.conv2d(a2, _prep.krsc(w3), scale=s3, shift=b3, residual=idt, act=ACT_RELU)
         ctx.save_for_backward(x, a1, a2, y, w1, w2, w3, wd, s1, s2, s3, sd)
         ctx.cfg = (stride, mask_input, mask_gy, wino)
+        # first block of a stage: its input is a backbone tap that the FPN lateral reads too -- the lateral's backward pass runs
+        # first and leaves its share of d/dx in _STASH; the shortcut's data gradient below adds it in its epilogue
+        ctx.take_x = wd is not None and stash_accept(x, ctx.needs_input_grad[0])
         return y
 
     @staticmethod
@@ -218,7 +274,9 @@ class Bottleneck(Function):
             if need[4]:
                 gwd = wgrad(g3r, x, kd, wd, sd, B=B, H=H, W=W, Cin=Cin, N=N3, stride=stride)
             gid = torch.empty_like(x)                                    # strided 1x1: only the (even, even) class has a tap
-            ops.conv_dgrad(g3r, kd, gid, B=B, H=H, W=W, Cin=Cin, N=N3, stride=stride, g_ld=N3, w_ld=kd.shape[1], a_scale=sd)
+            other = _STASH.pop(x.data_ptr(), None) if ctx.take_x else None     # the FPN lateral's share of d/dx (see _STASH)
+            ops.conv_dgrad(g3r, kd, gid, B=B, H=H, W=W, Cin=Cin, N=N3, stride=stride, g_ld=N3, w_ld=kd.shape[1], a_scale=sd,
+                           residual=other)
         gw1 = wgrad(g1r, x, k1, w1, s1, B=B, H=H, W=W, Cin=Cin, N=P) if need[1] else None
         gx = None
         if need[0]:
@@ -229,7 +287,7 @@ class Bottleneck(Function):
 
 
 def conv(x, weight, bias=None, scale=None, shift=None, residual=None, kh=1, kw=1, stride=1, pad=0, act=ACT_NONE, alpha=1.0,
-         up=None, lazy_stride=None):
+         up=None, lazy_stride=None, accept_stash=False):
     """`up` [B,h,w,N]: + bilinear_align_corners(up) in the GEMM epilogue (FPN top-down merge, act must be NONE).
     `lazy_stride`: the output has exactly two consumers, a 3x3 / lazy_stride / pad 1 convolution and the RoI pooling: only the
     pixels they read are computed (3x3 Winograd layers only; ignored elsewhere)."""
@@ -246,13 +304,13 @@ def conv(x, weight, bias=None, scale=None, shift=None, residual=None, kh=1, kw=1
         # with one of the listed backward passes switched off (A/B switches) a DENSE backward kernel multiplies the holes of the
         # sparse maps by exact-zero gradients: the holes must then be zeros, not uninitialised memory
         ondemand.ZERO_FILL = not (LAZY_WGRAD and LAZY_DGRAD)
-    return Conv.apply(x, weight, bias, scale, shift, residual, kh, kw, stride, pad, act, alpha, up, lazy_stride)
+    return Conv.apply(x, weight, bias, scale, shift, residual, kh, kw, stride, pad, act, alpha, up, lazy_stride, accept_stash)
 
 
 def linear(x2d, weight, bias=None, act=ACT_NONE, residual=None):
     M, K = x2d.shape
     res = residual.view(1, M, 1, -1) if residual is not None else None
-    return Conv.apply(x2d.view(1, M, 1, K), weight, bias, None, None, res, 1, 1, 1, 0, act, 1.0, None, None).view(M, -1)
+    return Conv.apply(x2d.view(1, M, 1, K), weight, bias, None, None, res, 1, 1, 1, 0, act, 1.0, None, None, False).view(M, -1)
 
 
 class Add(Function):
@@ -394,13 +452,15 @@ class MaxPool(Function):
         y, idx = ops.maxpool3x3s2(x, with_index=True)
         ctx.save_for_backward(idx)
         ctx.hw = x.shape[1:3]
+        ctx.x_ptr, ctx.take_x = x.data_ptr(), stash_accept(x, ctx.needs_input_grad[0])   # the stem output is also read by the finest FPN lateral
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
         (idx,) = ctx.saved_tensors
-        return ops.maxpool3x3s2_bwd(idx, gy.contiguous(), *ctx.hw)
+        other = _STASH.pop(ctx.x_ptr, None) if ctx.take_x else None     # the lateral's share of d/dx, added in the kernel
+        return ops.maxpool3x3s2_bwd(idx, gy.contiguous(), *ctx.hw, residual=other)
 
 
 class UpsampleAdd(Function):

@@ -33,8 +33,8 @@ class Faster_RCNN(nn.Module):
         """fpn_pyramid_out: list of NCHW-shaped maps -> (rois [B,R,4] | empty, cls_scores, bbox_reg) (head.py:32-38)."""
         fm = [f.permute(0, 2, 3, 1).contiguous() for f in fpn_pyramid_out]
         rois, _, n_roi, cls, reg, _ = self.forward_first_stage_device(fm)
-        if host_work is not None:
-            host_work()
+        if host_work is not None:           # everything of the first stage is queued; the host is still ahead of the GPU here
+            host_work(cls.permute(0, 3, 1, 2), reg.permute(0, 3, 1, 2))
         n = int(n_roi.item())
         if n == 0:
             print('Not enough possible RoIs, RPN failed')

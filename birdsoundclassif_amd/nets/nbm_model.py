@@ -50,6 +50,7 @@ class NbmModel(nn.Module):
         if samples.dim() != 4 or samples.shape[1] != self.args.inpt_channels:
             raise ValueError(f'expected [B,{self.args.inpt_channels},H,W], got {tuple(samples.shape)}')
         x = samples.permute(0, 2, 3, 1).contiguous()
+        Fn.stash_reset()                       # gradient hand-over registrations are per forward pass (functional._STASH)
         features, _ = self.backbone(x)
         if getattr(self.args, 'add_posenc', False):                       # nbm_model.py:45-46
             pe = self.backbone[1]
@@ -64,8 +65,8 @@ class NbmModel(nn.Module):
 
     def forward_first_stage(self, samples, host_work=None, lazy=False):
         """samples [B,1,H,W] f32 on the GPU -> {'rois','rpn_cls_scores','rpn_bbox_reg','fpn_out'} (nbm_model.py:39-54).
-        Tensors are NCHW-shaped views of NHWC storage.  `host_work` (optional callable) runs after every kernel of the
-        first stage has been queued and before the host waits for the RoI count, i.e. hidden behind the GPU work.
+        Tensors are NCHW-shaped views of NHWC storage.  `host_work(rpn_cls_scores, rpn_bbox_reg)` (optional callable) runs after
+        every kernel of the first stage has been queued and before the host waits for the RoI count, i.e. hidden behind the GPU work.
         `lazy=False` (default): every map of 'fpn_out' is dense, like the reference's.  `lazy=True` (what this package's own
         `train.step` and `detect` pass): 'fpn_out'[0] holds only the pixels its consumers read -- the RPN pattern now, the tiles
         under the RoI windows once a RoI pooling (`forward_second_stage`, any number of times, any RoIs) runs on THIS tensor or a

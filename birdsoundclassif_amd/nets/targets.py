@@ -195,4 +195,5 @@ class ProposalTargetLayer(nn.Module):
         bsel, rsel = np.nonzero(li >= 1)                               # one slot of 4 per class (nets_utils.py:248-259)
         for k in range(4):
             out_t[bsel, rsel, 4 * li[bsel, rsel] + k] = t4[bsel, rsel, k]
+        self.last_labels_host = out_l
         return torch.from_numpy(out_r).to(device), torch.from_numpy(out_t).to(device), torch.from_numpy(out_l).to(device)

@@ -164,7 +164,7 @@ def _wino_scratch(device, n_v, n_m):
 WINO_FUSED_VARIANT = int(os.environ.get('NBM_WINO_FUSED_VARIANT', '0'))     # 0 auto, 128 / 64: channel-tile width
 
 
-def conv3x3_winograd(x, U, bias=None, m=2, scale=None, relu=False, mask=None):
+def conv3x3_winograd(x, U, bias=None, m=2, scale=None, relu=False, mask=None, residual=None):
     """3x3 / stride 1 / pad 1 convolution through Winograd F(m x m, 3x3): x [B,H,W,C], U [(m+2)^2,N,C] from
     `_prep.wino23` -> [B,H,W,N].  m = 2 (the forward setting, error ~3e-6): row half of the input transform (2x the input
     in HBM), then ONE kernel that finishes the input transform while staging its operand, runs the 16 transformed-domain
@@ -181,6 +181,7 @@ def conv3x3_winograd(x, U, bias=None, m=2, scale=None, relu=False, mask=None):
     y = torch.empty((B, H, W, N), device=x.device, dtype=torch.float32)
     tiles = (-(-H // m)) * (-(-W // m))
     fused = m == 2 and C_ >= 64                  # the fused pipeline wants >= 2 K-steps per plane (every real layer has)
+    assert residual is None or m == 4, 'residual: F(4x4,3x3) output transform only' 
     if fused:                                     # R: four row-combination images, 2 (TW + 1) columns per tile row
         per_img = 4 * (-(-H // 2)) * (2 * (-(-W // 2)) + 2) * C_ * 4
     else:
@@ -218,8 +219,8 @@ def conv3x3_winograd(x, U, bias=None, m=2, scale=None, relu=False, mask=None):
             gemm_conv(V, U, M, B=1, H=T, W=1, Cin=C_, N=N, groups=nxi, x_gs=T * C_, w_gs=N * C_, y_gs=T * N)
         finally:
             _PROFILE_LABEL = None
-        check(lib().nbm_wino_output(_ptr(M), _ptr(scale), _ptr(bias), mk, int(relu), nb, H, W, N, _ptr(y[b0:b0 + nb]), m, st),
-              'nbm_wino_output')
+        check(lib().nbm_wino_output(_ptr(M), _ptr(scale), _ptr(bias), mk, int(relu), nb, H, W, N, _ptr(y[b0:b0 + nb]), m,
+                                    _ptr(residual[b0:b0 + nb]) if residual is not None else None, st), 'nbm_wino_output')
     if _prof_all():
         ev[1].record()
         PROFILE.append((('wino23', C_, N, H, W, B), *ev))
@@ -738,10 +739,11 @@ def colsum(g2d, n=None):
     return out
 
 
-def maxpool3x3s2_bwd(idx, gy, H, W):
+def maxpool3x3s2_bwd(idx, gy, H, W, residual=None):
+    """`residual` [B,H,W,C]: added to the result (the gradient another consumer of the pooled tensor has produced)."""
     B, Ho, Wo, C_ = gy.shape
     gx = torch.empty((B, H, W, C_), device=gy.device, dtype=torch.float32)
-    check(lib().nbm_maxpool3x3s2_bwd(_ptr(idx), _ptr(_chk(gy)), _ptr(gx), B, H, W, C_, Ho, Wo, _stream()),
+    check(lib().nbm_maxpool3x3s2_bwd(_ptr(idx), _ptr(_chk(gy)), _ptr(gx), B, H, W, C_, Ho, Wo, _ptr(residual), _stream()),
           'nbm_maxpool3x3s2_bwd')
     return gx
 

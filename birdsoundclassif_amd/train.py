@@ -233,9 +233,10 @@ def step(model, criterion, batch, device, negative_sample):
     loss = {}
     inpt = (neg_img if negative_sample else img)[:, None]
     host_work = None
-    if not negative_sample and hasattr(criterion, 'precompute_first_stage_targets'):
-        # AnchorTargetLayer (host, NumPy RNG) runs while the GPU executes the first-stage forward queued before it
-        host_work = lambda: criterion.precompute_first_stage_targets(bb_coord, lengths)
+    if not negative_sample and hasattr(criterion, 'precompute_first_stage_loss'):
+        # AnchorTargetLayer (host, NumPy RNG) runs while the GPU executes the first-stage forward queued before it, and the
+        # first-stage loss kernels are queued behind that forward pass before the host waits for the RoI count
+        host_work = lambda cls, reg: criterion.precompute_first_stage_loss(cls, reg, bb_coord, lengths)
     # lazy=True: the finest FPN map is computed where it is read; it goes straight into forward_second_stage below
     out_first_stage = model.forward_first_stage(inpt, host_work, lazy=True)
     loss.update(criterion.first_stage_loss(out_first_stage['rpn_cls_scores'], out_first_stage['rpn_bbox_reg'],
@@ -320,6 +321,8 @@ def train_one_step(model, criterion, optimizer, batch, max_norm, device, negativ
     losses = sum(loss_dict[k] * weight_dict[k] for k in loss_dict.keys() if k in weight_dict)
     optimizer.zero_grad()
     losses.backward()
+    from .nets import functional as Fn
+    Fn.stash_check_empty()                 # a handed-over gradient that nobody picked up would be a silently dropped gradient
     allreduce_grads(optimizer if isinstance(optimizer, FusedAdamW) else model)
     if isinstance(optimizer, FusedAdamW):
         optimizer.step(max_norm=max_norm)

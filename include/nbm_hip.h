@@ -92,10 +92,12 @@ int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream);
  * the two backward convolutions only (error ~2e-5).  V[xi][t][c] = (B^T d B)[xi] of the (m+2)x(m+2) input patch of tile t
  * (zero padded); the (m+2)^2 GEMMs M[xi] = V[xi] x U[xi]^T run through nbm_gemm_conv with groups = (m+2)^2;
  * y = act((A^T M A) * scale + shift), zeroed where mask <= 0 (scale / shift / mask may be NULL: FrozenBN + ReLU of the ResNet
- * 3x3 layers, the producer's ReLU mask of a data gradient).  T = B*ceil(H/m)*ceil(W/m) tiles; V: [(m+2)^2][T][C], M: [(m+2)^2][T][N]. */
+ * 3x3 layers, the producer's ReLU mask of a data gradient).  T = B*ceil(H/m)*ceil(W/m) tiles; V: [(m+2)^2][T][C], M: [(m+2)^2][T][N].
+ * residual [B][H][W][N] (optional, m = 4 only): added after the epilogue -- the gradient that another consumer of the same
+ * tensor has already produced (what autograd would otherwise add in a pass of its own). */
 int nbm_wino_input(const float* x, int B, int H, int W, int C, float* V, int m, void* stream);
 int nbm_wino_output(const float* M, const float* scale, const float* shift, const float* mask, int relu, int B, int H, int W,
-                    int N, float* y, int m, void* stream);
+                    int N, float* y, int m, const float* residual, void* stream);
 /* weight gradient side: dM[xi][t][n] = (A g A^T)[xi] of the m x m output-gradient tile; dU[xi] = dM[xi]^T V[xi] through
  * nbm_conv_wgrad (groups = (m+2)^2) and dW = G^T dU G on the host.  bias_grad [N] (may be NULL): += sum over pixels of g. */
 int nbm_wino_outgrad(const float* g, int B, int H, int W, int N, float* dM, float* bias_grad, int m, void* stream);
@@ -389,7 +391,7 @@ int nbm_weighted_sum_bwd(const float* x0, const float* x1, const float* x2, cons
 /* out[n] = sum_m g[m][n] (bias gradients) */
 int nbm_colsum(const float* g, int64_t M, int N, int ld, float* out, void* stream);
 int nbm_maxpool3x3s2_bwd(const uint8_t* idx, const float* gy, float* gx, int B, int H, int W, int C, int Ho, int Wo,
-                         void* stream);
+                         const float* residual /* [B][H][W][C], optional: added to gx (another consumer's gradient) */, void* stream);
 /* out = gy * (y > 0 ? 1 : slope) -- nn.LeakyReLU backward (Transformer_RCNN embeddings / DETR-style feed-forward) */
 int nbm_leaky_relu_bwd(const float* gy, const float* y, float* out, float slope, int64_t n, void* stream);
 /* nn.LayerNorm backward over rows of E <= 1024 floats; gw, gb (E floats each) must be zeroed, they are added to */
