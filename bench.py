@@ -115,6 +115,9 @@ def train_bench(rank, world, dist, batch, steps, warmup, mix_steps=10):
     # the reference's schedule: one negative step in ten
     mix = None
     if mix_steps:
+        # one untimed negative step first: its 1000 RoIs per image grow the allocator's pools by ~17 GiB (hipMalloc under a
+        # running stream: 300 ms once per process, 35 ms / step if it lands inside a 10-step window)
+        train_one_step(model, crit, opt, data, args.clip_max_norm, 'cuda', negative_sample=True)
         dtm, _ = timed([(i % 10) == 9 for i in range(mix_steps)])
         mix = {'steps': mix_steps, 'negative_every': 10, 'ms_per_step': dtm / mix_steps * 1e3,
                'clips_per_s': world * batch * mix_steps / dtm}
