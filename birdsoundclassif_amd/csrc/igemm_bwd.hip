@@ -59,14 +59,18 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsi
 }
 
 // ---------------------------------------------------------------------------------------------------- NN
-template <int BN>
-__global__ __launch_bounds__(256, 2) void igemm_nn_kernel(const BwdParams p) {
+// STAGES = 2: the deep-K pipeline.  STAGES = 1 (round 3): short-K layers (N * taps <= 256: the 1x1 data gradients of the ResNet
+// bottlenecks, whose time is the dX / shortcut-gradient / ReLU-mask traffic of the epilogue, not MFMA): one LDS buffer (35 KB)
+// and an epilogue staged in two halves, so THREE workgroups fit a CU and their load / compute / store phases overlap -- the same
+// trade as igemm.hip's STAGES = 1 forward variant.
+template <int BN, int STAGES = 2>
+__global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(const BwdParams p) {
   constexpr int BM = 128, WM = 64, WN = BN / 2, MT = 2, NT = WN / 32;
   constexpr int BP = BN + 4;                                   // K-major B tile pitch
-  __shared__ __attribute__((aligned(16))) float lds[2 * BM * PITCH + 2 * BK * BP];
+  __shared__ __attribute__((aligned(16))) float lds[STAGES * (BM * PITCH + BK * BP)];
   float* As = lds;
-  float* Bs = lds + 2 * BM * PITCH;
-  nbm_stagger_priority();
+  float* Bs = lds + STAGES * BM * PITCH;
+  if constexpr (STAGES == 2) nbm_stagger_priority();
 
   const int wg = xcd_tile(gridDim.x, blockIdx.x);
   const int tile_m = wg / p.n_tiles, tile_n = wg - tile_m * p.n_tiles;
@@ -206,11 +210,13 @@ __global__ __launch_bounds__(256, 2) void igemm_nn_kernel(const BwdParams p) {
   const int n_r = r_begin < p.kh ? (p.kh - r_begin + t_step - 1) / t_step : 0;
   const int n_s = s_begin < p.kw ? (p.kw - s_begin + t_step - 1) / t_step : 0;
   const int nk = ((p.N + BK - 1) / BK) * n_r * n_s;          // 0: no tap reaches this parity class, dX = residual
-  if (nk > 0) {
-    load_tiles();
-    store_lds(0);
+  if constexpr (STAGES == 2) {
+    if (nk > 0) {
+      load_tiles();
+      store_lds(0);
+    }
+    if (nk > 1) load_tiles();
   }
-  if (nk > 1) load_tiles();
 
   auto k_step = [&](int kt, auto store_c, auto load_c) {
     constexpr bool STORE = decltype(store_c)::value, LOAD = decltype(load_c)::value;
@@ -245,13 +251,27 @@ __global__ __launch_bounds__(256, 2) void igemm_nn_kernel(const BwdParams p) {
     mfma_group(Ab, Bb, 2);
     mfma_group(Ab, Bb, 3);
   };
-  {
+  if constexpr (STAGES == 2) {
     using T = std::true_type;
     using F = std::false_type;
     int kt = 0;
     for (; kt + 2 < nk; ++kt) k_step(kt, T{}, T{});
     if (nk >= 2) { k_step(kt, T{}, F{}); ++kt; }
     if (nk >= 1) k_step(kt, F{}, F{});
+  } else {
+    // short K: load -> LDS -> MFMA, the next tile's loads in flight during the MFMAs; the other two workgroups of the CU cover
+    // the barriers
+    if (nk > 0) load_tiles();
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt) __syncthreads();                       // everyone finished reading the previous tile
+      store_lds(0);
+      if (kt + 1 < nk) load_tiles();
+      __syncthreads();
+      const float* Ab = As + (wm0 + lrow) * PITCH + lh * 16;
+      const float* Bb = Bs + (lh * 16) * BP + wn0 + lrow;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mfma_group(Ab, Bb, q);
+    }
   }
   __syncthreads();
 
@@ -266,25 +286,33 @@ __global__ __launch_bounds__(256, 2) void igemm_nn_kernel(const BwdParams p) {
   if (p.vec_epi) {
     // accumulator tile -> LDS -> 16-byte residual / mask loads and stores (see igemm.hip)
     constexpr int CP = BN + 4;
-    static_assert(BM * CP <= 2 * BM * PITCH + 2 * BK * BP, "epilogue tile must fit the operand buffers");
+    constexpr int HALVES = STAGES == 1 ? BM / WM : 1;          // the single-stage LDS holds WM rows of the tile at a time
+    constexpr int HROWS = BM / HALVES;
+    static_assert(HROWS * CP <= STAGES * (BM * PITCH + BK * BP), "epilogue tile must fit the operand buffers");
     float* Cs = lds;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-          Cs[(wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * CP + wn0 + j * 32 + lrow] = acc[i][j][e];
-    __syncthreads();
     constexpr int CH = BN / 4, RPP = 256 / CH;
     const int cc = tid % CH, rr = tid / CH;
     const int c = bn0 + cc * 4;
-    if (c < p.Cin) {
+#pragma unroll
+    for (int half = 0; half < HALVES; ++half) {
+      if (HALVES > 1 && half) __syncthreads();                  // the previous half has been read
+      if (HALVES == 1 || wm0 == half * HROWS) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+              Cs[(wm0 - half * HROWS + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * CP + wn0 + j * 32 + lrow] = acc[i][j][e];
+      }
+      __syncthreads();
+      if (c >= p.Cin) continue;
 #pragma unroll 4
-      for (int r = rr; r < BM; r += RPP) {
+      for (int rl = rr; rl < HROWS; rl += RPP) {
+        const int r = half * HROWS + rl;
         if (q0 + r >= rows_here) break;
         const long long m = out_pixel(q0 + r);
-        f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CP + cc * 4);
+        f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rl * CP + cc * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
         if (rg) {
@@ -635,12 +663,19 @@ extern "C" int nbm_conv_dgrad(const nbm_bwd_desc* d, void* stream) {
     p.m_tiles = 4 * tmax;
   }
   hipStream_t st = (hipStream_t)stream;
+  // short K (<= 8 steps of 32) and a 16-byte epilogue: the three-workgroups-per-CU variant (see the template comment)
+  static const int shortk_max = getenv("NBM_NN_SHORTK_MAX") ? atoi(getenv("NBM_NN_SHORTK_MAX")) : 8;   // 0 disables
+  const bool shortk = !p.phased && p.vec_epi && ((d->N + BK - 1) / BK) * d->kh * d->kw <= shortk_max;
   if (d->Cin > 64) {
     p.n_tiles = (d->Cin + 127) / 128;
-    hipLaunchKernelGGL(igemm_nn_kernel<128>, dim3(p.m_tiles * p.n_tiles, 1, d->groups), dim3(256), 0, st, p);
+    const dim3 grid(p.m_tiles * p.n_tiles, 1, d->groups);
+    if (shortk) hipLaunchKernelGGL((igemm_nn_kernel<128, 1>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((igemm_nn_kernel<128, 2>), grid, dim3(256), 0, st, p);
   } else {
     p.n_tiles = 1;
-    hipLaunchKernelGGL(igemm_nn_kernel<64>, dim3(p.m_tiles, 1, d->groups), dim3(256), 0, st, p);
+    const dim3 grid(p.m_tiles, 1, d->groups);
+    if (shortk) hipLaunchKernelGGL((igemm_nn_kernel<64, 1>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((igemm_nn_kernel<64, 2>), grid, dim3(256), 0, st, p);
   }
   return nbm_launch_status();
 }
