@@ -57,7 +57,11 @@ for tag, ms in rows:
         print(f'{ms:8.3f}      -         -      fused Winograd kernel of 3x3 {Cin}->{N} @{label[1]}x{label[2]}, tiles under the RoIs (device-side list)')
         tot += ms
         continue
-    if label is not None:
+    if label is not None and label[0] == 'cell-fwd':
+        what = (f'25 plane GEMMs of the cell transforms, 3x3 {Cin}->{N} @{label[1]}x{label[2]} on demand (pattern pixels: {H} cells; '
+                'nbm_cell_input / nbm_cell_output are separate HBM-bound kernels, not in this table)')
+        by = 4.0 * G * (H * Cin + H * N + N * Cin) / 1e9
+    elif label is not None:
         what = f'fused Winograd kernel of 3x3 {Cin}->{N} @{label[1]}x{label[2]} ({G} planes x {H} tiles)'
         by = 4.0 * (H * 4 * Cin * 0.5 + H * 4 * N + G * N * Cin) / 1e9          # R (2x input) + y + U
     tot += ms
