@@ -21,19 +21,20 @@ __global__ __launch_bounds__(256) void wino23_input_kernel(const float* __restri
   const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
   f32x4* v4 = reinterpret_cast<f32x4*>(V);
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % C4);
-    const long long t = i / C4;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) {      // 32-bit: see idx32_ok
+    const int c = (int)(i % (unsigned)C4);
+    const unsigned t = i / (unsigned)C4;
     const long long id = tiles ? (long long)tiles[t] : t;
     if (id < 0) {
 #pragma unroll
       for (int a = 0; a < 16; ++a) v4[((long long)a * T + t) * C4 + c] = zero;
       continue;
     }
-    const int tx = (int)(id % TW);
-    const long long r = id / TW;
-    const int ty = (int)(r % TH);
-    const int b = (int)(r / TH);
+    const unsigned uid = (unsigned)id;
+    const int tx = (int)(uid % (unsigned)TW);
+    const unsigned r = uid / (unsigned)TW;
+    const int ty = (int)(r % (unsigned)TH);
+    const int b = (int)(r / (unsigned)TH);
     f32x4 d[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -95,13 +96,13 @@ __global__ __launch_bounds__(256) void wino23_output_kernel(const float* __restr
   const long long total = T * N4;
   const f32x4* m4 = reinterpret_cast<const f32x4*>(M);
   f32x4* y4 = reinterpret_cast<f32x4*>(y);
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % N4);
-    long long t = i / N4;
-    const int tx = (int)(t % TW);
-    long long r = t / TW;
-    const int ty = (int)(r % TH);
-    const int b = (int)(r / TH);
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) {      // 32-bit: see idx32_ok
+    const int c = (int)(i % (unsigned)N4);
+    const unsigned t = i / (unsigned)N4;
+    const int tx = (int)(t % (unsigned)TW);
+    const unsigned r = t / (unsigned)TW;
+    const int ty = (int)(r % (unsigned)TH);
+    const int b = (int)(r / (unsigned)TH);
     f32x4 s[2][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -147,10 +148,10 @@ __global__ __launch_bounds__(256) void wino23_outgrad_kernel(const float* __rest
   f32x4* m4 = reinterpret_cast<f32x4*>(dM);
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
   int my_c = -1;
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % N4);
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) {      // 32-bit: see idx32_ok
+    const int c = (int)(i % (unsigned)N4);
     my_c = c;
-    const long long t = i / N4;
+    const unsigned t = i / (unsigned)N4;
     const long long id = tiles ? (long long)tiles[t] : t;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     if (id < 0) {
@@ -158,10 +159,11 @@ __global__ __launch_bounds__(256) void wino23_outgrad_kernel(const float* __rest
       for (int a = 0; a < 16; ++a) m4[((long long)a * T + t) * N4 + c] = zero;
       continue;
     }
-    const int tx = (int)(id % TW);
-    const long long r = id / TW;
-    const int ty = (int)(r % TH);
-    const int b = (int)(r / TH);
+    const unsigned uid = (unsigned)id;
+    const int tx = (int)(uid % (unsigned)TW);
+    const unsigned r = uid / (unsigned)TW;
+    const int ty = (int)(r % (unsigned)TH);
+    const int b = (int)(r / (unsigned)TH);
     const long long row = ((long long)b * H + 2 * ty) * W + 2 * tx;
     const bool in_y = 2 * ty + 1 < H, in_x = 2 * tx + 1 < W;          // odd sizes: the last tile row / column is half outside
     const f32x4 y00 = in_pattern(2 * ty, 2 * tx) ? zero : g4[row * N4 + c];
@@ -215,13 +217,13 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(const float* __restri
   const f32x2* x2 = reinterpret_cast<const f32x2*>(x);
   f32x2* v2 = reinterpret_cast<f32x2*>(V);
   const f32x2 zero = {0.f, 0.f};
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % C2);
-    long long t = i / C2;
-    const int tx = (int)(t % TW);
-    long long r = t / TW;
-    const int ty = (int)(r % TH);
-    const int b = (int)(r / TH);
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) {      // 32-bit: see idx32_ok
+    const int c = (int)(i % (unsigned)C2);
+    const unsigned t = i / (unsigned)C2;
+    const int tx = (int)(t % (unsigned)TW);
+    const unsigned r = t / (unsigned)TW;
+    const int ty = (int)(r % (unsigned)TH);
+    const int b = (int)(r / (unsigned)TH);
     f32x2 u[6][6];                                   // u = B^T d, built column by column
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
@@ -264,13 +266,13 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restr
   const f32x2* m2 = reinterpret_cast<const f32x2*>(M);
   f32x2* y2 = reinterpret_cast<f32x2*>(y);
   const f32x2 zero = {0.f, 0.f};
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % N2);
-    long long t = i / N2;
-    const int tx = (int)(t % TW);
-    long long r = t / TW;
-    const int ty = (int)(r % TH);
-    const int b = (int)(r / TH);
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) {      // 32-bit: see idx32_ok
+    const int c = (int)(i % (unsigned)N2);
+    const unsigned t = i / (unsigned)N2;
+    const int tx = (int)(t % (unsigned)TW);
+    const unsigned r = t / (unsigned)TW;
+    const int ty = (int)(r % (unsigned)TH);
+    const int b = (int)(r / (unsigned)TH);
     f32x2 s[4][6];                                   // s = A^T m, built column by column
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
@@ -320,14 +322,14 @@ __global__ __launch_bounds__(256) void wino43_outgrad_kernel(const float* __rest
   const f32x2 zero = {0.f, 0.f};
   f32x2 bsum = zero;
   int my_c = -1;
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % N2);
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total; i += gridDim.x * 256u) {      // 32-bit: see idx32_ok
+    const int c = (int)(i % (unsigned)N2);
     my_c = c;
-    long long t = i / N2;
-    const int tx = (int)(t % TW);
-    long long r = t / TW;
-    const int ty = (int)(r % TH);
-    const int b = (int)(r / TH);
+    const unsigned t = i / (unsigned)N2;
+    const int tx = (int)(t % (unsigned)TW);
+    const unsigned r = t / (unsigned)TW;
+    const int ty = (int)(r % (unsigned)TH);
+    const int b = (int)(r / (unsigned)TH);
     f32x2 u[6][4];                                   // u = A g, built column by column
 #pragma unroll
     for (int o = 0; o < 4; ++o) {
@@ -448,6 +450,10 @@ __global__ void wino_weight_grad_kernel(const float* __restrict__ dU, const floa
   }
 }
 
+// the transform kernels index their threads with 32 bits (a 64-bit div / mod chain per thread cost them 20-25 %): every launcher
+// below refuses a launch with >= 2^31 (tile, channel-chunk) threads -- the callers cut the batch into chunks far below that
+inline bool idx32_ok(long long threads) { return threads < 0x7fffffffll; }
+
 inline int grid_for(long long n) {
   long long g = (n + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
@@ -459,6 +465,7 @@ extern "C" int nbm_wino_input(const float* x, int B, int H, int W, int C, float*
   if (!x || !V || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || (m != 2 && m != 4)) return NBM_EINVAL;
   if (!nbm_aligned16(x) || !nbm_aligned16(V)) return NBM_EALIGN;
   const long long tiles = (long long)B * ((H + m - 1) / m) * ((W + m - 1) / m);
+  if (!idx32_ok(tiles * (C / 2))) return NBM_EUNSUPPORTED;
   if (m == 2)
     hipLaunchKernelGGL(wino23_input_kernel, dim3(grid_for(tiles * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, B, H, W, C / 4, V,
                        (const int*)nullptr, 0, (const unsigned*)nullptr);
@@ -472,6 +479,7 @@ extern "C" int nbm_wino_outgrad(const float* g, int B, int H, int W, int N, floa
   if (!nbm_aligned16(g) || !nbm_aligned16(dM)) return NBM_EALIGN;
   const int per = m == 2 ? N / 4 : N / 2;             // channel chunks per tile
   const long long total = (long long)B * ((H + m - 1) / m) * ((W + m - 1) / m) * per;
+  if (!idx32_ok(total)) return NBM_EUNSUPPORTED;
   // the grid stride must be a multiple of `per` so that a thread keeps one channel chunk (bias-gradient accumulation)
   long long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
@@ -490,6 +498,7 @@ extern "C" int nbm_wino23_input_tiles(const float* x, int B, int H, int W, int C
   if (!x || !V || !tiles || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || n_list < 0) return NBM_EINVAL;
   if (!nbm_aligned16(x) || !nbm_aligned16(V)) return NBM_EALIGN;
   if (n_list == 0) return NBM_OK;
+  if (!idx32_ok((long long)n_list * (C / 4)) || !idx32_ok((long long)B * ((H + 1) / 2) * ((W + 1) / 2))) return NBM_EUNSUPPORTED;
   hipLaunchKernelGGL(wino23_input_kernel, dim3(grid_for((long long)n_list * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, B, H,
                      W, C / 4, V, tiles, n_list, blk_info);
   return nbm_launch_status();
@@ -502,6 +511,7 @@ extern "C" int nbm_wino23_outgrad_tiles(const float* g, int B, int H, int W, int
   if (!nbm_aligned16(g) || !nbm_aligned16(dM)) return NBM_EALIGN;
   if (n_list == 0) return NBM_OK;
   const int per = N / 4;
+  if (!idx32_ok((long long)n_list * per) || !idx32_ok((long long)B * ((H + 1) / 2) * ((W + 1) / 2))) return NBM_EUNSUPPORTED;
   long long blocks = ((long long)n_list * per + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   while ((blocks * 256) % per) ++blocks;              // a thread keeps one channel chunk (bias-gradient accumulation)
@@ -518,6 +528,7 @@ extern "C" int nbm_wino_output(const float* M, const float* scale, const float* 
       (mask && !nbm_aligned16(mask)))
     return NBM_EALIGN;
   const long long tiles = (long long)B * ((H + m - 1) / m) * ((W + m - 1) / m);
+  if (!idx32_ok(tiles * (N / 2))) return NBM_EUNSUPPORTED;
   if (m == 2)
     hipLaunchKernelGGL(wino23_output_kernel, dim3(grid_for(tiles * (N / 4))), dim3(256), 0, (hipStream_t)stream, M, scale, shift,
                        mask, relu, B, H, W, N / 4, y);      // (residual: F(4x4) only, checked above)

@@ -403,6 +403,7 @@ int nbm_mha_small_bwd(const float* q, const float* k, const float* v, const floa
                       int go_ld, float* gq, float* gk, float* gv, int gq_ld, int gk_ld, int gv_ld, float* workspace, int S,
                       int N, int nhead, int hd, int64_t seq_stride, int64_t batch_stride, const int32_t* n_valid,
                       float scale, void* stream);
+/* gradient of the bilinear (align_corners) up-sampling of fpn.py:143-144 wrt the coarse map [B][Hi][Wi][C], gather form */
 int nbm_upsample_bilinear_bwd(const float* gy, int B, int Hi, int Wi, int C, float* gsrc, int Ho, int Wo, void* stream);
 int nbm_softmax_rows_bwd(const float* p, const float* gp, float* out, int64_t rows, int cols, float alpha, void* stream);
 int nbm_pair_softmax_bwd(const float* y, const float* gy, float* gx, int64_t n_pairs, void* stream);
