@@ -1,0 +1,24 @@
+"""Kernel-time breakdown of a NEGATIVE training step (1000 RoIs per image through the head) vs a positive one: torch profiler-free,
+HIP events around whole phases."""
+import sys, os, time, torch, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from birdsoundclassif_amd import synth
+from birdsoundclassif_amd.nets import build_model
+from birdsoundclassif_amd.train import default_args, build_optimizer, train_one_step
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+neg = (sys.argv[2] == 'neg') if len(sys.argv) > 2 else True
+args = default_args(device='cuda')
+model, crit = build_model(args)
+model.load_state_dict(synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}))
+model = model.cuda().train(); crit.train()
+opt, _ = build_optimizer(model, args)
+img = torch.from_numpy(np.tile(synth.image_batch(0, 8), (-(-B//8),1,1))[:B].copy()).cuda()
+bbs, idss, lens = [], [], []
+for i in range(B):
+    bb, ids, l = synth.label_batch(i % 8, 1); bbs.append(bb); idss.append(ids); lens += l
+batch = [img, img, torch.cat(bbs), torch.cat(idss), lens]
+np.random.seed(0)
+for it in range(4):
+    torch.cuda.synchronize(); t = time.perf_counter()
+    train_one_step(model, crit, opt, batch, args.clip_max_norm, 'cuda', negative_sample=neg)
+    torch.cuda.synchronize(); print(f'neg={neg} {1e3 * (time.perf_counter() - t):.0f} ms', flush=True)

@@ -1,0 +1,44 @@
+"""GPU: RCCL itself, on the one device a test box has.  A one-rank `nccl` process group exercises everything of the data-parallel
+exchange that does not need a second GPU: the backend loads and initialises on this ROCm build, `all_reduce` runs on the FusedAdamW
+flat gradient buffers with the reduce op the exchange uses (`ReduceOp.AVG`), on int32 (the touched bitmap, `ReduceOp.MAX`) and
+float64 (the bench's timing reduction), and `allreduce_grads` itself leaves a one-rank job's gradients untouched.  The multi-rank
+semantics are covered on the CPU with gloo (tests/test_dp_gloo.py); RCCL refuses two ranks on one device."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rccl_one_rank_group_runs_the_collectives_of_the_exchange_step():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1,
+                            device_id=torch.device('cuda', torch.cuda.current_device()))
+    try:
+        assert dist.get_backend() == 'nccl' and dist.get_world_size() == 1
+        flat = torch.arange(1 << 20, device='cuda', dtype=torch.float32)             # a flat gradient buffer
+        ref = flat.clone()
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+        bits = torch.tensor([0, 1, 1, 0, 1], device='cuda', dtype=torch.int32)        # the touched bitmap
+        dist.all_reduce(bits, op=dist.ReduceOp.MAX)
+        t = torch.tensor([0.125], device='cuda', dtype=torch.float64)                 # bench.py: max-over-ranks time
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        one = torch.ones(1, device='cuda')
+        dist.all_reduce(one)                                                          # bench.py: ranks_seen
+        dist.barrier()
+        torch.cuda.synchronize()
+        assert torch.equal(flat, ref) and bits.tolist() == [0, 1, 1, 0, 1] and float(t) == 0.125 and int(one.item()) == 1
+        from birdsoundclassif_amd.train import allreduce_grads
+        m = torch.nn.Linear(4, 3).cuda()
+        m(torch.ones(2, 4, device='cuda')).sum().backward()
+        g = m.weight.grad.clone()
+        allreduce_grads(m)                                                            # world_size 1: a no-op by contract
+        assert torch.equal(m.weight.grad, g)
+    finally:
+        dist.destroy_process_group()
