@@ -166,26 +166,18 @@ def bulk_bench(model, rank, world, dist, n_files, batch, min_score, headline_cli
             os.remove(bulk.txt_path(f))
         stats = {}
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
         t0 = time.perf_counter()
         bulk.detect_files(model, files, stats=stats, **kw)
         torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        dt = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([dt], device='cuda', dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+        dt = time.perf_counter() - t0          # this rank's shard; the caller takes the max over the ranks (no collective in here:
         n_txt = sum(1 for f in files if os.path.isfile(bulk.txt_path(f)))
         import ast
         n_det = sum(len(v['scores']) for f in files[:batch] for v in ast.literal_eval(open(bulk.txt_path(f)).read()).values())
         del det
         torch.cuda.empty_cache()
-        v = world * n_files / dt
-        return {'value': v, 'unit': 'clips/s', 'files_per_gpu': n_files, 'txt_files_written_rank0': n_txt, 'batch': batch,
-                'wall_s': dt, 'ratio_to_resident_hbm_headline': v / world / headline_clips_per_s_per_gpu,
+        # a rank that fails in this optional leg must not leave the others in a barrier)
+        return {'value': None, 'unit': 'clips/s', 'files_per_gpu': n_files, 'txt_files_written_rank0': n_txt, 'batch': batch,
+                'wall_s': dt, 'ratio_to_resident_hbm_headline': None,
                 'detections_in_first_batch': n_det,
                 'stages_rank0': {k: (round(x, 4) if isinstance(x, float) else x) for k, x in stats.items()},
                 'workload': 'BASELINE.json configs[4] on one shard per GPU: synthetic 3 s 22.05 kHz PCM16 wav files on tmpfs -> '
@@ -560,9 +552,17 @@ def main(argv=None):
         try:
             bulk_leg = bulk_bench(model, rank, world, dist, a.bulk_files, B, a.min_score, B * a.steps / dt)
         except Exception as exc:                  # never lose the headline line over an extra leg
-            if dist is not None:
-                raise                             # ... but in a multi-rank run the other ranks sit in this leg's barrier
             bulk_leg = {'error': f'{type(exc).__name__}: {exc}'[:500]}
+        ok, wall = (0.0, 0.0) if 'error' in bulk_leg else (1.0, bulk_leg['wall_s'])
+        if dist is not None:                      # every rank gets here, failed or not: max time, min ok over the ranks
+            tt = torch.tensor([wall, -ok], device='cuda', dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            wall, ok = float(tt[0].item()), -float(tt[1].item())
+        if ok > 0 and 'error' not in bulk_leg:
+            v = world * a.bulk_files / wall
+            bulk_leg.update(value=v, wall_s=wall, ratio_to_resident_hbm_headline=v / world / (B * a.steps / dt))
+        elif 'error' not in bulk_leg:
+            bulk_leg = {'error': 'the bulk_inference leg failed on another rank'}
     train = None
     if not a.no_train:
         del model
