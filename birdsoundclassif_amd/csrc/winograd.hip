@@ -8,6 +8,9 @@
 
 namespace {
 
+constexpr int WINO_MAX_BIAS_N = 2048;   // channels of a bias gradient that the output-gradient transforms reduce in LDS first
+
+
 // x [B][H][W][C] -> V [16][T][C], T = B * ceil(H/2) * ceil(W/2); tile (ty, tx) reads rows 2ty-1 .. 2ty+2, cols 2tx-1 .. 2tx+2.
 // With a tile list (tiles != NULL: n_list linear tile ids b * TH * TW + ty * TW + tx, or -1) V is compact: [16][n_list][C],
 // row t holds the listed tile t (zeros for -1) -- the weight gradient of a demand-driven map only sums over the tiles
@@ -183,9 +186,17 @@ __global__ __launch_bounds__(256) void wino23_outgrad_kernel(const float* __rest
       m4[((long long)(a * 4 + 3) * T + t) * N4 + c] = -q;
     }
   }
-  if (bias_grad && my_c >= 0) {
+  if (bias_grad) {                     // uniform: per-thread sums -> LDS -> one global atomic per channel and workgroup
+    __shared__ float red[WINO_MAX_BIAS_N];
+    const int n = N4 * 4;
+    for (int k = threadIdx.x; k < n; k += 256) red[k] = 0.f;
+    __syncthreads();
+    if (my_c >= 0) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) atomicAdd(bias_grad + my_c * 4 + e, bsum[e]);
+      for (int e = 0; e < 4; ++e) atomicAdd(&red[my_c * 4 + e], bsum[e]);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < n; k += 256) atomicAdd(bias_grad + k, red[k]);
   }
 }
 
@@ -359,9 +370,17 @@ __global__ __launch_bounds__(256) void wino43_outgrad_kernel(const float* __rest
         m2[((long long)(k * 6 + j) * T + t) * N2 + c] = acc;
       }
   }
-  if (bias_grad && my_c >= 0) {
-    atomicAdd(bias_grad + my_c * 2, bsum[0]);
-    atomicAdd(bias_grad + my_c * 2 + 1, bsum[1]);
+  if (bias_grad) {                     // uniform: per-thread sums -> LDS -> one global atomic per channel and workgroup
+    __shared__ float red[WINO_MAX_BIAS_N];
+    const int n = N2 * 2;
+    for (int k = threadIdx.x; k < n; k += 256) red[k] = 0.f;
+    __syncthreads();
+    if (my_c >= 0) {
+      atomicAdd(&red[my_c * 2], bsum[0]);
+      atomicAdd(&red[my_c * 2 + 1], bsum[1]);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < n; k += 256) atomicAdd(bias_grad + k, red[k]);
   }
 }
 
@@ -477,6 +496,7 @@ extern "C" int nbm_wino_input(const float* x, int B, int H, int W, int C, float*
 extern "C" int nbm_wino_outgrad(const float* g, int B, int H, int W, int N, float* dM, float* bias_grad, int m, void* stream) {
   if (!g || !dM || B <= 0 || H <= 0 || W <= 0 || N <= 0 || (N & 3) || (m != 2 && m != 4)) return NBM_EINVAL;
   if (!nbm_aligned16(g) || !nbm_aligned16(dM)) return NBM_EALIGN;
+  if (bias_grad && N > WINO_MAX_BIAS_N) return NBM_EUNSUPPORTED;
   const int per = m == 2 ? N / 4 : N / 2;             // channel chunks per tile
   const long long total = (long long)B * ((H + m - 1) / m) * ((W + m - 1) / m) * per;
   if (!idx32_ok(total)) return NBM_EUNSUPPORTED;
@@ -510,6 +530,7 @@ extern "C" int nbm_wino23_outgrad_tiles(const float* g, int B, int H, int W, int
   if (!g || !dM || !tiles || B <= 0 || H <= 0 || W <= 0 || N <= 0 || (N & 3) || n_list < 0 || skip_pattern_stride < 0) return NBM_EINVAL;
   if (!nbm_aligned16(g) || !nbm_aligned16(dM)) return NBM_EALIGN;
   if (n_list == 0) return NBM_OK;
+  if (bias_grad && N > WINO_MAX_BIAS_N) return NBM_EUNSUPPORTED;
   const int per = N / 4;
   if (!idx32_ok((long long)n_list * per) || !idx32_ok((long long)B * ((H + 1) / 2) * ((W + 1) / 2))) return NBM_EUNSUPPORTED;
   long long blocks = ((long long)n_list * per + 255) / 256;
