@@ -188,7 +188,8 @@ def detect_files(model, files, batch=64, min_score=0.2, bird_dict=None, write_tx
         try:
             for i in range(n_batches):
                 s = free_q.get()
-                if s is None:
+                if s is None:                        # the writer failed (or the main loop is shutting down): pass it on
+                    ready_q.put(None)
                     return
                 t0 = time.perf_counter()
                 chunk = files[i * batch:(i + 1) * batch]

@@ -71,3 +71,11 @@ def test_rows_to_result_equals_merge_images_for_a_single_window():
         if n:
             dropped = n - sum(len(v['scores']) for v in got.values())
             assert dropped > 0 or L == 1003 and seed == 3
+
+
+def test_txt_path_and_result_order():
+    assert bulk.txt_path('/a/b/clip.wav') == '/a/b/clip.txt'
+    rows = np.array([[3, 10, 10, 40, 40, 0.9], [3, 100, 10, 140, 40, 0.5], [7, 10, 100, 60, 160, 0.8]], dtype=np.float32)
+    got = bulk.rows_to_result(rows, 3, 1024, 819, 1003, None)
+    assert list(got) == ['3', '7'] and got['3']['scores'] == [float(np.float32(0.9)), 0.5]
+    assert bulk.rows_to_result(rows, 0, 1024, 819, 1003, None) == {}
