@@ -116,7 +116,8 @@ SIGNATURES = {
     'nbm_wino23_input_tiles': [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P],
     'nbm_wino23_outgrad_tiles': [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P],
     'nbm_cell_outgrad': [_P, _I, _I, _I, _I, _I, _P, _P, _P],
-    'nbm_cell_input': [_P, _I, _I, _I, _I, _I, _P, _P],
+    'nbm_cell_input': [_P, _I, _I, _I, _I, _I, _P, _I, _I, _P],
+    'nbm_cell_input_up': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     'nbm_cell_dgrad_output': [_P, _I, _I, _I, _I, _I, _P, _P],
     'nbm_cell_output': [_P, _P, _I, _I, _I, _I, _I, _P, _P],
     'nbm_weighted_sum': [_P, _P, _P, _P, _P, _L, _P],

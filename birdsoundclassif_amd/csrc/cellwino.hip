@@ -101,7 +101,9 @@ __global__ __launch_bounds__(256) void cell_outgrad_kernel(const float* __restri
 
 // x [B][H][W][C] -> Vx [25][T][C] = Vinv^T patch Vinv per cell (5x5 patch, rows S*oy-2 .. S*oy+2; outside the image = the
 // convolution's zero padding)
-__global__ __launch_bounds__(256) void cell_input_kernel(const float* __restrict__ x, const CellGeom q, float* __restrict__ Vx) {
+// ld4 / coff4 (in 16-byte units): row pitch of Vx and the channel offset this call writes at -- two sources can fill one operand
+__global__ __launch_bounds__(256) void cell_input_kernel(const float* __restrict__ x, const CellGeom q, float* __restrict__ Vx, int ld4,
+                                                         int coff4) {
   const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
   f32x4* v4 = reinterpret_cast<f32x4*>(Vx);
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -137,7 +139,67 @@ __global__ __launch_bounds__(256) void cell_input_kernel(const float* __restrict
 #pragma unroll
         for (int l = 0; l < NP; ++l)
           if (CV[l][e] != 0.f) o += CV[l][e] * t[a][l];
-        v4[((long long)(a * NP + e) * q.T + cell) * q.C4 + c] = o;
+        v4[((long long)(a * NP + e) * q.T + cell) * ld4 + coff4 + c] = o;
+      }
+  }
+}
+
+// The same transform of a patch that is not in memory: patch pixel = bilinear_align_corners(x1)[pixel] + bias (the top-down merge of
+// fpn.py:143-144 without the lateral term, which enters the plane GEMMs through its own 64-channel operand), 0 outside the image.
+// x1 [B][Hc][Wc][C]; same interpolation arithmetic as the merge epilogue of igemm.hip.
+__global__ __launch_bounds__(256) void cell_input_up_kernel(const float* __restrict__ x1, const float* __restrict__ bias, const CellGeom q,
+                                                            int Hc, int Wc, float sh, float sw, float* __restrict__ Vx, int ld4, int coff4) {
+#pragma clang fp contract(off)
+  const f32x4* s4 = reinterpret_cast<const f32x4*>(x1);
+  f32x4* v4 = reinterpret_cast<f32x4*>(Vx);
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const unsigned total = (unsigned)(q.T * q.C4);
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const int c = (int)(i % (unsigned)q.C4);
+    const unsigned cell = i / (unsigned)q.C4;
+    int b, oy, ox;
+    cell_of(q, cell, b, oy, ox);
+    const f32x4 bv = bias ? reinterpret_cast<const f32x4*>(bias)[c] : zero;
+    f32x4 t[NP][NP];
+#pragma unroll
+    for (int a = 0; a < NP; ++a)
+#pragma unroll
+      for (int l = 0; l < NP; ++l) t[a][l] = zero;
+    const long long rb = (long long)b * Hc;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int y = q.S * oy - 2 + j;
+      const bool yin = (unsigned)y < (unsigned)q.H;
+      const float fy = sh * (yin ? y : 0);
+      const int y0 = (int)fy, y1 = y0 + (y0 < Hc - 1 ? 1 : 0);
+      const float ly = fminf(fmaxf(fy - y0, 0.f), 1.f), hy = 1.f - ly;
+#pragma unroll
+      for (int l = 0; l < NP; ++l) {
+        const int xx = q.S * ox - 2 + l;
+        f32x4 v = zero;
+        if (yin && (unsigned)xx < (unsigned)q.W) {
+          const float fx = sw * xx;
+          const int x0 = (int)fx, x1i = x0 + (x0 < Wc - 1 ? 1 : 0);
+          const float lx = fminf(fmaxf(fx - x0, 0.f), 1.f), hx = 1.f - lx;
+          const f32x4 v00 = s4[((rb + y0) * Wc + x0) * q.C4 + c], v01 = s4[((rb + y0) * Wc + x1i) * q.C4 + c];
+          const f32x4 v10 = s4[((rb + y1) * Wc + x0) * q.C4 + c], v11 = s4[((rb + y1) * Wc + x1i) * q.C4 + c];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e])) + bv[e];
+        }
+#pragma unroll
+        for (int a = 0; a < NP; ++a)
+          if (CV[j][a] != 0.f) t[a][l] += CV[j][a] * v;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < NP; ++a)
+#pragma unroll
+      for (int e = 0; e < NP; ++e) {
+        f32x4 o = zero;
+#pragma unroll
+        for (int l = 0; l < NP; ++l)
+          if (CV[l][e] != 0.f) o += CV[l][e] * t[a][l];
+        v4[((long long)(a * NP + e) * q.T + cell) * ld4 + coff4 + c] = o;
       }
   }
 }
@@ -261,11 +323,23 @@ extern "C" int nbm_cell_outgrad(const float* g, int B, int H, int W, int N, int 
   return nbm_launch_status();
 }
 
-extern "C" int nbm_cell_input(const float* x, int B, int H, int W, int C, int stride, float* Vx, void* stream) {
+extern "C" int nbm_cell_input(const float* x, int B, int H, int W, int C, int stride, float* Vx, int ld, int c_off, void* stream) {
   CellGeom q;
-  if (!x || !Vx || !cell_geom(B, H, W, C, stride, q)) return NBM_EINVAL;
-  if (!nbm_aligned16(x) || !nbm_aligned16(Vx)) return NBM_EALIGN;
-  hipLaunchKernelGGL(cell_input_kernel, dim3(stream_grid(q.T * q.C4, q.C4)), dim3(256), 0, (hipStream_t)stream, x, q, Vx);
+  if (!x || !Vx || !cell_geom(B, H, W, C, stride, q) || ld < c_off + C || c_off < 0) return NBM_EINVAL;
+  if (!nbm_aligned16(x) || !nbm_aligned16(Vx) || (ld & 3) || (c_off & 3)) return NBM_EALIGN;
+  hipLaunchKernelGGL(cell_input_kernel, dim3(stream_grid(q.T * q.C4, q.C4)), dim3(256), 0, (hipStream_t)stream, x, q, Vx, ld / 4,
+                     c_off / 4);
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_cell_input_up(const float* x1, const float* bias, int B, int H, int W, int C, int Hc, int Wc, int stride, float* Vx,
+                                 int ld, int c_off, void* stream) {
+  CellGeom q;
+  if (!x1 || !Vx || !cell_geom(B, H, W, C, stride, q) || Hc <= 0 || Wc <= 0 || ld < c_off + C || c_off < 0) return NBM_EINVAL;
+  if (!nbm_aligned16(x1) || !nbm_aligned16(Vx) || (bias && !nbm_aligned16(bias)) || (ld & 3) || (c_off & 3)) return NBM_EALIGN;
+  const float sh = H > 1 ? (float)(Hc - 1) / (float)(H - 1) : 0.f, sw = W > 1 ? (float)(Wc - 1) / (float)(W - 1) : 0.f;
+  hipLaunchKernelGGL(cell_input_up_kernel, dim3(stream_grid(q.T * q.C4, q.C4)), dim3(256), 0, (hipStream_t)stream, x1, bias, q, Hc, Wc, sh,
+                     sw, Vx, ld / 4, c_off / 4);
   return nbm_launch_status();
 }
 

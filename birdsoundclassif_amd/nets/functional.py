@@ -307,6 +307,22 @@ def conv(x, weight, bias=None, scale=None, shift=None, residual=None, kh=1, kw=1
     return Conv.apply(x, weight, bias, scale, shift, residual, kh, kw, stride, pad, act, alpha, up, lazy_stride, accept_stash)
 
 
+def finest_fused_ok(t, w_lat, w_out):
+    """No gradients wanted (inference) and shapes the cell kernels take: see ondemand.finest_level_lazy."""
+    return bool(ondemand.FUSED_FINEST and ondemand.CELL_FWD and ondemand.LAZY_FINEST and ondemand.LAZY_LATERAL and WINOGRAD
+                and not torch.is_grad_enabled() and w_lat.dim() == 4 and tuple(w_lat.shape[2:]) == (1, 1)
+                and t.shape[-1] % 4 == 0 and (t.shape[-1] + w_lat.shape[0]) % 32 == 0 and w_lat.shape[0] % 32 == 0
+                and w_out.shape[0] % 4 == 0)
+
+
+def finest_level(t, w_lat, b_lat, alpha, up, w_out, b_out, stride):
+    """Finest FPN level on demand, inference only: -> y [B,H,W,N] holding the pattern pixels (ondemand.finest_level_lazy)."""
+    y, _ = ondemand.finest_level_lazy(t, _prep.krsc(w_lat), b_lat.detach() if b_lat is not None else None, alpha, up,
+                                      _prep.wino23(w_out), _prep.cell_weight_folded(w_out, w_lat, alpha),
+                                      b_out.detach() if b_out is not None else None, int(stride))
+    return y
+
+
 def linear(x2d, weight, bias=None, act=ACT_NONE, residual=None):
     M, K = x2d.shape
     res = residual.view(1, M, 1, -1) if residual is not None else None

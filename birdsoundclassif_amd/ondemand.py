@@ -304,7 +304,7 @@ def conv3x3_winograd_lazy(x, U, bias, stride, Ucell=None):
             T = cell_count(nb, H, W, stride)
             Vx, M = ops._wino_scratch(x.device, 25 * T * C_, 25 * T * N)
             stream = _stream()
-            check(lib().nbm_cell_input(_ptr(x[b0:b0 + nb]), nb, H, W, C_, stride, _ptr(Vx), stream), 'nbm_cell_input')
+            check(lib().nbm_cell_input(_ptr(x[b0:b0 + nb]), nb, H, W, C_, stride, _ptr(Vx), C_, 0, stream), 'nbm_cell_input')
             keep_label, ops._PROFILE_LABEL = ops._PROFILE_LABEL, ('cell-fwd', H, W)
             try:
                 gemm_conv(Vx, Ucell, M, B=1, H=T, W=1, Cin=C_, N=N, groups=25, x_gs=T * C_, w_gs=N * C_, y_gs=T * N)
@@ -322,6 +322,55 @@ def conv3x3_winograd_lazy(x, U, bias, stride, Ucell=None):
         del _LAZY[k]
     _LAZY[y.data_ptr()] = (st, weakref.ref(y))      # valid while the map object itself (or a view of it) is alive
     weakref.finalize(y, _forget, _LAZY, y.data_ptr(), id(st))     # ... and gone with it (operands included)
+    return y, st
+
+
+FUSED_FINEST = os.environ.get('NBM_FUSED_FINEST', '1') != '0'     # inference: finest level without materialising its merged map
+
+
+def finest_level_lazy(t, wk, b_lat, alpha, up, U, Ufold, b_out, stride):
+    """Finest FPN level, inference: lateral 1x1 + top-down merge (fpn.py:143-144) and the output 3x3 (:145) on the pattern pixels in
+    ONE chain of cell-domain operations -- the merged map x = alpha * W_lat t + b + up(x1) is never written on the pattern patches:
+    [transform(up(x1) + b) | transform(t)] (nbm_cell_input_up, nbm_cell_input: K = C + Cin channels) x [U | alpha U W_lat]^T
+    (`_prep.cell_weight_folded`) -> 3x3 blocks (nbm_cell_output).  Replaces the listed lateral GEMM with its gathered bilinear
+    epilogue (3.0 ms at B = 64, the kernel furthest below its roofs in round 2) and the patch transform of its output (1.6 ms).
+    The RoI phase (`lazy_complete`) still computes the merged map on the 4x4 patches of its tiles: `x` is their dense-addressed,
+    otherwise untouched home.  t [B,H,W,Cin], wk [C,Cin] KRSC, up [B,Hc,Wc,C], U [16,N,C] (RoI phase), Ufold [25,N,C+Cin].
+    -> (y [B,H,W,N] pattern pixels only, LazyMap)."""
+    _chk(t, name='t'), _chk(up, name='up'), _chk(Ufold, name='Ufold')
+    B, H, W, Cin = t.shape
+    C_, N = wk.shape[0], U.shape[1]
+    K = C_ + Cin
+    assert Ufold.shape == (25, N, K) and K % 32 == 0 and C_ % 4 == 0 and Cin % 4 == 0 and up.shape[0] == B and up.shape[3] == C_
+    x = _sparse_map((B, H, W, C_), t.device)
+    y = _sparse_map((B, H, W, N), t.device)
+    st = LazyMap(x, U, b_out, stride)
+    st.lateral = LateralState(t, wk, b_lat, alpha, up)
+    st.skip = None
+    img_bytes = H * W * N * 4
+    chunk = lazy_chunk(x)
+    stream = _stream()
+    for b0 in range(0, B, chunk):
+        nb = min(chunk, B - b0)
+        pat = wino23_pattern(nb, H, W, stride, t.device)
+        st.chunks.append((b0, nb, pat))
+        st.sparse = pat.frac < 0.6
+        T = cell_count(nb, H, W, stride)
+        V, M = ops._wino_scratch(t.device, 25 * T * K, 25 * T * N)
+        check(lib().nbm_cell_input_up(_ptr(up[b0:b0 + nb]), _ptr(b_lat), nb, H, W, C_, up.shape[1], up.shape[2], stride, _ptr(V), K, 0,
+                                      stream), 'nbm_cell_input_up')
+        check(lib().nbm_cell_input(_ptr(t[b0:b0 + nb]), nb, H, W, Cin, stride, _ptr(V), K, C_, stream), 'nbm_cell_input')
+        keep_label, ops._PROFILE_LABEL = ops._PROFILE_LABEL, ('cell-fwd', H, W)
+        try:
+            gemm_conv(V, Ufold, M, B=1, H=T, W=1, Cin=K, N=N, groups=25, x_gs=T * K, w_gs=N * K, y_gs=T * N)
+        finally:
+            ops._PROFILE_LABEL = keep_label
+        check(lib().nbm_cell_output(_ptr(M), _ptr(b_out), nb, H, W, N, stride, C.c_void_p(y.data_ptr() + b0 * img_bytes), stream),
+              'nbm_cell_output')
+    for k in [k for k, v in _LAZY.items() if v[1]() is None]:
+        del _LAZY[k]
+    _LAZY[y.data_ptr()] = (st, weakref.ref(y))
+    weakref.finalize(y, _forget, _LAZY, y.data_ptr(), id(st))
     return y, st
 
 
@@ -495,7 +544,7 @@ def conv3x3_winograd_wgrad_tiles(st, x, g, want_bias=False, cell=None):
             vg = _cell_outgrad(st, g, ci, b0, nb)              # from the data gradient's pass when that ran first
             T = vg.shape[1]
             Vx, _ = ops._wino_scratch(x.device, 25 * T * C_, 0)
-            check(lib().nbm_cell_input(_ptr(x[b0:b0 + nb]), nb, H, W, C_, st.stride, _ptr(Vx), stream), 'nbm_cell_input')
+            check(lib().nbm_cell_input(_ptr(x[b0:b0 + nb]), nb, H, W, C_, st.stride, _ptr(Vx), C_, 0, stream), 'nbm_cell_input')
             conv_wgrad(vg, Vx, dUc, B=1, H=T, W=1, Cin=C_, N=N, groups=25, g_gs=T * N, x_gs=T * C_, out_gs=N * C_)
             st.vg.pop(ci, None)
         parts = []

@@ -172,7 +172,12 @@ int nbm_wino23_outgrad_tiles(const float* g, int B, int H, int W, int N, const i
  *                          are not written)
  * the weight gradient's 25 TN GEMMs dU_xi = Vg_xi^T Vx_xi are nbm_conv_wgrad with groups = 25; dW = E^T dU E on the host. */
 int nbm_cell_outgrad(const float* g, int B, int H, int W, int N, int stride, float* Vg, float* bias_grad, void* stream);
-int nbm_cell_input(const float* x, int B, int H, int W, int C, int stride, float* Vx, void* stream);
+int nbm_cell_input(const float* x, int B, int H, int W, int C, int stride, float* Vx, int ld /* row pitch of Vx, >= c_off + C */,
+                   int c_off /* channel offset written */, void* stream);
+/* the same transform of patches that are not in memory: pixel = bilinear_align_corners(x1 [B][Hc][Wc][C])[pixel] + bias[C] (the
+ * top-down merge of fpn.py:143-144 without its lateral term), 0 outside the image */
+int nbm_cell_input_up(const float* x1, const float* bias, int B, int H, int W, int C, int Hc, int Wc, int stride, float* Vx, int ld,
+                      int c_off, void* stream);
 int nbm_cell_dgrad_output(const float* M, int B, int H, int W, int C, int stride, float* gx, void* stream);
 /* FORWARD of the pattern pixels with the same 25 products per cell (the correlation form, F(3x3,3x3)): nbm_cell_input of the
  * input, M_xi = Vx_xi U_xi^T (U = E w E^T as [25][N][C]), then blk = E^T M E + bias into the 3x3 pattern block of every cell of

@@ -136,6 +136,50 @@ def test_cell_forward_stores_exactly_the_pattern_pixels(shape):
     assert torch.equal(y[changed], dense[changed])
 
 
+@pytest.mark.parametrize('shape', [(2, 47, 66, 64, 384, 128, 8), (1, 188, 512, 64, 384, 256, 8), (2, 45, 61, 32, 96, 64, 6)])
+def test_finest_level_without_its_merged_map(shape):
+    """ondemand.finest_level_lazy (inference): lateral 1x1 + bilinear merge + output 3x3 on the pattern pixels through
+    [transform(up(x1) + b) | transform(t)] x [U | alpha U W_lat]^T -- the merged map never exists on the pattern patches.  The
+    stored pixels are the dense chain's (lateral GEMM with merge epilogue, then the dense 3x3) within fp32 rounding, nothing else is
+    written, and the RoI phase afterwards (its own lateral patches + listed F(2x2,3x3) tiles) is bit-identical to the dense chain."""
+    B, H, W, Cin, C, N, S = shape
+    t = rnd(('ft', shape), B, H, W, Cin).cuda()
+    wl = rnd(('fwl', shape), C, Cin, 1, 1, scale=0.1).cuda()
+    bl = rnd(('fbl', shape), C).cuda()
+    up = rnd(('fup', shape), B, (H + 1) // 2, (W + 1) // 2, C).cuda()
+    wo = rnd(('fwo', shape), N, C, 3, 3, scale=0.05).cuda()
+    bo = rnd(('fbo', shape), N).cuda()
+    alpha = 2.0
+    merged = ops.conv2d(t, _prep.krsc(wl), shift=bl, alpha=alpha, up=up)
+    dense = ops.conv3x3_winograd(merged, _prep.wino23(wo), bo)
+    ondemand.LAZY_POISON = True
+    try:
+        y, st = ondemand.finest_level_lazy(t, _prep.krsc(wl), bl, alpha, up, _prep.wino23(wo), _prep.cell_weight_folded(wo, wl, alpha), bo, S)
+    finally:
+        ondemand.LAZY_POISON = False
+    rows = torch.zeros(H, dtype=torch.bool)
+    cols = torch.zeros(W, dtype=torch.bool)
+    for n_, v in ((H, rows), (W, cols)):
+        for o in range((n_ - 1) // S + 1):
+            for k in range(3):
+                if 0 <= S * o - 1 + k < n_:
+                    v[S * o - 1 + k] = True
+    m = (rows[:, None] & cols[None, :]).cuda()
+    assert bool(torch.isnan(y[:, ~m]).all()), 'a pixel outside the pattern was written'
+    err = float((y[:, m] - dense[:, m]).abs().max())
+    assert err < 2e-5 * max(1.0, float(dense.abs().max())), (err, float(dense.abs().max()))
+    assert bool(torch.isnan(st.x).all())                                     # the merged map: still untouched
+    fh = [H, (H + 1) // 2, (H + 3) // 4, (H + 7) // 8, (H + 15) // 16]
+    fw = [W, (W + 1) // 2, (W + 3) // 4, (W + 7) // 8, (W + 15) // 16]
+    rois = torch.tensor([[[10., 12., 25., 20.], [60., 40., 70., 66.], [0., 0., 8., 9.]]] * B).cuda()
+    before = y.clone()
+    ondemand.lazy_complete(y, rois, torch.tensor([3], dtype=torch.int32, device='cuda'), list(zip(fh, fw)))
+    new = ~torch.isnan(y[..., 0]) & torch.isnan(before[..., 0])
+    assert int(new.sum()) > 0 and torch.equal(y[new], dense[new])
+    xm = ~torch.isnan(st.x[..., 0])
+    assert int(xm.sum()) > 0 and torch.equal(st.x[xm], merged[xm])
+
+
 def test_many_rois_at_the_real_geometry():
     """1000 RoIs per image (the negative training step's load) on the 188x512 map: every pixel of every level-0 window equals the
     dense convolution, nothing outside pattern pixels + window tiles is written, and the dilated list covers the data gradient."""
