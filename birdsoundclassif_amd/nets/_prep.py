@@ -98,17 +98,18 @@ def cell_weight(weight, forward=False):
     return _cached(weight, ('cell', forward), make)
 
 
-def cell_weight_folded(w_out, w_lat, alpha):
-    """Forward operand of the finest FPN level with its lateral folded in (ondemand.finest_level_lazy): [25][N][C + Cin] =
-    [ U | alpha * U W_lat ] with U = E w_out E^T ([25][N][C]) and W_lat [C][Cin] the lateral 1x1 -- the merged map
-    x = alpha * W_lat t + b + up(x1) never exists on the pattern patches: its transform is [transform(up(x1) + b) | transform(t)]."""
+def cell_weight_folded(w_out, wk_lat, alpha):
+    """B operand of the cell-domain plane GEMMs of a demand-driven 3x3 convolution whose lateral was deferred
+    (ondemand.conv1x1_lazy(defer=True)): [25][N][C + Cin] = [ U | alpha * U W_lat ] with U = E w_out E^T ([25][N][C]) and
+    W_lat = wk_lat[:, :Cin] the lateral's KRSC weights [C][Cin] -- the merged map x = alpha * W_lat t + b + up(x1) never exists
+    on the pattern patches: its transform is [transform(up(x1) + b) | transform(t)]."""
     def make():
         E = _cell_e(w_out.device)
         u = torch.einsum('ar,bs,ncrs->abnc', E, E, w_out.detach().double())                  # [5,5,N,C]
-        wl = w_lat.detach().double().reshape(w_lat.shape[0], w_lat.shape[1])                 # [C, Cin]
+        wl = wk_lat.detach().double()                                                         # [C, Cin (+ padding)]
         uf = torch.cat([u, float(alpha) * torch.einsum('abnc,ck->abnk', u, wl)], dim=-1)
         return uf.reshape(25, uf.shape[2], uf.shape[3]).float().contiguous()
-    return _cached(w_out, ('cellfold', float(alpha)), make, extra=(w_lat.data_ptr(), w_lat._version))
+    return _cached(w_out, ('cellfold', float(alpha)), make, extra=(wk_lat.data_ptr(), wk_lat._version, tuple(wk_lat.shape)))
 
 
 def cell_weight_grad(dU):

@@ -114,10 +114,6 @@ class FPN(nn.Module):
             # the finest level has no finer level that would read `merged`
             oc = self.out_convs[str(len(x) - 1 - i)]
             lz = (lazy_strides or {}).get(i) if i == 0 and Fn.lazy3x3_ok(t.shape[1], t.shape[2], c.weight.shape[0], oc.weight) else None
-            if lz and merged is not None and Fn.finest_fused_ok(t, c.weight, oc.weight):
-                # inference: the whole level on the pattern pixels in the cell domain, no merged map (ondemand.finest_level_lazy)
-                outs.insert(0, Fn.finest_level(t, c.weight, c.bias, alpha, merged, oc.weight, oc.bias, lz))
-                continue
             merged = Fn.conv(t, c.weight, bias=c.bias, alpha=alpha, up=merged, lazy_stride=lz)
             # (i > 0: `merged` is also the `up` of the next finer lateral, whose backward pass runs first and hands its share of the
             # gradient over: Fn._STASH)

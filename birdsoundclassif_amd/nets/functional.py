@@ -112,11 +112,15 @@ class Conv(Function):
             # the RoIs when the RoI pooling asks for them; the backward pass is the dense one (the incoming gradient is
             # zero wherever nothing was read)
             y, ctx.lazy = ondemand.conv3x3_winograd_lazy(x, _prep.wino23(weight), sh, lazy_stride[0],
-                                                         _prep.cell_weight(weight, forward=True) if ondemand.CELL_FWD else None)
-            ctx.lazy.keep = lazy_stride[1]        # a backward pass will follow: keep the RoI tile lists for the weight gradient
+                                                         _prep.cell_weight(weight, forward=True) if ondemand.CELL_FWD else None,
+                                                         fold=lambda wk, alpha: _prep.cell_weight_folded(weight, wk, alpha),
+                                                         keep=lazy_stride[1])
         elif lazy_stride and kh == 1:
             # the lateral 1x1 (+ top-down merge) in front of a demand-driven 3x3: only the pixels that convolution reads
-            y = ondemand.conv1x1_lazy(x, _prep.krsc(weight), sh, alpha, up, lazy_stride[0])
+            # deferred: write nothing, the consumer takes t / up / the weights into its cell-domain GEMMs -- provided its backward
+            # pass (if one can follow) is the cell-domain one, the only one that does not read the pattern patches of this map
+            defer = not any(ctx.needs_input_grad) or (ondemand.CELL_BWD and LAZY_WGRAD and LAZY_DGRAD)
+            y = ondemand.conv1x1_lazy(x, _prep.krsc(weight), sh, alpha, up, lazy_stride[0], defer=defer)
         elif ctx.wino:        # large 3x3 (FPN output convolutions): Winograd F(2x2,3x3), 2.25x fewer multiplies
             y = ops.conv3x3_winograd(x, _prep.wino23(weight), sh)
         else:
@@ -305,22 +309,6 @@ def conv(x, weight, bias=None, scale=None, shift=None, residual=None, kh=1, kw=1
         # sparse maps by exact-zero gradients: the holes must then be zeros, not uninitialised memory
         ondemand.ZERO_FILL = not (LAZY_WGRAD and LAZY_DGRAD)
     return Conv.apply(x, weight, bias, scale, shift, residual, kh, kw, stride, pad, act, alpha, up, lazy_stride, accept_stash)
-
-
-def finest_fused_ok(t, w_lat, w_out):
-    """No gradients wanted (inference) and shapes the cell kernels take: see ondemand.finest_level_lazy."""
-    return bool(ondemand.FUSED_FINEST and ondemand.CELL_FWD and ondemand.LAZY_FINEST and ondemand.LAZY_LATERAL and WINOGRAD
-                and not torch.is_grad_enabled() and w_lat.dim() == 4 and tuple(w_lat.shape[2:]) == (1, 1)
-                and t.shape[-1] % 4 == 0 and (t.shape[-1] + w_lat.shape[0]) % 32 == 0 and w_lat.shape[0] % 32 == 0
-                and w_out.shape[0] % 4 == 0)
-
-
-def finest_level(t, w_lat, b_lat, alpha, up, w_out, b_out, stride):
-    """Finest FPN level on demand, inference only: -> y [B,H,W,N] holding the pattern pixels (ondemand.finest_level_lazy)."""
-    y, _ = ondemand.finest_level_lazy(t, _prep.krsc(w_lat), b_lat.detach() if b_lat is not None else None, alpha, up,
-                                      _prep.wino23(w_out), _prep.cell_weight_folded(w_out, w_lat, alpha),
-                                      b_out.detach() if b_out is not None else None, int(stride))
-    return y
 
 
 def linear(x2d, weight, bias=None, act=ACT_NONE, residual=None):

@@ -184,7 +184,7 @@ class LazyMap:
     12 GB alive until the garbage collector runs); its consumers keep it alive and hand it back to `lazy_complete`.
     The operands stay here for as long as the map lives, so EVERY RoI pooling on the map -- not only the first -- finds the
     tiles under its windows computed (`done` counts them); the state goes when the map does (`_forget`)."""
-    __slots__ = ('x', 'U', 'bias', 'skip', 'stride', 'chunks', 'roi', 'keep', 'sparse', 'lateral', 'rois', 'done', 'vg', 'cell_gb', 'cell_gb_done', '__weakref__')
+    __slots__ = ('x', 'U', 'bias', 'skip', 'stride', 'chunks', 'roi', 'keep', 'sparse', 'lateral', 'rois', 'done', 'vg', 'cell_gb', 'cell_gb_done', 'vx', '__weakref__')
 
     def __init__(self, x, U, bias, stride):
         self.x, self.U, self.bias, self.stride = x, U, bias, stride
@@ -195,10 +195,11 @@ class LazyMap:
         self.vg = None          # backward pass: {chunk: Vg} of the cell transforms, shared by the data and the weight gradient
         self.cell_gb = None     # ... and the bias gradient of the pattern pixels, summed by the same kernel
         self.cell_gb_done = None    # chunks whose pattern pixels are in cell_gb already (a chunk's Vg may be computed twice)
+        self.vx = None          # deferred lateral + a backward pass to come: {chunk: [transform(up + b) | transform(t)]} of the forward pass
 
     def release(self):
         """Called by the backward pass of the convolution: no RoI pooling can follow on a map whose gradient has been consumed."""
-        self.x = self.U = self.bias = self.lateral = self.vg = self.cell_gb = self.cell_gb_done = None
+        self.x = self.U = self.bias = self.lateral = self.vg = self.cell_gb = self.cell_gb_done = self.vx = None
 
     def __del__(self):          # the pinned counters go back to the pool
         try:
@@ -227,11 +228,12 @@ _LAZY_LATERAL = {}                  # data_ptr of a sparse lateral map -> (Later
 class LateralState:
     """Operands of a lateral 1x1 convolution (+ top-down merge) whose output only exists where its one consumer, a demand-driven
     3x3 convolution, reads it; `conv3x3_winograd_lazy` picks the state up and `lazy_complete` finishes the pixels under the RoI
-    tiles before it convolves them."""
-    __slots__ = ('t', 'wk', 'bias', 'alpha', 'up')
+    tiles before it convolves them.  `deferred`: not even the pattern patches were computed -- the consumer takes the lateral's
+    OPERANDS into its cell-domain GEMMs instead (`conv3x3_winograd_lazy`, Ufold)."""
+    __slots__ = ('t', 'wk', 'bias', 'alpha', 'up', 'deferred', 'stride')
 
-    def __init__(self, t, wk, bias, alpha, up):
-        self.t, self.wk, self.bias, self.alpha, self.up = t, wk, bias, alpha, up
+    def __init__(self, t, wk, bias, alpha, up, deferred=False, stride=0):
+        self.t, self.wk, self.bias, self.alpha, self.up, self.deferred, self.stride = t, wk, bias, alpha, up, deferred, stride
 
 
 ZERO_FILL = False                   # functional.py sets it when a DENSE backward kernel may read a sparse map (A/B switches off)
@@ -253,23 +255,41 @@ def _forget(table, key, ident):
         del table[key]
 
 
-def conv1x1_lazy(t, wk, bias, alpha, up, stride):
+FUSED_FINEST = os.environ.get('NBM_FUSED_FINEST', '1') != '0'     # the lateral's operands go into the consumer's cell-domain GEMMs
+
+
+def _lateral_pattern_pass(x, ls, stride):
+    """The lateral + merge on the pattern patches (`TilePattern.px_rows`) into the sparse map x."""
+    B, H, W, N = x.shape
+    chunk = lazy_chunk(x)                      # the same batch chunks as the convolution that follows
+    for b0 in range(0, B, chunk):
+        nb = min(chunk, B - b0)
+        pat = wino23_pattern(nb, H, W, stride, x.device)
+        gemm_conv(ls.t[b0:b0 + nb], ls.wk, x[b0:b0 + nb], B=nb, H=H, W=W, Cin=ls.t.shape[-1], N=N, w_ld=ls.wk.shape[1], shift=ls.bias,
+                  alpha=ls.alpha, up=ls.up[b0:b0 + nb] if ls.up is not None else None, rows=pat.px_rows, rows_mode=1,
+                  rows_count=pat.px_rows.numel())
+
+
+def conv1x1_lazy(t, wk, bias, alpha, up, stride, defer=False):
     """Lateral 1x1 convolution + bilinear top-down merge (fpn.py:143-144) on the pixels that the pattern tiles of the following
     demand-driven 3x3 convolution read (`TilePattern.px_rows`): t [B,H,W,Cin] -> x [B,H,W,N], other pixels unwritten.  Same
-    kernel, same arithmetic per pixel as the dense call."""
+    kernel, same arithmetic per pixel as the dense call.
+    `defer` (round 3): write NOTHING now.  The consumer's pattern pass works in the cell domain, where the merged map
+    x = alpha W t + b + up(x1) need not exist: its patch transform is [transform(up(x1) + b) | transform(t)], and the lateral's
+    weights fold into the consumer's ([U | alpha U W], `_prep.cell_weight_folded`).  That removes this GEMM -- with its gathered
+    bilinear epilogue the kernel furthest below its roofs in round 2 (3.0 ms at B = 64) -- and the patch transform of its output.
+    A consumer that cannot take the operands runs the pattern pass itself (`_lateral_pattern_pass`)."""
     _chk(t, name='t'), _chk(wk, name='w')
     B, H, W, Cin = t.shape
     N = wk.shape[0]
     x = _sparse_map((B, H, W, N), t.device)
-    chunk = lazy_chunk(x)                      # the same batch chunks as the convolution that follows
-    for b0 in range(0, B, chunk):
-        nb = min(chunk, B - b0)
-        pat = wino23_pattern(nb, H, W, stride, t.device)
-        gemm_conv(t[b0:b0 + nb], wk, x[b0:b0 + nb], B=nb, H=H, W=W, Cin=Cin, N=N, w_ld=wk.shape[1], shift=bias, alpha=alpha,
-                  up=up[b0:b0 + nb] if up is not None else None, rows=pat.px_rows, rows_mode=1, rows_count=pat.px_rows.numel())
+    defer = bool(defer and FUSED_FINEST and CELL_FWD and up is not None and stride >= 3 and Cin % 4 == 0 and N % 32 == 0 and
+                 (N + Cin) % 32 == 0 and wk.shape[1] == Cin)
+    ls = LateralState(t, wk, bias, alpha, up, deferred=defer, stride=stride)
+    if not defer:
+        _lateral_pattern_pass(x, ls, stride)
     for k in [k for k, v in _LAZY_LATERAL.items() if v[1]() is None]:
         del _LAZY_LATERAL[k]
-    ls = LateralState(t, wk, bias, alpha, up)
     _LAZY_LATERAL[x.data_ptr()] = (ls, weakref.ref(x))
     weakref.finalize(x, _forget, _LAZY_LATERAL, x.data_ptr(), id(ls))
     return x
@@ -278,36 +298,72 @@ def conv1x1_lazy(t, wk, bias, alpha, up, stride):
 CELL_FWD = os.environ.get('NBM_CELL_FWD', '1') != '0'     # pattern pixels of the FORWARD pass through the cell transforms
 
 
-def conv3x3_winograd_lazy(x, U, bias, stride, Ucell=None):
+def _cell_operand(st, b0, nb, H, W, C_, x, n_out=0, ci=None):
+    """A operand of the cell-domain plane GEMMs of batch chunk [b0, b0 + nb): the transformed 5x5 input patches, [25][cells][K].
+    From the map x itself (K = C), or -- deferred lateral -- from the lateral's operands: [transform(up(x1) + b) | transform(t)],
+    K = C + Cin.  -> (V, M: views of the shared scratch, M with room for [25][cells][n_out]; K; cells).  Deferred lateral with a
+    backward pass to come (`st.keep`, chunk index `ci`): V is an allocation of its own, kept in st.vx for the weight gradient (8.8 GB
+    at B = 128 for -4 ms: the interpolating transform is not run twice)."""
+    T = cell_count(nb, H, W, st.stride)
+    stream = _stream()
+    lt = st.lateral
+    if lt is not None and lt.deferred:
+        Cin = lt.t.shape[-1]
+        K = C_ + Cin
+        if st.vx is not None and ci in st.vx:            # the forward pass left it here
+            return st.vx.pop(ci), ops._wino_scratch(lt.t.device, 25 * T * n_out, 0)[0], K, T
+        if st.keep and ci is not None and n_out:         # forward pass, a backward pass will follow
+            if st.vx is None:
+                st.vx = {}
+            V = st.vx[ci] = torch.empty((25 * T * K,), device=lt.t.device, dtype=torch.float32)
+            M = ops._wino_scratch(lt.t.device, 25 * T * n_out, 0)[0]
+        else:
+            V, M = ops._wino_scratch(lt.t.device, 25 * T * K, 25 * T * n_out)
+        check(lib().nbm_cell_input_up(_ptr(lt.up[b0:b0 + nb]), _ptr(lt.bias), nb, H, W, C_, lt.up.shape[1], lt.up.shape[2], st.stride,
+                                      _ptr(V), K, 0, stream), 'nbm_cell_input_up')
+        check(lib().nbm_cell_input(_ptr(lt.t[b0:b0 + nb]), nb, H, W, Cin, st.stride, _ptr(V), K, C_, stream), 'nbm_cell_input')
+        return V, M, K, T
+    V, M = ops._wino_scratch(x.device, 25 * T * C_, 25 * T * n_out)
+    check(lib().nbm_cell_input(_ptr(x[b0:b0 + nb]), nb, H, W, C_, st.stride, _ptr(V), C_, 0, stream), 'nbm_cell_input')
+    return V, M, C_, T
+
+
+def conv3x3_winograd_lazy(x, U, bias, stride, Ucell=None, fold=None, keep=False):
     """Finest-level output convolution, pattern tiles only (see above) -> (y [B,H,W,N] with the other pixels unwritten,
     LazyMap).  `Ucell` (_prep.cell_weight(w, forward=True)): the pattern pixels through the cell transforms (F(3x3,3x3) per
     stride x stride cell: 25 plane products per cell instead of the ~49 of the listed F(2x2,3x3) tiles) -- exactly the 9 / 64
-    pattern pixels are stored."""
+    pattern pixels are stored.  `fold` (callable (wk, alpha) -> [25][N][C + Cin], `_prep.cell_weight_folded`): needed when the
+    lateral in front was deferred (`conv1x1_lazy(defer=True)`): its operands enter the plane GEMMs directly."""
     _chk(x, name='x'), _chk(U, name='U')
     B, H, W, C_ = x.shape
     N = U.shape[1]
     assert U.shape == (16, N, C_) and C_ % 32 == 0 and C_ >= 64 and N % 4 == 0
     y = _sparse_map((B, H, W, N), x.device)
     st = LazyMap(x, U, bias, stride)
+    st.keep = bool(keep)                              # a backward pass will follow: RoI tile lists (and a deferred lateral's operand) are kept
     lat = _LAZY_LATERAL.pop(x.data_ptr(), None)      # x itself only exists where the pattern tiles read it
     if lat is not None and lat[1]() is not None:
         st.lateral = lat[0]
+    cell_ok = Ucell is not None and stride >= 3 and C_ % 32 == 0 and N % 4 == 0
+    if st.lateral is not None and st.lateral.deferred and not (cell_ok and fold is not None):
+        _lateral_pattern_pass(x, st.lateral, stride)             # this consumer cannot take the operands: the patches after all
+        st.lateral.deferred = False
+    Ufold = fold(st.lateral.wk, st.lateral.alpha) if st.lateral is not None and st.lateral.deferred else None
     img_bytes = H * W * N * 4
     chunk = lazy_chunk(x)
-    for b0 in range(0, B, chunk):
+    for ci, b0 in enumerate(range(0, B, chunk)):
         nb = min(chunk, B - b0)
         pat = wino23_pattern(nb, H, W, stride, x.device)
         st.skip = pat.full
         st.chunks.append((b0, nb, pat))
         st.sparse = pat.frac < 0.6               # the weight gradient over the listed tiles pays off when most are not listed
-        if Ucell is not None and stride >= 3 and C_ % 32 == 0 and N % 4 == 0:       # (3x3 blocks of different cells never overlap)
-            T = cell_count(nb, H, W, stride)
-            Vx, M = ops._wino_scratch(x.device, 25 * T * C_, 25 * T * N)
+        if cell_ok:                                  # (3x3 blocks of different cells never overlap)
             stream = _stream()
-            check(lib().nbm_cell_input(_ptr(x[b0:b0 + nb]), nb, H, W, C_, stride, _ptr(Vx), C_, 0, stream), 'nbm_cell_input')
+            Vx, M, K, T = _cell_operand(st, b0, nb, H, W, C_, x, n_out=N, ci=ci)
             keep_label, ops._PROFILE_LABEL = ops._PROFILE_LABEL, ('cell-fwd', H, W)
             try:
-                gemm_conv(Vx, Ucell, M, B=1, H=T, W=1, Cin=C_, N=N, groups=25, x_gs=T * C_, w_gs=N * C_, y_gs=T * N)
+                gemm_conv(Vx, Ufold if Ufold is not None else Ucell, M, B=1, H=T, W=1, Cin=K, N=N, groups=25, x_gs=T * K, w_gs=N * K,
+                          y_gs=T * N)
             finally:
                 ops._PROFILE_LABEL = keep_label
             check(lib().nbm_cell_output(_ptr(M), _ptr(bias), nb, H, W, N, stride, C.c_void_p(y.data_ptr() + b0 * img_bytes), stream),
@@ -322,55 +378,6 @@ def conv3x3_winograd_lazy(x, U, bias, stride, Ucell=None):
         del _LAZY[k]
     _LAZY[y.data_ptr()] = (st, weakref.ref(y))      # valid while the map object itself (or a view of it) is alive
     weakref.finalize(y, _forget, _LAZY, y.data_ptr(), id(st))     # ... and gone with it (operands included)
-    return y, st
-
-
-FUSED_FINEST = os.environ.get('NBM_FUSED_FINEST', '1') != '0'     # inference: finest level without materialising its merged map
-
-
-def finest_level_lazy(t, wk, b_lat, alpha, up, U, Ufold, b_out, stride):
-    """Finest FPN level, inference: lateral 1x1 + top-down merge (fpn.py:143-144) and the output 3x3 (:145) on the pattern pixels in
-    ONE chain of cell-domain operations -- the merged map x = alpha * W_lat t + b + up(x1) is never written on the pattern patches:
-    [transform(up(x1) + b) | transform(t)] (nbm_cell_input_up, nbm_cell_input: K = C + Cin channels) x [U | alpha U W_lat]^T
-    (`_prep.cell_weight_folded`) -> 3x3 blocks (nbm_cell_output).  Replaces the listed lateral GEMM with its gathered bilinear
-    epilogue (3.0 ms at B = 64, the kernel furthest below its roofs in round 2) and the patch transform of its output (1.6 ms).
-    The RoI phase (`lazy_complete`) still computes the merged map on the 4x4 patches of its tiles: `x` is their dense-addressed,
-    otherwise untouched home.  t [B,H,W,Cin], wk [C,Cin] KRSC, up [B,Hc,Wc,C], U [16,N,C] (RoI phase), Ufold [25,N,C+Cin].
-    -> (y [B,H,W,N] pattern pixels only, LazyMap)."""
-    _chk(t, name='t'), _chk(up, name='up'), _chk(Ufold, name='Ufold')
-    B, H, W, Cin = t.shape
-    C_, N = wk.shape[0], U.shape[1]
-    K = C_ + Cin
-    assert Ufold.shape == (25, N, K) and K % 32 == 0 and C_ % 4 == 0 and Cin % 4 == 0 and up.shape[0] == B and up.shape[3] == C_
-    x = _sparse_map((B, H, W, C_), t.device)
-    y = _sparse_map((B, H, W, N), t.device)
-    st = LazyMap(x, U, b_out, stride)
-    st.lateral = LateralState(t, wk, b_lat, alpha, up)
-    st.skip = None
-    img_bytes = H * W * N * 4
-    chunk = lazy_chunk(x)
-    stream = _stream()
-    for b0 in range(0, B, chunk):
-        nb = min(chunk, B - b0)
-        pat = wino23_pattern(nb, H, W, stride, t.device)
-        st.chunks.append((b0, nb, pat))
-        st.sparse = pat.frac < 0.6
-        T = cell_count(nb, H, W, stride)
-        V, M = ops._wino_scratch(t.device, 25 * T * K, 25 * T * N)
-        check(lib().nbm_cell_input_up(_ptr(up[b0:b0 + nb]), _ptr(b_lat), nb, H, W, C_, up.shape[1], up.shape[2], stride, _ptr(V), K, 0,
-                                      stream), 'nbm_cell_input_up')
-        check(lib().nbm_cell_input(_ptr(t[b0:b0 + nb]), nb, H, W, Cin, stride, _ptr(V), K, C_, stream), 'nbm_cell_input')
-        keep_label, ops._PROFILE_LABEL = ops._PROFILE_LABEL, ('cell-fwd', H, W)
-        try:
-            gemm_conv(V, Ufold, M, B=1, H=T, W=1, Cin=K, N=N, groups=25, x_gs=T * K, w_gs=N * K, y_gs=T * N)
-        finally:
-            ops._PROFILE_LABEL = keep_label
-        check(lib().nbm_cell_output(_ptr(M), _ptr(b_out), nb, H, W, N, stride, C.c_void_p(y.data_ptr() + b0 * img_bytes), stream),
-              'nbm_cell_output')
-    for k in [k for k, v in _LAZY.items() if v[1]() is None]:
-        del _LAZY[k]
-    _LAZY[y.data_ptr()] = (st, weakref.ref(y))
-    weakref.finalize(y, _forget, _LAZY, y.data_ptr(), id(st))
     return y, st
 
 
@@ -532,6 +539,9 @@ def conv3x3_winograd_wgrad_tiles(st, x, g, want_bias=False, cell=None):
     N = g.shape[-1]
     if cell is None:
         cell = cell_usable(st, H, W, C_, N)
+    if st.lateral is not None and st.lateral.deferred and not cell:
+        raise RuntimeError('the lateral in front of this demand-driven convolution was deferred (its pattern patches were never '
+                           'written): only the cell-domain weight gradient can run')
     dU = torch.zeros((16, N, C_), device=x.device, dtype=torch.float32)
     dUc = torch.zeros((25, N, C_), device=x.device, dtype=torch.float32) if cell else None
     gb = torch.zeros((N,), device=x.device, dtype=torch.float32) if want_bias else None
@@ -542,10 +552,10 @@ def conv3x3_winograd_wgrad_tiles(st, x, g, want_bias=False, cell=None):
         lists, infos = ([], []) if cell else ([pat.tiles], [pat.entry_pm])
         if cell:
             vg = _cell_outgrad(st, g, ci, b0, nb)              # from the data gradient's pass when that ran first
-            T = vg.shape[1]
-            Vx, _ = ops._wino_scratch(x.device, 25 * T * C_, 0)
-            check(lib().nbm_cell_input(_ptr(x[b0:b0 + nb]), nb, H, W, C_, st.stride, _ptr(Vx), C_, 0, stream), 'nbm_cell_input')
-            conv_wgrad(vg, Vx, dUc, B=1, H=T, W=1, Cin=C_, N=N, groups=25, g_gs=T * N, x_gs=T * C_, out_gs=N * C_)
+            Vx, _, K, T = _cell_operand(st, b0, nb, H, W, C_, x, ci=ci)   # deferred lateral: K = C + Cin, dUc is the gradient of [U | alpha U W]
+            if dUc.shape[2] != K:
+                dUc = torch.zeros((25, N, K), device=x.device, dtype=torch.float32)
+            conv_wgrad(vg, Vx, dUc, B=1, H=T, W=1, Cin=K, N=N, groups=25, g_gs=T * N, x_gs=T * K, out_gs=N * K)
             st.vg.pop(ci, None)
         parts = []
         for per_chunk in st.roi:                    # one entry per RoI pooling that read the map
@@ -588,4 +598,7 @@ def conv3x3_winograd_wgrad_tiles(st, x, g, want_bias=False, cell=None):
         gb += st.cell_gb
     if cell:
         st.vg = st.cell_gb = st.cell_gb_done = None
+        if dUc.shape[2] != C_:          # deferred lateral: d/dU = d/d(first block) + alpha * d/d(second block) W^T  (second block = alpha U W)
+            lt = st.lateral
+            dUc = (dUc[:, :, :C_] + float(lt.alpha) * torch.matmul(dUc[:, :, C_:], lt.wk[:, :dUc.shape[2] - C_].t())).contiguous()
     return dU, gb, dUc

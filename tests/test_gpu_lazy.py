@@ -138,8 +138,8 @@ def test_cell_forward_stores_exactly_the_pattern_pixels(shape):
 
 @pytest.mark.parametrize('shape', [(2, 47, 66, 64, 384, 128, 8), (1, 188, 512, 64, 384, 256, 8), (2, 45, 61, 32, 96, 64, 6)])
 def test_finest_level_without_its_merged_map(shape):
-    """ondemand.finest_level_lazy (inference): lateral 1x1 + bilinear merge + output 3x3 on the pattern pixels through
-    [transform(up(x1) + b) | transform(t)] x [U | alpha U W_lat]^T -- the merged map never exists on the pattern patches.  The
+    """Deferred lateral (conv1x1_lazy(defer=True)) + its consumer: lateral 1x1 + bilinear merge + output 3x3 on the pattern pixels
+    through [transform(up(x1) + b) | transform(t)] x [U | alpha U W_lat]^T -- the merged map never exists on the pattern patches.  The
     stored pixels are the dense chain's (lateral GEMM with merge epilogue, then the dense 3x3) within fp32 rounding, nothing else is
     written, and the RoI phase afterwards (its own lateral patches + listed F(2x2,3x3) tiles) is bit-identical to the dense chain."""
     B, H, W, Cin, C, N, S = shape
@@ -154,7 +154,20 @@ def test_finest_level_without_its_merged_map(shape):
     dense = ops.conv3x3_winograd(merged, _prep.wino23(wo), bo)
     ondemand.LAZY_POISON = True
     try:
-        y, st = ondemand.finest_level_lazy(t, _prep.krsc(wl), bl, alpha, up, _prep.wino23(wo), _prep.cell_weight_folded(wo, wl, alpha), bo, S)
+        x = ondemand.conv1x1_lazy(t, _prep.krsc(wl), bl, alpha, up, S, defer=True)
+        y, st = ondemand.conv3x3_winograd_lazy(x, _prep.wino23(wo), bo, S, _prep.cell_weight(wo, forward=True),
+                                               fold=lambda wk, a: _prep.cell_weight_folded(wo, wk, a))
+    finally:
+        ondemand.LAZY_POISON = False
+    assert st.lateral is not None and st.lateral.deferred and bool(torch.isnan(x).all())
+    ondemand.LAZY_POISON = True
+    try:
+        # a consumer that cannot take the operands (no cell weights) runs the lateral's pattern pass itself
+        x2 = ondemand.conv1x1_lazy(t, _prep.krsc(wl), bl, alpha, up, S, defer=True)
+        y2, st2 = ondemand.conv3x3_winograd_lazy(x2, _prep.wino23(wo), bo, S)
+        assert not st2.lateral.deferred and not bool(torch.isnan(x2).all())
+        w2 = ~torch.isnan(y2[..., 0])
+        assert torch.equal(y2[w2], dense[w2])
     finally:
         ondemand.LAZY_POISON = False
     rows = torch.zeros(H, dtype=torch.bool)
