@@ -254,7 +254,8 @@ __global__ void colsum_kernel(const float* __restrict__ g, long long M, int N, i
 // gradient of 3x3/s2/p1 max pooling, gather form over the arg-max positions the forward pass recorded (r*3+s, one byte
 // per output element): every input pixel looks at the <= 4 windows that contain it.  Reads idx + gy, writes gx once.
 __global__ void maxpool_bwd_kernel(const uint8_t* __restrict__ idx, const float* __restrict__ gy, float* __restrict__ gx,
-                                   int B, int H, int W, int C4, int Ho, int Wo, const float* __restrict__ residual) {
+                                   int B, int H, int W, int C4, int Ho, int Wo, const float* __restrict__ residual,
+                                   const float* __restrict__ mask) {
   const long long total = (long long)B * H * W * C4;
   const uint32_t* idx4 = reinterpret_cast<const uint32_t*>(idx);
   const f32x4* g4 = reinterpret_cast<const f32x4*>(gy);
@@ -279,6 +280,11 @@ __global__ void maxpool_bwd_kernel(const uint8_t* __restrict__ idx, const float*
         for (int e = 0; e < 4; ++e)
           if (((w4 >> (8 * e)) & 0xFFu) == me) acc[e] += g[e];
       }
+    }
+    if (mask) {                         // the pooled tensor is a ReLU output: hand its producer the gradient already masked
+      const f32x4 m = reinterpret_cast<const f32x4*>(mask)[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = m[e] > 0.f ? acc[e] : 0.f;
     }
     o4[i] = acc;
   }
@@ -836,13 +842,13 @@ extern "C" int nbm_colsum(const float* g, int64_t M, int N, int ld, float* out, 
   return nbm_launch_status();
 }
 extern "C" int nbm_maxpool3x3s2_bwd(const uint8_t* idx, const float* gy, float* gx, int B, int H, int W, int C, int Ho,
-                                    int Wo, const float* residual, void* stream) {
+                                    int Wo, const float* residual, const float* mask, void* stream) {
   if (!idx || !gy || !gx || B <= 0 || C <= 0 || (C & 3)) return NBM_EINVAL;
-  if (residual && !nbm_aligned16(residual)) return NBM_EALIGN;
+  if ((residual && !nbm_aligned16(residual)) || (mask && !nbm_aligned16(mask))) return NBM_EALIGN;
   if ((H + 2 - 3) / 2 + 1 != Ho || (W + 2 - 3) / 2 + 1 != Wo) return NBM_EINVAL;
   if (!nbm_aligned16(gy) || !nbm_aligned16(gx) || (((uintptr_t)idx) & 3u)) return NBM_EALIGN;
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((long long)B * H * W * (C / 4))), dim3(TPB), 0, ST, idx, gy, gx, B, H,
-                     W, C / 4, Ho, Wo, residual);
+                     W, C / 4, Ho, Wo, residual, mask);
   return nbm_launch_status();
 }
 extern "C" int nbm_upsample_bilinear_bwd(const float* gy, int B, int Hi, int Wi, int C, float* gsrc, int Ho, int Wo,

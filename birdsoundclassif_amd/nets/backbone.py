@@ -108,7 +108,7 @@ class _ResNetBody(nn.Module):
         else:
             x = Fn.conv(x, self.conv1.weight, scale=s, shift=b, kh=7, kw=7, stride=2, pad=3, act=ops.ACT_RELU)
         taps = [x]
-        x = Fn.MaxPool.apply(x)
+        x = Fn.MaxPool.apply(x, True)              # the stem output is a ReLU output
         for li in range(1, 5):
             for blk in getattr(self, f'layer{li}'):
                 x = blk(x)

@@ -739,11 +739,13 @@ def colsum(g2d, n=None):
     return out
 
 
-def maxpool3x3s2_bwd(idx, gy, H, W, residual=None):
-    """`residual` [B,H,W,C]: added to the result (the gradient another consumer of the pooled tensor has produced)."""
+def maxpool3x3s2_bwd(idx, gy, H, W, residual=None, mask=None):
+    """`residual` [B,H,W,C]: added to the result (the gradient another consumer of the pooled tensor has produced); `mask`
+    [B,H,W,C]: result *= (mask > 0) after that addition."""
     B, Ho, Wo, C_ = gy.shape
     gx = torch.empty((B, H, W, C_), device=gy.device, dtype=torch.float32)
-    check(lib().nbm_maxpool3x3s2_bwd(_ptr(idx), _ptr(_chk(gy)), _ptr(gx), B, H, W, C_, Ho, Wo, _ptr(residual), _stream()),
+    check(lib().nbm_maxpool3x3s2_bwd(_ptr(idx), _ptr(_chk(gy)), _ptr(gx), B, H, W, C_, Ho, Wo, _ptr(residual),
+                                     _ptr(_chk(mask, name='mask')) if mask is not None else None, _stream()),
           'nbm_maxpool3x3s2_bwd')
     return gx
 

@@ -396,7 +396,10 @@ int nbm_weighted_sum_bwd(const float* x0, const float* x1, const float* x2, cons
 /* out[n] = sum_m g[m][n] (bias gradients) */
 int nbm_colsum(const float* g, int64_t M, int N, int ld, float* out, void* stream);
 int nbm_maxpool3x3s2_bwd(const uint8_t* idx, const float* gy, float* gx, int B, int H, int W, int C, int Ho, int Wo,
-                         const float* residual /* [B][H][W][C], optional: added to gx (another consumer's gradient) */, void* stream);
+                         const float* residual /* [B][H][W][C], optional: added to gx (another consumer's gradient) */,
+                         const float* mask /* [B][H][W][C], optional: gx *= (mask > 0), after the addition -- the pooled tensor is a
+                                              ReLU output (backbone.py:131) and its producer need not mask the gradient again */,
+                         void* stream);
 /* out = gy * (y > 0 ? 1 : slope) -- nn.LeakyReLU backward (Transformer_RCNN embeddings / DETR-style feed-forward) */
 int nbm_leaky_relu_bwd(const float* gy, const float* y, float* out, float slope, int64_t n, void* stream);
 /* nn.LayerNorm backward over rows of E <= 1024 floats; gw, gb (E floats each) must be zeroed, they are added to */

@@ -547,3 +547,56 @@ def test_weighted_sum_fusion_backward():
         for a, b in zip(xd, xs):
             close(a.grad, b.grad, 2e-6, 'weighted sum dx')
         close(wd.grad, w.grad, 2e-5, 'weighted sum dw')
+
+
+@pytest.mark.parametrize('third_consumer', [False, True])
+def test_premasked_gradient_handover(third_consumer, monkeypatch):
+    """A ReLU output with two consumers (stem output: max pooling + finest FPN lateral; layer tap: next stage's first block + lateral):
+    the consumer that forms the complete gradient (its own share + the stashed one) masks it by (y > 0) in its own kernel, and the
+    producer skips its masking pass -- unless autograd touched the gradient in between (a third consumer), in which case the producer
+    masks as before.  Either way the gradients equal torch autograd's."""
+    B, H, W, C0, P = 2, 18, 22, 64, 32
+    x0 = rnd('pmx', B, C0, H, W).requires_grad_(True)
+    w0 = rnd('pmw0', C0, C0, 1, 1, scale=(2.0 / C0) ** 0.5).requires_grad_(True)
+    wl0 = rnd('pmwl0', 96, C0, 1, 1, scale=(1.0 / C0) ** 0.5).requires_grad_(True)
+    wl1 = rnd('pmwl1', 96, C0, 1, 1, scale=(1.0 / C0) ** 0.5).requires_grad_(True)
+    ws = dict(w1=rnd('pmb1', P, C0, 1, 1, scale=(2.0 / C0) ** 0.5), w2=rnd('pmb2', P, P, 3, 3, scale=(2.0 / (9 * P)) ** 0.5),
+              w3=rnd('pmb3', 4 * P, P, 1, 1, scale=(2.0 / P) ** 0.5), wd=rnd('pmbd', 4 * P, C0, 1, 1, scale=(2.0 / C0) ** 0.5))
+    for v in ws.values():
+        v.requires_grad_(True)
+    # torch reference
+    y = F.relu(F.conv2d(x0, w0))                                  # "stem": ReLU output, read by the pooling and a lateral
+    lat0 = F.conv2d(y, wl0)
+    p = F.max_pool2d(y, 3, 2, 1)                                  # p is not a ReLU output of a block here, but >= 0 all the same
+    lat1 = F.conv2d(p, wl1)
+    o = F.relu(F.conv2d(p, ws['w1']))
+    o = F.relu(F.conv2d(o, ws['w2'], stride=2, padding=1))
+    h = F.relu(F.conv2d(o, ws['w3']) + F.conv2d(p, ws['wd'], stride=2))
+    extra = (y * 0.5).sum() + (p * 0.25).sum() if third_consumer else 0.0
+    g0, g1, gh = rnd('pmg0', *lat0.shape), rnd('pmg1', *lat1.shape), rnd('pmgh', *h.shape)
+    ((lat0 * g0).sum() + (lat1 * g1).sum() + (h * gh).sum() + extra).backward()
+    # device
+    calls = []
+    real = ops.relu_bwd
+    monkeypatch.setattr(ops, 'relu_bwd', lambda gy, yy: (calls.append(tuple(gy.shape)), real(gy, yy))[1])
+    Fn.stash_reset()
+    dv = {k: v.detach().cuda().requires_grad_(True) for k, v in dict(ws, w0=w0, wl0=wl0, wl1=wl1).items()}
+    xd = nhwc(x0).requires_grad_(True)
+    one = torch.ones(4 * P, device='cuda'); zero = torch.zeros(4 * P, device='cuda')
+    yd = Fn.conv(xd, dv['w0'], act=ops.ACT_RELU)
+    pd = Fn.MaxPool.apply(yd, True)                               # registers itself as the consumer that picks the stash up
+    hd = Fn.Bottleneck.apply(pd, dv['w1'], dv['w2'], dv['w3'], dv['wd'], one[:P], zero[:P], one[:P], zero[:P], one, zero, one, zero,
+                             2, False, True)
+    l0 = Fn.conv(yd, dv['wl0'])                                   # created last -> their backward nodes run first and stash
+    l1 = Fn.conv(pd, dv['wl1'])
+    extra_d = (yd * 0.5).sum() + (pd * 0.25).sum() if third_consumer else 0.0
+    ((l0 * nhwc(g0)).sum() + (l1 * nhwc(g1)).sum() + (hd * nhwc(gh)).sum() + extra_d).backward()
+    Fn.stash_check_empty()
+    close(nchw(xd.grad), x0.grad, 3e-5, 'premask dx')
+    for k, ref in dict(ws, w0=w0, wl0=wl0, wl1=wl1).items():
+        close(dv[k].grad, ref.grad, 5e-5, f'premask d{k}')
+    stem_masks = [c for c in calls if c == tuple(yd.shape)]
+    if third_consumer:
+        assert len(stem_masks) == 1, calls                        # autograd summed a third share in: masked by the producer
+    else:
+        assert not stem_masks, calls                              # complete and masked inside maxpool_bwd: no extra pass
