@@ -472,6 +472,43 @@ __global__ __launch_bounds__(256) void rcnn_post_kernel(const float* __restrict_
   if (tid == 0) n_det[b] = s_cnt;
 }
 
+
+// Proposal targets, the arithmetic half (layers.py:320-330 -> nets_utils.py:103-126): IoU with the inclusive-pixel (+1) convention
+// of every proposal and every ground-truth box of an image against the image's ground-truth boxes, best overlap and FIRST best
+// box per row.  One thread per row; the fp32 operations and their order are those of the reference's torch-CPU expressions (this
+// file is compiled without contraction, the division is correctly rounded), so the thresholds the host applies afterwards
+// resolve exactly as they do there.
+__global__ void proposal_iou_kernel(const float* __restrict__ rois, const float* __restrict__ gt, const int* __restrict__ n_gt,
+                                    int B, int R, int G, float* __restrict__ mx, int* __restrict__ asg) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (j >= R + G) return;
+  const float* a = j < R ? rois + ((size_t)b * R + j) * 4 : gt + ((size_t)b * G + (j - R)) * 4;
+  const float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+  const float area_a = (a2 - a0 + 1.f) * (a3 - a1 + 1.f);
+  const int ng = n_gt[b];
+  float best = 0.f;
+  int arg = 0;
+  for (int g = 0; g < G; ++g) {
+    float ov = -1.f;                                     // padded column: can never win
+    if (g < ng) {
+      const float* q = gt + ((size_t)b * G + g) * 4;
+      const float g0 = q[0], g1 = q[1], g2 = q[2], g3 = q[3];
+      float xi = fminf(a2, g2) - fmaxf(a0, g0) + 1.f;
+      xi = fmaxf(xi, 0.f);
+      float yi = fminf(a3, g3) - fmaxf(a1, g1) + 1.f;
+      yi = fmaxf(yi, 0.f);
+      const float inter = xi * yi;
+      const float area_g = (g2 - g0 + 1.f) * (g3 - g1 + 1.f);
+      const float den = (area_a + area_g) - inter;
+      ov = __fdiv_rn(inter, den);
+    }
+    // numpy max / argmax: a NaN wins and stays, otherwise the first strictly greater value
+    if (g == 0 || (!(best != best) && (ov > best || ov != ov))) { best = ov; arg = g; }
+  }
+  mx[(size_t)b * (R + G) + j] = best;
+  asg[(size_t)b * (R + G) + j] = arg;
+}
+
 }  // namespace
 
 extern "C" int nbm_rpn_decode(const float* cls, const float* reg, const float* anchors, int B, int KA,
@@ -567,5 +604,14 @@ extern "C" int nbm_rcnn_post(const float* rois, const int* n_roi, int B, int roi
     return NBM_EINVAL;
   hipLaunchKernelGGL(rcnn_post_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, rois, n_roi, roi_cap, bbox_reg,
                      bbox_cls, n_cls1, img_w, img_h, nms_thresh, min_score, proposal_number, det, n_det, per_image ? 1 : 0);
+  return nbm_launch_status();
+}
+
+// IoU / best ground-truth box of the proposal target layer -- see nbm_hip.h.
+extern "C" int nbm_proposal_iou(const float* rois, const float* gt, const int* n_gt, int B, int R, int G, float* mx, int* asg,
+                                void* stream) {
+  if (!rois || !gt || !n_gt || !mx || !asg || B <= 0 || R < 0 || G <= 0 || B > 65535) return NBM_EINVAL;
+  hipLaunchKernelGGL(proposal_iou_kernel, dim3((R + G + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, rois, gt, n_gt, B, R, G,
+                     mx, asg);
   return nbm_launch_status();
 }

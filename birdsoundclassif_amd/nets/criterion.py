@@ -94,8 +94,41 @@ class SetCriterion(nn.Module):
         return {'first_class_loss': class_loss, 'first_regression_loss': regression_loss}
 
     @torch.no_grad()
-    def generate_all_rois(self, *args, **kwargs):
-        rois, bbox_targets, labels = self.proposal_target_layer(*args, **kwargs)
+    def precompute_proposal_iou(self, rois, gt_bbox, lengths):
+        """Positive step, queued behind the proposal layer before the host waits for the RoI count: the arithmetic half of the
+        ProposalTargetLayer (IoU of every proposal / ground-truth box with the image's boxes, best box per row: nbm_proposal_iou)
+        on the device, and RoIs + results on their way to pinned host memory -- the host then only thresholds and draws
+        (`generate_all_rois(..., use_precomputed=True)`, called by the step that queued this for the first rows of these very
+        RoIs).  rois: [B,cap,4] device tensor of the proposal layer (rows beyond the RoI count are never looked at)."""
+        from .. import ops
+        self._pre_iou = None
+        if rois.device.type != 'cuda' or rois.dim() != 3 or not len(lengths):
+            return
+        gt_c = np.ascontiguousarray(gt_bbox.detach().float().cpu().numpy(), dtype=np.float32)      # labels live on the host
+        gt_pad, batched = self.proposal_target_layer.pad_gt(gt_c, lengths)
+        if not batched:
+            return
+        dev = rois.device
+        mx, asg = ops.proposal_iou(rois, self._upload('gt_pad', gt_pad, dev), self._upload('n_gt', np.asarray(lengths, dtype=np.int32), dev))
+        host = []
+        for name, t in (('rois', rois), ('mx', mx), ('asg', asg)):
+            buf = self._pinned.get('d2h_' + name)
+            if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+                buf = self._pinned['d2h_' + name] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+            buf.copy_(t, non_blocking=True)
+            host.append(buf)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pre_iou = (rois.shape[0], rois.shape[1], host, ev)
+
+    @torch.no_grad()
+    def generate_all_rois(self, rois, *args, use_precomputed=False, **kwargs):
+        """`use_precomputed`: `rois` are the first rows of the RoIs `precompute_proposal_iou` was called with in this step."""
+        pre, self._pre_iou = getattr(self, '_pre_iou', None), None
+        if use_precomputed and pre is not None and rois.dim() == 3 and rois.shape[0] == pre[0] and rois.shape[1] <= pre[1]:
+            pre[3].synchronize()                 # long done: the host has read the RoI count, queued behind these copies
+            kwargs['pre'] = (pre[2][0].numpy(), pre[2][1].numpy(), pre[2][2].numpy(), pre[1])
+        rois, bbox_targets, labels = self.proposal_target_layer(rois, *args, **kwargs)
         # the labels were built on the host: keep that copy for second_stage_loss (a .cpu() there is a device sync)
         self._labels_host = (labels, self.proposal_target_layer.last_labels_host) if labels is not None else None
         return {'rois': rois, 'bbox_targets': bbox_targets, 'labels': labels}

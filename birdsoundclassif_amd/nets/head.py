@@ -34,7 +34,10 @@ class Faster_RCNN(nn.Module):
         fm = [f.permute(0, 2, 3, 1).contiguous() for f in fpn_pyramid_out]
         rois, _, n_roi, cls, reg, _ = self.forward_first_stage_device(fm)
         if host_work is not None:           # everything of the first stage is queued; the host is still ahead of the GPU here
-            host_work(cls.permute(0, 3, 1, 2), reg.permute(0, 3, 1, 2))
+            if getattr(host_work, 'wants_rois', False):          # device-side work on the proposals, queued before the sync below
+                host_work(cls.permute(0, 3, 1, 2), reg.permute(0, 3, 1, 2), rois=rois)
+            else:
+                host_work(cls.permute(0, 3, 1, 2), reg.permute(0, 3, 1, 2))
         n = int(n_roi.item())
         if n == 0:
             print('Not enough possible RoIs, RPN failed')

@@ -40,6 +40,14 @@ def box_encode(anchors, bbox):
     return np.stack([(x - xa) / wa, (y - ya) / ha, tw, th], axis=1).astype(_F)
 
 
+def _draw(pop, k):
+    """`np.random.choice(pop, k, replace=False)` without its argument checks (4 us of 12 per call, 3 calls per image): the legacy
+    RandomState draws `permutation(len(pop))[:k]` for it, so values and stream position are the same (checked in
+    tests/test_targets_host.py)."""
+    assert k <= len(pop)
+    return pop[np.random.permutation(len(pop))[:k]]
+
+
 def _f32(t):
     return np.ascontiguousarray(t.detach().float().cpu().numpy(), dtype=_F)
 
@@ -107,36 +115,51 @@ class ProposalTargetLayer(nn.Module):
         super().__init__()
         self.config = config
 
-    def forward(self, rois, gt_bbox, bird_ids, lengths):
+    @staticmethod
+    def pad_gt(gt_c, lengths):
+        """-> (gt_pad [B,gmax,4] (-1 where there is no box), batched: every image has a real box -- the only case the batched IoU
+        (host or device) reproduces; the reference's per-image special case `gt.max() > -1` takes the loop below otherwise)."""
+        B, gmax = len(lengths), max(lengths)
+        idx = np.cumsum([0] + list(lengths))
+        gt_pad = np.full((B, gmax, 4), -1, dtype=_F)
+        for b, (i0, i1) in enumerate(zip(idx[:-1], idx[1:])):
+            gt_pad[b, :i1 - i0] = gt_c[i0:i1]
+        batched = all(gt_c[i0:i1].max() > -1 for i0, i1 in zip(idx[:-1], idx[1:]))
+        return gt_pad, batched
+
+    def forward(self, rois, gt_bbox, bird_ids, lengths, pre=None):
         """rois [B,R,4] -> (rois [B,16,4], bbox_targets [B,16,4(1+nc)], labels [B,16] float) on rois.device, or
-        (None, None, None) when the batch cannot be filled (reference layers.py:359-364)."""
+        (None, None, None) when the batch cannot be filled (reference layers.py:359-364).
+        `pre` (optional, from `SetCriterion.precompute_proposal_iou`): (rois_host [B,>=R,4], mx [B,cap+gmax], asg [B,cap+gmax], cap)
+        -- the IoU / best-box arithmetic already done on the device (nbm_proposal_iou) and copied to the host with the RoIs."""
         cfg = self.config
         device = rois.device
-        rois_c, gt_c, ids_c = _f32(rois), _f32(gt_bbox), _f32(bird_ids)
+        gt_c, ids_c = _f32(gt_bbox), _f32(bird_ids)
         nc, nb = cfg.num_classes, cfg.rcnn_batch_size
         assert cfg.bg_threshold_hi <= cfg.fg_threshold
         fg_t, lo_t, hi_t = _F(cfg.fg_threshold), _F(cfg.bg_threshold_lo), _F(cfg.bg_threshold_hi)
         B = len(lengths)
-        out_r = np.zeros((B, nb, 4), dtype=_F)
-        out_t = np.zeros((B, nb, 4 * (1 + nc)), dtype=_F)
-        out_l = np.zeros((B, nb), dtype=_F)
-        gt_keep = np.zeros((B, nb, 4), dtype=_F)
+        R, gmax = rois.shape[1], max(lengths)
         idx = np.cumsum([0] + list(lengths))
-        # IoU / best-GT assignment for the whole batch in one shot (GT padded to the largest count; padded columns can
-        # never win the max), then the per-image sampling with the reference's RNG call order
-        R, gmax = rois_c.shape[1], max(lengths)
-        gt_pad = np.full((B, gmax, 4), -1, dtype=_F)
-        valid = np.zeros((B, gmax), dtype=bool)
-        for b, (i0, i1) in enumerate(zip(idx[:-1], idx[1:])):
-            gt_pad[b, :i1 - i0] = gt_c[i0:i1]
-            valid[b, :i1 - i0] = True
-        batched = all(gt_c[i0:i1].max() > -1 for i0, i1 in zip(idx[:-1], idx[1:]))
-        if batched:
+        gt_pad, batched = self.pad_gt(gt_c, lengths)
+        if pre is not None and batched:
+            rois_h, mx_h, asg_h, cap = pre
+            rois_c = rois_h[:, :R]
+            mx_all = np.concatenate([mx_h[:, :R], mx_h[:, cap:cap + gmax]], axis=1)
+            asg_all = np.concatenate([asg_h[:, :R], asg_h[:, cap:cap + gmax]], axis=1).astype(np.int64)
+            all_pad = np.concatenate([rois_c, gt_pad], axis=1)
+        else:
+            rois_c = _f32(rois)
+        out_t = np.zeros((B, nb, 4 * (1 + nc)), dtype=_F)
+        if batched and pre is None:
+            # IoU / best-GT assignment for the whole batch in one shot (GT padded to the largest count; padded columns can
+            # never win the max), then the per-image sampling with the reference's RNG call order
+            valid = np.arange(gmax)[None, :] < np.asarray(lengths)[:, None]
             all_pad = np.concatenate([rois_c, gt_pad], axis=1)                       # [B, R + gmax, 4]
             # [B, gmax, R + gmax] with the long axis innermost: the same fp32 operations per element as the reference's IoU
-            # (nets_utils.py:103-126), 3x faster in NumPy than the [.., R + gmax, gmax] broadcast (inner loops of length gmax);
-            # the GPU idles while this runs.  (torch's CPU kernels were tried: bit-identical too, but waking 32 threads for
-            # 1 M-element tensors made it 43 ms on the GPU box.)
+            # (nets_utils.py:103-126), 3x faster in NumPy than the [.., R + gmax, gmax] broadcast (inner loops of length gmax).
+            # (torch's CPU kernels were tried: bit-identical too, but waking 32 threads for 1 M-element tensors made it 43 ms on
+            # the GPU box.)  The training step does this on the device instead (`pre`).
             a0, a1, a2, a3 = (np.ascontiguousarray(all_pad[:, None, :, k]) for k in range(4))
             g0, g1, g2, g3 = (np.ascontiguousarray(gt_pad[:, :, None, k]) for k in range(4))
             xi = np.minimum(a2, g2)
@@ -157,21 +180,35 @@ class ProposalTargetLayer(nn.Module):
                 ov_all = inter / den
             ov_all[~np.broadcast_to(valid[:, :, None], ov_all.shape)] = -1
             mx_all, asg_all = ov_all.max(axis=1), ov_all.argmax(axis=1)
+        if batched:
+            # thresholds for the whole batch; the GT columns an image does not have are neither foreground nor background (NaN)
+            n_all = R + np.asarray(lengths)
+            mx_m = mx_all.copy()
+            mx_m[np.arange(R + gmax)[None, :] >= n_all[:, None]] = np.nan
+            with np.errstate(invalid='ignore'):
+                fg_mask = mx_m > fg_t
+                bg_mask = (hi_t > mx_m) & (mx_m >= lo_t)
+            keep_all = np.zeros((B, nb), dtype=np.int64)
+        else:
+            out_r = np.zeros((B, nb, 4), dtype=_F)
+            out_l = np.zeros((B, nb), dtype=_F)
+            gt_keep = np.zeros((B, nb, 4), dtype=_F)
         for b, (i0, i1) in enumerate(zip(idx[:-1], idx[1:])):
-            gt = gt_c[i0:i1]
             if batched:
-                n_all = R + (i1 - i0)
-                allr, mx, asg = all_pad[b, :n_all], mx_all[b, :n_all], asg_all[b, :n_all]
+                n_rows = int(n_all[b])
+                fg, bg = np.flatnonzero(fg_mask[b]), np.flatnonzero(bg_mask[b])
             else:
+                gt = gt_c[i0:i1]
                 allr = np.concatenate([rois_c[b], gt], axis=0) if gt.max() > -1 else rois_c[b]
                 ov = box_iou_incl(allr, gt)
                 mx, asg = ov.max(axis=-1), ov.argmax(axis=-1)
-            lab = ids_c[i0:i1][asg].copy()
-            lab[mx < fg_t] = 0
-            gta = gt[asg]
-            fg = np.nonzero(mx > fg_t)[0]
-            bg = np.nonzero((hi_t > mx) & (mx >= lo_t))[0]
-            n_other = len(mx) - len(bg) - len(fg)          # fg and bg are disjoint; the set itself is built only if drawn from
+                n_rows = len(mx)
+                lab = ids_c[i0:i1][asg].copy()
+                lab[mx < fg_t] = 0
+                gta = gt[asg]
+                fg = np.nonzero(mx > fg_t)[0]
+                bg = np.nonzero((hi_t > mx) & (mx >= lo_t))[0]
+            n_other = n_rows - len(bg) - len(fg)           # fg and bg are disjoint; the set itself is built only if drawn from
             nfg = min(len(fg), int(cfg.rcnn_fg_prop * nb))
             if len(bg) + n_other < nb - nfg:
                 print(f'~~~~ NOT ENOUGH BG: {len(bg)} / IGNORED ROIS: {n_other}, FILLING WITH POSITIVES: {len(fg)} ~~~~')
@@ -180,15 +217,27 @@ class ProposalTargetLayer(nn.Module):
                     return None, None, None
                 nfg = max(nfg, nb - (len(bg) + n_other))
             nbg = min(len(bg), nb - nfg)
-            fgi = np.random.choice(fg, nfg, replace=False)
-            bgi = np.random.choice(bg, nbg, replace=False)
+            fgi = _draw(fg, nfg)
+            bgi = _draw(bg, nbg)
             if len(fgi) + len(bgi) < nb:
-                other = list(set(range(len(mx))) - set(bg) - set(fg))          # reference order: Python set iteration
-                bgi = np.hstack([bgi, np.random.choice(other, nb - len(fgi) - len(bgi), replace=False)])
-            keep = np.hstack((fgi, bgi)).astype(np.int64)
-            bl, br = lab[keep], allr[keep]
-            out_r[b], out_l[b] = br, bl
-            gt_keep[b] = gta[keep]
+                other = np.asarray(list(set(range(n_rows)) - set(bg) - set(fg)))   # reference order: Python set iteration
+                bgi = np.hstack([bgi, _draw(other, nb - len(fgi) - len(bgi))])
+            if batched:
+                keep_all[b, :len(fgi)] = fgi
+                keep_all[b, len(fgi):] = bgi
+            else:
+                keep = np.hstack((fgi, bgi)).astype(np.int64)
+                out_r[b], out_l[b] = allr[keep], lab[keep]
+                gt_keep[b] = gta[keep]
+        if batched:            # labels / boxes / assigned GT of the kept rows, gathered for the whole batch at once
+            ids_pad = np.zeros((B, gmax), dtype=_F)
+            ids_pad[np.arange(gmax)[None, :] < np.asarray(lengths)[:, None]] = ids_c
+            bi = np.arange(B)[:, None]
+            asg_k, mx_k = asg_all[bi, keep_all], mx_all[bi, keep_all]
+            out_l = ids_pad[bi, asg_k]
+            out_l[mx_k < fg_t] = 0
+            out_r = np.ascontiguousarray(all_pad[bi, keep_all])
+            gt_keep = gt_pad[bi, asg_k]
         # one encode for the whole batch (a torch.log call per image costs more in dispatch than in work)
         t4 = box_encode(out_r.reshape(-1, 4), gt_keep.reshape(-1, 4)).reshape(B, nb, 4)
         li = out_l.astype(np.int64)

@@ -510,6 +510,20 @@ def rpn_decode(cls, reg, anchors, n_anchor, img_w, img_h, min_size):
     return boxes, keys, cnt
 
 
+def proposal_iou(rois, gt, n_gt):
+    """rois [B,R,4], gt [B,G,4] (padded), n_gt int32 [B] -> (mx [B,R+G] best IoU of every proposal / ground-truth box with the
+    image's ground-truth boxes, asg int32 [B,R+G] index of the first best box): reference layers.py:320-330."""
+    _chk(rois, name='rois'), _chk(gt, name='gt')
+    B, R, _ = rois.shape
+    G = gt.shape[1]
+    if n_gt.dtype != torch.int32 or n_gt.numel() != B or gt.shape[0] != B:
+        raise ValueError('proposal_iou: n_gt must be int32 [B], gt [B,G,4]')
+    mx = torch.empty((B, R + G), device=rois.device, dtype=torch.float32)
+    asg = torch.empty((B, R + G), device=rois.device, dtype=torch.int32)
+    check(lib().nbm_proposal_iou(_ptr(rois), _ptr(gt), _ptr(n_gt), B, R, G, _ptr(mx), _ptr(asg), _stream()), 'nbm_proposal_iou')
+    return mx, asg
+
+
 def per_image_counts(n, B):
     """Count tensors are int32 [1] (one count for the whole batch: the reference's batch-coupled semantics) or int32 [B] (every
     image a batch of its own, `independent` detection) -> the `per_image` flag of the C ABI."""

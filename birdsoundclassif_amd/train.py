@@ -236,7 +236,11 @@ def step(model, criterion, batch, device, negative_sample):
     if not negative_sample and hasattr(criterion, 'precompute_first_stage_loss'):
         # AnchorTargetLayer (host, NumPy RNG) runs while the GPU executes the first-stage forward queued before it, and the
         # first-stage loss kernels are queued behind that forward pass before the host waits for the RoI count
-        host_work = lambda cls, reg: criterion.precompute_first_stage_loss(cls, reg, bb_coord, lengths)
+        def host_work(cls, reg, rois=None):
+            if rois is not None and hasattr(criterion, 'precompute_proposal_iou'):
+                criterion.precompute_proposal_iou(rois, bb_coord, lengths)      # device IoU + D2H, queued right behind the proposals
+            criterion.precompute_first_stage_loss(cls, reg, bb_coord, lengths)
+        host_work.wants_rois = True
     # lazy=True: the finest FPN map is computed where it is read; it goes straight into forward_second_stage below
     out_first_stage = model.forward_first_stage(inpt, host_work, lazy=True)
     loss.update(criterion.first_stage_loss(out_first_stage['rpn_cls_scores'], out_first_stage['rpn_bbox_reg'],
@@ -244,7 +248,8 @@ def step(model, criterion, batch, device, negative_sample):
     if len(out_first_stage['rois']) == 0:            # "RPN failed": first-stage loss only
         return loss
     if not negative_sample:
-        proposal_tgt_out = criterion.generate_all_rois(out_first_stage['rois'], bb_coord, bird_ids, lengths)
+        proposal_tgt_out = criterion.generate_all_rois(out_first_stage['rois'], bb_coord, bird_ids, lengths,
+                                                       **({'use_precomputed': True} if host_work is not None else {}))
         if proposal_tgt_out['rois'] is None:
             return loss
     else:

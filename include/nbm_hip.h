@@ -349,6 +349,13 @@ int nbm_rcnn_post(const float* rois, const int* n_roi, int B, int roi_cap, const
                   float nms_thresh, float min_score, int proposal_number, float* det, int* n_det,
                   int per_image /* n_roi[b] */, void* stream);
 
+/* Training, ProposalTargetLayer (layers.py:320-330, nets_utils.py:103-126): rows j < R = proposals rois[b][j], rows R + i = the
+ * image's own ground-truth boxes gt[b][i] (the reference appends them to the proposals); for every row the IoU (inclusive-pixel
+ * convention, the reference's fp32 operations in its order) with the n_gt[b] <= G boxes of gt[b]: mx[b][j] = best overlap,
+ * asg[b][j] = index of the FIRST best box.  The thresholds and the NumPy RNG draws stay on the host (layers.py:332-376). */
+int nbm_proposal_iou(const float* rois /*[B][R][4]*/, const float* gt /*[B][G][4]*/, const int* n_gt /*[B]*/, int B, int R, int G,
+                     float* mx /*[B][R+G]*/, int* asg /*[B][R+G]*/, void* stream);
+
 /* ================================================================================================
  * Training path: backward implicit GEMMs, point-wise gradients, train-mode BatchNorm, optimiser.
  * Replaces what torch.autograd derives for the reference's train step (train.py:205-217):

@@ -345,3 +345,41 @@ def test_winograd_weight_transform_kernels():
         dw = ops.wino_weight_grad(dU.cuda(), m, row_scale=sc.cuda()).cpu()
         refw = torch.einsum('ia,ijnc,jb->ncab', G[m], dU.double().view(a, a, 96, 160), G[m]) * sc.double().view(-1, 1, 1, 1)
         assert (dw.double() - refw).abs().max() <= 2e-6 * refw.abs().max()
+
+
+def test_proposal_iou_bit_exact_and_criterion_handover():
+    """nbm_proposal_iou == the reference-order NumPy IoU (nets_utils.py:103-126) bit for bit -- overlaps, exact ties (first best
+    box), disjoint boxes, boxes equal to a ground-truth box -- and the training step's hand-over (device IoU + pinned copies ->
+    host thresholds and draws) returns what the all-host ProposalTargetLayer returns, from the same RNG position."""
+    from birdsoundclassif_amd.nets import targets
+    from birdsoundclassif_amd.nets.criterion import SetCriterion
+    from birdsoundclassif_amd.train import default_args
+    from test_targets_host import _batch, _pre_from_numpy
+    args = default_args(device='cuda')
+    layer = targets.ProposalTargetLayer(args)
+    for seed, (B, R, cap) in enumerate([(16, 1000, 1024), (8, 40, 64), (5, 17, 32)]):
+        rois, gt, ids, lens = _batch(B, R, seed)
+        rois[0, 1] = rois[0, 0]                                   # duplicate proposal
+        rois[1, 2] = torch.tensor([5., 5., 4., 4.])               # degenerate (x2 < x1): area 0, the reference divides anyway
+        gt_pad, _ = layer.pad_gt(gt.numpy(), lens)
+        full = torch.full((B, cap, 4), 3.25)
+        full[:, :R] = rois
+        mx, asg = ops.proposal_iou(full.cuda(), torch.from_numpy(gt_pad).cuda(), torch.tensor(lens, dtype=torch.int32).cuda())
+        _, mx_ref, asg_ref, _ = _pre_from_numpy(layer, rois, gt, lens, cap)
+        rows = np.r_[0:R, cap:cap + gt_pad.shape[1]]
+        # rows of GT boxes an image does not have compare -1 boxes with real ones: never read by the host, skip them
+        for b in range(B):
+            r = np.r_[0:R, cap:cap + lens[b]]
+            assert np.array_equal(mx.cpu().numpy()[b, r].view(np.uint32), mx_ref[b, r].view(np.uint32)), (seed, b)
+            assert np.array_equal(asg.cpu().numpy()[b, r], asg_ref[b, r]), (seed, b)
+        # the criterion's flow, as train.step drives it
+        crit = SetCriterion(args, {})
+        dev_rois = full.cuda()
+        crit.precompute_proposal_iou(dev_rois, gt, lens)
+        np.random.seed(seed)
+        got, s_got = crit.generate_all_rois(dev_rois[:, :R].contiguous(), gt, ids, lens, use_precomputed=True), np.random.get_state()
+        np.random.seed(seed)
+        ref, s_ref = layer(rois, gt, ids, lens), np.random.get_state()
+        for k, a in zip(('rois', 'bbox_targets', 'labels'), ref):
+            assert torch.equal(got[k].cpu(), a), (seed, k)
+        assert np.array_equal(s_ref[1], s_got[1]) and s_ref[2] == s_got[2]
