@@ -96,6 +96,9 @@ SIGNATURES = {
     'nbm_leaky_relu_bwd': [_P, _P, _P, _F, _L, _P],
     'nbm_layernorm_bwd': [_P, _P, _P, _L, _I, _F, _P, _P, _P, _P],
     'nbm_mha_small_bwd': [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _L, _L, _P, _F, _P],
+    'nbm_zero_roi_windows': [_P, _I, _I, _I, _P, _P, _I, _I, _I, _P],
+    'nbm_zero_pattern': [_P, _I, _I, _I, _I, _I, _P],
+    'nbm_zero_tiles': [_P, _I, _I, _I, _I, _P, _I, _P, _P],
     'nbm_proposal_iou': [_P, _P, _P, _I, _I, _I, _P, _P, _P],
     'nbm_maxpool3x3s2_bwd': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     'nbm_upsample_bilinear_bwd': [_P, _I, _I, _I, _I, _P, _I, _I, _P],

@@ -741,6 +741,59 @@ __global__ void roi_pool_bwd_kernel(const RoiBwdParams p) {
   }
 }
 
+// ---- targeted re-zeroing of the persistent gradient maps of a demand-driven FPN level (nbm_hip.h: nbm_zero_*): the map is zero
+// everywhere except where these three writers left something, so restoring it costs their footprint, not a fill of the whole map.
+__global__ void zero_roi_windows_kernel(float* __restrict__ g, int H, int W, int C4, const float* __restrict__ rois,
+                                        const int* __restrict__ level, int n_roi, int lvl) {
+  const int slot = blockIdx.x;
+  if (level[slot] != lvl) return;
+  const int b = slot / n_roi;
+  const float* roi = rois + (long long)slot * 4;
+  const float stride = (float)(2 << lvl);
+  int x1 = (int)rintf(roi[0] / stride), y1 = (int)rintf(roi[1] / stride);           // the window of roi_pool_bwd_kernel
+  int x2 = (int)rintf(roi[2] / stride), y2 = (int)rintf(roi[3] / stride);
+  y2 = min(y2, H - 1);
+  while (y2 - y1 + 1 < 2) { y1 = max(0, y1 - 1); y2 = min(H - 1, y2 + 1); }
+  while (x2 - x1 + 1 < 2) { x1 = max(0, x1 - 1); x2 = min(W - 1, x2 + 1); }
+  const int h = y2 - y1 + 1, w = min(x2, W - 1) - x1 + 1;
+  f32x4* g4 = reinterpret_cast<f32x4*>(g);
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < h * w * C4; i += blockDim.x) {
+    const int c = i % C4, px = i / C4;
+    const int yy = px / w, xx = px - yy * w;
+    g4[(((long long)b * H + y1 + yy) * W + x1 + xx) * C4 + c] = z;
+  }
+}
+__global__ void zero_pattern_kernel(float* __restrict__ g, int H, int W, int C4, int stride, int OH, int OW) {
+  const int cell = blockIdx.x, b = blockIdx.y;
+  const int oy = cell / OW, ox = cell - oy * OW;
+  f32x4* g4 = reinterpret_cast<f32x4*>(g);
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  for (int i = threadIdx.x; i < 9 * C4; i += blockDim.x) {
+    const int c = i % C4, t = i / C4;
+    const int y = oy * stride - 1 + t / 3, x = ox * stride - 1 + t % 3;
+    if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) g4[(((long long)b * H + y) * W + x) * C4 + c] = z;
+  }
+}
+__global__ void zero_tiles_kernel(float* __restrict__ g, int H, int W, int C4, const int* __restrict__ tiles,
+                                  const int* __restrict__ n_blocks) {
+  if (n_blocks && (int)blockIdx.x >= *n_blocks) return;
+  const int TH = (H + 1) >> 1, TW = (W + 1) >> 1;
+  f32x4* g4 = reinterpret_cast<f32x4*>(g);
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  for (int e = 0; e < 128; ++e) {
+    const int t = tiles[blockIdx.x * 128 + e];
+    if (t < 0) continue;                       // block-uniform
+    const int b = t / (TH * TW), rem = t - b * (TH * TW);
+    const int ty = rem / TW, tx = rem - ty * TW;
+    for (int i = threadIdx.x; i < 4 * C4; i += blockDim.x) {
+      const int c = i % C4, px = i / C4;
+      const int y = 2 * ty + (px >> 1), x = 2 * tx + (px & 1);
+      if (y < H && x < W) g4[(((long long)b * H + y) * W + x) * C4 + c] = z;
+    }
+  }
+}
+
 // ---- optimiser: squared gradient norm, then clip + AdamW (torch.optim.AdamW semantics, decoupled decay)
 __global__ void sqnorm_kernel(const float* __restrict__ g, long long n, double* __restrict__ out) {
   double acc = 0.0;
@@ -962,6 +1015,27 @@ extern "C" int nbm_roi_pool_bwd(float* const* gfmap, const int* fh, const int* f
   for (int i = 0; i < 5; ++i) { p.gfmap[i] = i < n_levels ? gfmap[i] : nullptr; p.fh[i] = i < n_levels ? fh[i] : 0; p.fw[i] = i < n_levels ? fw[i] : 0; }
   p.C = C; p.rois = rois; p.level = level; p.B = B; p.n_roi = n_roi; p.gpool = gpool;
   hipLaunchKernelGGL(roi_pool_bwd_kernel, dim3(B * n_roi), dim3(256), 0, ST, p);
+  return nbm_launch_status();
+}
+extern "C" int nbm_zero_roi_windows(float* g, int H, int W, int C, const float* rois, const int* level, int B, int n_roi, int lvl,
+                                    void* stream) {
+  if (!g || !rois || !level || B <= 0 || n_roi <= 0 || H < 2 || W < 2 || C <= 0 || (C & 3) || lvl < 0 || lvl > 4) return NBM_EINVAL;
+  if (!nbm_aligned16(g)) return NBM_EALIGN;
+  hipLaunchKernelGGL(zero_roi_windows_kernel, dim3(B * n_roi), dim3(256), 0, ST, g, H, W, C / 4, rois, level, n_roi, lvl);
+  return nbm_launch_status();
+}
+extern "C" int nbm_zero_pattern(float* g, int B, int H, int W, int C, int stride, void* stream) {
+  if (!g || B <= 0 || B > 65535 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || stride < 1) return NBM_EINVAL;
+  if (!nbm_aligned16(g)) return NBM_EALIGN;
+  const int OH = (H + 2 - 3) / stride + 1, OW = (W + 2 - 3) / stride + 1;
+  hipLaunchKernelGGL(zero_pattern_kernel, dim3(OH * OW, B), dim3(256), 0, ST, g, H, W, C / 4, stride, OH, OW);
+  return nbm_launch_status();
+}
+extern "C" int nbm_zero_tiles(float* g, int B, int H, int W, int C, const int* tiles, int n_entries, const int* n_blocks,
+                              void* stream) {
+  if (!g || !tiles || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || n_entries <= 0 || (n_entries & 127)) return NBM_EINVAL;
+  if (!nbm_aligned16(g)) return NBM_EALIGN;
+  hipLaunchKernelGGL(zero_tiles_kernel, dim3(n_entries / 128), dim3(256), 0, ST, g, H, W, C / 4, tiles, n_blocks);
   return nbm_launch_status();
 }
 extern "C" int nbm_sqnorm_accum(const float* g, int64_t n, double* out, void* stream) {

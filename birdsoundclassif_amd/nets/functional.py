@@ -74,6 +74,7 @@ def stash_reset():
     _STASH.clear()
     _STASH_OK.clear()
     _PREMASKED.clear()
+    ondemand.zero_pool_new_pass()
 
 
 def stash_accept(t, needs_grad):
@@ -220,6 +221,8 @@ class Conv(Function):
             if ctx.stash_up:                          # the coarse map's output convolution adds it in its data-gradient epilogue
                 _STASH[ctx.up_ptr] = gup
                 gup = None
+        if gres is None:
+            ondemand.zero_recycle(gy)   # a persistent gradient map (ondemand.zero_acquire): this node was its last reader
         return gx, gw, gb, None, None, gres, None, None, None, None, None, None, gup, None, None
 
 
@@ -620,6 +623,14 @@ class RoiPool(Function):
         pool, pe, level = ops.roi_pool(list(fmaps), rois, n_roi, pe_f, pe_t, img_h, img_w)
         ctx.shapes = [tuple(f.shape) for f in fmaps]
         ctx.fm_ptrs = [f.data_ptr() for f in fmaps]
+        # demand-driven levels whose backward pass goes through the cell transforms: their gradient maps are persistent
+        # (ondemand.zero_acquire); the map's producer (Conv.backward) recycles them
+        ctx.pooled = {}
+        if ondemand.ZERO_POOL and GRAD_SHARE and LAZY_DGRAD and LAZY_WGRAD and ondemand.CELL_BWD:
+            for i, f in enumerate(fmaps):
+                st = ondemand.lazy_state(f)
+                if st is not None and st.sparse and st.keep and st.stride >= 5:
+                    ctx.pooled[i] = st.stride
         _GRAD_ACC.clear()                      # nothing of an earlier step may survive into this one's backward pass
         ctx.save_for_backward(rois, level)
         ctx.mark_non_differentiable(pe, level)
@@ -629,7 +640,7 @@ class RoiPool(Function):
     @once_differentiable
     def backward(ctx, gpool, _gpe, _glvl):
         rois, level = ctx.saved_tensors
-        gf = ops.roi_pool_bwd(gpool.contiguous(), rois, level, ctx.shapes)
+        gf = ops.roi_pool_bwd(gpool.contiguous(), rois, level, ctx.shapes, pooled=ctx.pooled)
         _GRAD_ACC.clear()
         if GRAD_SHARE:                         # the other consumer of each map may add its gradient here (Fn.DwConv.backward)
             for ptr, g in zip(ctx.fm_ptrs, gf):

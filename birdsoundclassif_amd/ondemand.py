@@ -381,6 +381,12 @@ def conv3x3_winograd_lazy(x, U, bias, stride, Ucell=None, fold=None, keep=False)
     return y, st
 
 
+def lazy_state(fm):
+    """The LazyMap of a demand-driven map (or None)."""
+    hit = _LAZY.get(fm.data_ptr())
+    return hit[0] if hit is not None and hit[1]() is not None else None
+
+
 def lazy_pending(fm):
     hit = _LAZY.get(fm.data_ptr())
     return hit is not None and hit[1]() is not None
@@ -448,6 +454,74 @@ def lazy_complete(fm, rois, n_roi, fmap_hw, level=0):
 CELL_BWD = os.environ.get('NBM_CELL_BWD', '1') != '0'     # pattern share of both gradients through the cell transforms (cellwino.hip)
 
 
+# ---- persistent gradient maps of a demand-driven level (training)
+# The two big gradient maps of the finest level -- d/d(output map) [B,188,512,256], filled by the RoI pooling's scatter and the
+# RPN's strided taps, and d/d(merged map) [B,188,512,384], written on the cell patches and the RoI tiles -- are zero almost
+# everywhere, yet a fresh `torch.zeros` per step fills 31.5 GB (4.8 ms at B = 128).  They are kept across steps instead: every
+# writer notes how to undo its footprint (`zero_note`), the LAST reader (Conv.backward of the node that consumes the map) calls
+# `zero_recycle`, which runs those targeted kernels (nbm_zero_*) and marks the buffer clean.  A buffer that was not recycled (other
+# consumer, exception, autograd accumulated something into it in place: its version counter moved) is filled completely at its next
+# `zero_acquire`.  Because the buffer is handed to autograd as a gradient, code that KEEPS that gradient beyond the backward pass
+# (`retain_grad()` on the FPN map) sees it change in the next step: set NBM_ZERO_POOL=0 for that.
+ZERO_POOL = os.environ.get('NBM_ZERO_POOL', '1') != '0'
+ZERO_POOL_CHECK = os.environ.get('NBM_ZERO_POOL_CHECK', '0') == '1'      # tests: verify the buffer after every recycle (synchronises)
+_ZERO_POOL = {}
+
+
+def zero_pool_new_pass():
+    """Start of a forward pass: a buffer still marked busy was never handed back by a reader -- its content is unknown."""
+    for e in _ZERO_POOL.values():
+        if e['busy']:
+            e['busy'], e['stale'] = False, True
+
+
+def zero_acquire(shape, device, tag):
+    """-> (zero-filled [shape] buffer, entry) from the pool (see above), or (None, None) when the buffer is in flight in THIS
+    backward pass (a second RoI pooling on the same map: autograd will sum two maps, they cannot be one buffer); `tag` separates
+    users whose footprints differ."""
+    key = (str(device), tuple(shape), tag)
+    e = _ZERO_POOL.get(key)
+    if e is not None and e['busy']:
+        return None, None
+    if e is None:
+        for k in [k for k in _ZERO_POOL if k[0] == key[0] and k[2] == tag]:       # another batch size: the old buffer goes
+            del _ZERO_POOL[k]
+        e = _ZERO_POOL[key] = dict(buf=torch.zeros(shape, device=device, dtype=torch.float32), busy=False, stale=False, zeroers=[],
+                                   check=None)
+    elif e['stale']:                     # never recycled: anything may have been written anywhere
+        e['buf'].zero_()
+    e['busy'], e['stale'], e['zeroers'], e['version'] = True, False, [], e['buf']._version
+    return e['buf'], e
+
+
+def zero_note(e, fn):
+    e['zeroers'].append(fn)
+
+
+def zero_recycle(t):
+    """Called by the last reader of a gradient map: if `t` is a pool buffer that autograd has not touched, undo the writers'
+    footprints.  -> True if it was."""
+    if not _ZERO_POOL or t is None:
+        return False
+    for e in _ZERO_POOL.values():
+        if e['busy'] and e['buf'].data_ptr() == t.data_ptr() and e['buf'].shape == t.shape:
+            break
+    else:
+        return False
+    if t._version != e['version']:       # accumulated into in place by autograd: unknown footprint, fill next time
+        return False
+    for fn in e['zeroers']:
+        fn()
+    if ZERO_POOL_CHECK and e['check'] is not None:
+        e['check'](e['buf'])
+    e['busy'], e['zeroers'] = False, []
+    return True
+
+
+def zero_pool_clear():
+    _ZERO_POOL.clear()
+
+
 def cell_count(B, H, W, stride):
     return B * ((H + 2 - 3) // stride + 1) * ((W + 2 - 3) // stride + 1)
 
@@ -489,10 +563,17 @@ def conv3x3_winograd_dgrad_tiles(st, g, Ut, Ucell=None):
     B, H, W, N = g.shape
     C_ = Ut.shape[1]
     assert Ut.shape == (16, C_, N)
-    gx = torch.zeros((B, H, W, C_), device=g.device, dtype=torch.float32)
     img_bytes = H * W * C_ * 4
     blocks_per_img = -(-((H + 1) // 2 * ((W + 1) // 2)) // 128)
     cell = Ucell is not None and cell_usable(st, H, W, C_, N)
+    pool = None
+    if cell and ZERO_POOL:
+        # persistent map (see zero_acquire): the cell patches are rewritten by every pass, only the RoI tiles have to be undone
+        gx, pool = zero_acquire((B, H, W, C_), g.device, ('cell-dgrad', st.stride))
+        if pool is not None and ZERO_POOL_CHECK:
+            pool['check'] = lambda buf, s_=st.stride: _check_zero_outside_patches(buf, s_)
+    if pool is None:
+        gx = torch.zeros((B, H, W, C_), device=g.device, dtype=torch.float32)
     if cell:
         assert Ucell.shape == (25, C_, N)
     for ci, (b0, nb, _) in enumerate(st.chunks):
@@ -523,7 +604,24 @@ def conv3x3_winograd_dgrad_tiles(st, g, Ut, Ucell=None):
             check(lib().nbm_roi_tiles(_ptr(rois[b0:b0 + nb]), _ptr(n_roi[b0:b0 + nb] if per else n_roi), nb, rois.shape[1], nl, level,
                                       fh, fw, None if cell else _ptr(pat.full), 1, _ptr(tiles), _ptr(n_blocks), per, _stream()), 'nbm_roi_tiles')
             _wino23_tiles_run(g[b0:b0 + nb], Ut, None, gx.data_ptr() + b0 * img_bytes, tiles, n_blocks, None, 'wino23-dgrad-rois')
+            if pool is not None:
+                tl, nbk = tiles.clone(), n_blocks.clone()          # the list buffer is shared by all chunks / levels
+                zero_note(pool, lambda p_=gx.data_ptr() + b0 * img_bytes, nb_=nb, tl_=tl, nbk_=nbk: check(
+                    lib().nbm_zero_tiles(C.c_void_p(p_), nb_, H, W, C_, _ptr(tl_), tl_.numel(), _ptr(nbk_), _stream()), 'nbm_zero_tiles'))
     return gx
+
+
+def _check_zero_outside_patches(buf, stride):
+    """NBM_ZERO_POOL_CHECK: after a recycle the persistent data-gradient map may hold values on the 5x5 cell patches only."""
+    B, H, W, _ = buf.shape
+    def axis(n):
+        i = torch.arange(n, device=buf.device)
+        cells = (n + 2 - 3) // stride + 1
+        return ((i + 2) % stride < 5) & ((i + 2) // stride < cells)
+    outside = ~(axis(H)[:, None] & axis(W)[None, :])
+    bad = float(buf[:, outside].abs().max()) if bool(outside.any()) else 0.0
+    if bad != 0.0:
+        raise RuntimeError(f'persistent gradient map not clean after its recycle: {bad}')
 
 
 def conv3x3_winograd_wgrad_tiles(st, x, g, want_bias=False, cell=None):

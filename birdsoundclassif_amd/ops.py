@@ -844,11 +844,29 @@ def bn_train_bwd(g2d, x2d, mean, invstd, w):
     return gx, gw, gb
 
 
-def roi_pool_bwd(gpool, rois, level, fmap_shapes):
-    """gpool [B*R,2,2,C] -> list of zero-initialised-then-accumulated gradient maps (NHWC) for the FPN levels."""
+def roi_pool_bwd(gpool, rois, level, fmap_shapes, pooled=None):
+    """gpool [B*R,2,2,C] -> list of zero-initialised-then-accumulated gradient maps (NHWC) for the FPN levels.
+    `pooled` {level index: stride of the RPN's depthwise convolution on that map}: those maps come from the persistent pool of
+    `ondemand.zero_acquire` (demand-driven levels: the consumer of the gradient recycles them) instead of a fresh fill."""
     B, R = rois.shape[:2]
     C_ = gpool.shape[-1]
-    gf = [torch.zeros(s, device=gpool.device, dtype=torch.float32) for s in fmap_shapes]
+    gf = []
+    for i, s in enumerate(fmap_shapes):
+        buf = None
+        if pooled and i in pooled:
+            from . import ondemand
+            buf, e = ondemand.zero_acquire(s, gpool.device, ('roi-grad', i, pooled[i]))
+        if buf is not None:
+            # footprints: the RoI windows of this level, and the 3x3 blocks the strided taps add to (Fn.DwConv.backward)
+            ondemand.zero_note(e, lambda b_=buf, s_=s, i_=i: check(lib().nbm_zero_roi_windows(
+                _ptr(b_), s_[1], s_[2], s_[3], _ptr(rois), _ptr(level), B, R, i_, _stream()), 'nbm_zero_roi_windows'))
+            ondemand.zero_note(e, lambda b_=buf, s_=s, st_=pooled[i]: check(lib().nbm_zero_pattern(
+                _ptr(b_), s_[0], s_[1], s_[2], s_[3], st_, _stream()), 'nbm_zero_pattern'))
+            if ondemand.ZERO_POOL_CHECK:
+                e['check'] = _check_all_zero
+            gf.append(buf)
+        else:
+            gf.append(torch.zeros(s, device=gpool.device, dtype=torch.float32))
     n = len(gf)
     ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in gf])
     fh = (C.c_int * n)(*[s[1] for s in fmap_shapes])
@@ -856,6 +874,12 @@ def roi_pool_bwd(gpool, rois, level, fmap_shapes):
     check(lib().nbm_roi_pool_bwd(ptrs, fh, fw, n, C_, _ptr(_chk(rois)), _ptr(level), B, R, _ptr(_chk(gpool)), _stream()),
           'nbm_roi_pool_bwd')
     return gf
+
+
+def _check_all_zero(buf):
+    bad = float(buf.abs().max())
+    if bad != 0.0:
+        raise RuntimeError(f'persistent RoI-gradient map not clean after its recycle: {bad}')
 
 
 def sqnorm_accum(g, out):

@@ -549,3 +549,52 @@ def test_train_step_losses_and_gradients_do_not_change(negative):
     # AdamW step turns a gradient into lr * g / (|g| + eps), which amplifies that noise where g is tiny
     for k, v in res[False][2].items():
         assert torch.allclose(v, res[True][2][k], rtol=2e-4, atol=2e-6), k
+
+
+def test_persistent_gradient_maps_are_clean_after_every_step():
+    """Training keeps the two large, almost-empty gradient maps of the finest level across steps (ondemand.zero_acquire) and
+    undoes the writers' footprints instead of refilling them.  Four steps (positive, positive with other boxes, negative,
+    positive) with the check switch on -- after every recycle the maps are verified to be zero (outside the cell patches that
+    every pass rewrites) -- and the gradient norms / losses of every step equal those of a run with fresh maps."""
+    from birdsoundclassif_amd import train as T
+    from birdsoundclassif_amd.nets import build_model
+    args = T.default_args(device='cuda')
+    B = 2
+    batches = []
+    for s in (0, 3):
+        bb, ids, lens = synth.label_batch(s, B)
+        img = torch.from_numpy(synth.image_batch(s, B))
+        batches.append([img, img, bb, ids, lens])
+    plan = [(0, False), (1, False), (0, True), (1, False)]
+    res = {}
+    for pool in (False, True):
+        model, crit = build_model(args)
+        model.load_state_dict(filler_state_dict())
+        model = model.cuda().train()
+        crit.train()
+        opt, _ = T.build_optimizer(model, args)
+        np.random.seed(11)
+        ondemand.zero_pool_clear()
+        ondemand.ZERO_POOL, ondemand.ZERO_POOL_CHECK = pool, pool
+        out = []
+        try:
+            for bi, neg in plan:
+                loss = T.train_one_step(model, crit, opt, batches[bi], args.clip_max_norm, 'cuda', negative_sample=neg)
+                out.append(({k: float(v) for k, v in loss.items()}, float(opt.grad_norm())))
+            if pool:
+                tags = sorted(k[2][0] for k in ondemand._ZERO_POOL)
+                assert tags == ['cell-dgrad', 'roi-grad'], tags                       # both maps of level 0 came from the pool ...
+                assert not any(e['busy'] for e in ondemand._ZERO_POOL.values())       # ... and were handed back by their readers
+        finally:
+            ondemand.ZERO_POOL, ondemand.ZERO_POOL_CHECK = True, False
+            ondemand.zero_pool_clear()
+        res[pool] = out
+    # the switch's own guarantee is the check above (a dirty map raises); the numbers: step 0 strictly, the later steps loosely --
+    # float atomics order the weight-gradient sums differently from run to run and AdamW's g / (|g| + eps) amplifies that
+    # noise where g is tiny, so two runs drift apart by ~1e-5 per step with or without the pool
+    for si, ((l0, n0), (l1, n1)) in enumerate(zip(res[False], res[True])):
+        assert set(l0) == set(l1)
+        tol = 5e-6 if si == 0 else 2e-3
+        for k, v in l0.items():
+            assert abs(v - l1[k]) <= tol * max(1.0, abs(v)), (si, k, v, l1[k])
+        assert abs(n0 - n1) <= 4 * tol * n0, (si, n0, n1)
