@@ -487,6 +487,47 @@ __global__ void dwconv_bwd_data_kernel(const float* __restrict__ g, int B, int H
   }
 }
 
+// The same data gradient ADDED into gx, scatter form for strides >= 3: the 3x3 input blocks of different output pixels do not
+// overlap, so every (output pixel, tap, 4 input channels) item owns its 16 bytes of gx -- no atomics, and only the 9 / stride^2 of
+// the map a tap reaches is touched (the gather form above walks every pixel of every reached row: 2.5 ms for the 12.6 GB map of the
+// finest level at B = 128 where 1.8 GB are read and written).  Same products in the same order as the gather form.
+template <int MULT>
+__global__ void dwconv_bwd_data_scatter_kernel(const float* __restrict__ g, int B, int H, int W, int Cin, int mult_rt, int stride,
+                                               const float* __restrict__ w, float* __restrict__ gx, int Ho, int Wo) {
+  const int mult = MULT > 0 ? MULT : mult_rt;
+  const int Cout = Cin * mult, C4 = Cin >> 2;
+  const long long total = (long long)B * Ho * Wo * 9 * C4;
+  f32x4* o4 = reinterpret_cast<f32x4*>(gx);
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C4);
+    long long t = i / C4;
+    const int tap = (int)(t % 9); t /= 9;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    const int r = tap / 3, s = tap - r * 3;
+    const int iy = oy * stride - 1 + r, ix = ox * stride - 1 + s;
+    if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
+    const int c0 = c * 4;
+    const float* gp = g + ((long long)(b * Ho + oy) * Wo + ox) * Cout + c0 * mult;
+    const float* wp = w + (long long)c0 * mult * 9 + tap;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (MULT == 2) {
+      const f32x4 g0 = reinterpret_cast<const f32x4*>(gp)[0], g1 = reinterpret_cast<const f32x4*>(gp)[1];
+      acc[0] += g0[0] * wp[0];  acc[0] += g0[1] * wp[9];
+      acc[1] += g0[2] * wp[18]; acc[1] += g0[3] * wp[27];
+      acc[2] += g1[0] * wp[36]; acc[2] += g1[1] * wp[45];
+      acc[3] += g1[2] * wp[54]; acc[3] += g1[3] * wp[63];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        for (int e = 0; e < mult; ++e) acc[k] += gp[k * mult + e] * wp[(k * mult + e) * 9];
+    }
+    const long long o = (((long long)b * H + iy) * W + ix) * C4 + c;
+    o4[o] = o4[o] + acc;
+  }
+}
+
 // depthwise 3x3 weight (+bias) gradient: one block column per output channel group, atomics on 9(+1) scalars
 __global__ void dwconv_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ g, int B, int H, int W,
                                          int Cin, int mult, int stride, float* __restrict__ gw, float* __restrict__ gb,
@@ -965,6 +1006,12 @@ extern "C" int nbm_dwconv3x3_bwd_acc(const float* g, const float* w, int B, int 
   if (!g || !w || !gx || B <= 0 || Cin <= 0 || mult <= 0 || stride <= 0) return NBM_EINVAL;
   if ((H + 2 - 3) / stride + 1 != Ho || (W + 2 - 3) / stride + 1 != Wo) return NBM_EINVAL;
   if ((Cin & 3) || !nbm_aligned16(gx)) return NBM_EALIGN;
+  if (stride >= 3 && (mult != 2 || nbm_aligned16(g))) {          // disjoint 3x3 blocks: scatter form
+    const dim3 sg(grid_for((long long)B * Ho * Wo * 9 * (Cin / 4)));
+    if (mult == 2) hipLaunchKernelGGL(dwconv_bwd_data_scatter_kernel<2>, sg, dim3(TPB), 0, ST, g, B, H, W, Cin, mult, stride, w, gx, Ho, Wo);
+    else hipLaunchKernelGGL(dwconv_bwd_data_scatter_kernel<0>, sg, dim3(TPB), 0, ST, g, B, H, W, Cin, mult, stride, w, gx, Ho, Wo);
+    return nbm_launch_status();
+  }
   const int bx = (W * (Cin / 4) + TPB - 1) / TPB;
   const dim3 grid(bx < 64 ? bx : 64, (long long)B * H < 65535 ? B * H : 65535);
   if (mult == 2 && stride <= 2) hipLaunchKernelGGL((dwconv_bwd_data_kernel<2, true>), grid, dim3(TPB), 0, ST, g, B, H, W, Cin, mult, stride, w, gx, Ho, Wo, 1);

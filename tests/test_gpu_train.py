@@ -199,6 +199,27 @@ def test_dwconv_film_backward(cfg):
     close(nchw(fd.grad), film.grad, 1e-5, f'film grad {cfg}')
 
 
+@pytest.mark.parametrize('cfg', [(2, 33, 41, 32, 2, 4), (1, 24, 32, 32, 2, 8), (2, 47, 61, 64, 2, 8), (2, 19, 23, 16, 4, 3), (2, 17, 18, 8, 1, 5),
+                                 (2, 16, 20, 64, 2, 2)])
+def test_dwconv_data_gradient_added_into_a_map(cfg):
+    """nbm_dwconv3x3_bwd_acc (the RPN's strided taps add their gradient into the map the RoI pooling's backward pass filled): the
+    scatter form for strides >= 3 (disjoint 3x3 blocks) and the gather form for stride 2, both == content + torch's data gradient,
+    and every pixel no tap reaches keeps its bits."""
+    B, H, W, C, mult, st = cfg
+    x = rnd(('ax', cfg), B, C, H, W).requires_grad_(True)
+    w = rnd(('aw', cfg), C * mult, 1, 3, 3, scale=0.3)
+    z = F.conv2d(x, w, None, stride=st, padding=1, groups=C)
+    gy = rnd(('ag', cfg), *z.shape)
+    z.backward(gy)
+    base = rnd(('ab', cfg), B, C, H, W)
+    acc = nhwc(base).clone()
+    ops.dwconv3x3_bwd_acc(nhwc(gy), w.cuda(), mult, st, acc)
+    close(nchw(acc), base + x.grad, 2e-6, f'dw acc {cfg}')
+    untouched = (x.grad == 0) & (F.conv_transpose2d(torch.ones_like(gy), torch.ones_like(w), stride=st, padding=1, groups=C,
+                                                    output_padding=(H - ((z.shape[2] - 1) * st + 1), W - ((z.shape[3] - 1) * st + 1))) == 0)
+    assert torch.equal(nchw(acc)[untouched], base[untouched])
+
+
 def test_batchnorm_train():
     x = rnd('bnx', 3, 256, 6, 10, scale=2.0).requires_grad_(True)
     w = (1 + 0.1 * rnd('bnw', 256)).requires_grad_(True)
