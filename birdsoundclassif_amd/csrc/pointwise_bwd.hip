@@ -307,7 +307,9 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ gy, int B, int Hi,
     // weights for every candidate row and walked ~5 x 5 candidates of which <= 3 x 3 contribute.  (Measured at 188x512 -> 94x256 x 384,
     // B = 64: 4.36 ms flat 64-bit index + candidate walk -> 4.7 ms with the lists alone (!) -> 3.57 ms with 32-bit indices; skipping the
     // 61 % of the fine pixels that are known zeros in the data gradient of the demand-driven level -- pattern test + tile bitmap -- made
-    // it SLOWER, 4.26 ms: the reads are L2 hits, the tests are not free.  Not kept.)
+    // it SLOWER, 4.26 ms: the reads are L2 hits, the tests are not free.  Not kept.  Two more forms measured at B = 128 (6.86 ms, 18.9 GB
+    // read = 2.8 TB/s) and not kept either: one contiguous band of coarse rows per XCD (6.82 ms) and the per-axis lists derived once per
+    // workgroup and shared through LDS instead of once per thread (7.03 ms) -- it is neither L2 locality nor the list arithmetic.)
     constexpr int MAXT = 6;
     int ys[MAXT], xs[MAXT], ny = 0, nx = 0;
     float wys[MAXT], wxs[MAXT];
