@@ -432,6 +432,142 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_kernel(const I
   }
 }
 
+// ---- streaming 1x1 (stride 1) for the layers whose whole weight matrix fits LDS (N * K <= 16 K: ResNet layer1's 64 -> 64 / 64 -> 256 /
+// 256 -> 64 and their data gradients).  Those layers are HBM-bound (K = 64: 2.25 KB of activation / residual / output traffic per pixel
+// against 32 K MACs) and the tiled kernel above leaves them at ~3.1 TB/s: every K-step of every tile re-stages the weights and meets at
+// a workgroup barrier, so load, MFMA and store phases of the 8-12 waves of a CU line up instead of overlapping.  Here the weights are
+// written to LDS ONCE per (persistent) workgroup and every WAVE is on its own after that: it streams 32 pixel rows straight from
+// global memory into MFMA operand registers (lane (row, half h) holds k = 16 h .. 16 h + 15 of every 32-wide chunk: the same K
+// order as the tiled kernel, so the sums are bit-identical), multiplies against all N channels, and sends the 32 x N tile out through
+// a private 32 x 32 LDS patch (16-byte residual loads / stores, 128-byte row segments) -- no workgroup barrier after the prologue.
+// Measured at B = 64 (scripts/stream1x1_probe.py, tiled -> streaming, outputs bit-identical): 64 -> 256 + residual + ReLU 1.20 -> 1.05 ms,
+// 64 -> 64 0.28 -> 0.21, 256 -> 64 0.68 -> 0.63; 64 -> 256 without residual 0.78 -> 0.78 (left on the tiled kernel); the detect step
+// 73.4 -> 72.75 ms.  Accumulation groups of 8 blocks (8 spilled registers) or 12 waves per workgroup (28-74 spilled) were slower.
+struct StreamParams {
+  const float* x; const float* w; float* y; const float* scale; const float* shift; const float* residual;
+  int M, x_ld, w_ld, y_ld, res_ld, m_tiles; float alpha; int act;
+};
+constexpr int SPITCH = 36;
+// NTG: 32-wide channel blocks per accumulation group (the activation rows stay in registers for all groups); WAVES per workgroup
+template <int K32, int NT, int NTG, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 1) void stream1x1_kernel(const StreamParams p) {
+  constexpr int K = K32 * 32, N = NT * 32, WP = K + 4;
+  constexpr bool PREFETCH = K32 <= 2;
+  static_assert(NT % NTG == 0, "groups");
+  __shared__ __attribute__((aligned(16))) float Ws[N * WP];
+  __shared__ __attribute__((aligned(16))) float Stg[WAVES][32 * SPITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  for (int i = tid; i < N * (K / 4); i += WAVES * 64) {
+    const int n = i / (K / 4), c = i - n * (K / 4);
+    *reinterpret_cast<f32x4*>(Ws + n * WP + c * 4) = *reinterpret_cast<const f32x4*>(p.w + (long long)n * p.w_ld + c * 4);
+  }
+  __syncthreads();
+  float* stg = Stg[wave];
+  const int er = lane >> 3, ec = (lane & 7) * 4;            // epilogue: 8 rows x 8 chunks of 4 channels per pass
+  f32x4 a[K32][4], an[PREFETCH ? K32 : 1][4];
+  auto load_a = [&](int tile, f32x4 (*dst)[4]) {
+    int m = tile * 32 + li;
+    m = m < p.M ? m : p.M - 1;
+    const float* xp = p.x + (long long)m * p.x_ld + 16 * lh;
+#pragma unroll
+    for (int kc = 0; kc < K32; ++kc)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dst[kc][q] = *reinterpret_cast<const f32x4*>(xp + kc * 32 + 4 * q);
+  };
+  const int step = gridDim.x * WAVES;
+  int tile = blockIdx.x * WAVES + wave;
+  if (PREFETCH && tile < p.m_tiles) load_a(tile, an);
+  for (; tile < p.m_tiles; tile += step) {
+    if constexpr (PREFETCH) {
+#pragma unroll
+      for (int kc = 0; kc < K32; ++kc)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[kc][q] = an[kc][q];
+      if (tile + step < p.m_tiles) load_a(tile + step, an);
+    } else {
+      load_a(tile, a);
+    }
+    const int m0 = tile * 32;
+    // the residual rows of the block that goes out next are requested one block ahead: their latency hides behind the previous
+    // block's LDS round trip and stores (and, for the first block of a group, behind the group's MFMAs)
+    f32x4 rq[4], rn[4];
+    auto load_res = [&](int jn, f32x4* dst) {
+      if (!p.residual) return;
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) {
+        const int m = m0 + pass * 8 + er;
+        dst[pass] = *reinterpret_cast<const f32x4*>(p.residual + (long long)(m < p.M ? m : p.M - 1) * p.res_ld + jn * 32 + ec);
+      }
+    };
+    load_res(0, rn);
+#pragma unroll
+    for (int g = 0; g < NT / NTG; ++g) {
+      f32x16 acc[NTG];
+#pragma unroll
+      for (int j = 0; j < NTG; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+      for (int j = 0; j < NTG; ++j) {
+        const float* wb = Ws + ((g * NTG + j) * 32 + li) * WP + 16 * lh;
+#pragma unroll
+        for (int kc = 0; kc < K32; ++kc) {
+          f32x4 b[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) b[q] = *reinterpret_cast<const f32x4*>(wb + kc * 32 + 4 * q);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kc][q][e], b[q][e], acc[j], 0, 0, 0);
+        }
+      }
+      // epilogue, one 32 x 32 block at a time through this wave's LDS patch (same arithmetic as the tiled kernel's)
+#pragma unroll
+      for (int j = 0; j < NTG; ++j) {
+        const int jj = g * NTG + j;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) rq[pass] = rn[pass];
+        if (jj + 1 < NT) load_res(jj + 1, rn);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int e = 0; e < 16; ++e) stg[((e & 3) + 8 * (e >> 2) + 4 * lh) * SPITCH + li] = acc[j][e];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int n = jj * 32 + ec;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+        if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const int r = pass * 8 + er, m = m0 + r;
+          if (m >= p.M) continue;
+          f32x4 v = *reinterpret_cast<const f32x4*>(stg + r * SPITCH + ec);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (v[e] * p.alpha) * sc[e] + sh[e] + 0.f;
+          if (p.residual) { v[0] += rq[pass][0]; v[1] += rq[pass][1]; v[2] += rq[pass][2]; v[3] += rq[pass][3]; }
+          if (p.act == NBM_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+          } else if (p.act == NBM_ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + expf(-v[e]));
+          } else if (p.act == NBM_ACT_LEAKY) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
+          }
+          *reinterpret_cast<f32x4*>(p.y + (long long)m * p.y_ld + n) = v;
+        }
+      }
+    }
+  }
+}
+
+template <int K32, int NT, int NTG, int WAVES, int WG_PER_CU>
+int launch_stream(const StreamParams& p, hipStream_t st) {
+  const int wgs = (p.m_tiles + WAVES - 1) / WAVES;
+  hipLaunchKernelGGL((stream1x1_kernel<K32, NT, NTG, WAVES>), dim3(wgs < 256 * WG_PER_CU ? wgs : 256 * WG_PER_CU), dim3(WAVES * 64), 0, st, p);
+  return nbm_launch_status();
+}
+
 template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
 int launch(const IgemmParams& p, int groups, hipStream_t st) {
   dim3 grid(p.m_tiles * p.n_tiles, 1, groups);
@@ -499,6 +635,18 @@ extern "C" int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream) {
     p.m_tiles = p.M / BM;
     p.n_tiles = (d->N + 127) / 128;
     return launch_s1_rows(p, st);
+  }
+  // streaming form for 1x1 / stride 1 layers whose weights fit LDS (see stream1x1_kernel)
+  const char* stream_env = getenv("NBM_STREAM1X1");          // read per call: the parity test flips it inside one process
+  if (!(stream_env && stream_env[0] == '0') && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && d->groups == 1 && fast && p.vec_epi && !d->up &&
+      !d->shift_per_row && (d->N % 32) == 0 && p.M >= 8192) {
+    StreamParams sp{d->x, d->w, d->y, d->scale, d->shift, d->residual, p.M, d->x_ld, d->w_ld, d->y_ld, d->res_ld, (p.M + 31) / 32,
+                    d->alpha, d->act};
+    const int k32 = d->Cin / 32, nt = d->N / 32;
+    // 64 -> 256 without a residual is write-bound and gains nothing (0.78 ms either way at B = 64): tiled kernel
+    if (k32 == 2 && nt == 8 && d->residual) return launch_stream<2, 8, 4, 8, 1>(sp, st);
+    if (k32 == 2 && nt == 2) return launch_stream<2, 2, 2, 8, 2>(sp, st);
+    if (k32 == 8 && nt == 2) return launch_stream<8, 2, 2, 8, 1>(sp, st);
   }
   if (d->N > 64) {
     p.n_tiles = (d->N + 127) / 128;

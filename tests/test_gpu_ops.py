@@ -74,6 +74,30 @@ def test_conv_igemm(cfg):
     assert_close(nchw(got), ref, 2e-5, 2e-5, f'conv {cfg}')
 
 
+@pytest.mark.parametrize('cfg', [(64, 256, True, 'relu'), (64, 64, False, 'relu'), (256, 64, True, 'none'), (256, 64, False, 'silu'),
+                                 (64, 64, True, 'leaky')])
+def test_streaming_1x1_equals_the_tiled_kernel_bit_for_bit(cfg, monkeypatch):
+    """The 1x1 layers whose weights fit LDS (ResNet layer1) go through stream1x1_kernel (csrc/igemm.hip) once the map is large
+    enough: same K order, same epilogue arithmetic -> the SAME BITS as the tiled kernel (NBM_STREAM1X1=0), incl. a ragged last
+    32-row tile, and both within fp32 tolerance of torch."""
+    K, N, with_res, act = cfg
+    B, H, W = 2, 67, 63                                    # M = 8442: not a multiple of 32, above the streaming threshold
+    x = rnd(('sx', cfg), B, K, H, W)
+    w = rnd(('sw', cfg), N, K, 1, 1, scale=(2.0 / K) ** 0.5)
+    scale, shift = 1 + 0.1 * rnd(('ss', cfg), N), 0.1 * rnd(('sb', cfg), N)
+    res = rnd(('sr', cfg), B, N, H, W) if with_res else None
+    ref = F.conv2d(x, w) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + (res if with_res else 0)
+    ref = {'relu': F.relu, 'silu': F.silu, 'leaky': lambda t: F.leaky_relu(t, 0.01), 'none': lambda t: t}[act](ref)
+    code = {'relu': ops.ACT_RELU, 'silu': ops.ACT_SILU, 'leaky': ops.ACT_LEAKY, 'none': ops.ACT_NONE}[act]
+    out = {}
+    for flag in ('0', '1'):
+        monkeypatch.setenv('NBM_STREAM1X1', flag)
+        out[flag] = ops.conv2d(nhwc(x), krsc(w), scale=dev(scale), shift=dev(shift), residual=nhwc(res) if with_res else None, act=code)
+        torch.cuda.synchronize()
+    assert torch.equal(out['0'], out['1'])
+    assert_close(nchw(out['1']), ref, 2e-5, 2e-5, f'streaming 1x1 {cfg}')
+
+
 def test_conv_alpha_silu_bias():
     x = rnd('xa', 2, 64, 10, 12)
     w = rnd('wa', 96, 64, 1, 1, scale=0.2)
