@@ -61,8 +61,12 @@ struct IgemmParams {
 // 64-wide tiles at four workgroups per CU (4.19 / 6.05 ms); a persistent workgroup that keeps the weight tile in LDS and
 // has the next pixel tile's loads in flight under the current epilogue (3.99 / 7.96 ms), with or without a start stagger
 // of the two co-resident workgroups (3.85-3.91 ms).
+// Deep K, measured and dropped (round 3): a 256 x 128 tile (waves of 128 x 64: 128 accumulator registers in the AGPR file, 25 % fewer
+// LDS reads and half the barriers per MFMA, 110 KB of LDS -> ONE workgroup = one wave per SIMD) -- 2048 -> 3072 @24576: 2.34 ms
+// against 2.23 (132 vs 138.5 TF/s), 1024 -> 1536 @98304: 2.50 / 2.30, 1024 -> 256 @24x64: 0.42 / 0.39, small grids far worse
+// (512 -> 2048 @12x32: 0.60 / 0.44).  The second co-resident wave per SIMD is worth more than the larger tile.
 template <int BM, int BN, int WM, int WN, int AMODE, int EPI, int STAGES = 2, bool ROWS = false>
-__global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(256, BM > 128 ? 1 : STAGES == 1 ? 3 : 2) void igemm_kernel(const IgemmParams p) {
   constexpr int MT = WM / 32, NT = WN / 32;
   constexpr int WAVES_N = BN / WN;
   constexpr int AR = BM / 32, BR = BN / 32;  // rows per thread in the staging pass
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_kernel(const I
       // lane finishes 4 consecutive channels: 16-byte residual / scale / shift loads and 16-byte stores instead of
       // 64 dword stores per lane (store-issue bound on the short-K 1x1 layers).
       constexpr int CP = BN + 4;
-      constexpr int HALVES = STAGES == 1 ? BM / WM : 1;           // single-stage LDS holds WM rows of the tile at a time
+      constexpr int HALVES = (STAGES == 1 || BM > 128) ? BM / WM : 1;   // single-stage LDS (or a 256-row tile) holds WM rows of the tile at a time
       constexpr int HROWS = BM / HALVES;
       static_assert(HROWS * CP <= STAGES * (BM + BN) * PITCH, "epilogue tile must fit the operand buffers");
       float* Cs = lds;
@@ -654,6 +658,7 @@ extern "C" int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream) {
     static const int shortk_max = getenv("NBM_SHORTK_MAX") ? atoi(getenv("NBM_SHORTK_MAX")) : 8;   // 0 disables
     if (fast && p.vec_epi && p.nk <= shortk_max)
       return launch_s1(p, d->groups, st);
+
     return fast ? launch<128, 128, 64, 64, A_FAST, EPI_STD>(p, d->groups, st)
                 : launch<128, 128, 64, 64, A_GENERIC, EPI_STD>(p, d->groups, st);
   } else if (d->N > 32) {
