@@ -114,7 +114,7 @@ SIGNATURES = {
     'nbm_wino_weight_grad': [_P, _P, _I, _I, _I, _P, _P],
     'nbm_wino23_rows': [_P, _I, _I, _I, _I, _P, _P],
     'nbm_wino23_conv_fused': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _I, _P],
-    'nbm_wino23_rows_tiles': [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P],
+    'nbm_wino23_rows_tiles': [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P],
     'nbm_wino23_conv_fused_tiles': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P],
     'nbm_roi_tiles': [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P, _P, _I, _P],
     'nbm_wino23_input_tiles': [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P],
@@ -122,7 +122,7 @@ SIGNATURES = {
     'nbm_cell_outgrad': [_P, _I, _I, _I, _I, _I, _P, _P, _P],
     'nbm_cell_input': [_P, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     'nbm_cell_input_up': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P],
-    'nbm_cell_dgrad_output': [_P, _I, _I, _I, _I, _I, _P, _P],
+    'nbm_cell_dgrad_output': [_P, _I, _I, _I, _I, _I, _P, _I, _P],
     'nbm_cell_output': [_P, _P, _I, _I, _I, _I, _I, _P, _P],
     'nbm_weighted_sum': [_P, _P, _P, _P, _P, _L, _P],
     'nbm_weighted_sum_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P],

@@ -205,8 +205,11 @@ __global__ __launch_bounds__(256) void cell_input_up_kernel(const float* __restr
 }
 
 // M [25][T][C] -> gx [B][H][W][C]: patch = Vinv M Vinv^T written to the 5x5 pixels of the cell that lie inside the image
-// (S >= 5: patches of different cells do not overlap); the rest of gx is not touched
-__global__ __launch_bounds__(256) void cell_dgrad_output_kernel(const float* __restrict__ M, const CellGeom q, float* __restrict__ gx) {
+// (cls < 0, S >= 5: patches of different cells do not overlap); the rest of gx is not touched.
+// cls = 0..3 (S >= 3): only the cells with (oy & 1, ox & 1) == (cls >> 1, cls & 1), and the patch is ADDED to gx -- cells of one
+// parity class are 2 S >= 6 pixels apart, so four launches accumulate the overlapping patches of a stride-3 / 4 pattern without atomics
+__global__ __launch_bounds__(256) void cell_dgrad_output_kernel(const float* __restrict__ M, const CellGeom q, float* __restrict__ gx,
+                                                                int cls) {
   const f32x4* m4 = reinterpret_cast<const f32x4*>(M);
   f32x4* o4 = reinterpret_cast<f32x4*>(gx);
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -216,6 +219,7 @@ __global__ __launch_bounds__(256) void cell_dgrad_output_kernel(const float* __r
     const unsigned cell = i / (unsigned)q.C4;
     int b, oy, ox;
     cell_of(q, cell, b, oy, ox);
+    if (cls >= 0 && (((oy & 1) << 1) | (ox & 1)) != cls) continue;
     f32x4 t[NP][NP];                   // t[j][e] = sum_a Vinv[j][a] M[a][e]
 #pragma unroll
     for (int j = 0; j < NP; ++j)
@@ -242,7 +246,9 @@ __global__ __launch_bounds__(256) void cell_dgrad_output_kernel(const float* __r
 #pragma unroll
         for (int e = 0; e < NP; ++e)
           if (CV[l][e] != 0.f) o += CV[l][e] * t[j][e];
-        o4[(((long long)b * q.H + y) * q.W + xx) * q.C4 + c] = o;
+        const long long at = (((long long)b * q.H + y) * q.W + xx) * q.C4 + c;
+        if (cls >= 0) o += o4[at];
+        o4[at] = o;
       }
     }
   }
@@ -351,10 +357,13 @@ extern "C" int nbm_cell_output(const float* M, const float* bias, int B, int H, 
   return nbm_launch_status();
 }
 
-extern "C" int nbm_cell_dgrad_output(const float* M, int B, int H, int W, int C, int stride, float* gx, void* stream) {
+extern "C" int nbm_cell_dgrad_output(const float* M, int B, int H, int W, int C, int stride, float* gx, int parity_class,
+                                     void* stream) {
   CellGeom q;
-  if (!M || !gx || !cell_geom(B, H, W, C, stride, q, 5)) return NBM_EINVAL;      // 5x5 patches are WRITTEN: no overlap allowed
+  // parity_class < 0: 5x5 patches are WRITTEN, no overlap allowed (stride >= 5); 0..3: one parity class of cells, ADDED (stride >= 3)
+  if (!M || !gx || parity_class > 3 || !cell_geom(B, H, W, C, stride, q, parity_class < 0 ? 5 : 3)) return NBM_EINVAL;
   if (!nbm_aligned16(M) || !nbm_aligned16(gx)) return NBM_EALIGN;
-  hipLaunchKernelGGL(cell_dgrad_output_kernel, dim3(stream_grid(q.T * q.C4, q.C4)), dim3(256), 0, (hipStream_t)stream, M, q, gx);
+  hipLaunchKernelGGL(cell_dgrad_output_kernel, dim3(stream_grid(q.T * q.C4, q.C4)), dim3(256), 0, (hipStream_t)stream, M, q, gx,
+                     parity_class);
   return nbm_launch_status();
 }

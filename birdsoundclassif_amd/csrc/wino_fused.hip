@@ -89,7 +89,11 @@ __global__ __launch_bounds__(256) void wino23_rows_kernel(const float* __restric
 __global__ __launch_bounds__(256) void wino23_rows_tiles_kernel(const float* __restrict__ x, int B, int H, int W, int C4,
                                                                 int TH, int TW, int WP, const int* __restrict__ tiles,
                                                                 int n_entries, const int* __restrict__ n_blocks,
-                                                                const unsigned* __restrict__ blk_info, float* __restrict__ R) {
+                                                                const unsigned* __restrict__ blk_info, float* __restrict__ R,
+                                                                int pat_stride) {
+  // pat_stride S > 0: the pixels of the 3x3 / stride-S / pad-1 pattern read as zeros (as in wino23_outgrad_kernel: their share of a
+  // gradient map is taken by the cell transforms, this pass adds the rest)
+  const int S = pat_stride, OHp = S > 0 ? (H + 2 - 3) / S + 1 : 0, OWp = S > 0 ? (W + 2 - 3) / S + 1 : 0;
   const long long per_plane = (long long)B * TH * WP * C4;
   const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
   f32x4* r4 = reinterpret_cast<f32x4*>(R);
@@ -114,8 +118,9 @@ __global__ __launch_bounds__(256) void wino23_rows_tiles_kernel(const float* __r
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       const int iy = 2 * ty - 1 + a;
-      const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W &&
-                      !(a == 0 && !(pm & 0x000fu)) && !(a == 3 && !(pm & 0xf000u));
+      bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W &&
+                !(a == 0 && !(pm & 0x000fu)) && !(a == 3 && !(pm & 0xf000u));
+      if (S > 0 && ok && (iy + 1) % S < 3 && (iy + 1) / S < OHp && (ix + 1) % S < 3 && (ix + 1) / S < OWp) ok = false;
       d[a] = ok ? x4[(((long long)b * H + iy) * W + ix) * C4 + c] : zero;
     }
     const long long o = (((long long)b * TH + ty) * WP + xp) * C4 + c;
@@ -444,9 +449,13 @@ __global__ __launch_bounds__(256, BN == 128 ? 1 : 2) void wino23_fused_kernel(co
           const long long idx = ((rp >> 2) + pp * p.W + qq) * p.N + n;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[e] + sh[e];
-          if (p.relu) {
+          if (p.relu & 1) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+          if (p.relu & 2) {               // listed tiles, accumulate: y += result (every listed tile is listed once)
+            const f32x4 o = *reinterpret_cast<const f32x4*>(p.y + idx);
+            v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
           }
           if (p.mask) {
             const f32x4 mk = *reinterpret_cast<const f32x4*>(p.mask + idx);
@@ -475,8 +484,9 @@ extern "C" int nbm_wino23_rows(const float* x, int B, int H, int W, int C, float
 
 // Row transform of the listed tiles only -- see nbm_hip.h.
 extern "C" int nbm_wino23_rows_tiles(const float* x, int B, int H, int W, int C, const int* tiles, int n_entries,
-                                     const int* n_blocks, const unsigned* blk_info, float* R, void* stream) {
-  if (!x || !R || !tiles || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || n_entries < 0) return NBM_EINVAL;
+                                     const int* n_blocks, const unsigned* blk_info, float* R, int skip_pattern_stride,
+                                     void* stream) {
+  if (!x || !R || !tiles || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || n_entries < 0 || skip_pattern_stride < 0) return NBM_EINVAL;
   if (!nbm_aligned16(x) || !nbm_aligned16(R)) return NBM_EALIGN;
   if (n_entries == 0) return NBM_OK;
   const int TH = (H + 1) >> 1, TW = (W + 1) >> 1, WP = 2 * TW + 2;
@@ -484,7 +494,7 @@ extern "C" int nbm_wino23_rows_tiles(const float* x, int B, int H, int W, int C,
   long long g = (n + 255) / 256;
   if (g > 16384) g = 16384;
   hipLaunchKernelGGL(wino23_rows_tiles_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, x, B, H, W, C / 4, TH, TW,
-                     WP, tiles, n_entries, n_blocks, blk_info, R);
+                     WP, tiles, n_entries, n_blocks, blk_info, R, skip_pattern_stride);
   return nbm_launch_status();
 }
 

@@ -164,14 +164,16 @@ class Conv(Function):
         wk = _prep.krsc(weight) if weight.dim() == 4 else weight.detach()
         gp = _pad32_rows(g.view(-1, N), N)
         gx = gw = gb = None
-        if ctx.lazy is not None and ctx.lazy.sparse and ctx.lazy.done != len(ctx.lazy.rois):
+        if ctx.lazy is not None and (ctx.lazy.sparse or ctx.lazy.overlap) and ctx.lazy.done != len(ctx.lazy.rois):
             raise RuntimeError('demand-driven FPN map: a RoI pooling ran on it without recording its tile lists (the map was '
                                'produced under no_grad?) -- its gradient would be dropped')
-        if ctx.needs_input_grad[0] and ctx.lazy is not None and ctx.lazy.sparse and LAZY_DGRAD and N % 32 == 0 and N >= 64:
+        listed = ctx.lazy is not None and ondemand.listed_backward(ctx.lazy) and (ctx.lazy.sparse or (LAZY_DGRAD and LAZY_WGRAD))
+        if ctx.needs_input_grad[0] and listed and LAZY_DGRAD and N % 32 == 0 and N >= 64:
             # demand-driven map: the incoming gradient lives on the pattern pixels and in the RoI windows, the outgoing one
             # within a pixel of them -> the listed fused kernel on the tiles around them (F(2x2,3x3), no transforms through HBM)
+            other = _STASH.pop(x.data_ptr(), None) if ctx.take_x else None       # overlap level: taken over as the accumulation base
             gx = ondemand.conv3x3_winograd_dgrad_tiles(ctx.lazy, g.view(B, H, W, N), _prep.wino23(weight, transposed=True, m=2),
-                                                       _prep.cell_weight(weight) if ondemand.CELL_BWD else None)
+                                                       _prep.cell_weight(weight) if ondemand.CELL_BWD else None, base=other)
         elif ctx.needs_input_grad[0] and ctx.wino and N % 32 == 0:
             # data gradient of a 3x3 / stride 1 / pad 1 convolution = the same convolution with the kernel rotated by 180
             # degrees and the channel roles swapped: Winograd again
@@ -190,7 +192,7 @@ class Conv(Function):
                 _STASH[x.data_ptr()] = gx
                 gx = None
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[1] and ctx.lazy is not None and ctx.lazy.sparse and LAZY_WGRAD:
+        if ctx.needs_input_grad[1] and listed and LAZY_WGRAD:
             # demand-driven map: the gradient is zero outside the tiles that were computed -> F(2x2,3x3) over those tiles only
             dU, gb, dUc = ondemand.conv3x3_winograd_wgrad_tiles(ctx.lazy, x, g.view(B, H, W, N), want_bias=want_gb)
             gw = _prep.wino23_weight_grad(dU, 2)

@@ -133,9 +133,11 @@ def wino23_pattern(B, H, W, stride, device, dilate=0):
     return hit
 
 
-def _wino23_tiles_run(x, U, bias, y_ptr, tiles, n_blocks, n_listed, label, blk_info=None, dense_rows=False):
+def _wino23_tiles_run(x, U, bias, y_ptr, tiles, n_blocks, n_listed, label, blk_info=None, dense_rows=False, skip_pattern=0,
+                      accumulate=False):
     """Rows transform + fused kernel for the listed tiles of x [B,H,W,C] -> pixels of the map at device address y_ptr.
-    n_listed: executed work in 16-plane tile equivalents (None: device-side count in n_blocks)."""
+    n_listed: executed work in 16-plane tile equivalents (None: device-side count in n_blocks).  skip_pattern = S: the pixels of the
+    3x3 / stride-S pattern of x read as zeros; accumulate: the result is added to the map (every tile listed once)."""
     B, H, W, C_ = x.shape
     N = U.shape[1]
     per_img = 4 * (-(-H // 2)) * (2 * (-(-W // 2)) + 2) * C_
@@ -152,14 +154,14 @@ def _wino23_tiles_run(x, U, bias, y_ptr, tiles, n_blocks, n_listed, label, blk_i
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         if ops._prof_all():
             ev[0].record()
-    if dense_rows:                                # every tile is listed: the plain row transform writes half the bytes
+    if dense_rows and not skip_pattern:           # every tile is listed: the plain row transform writes half the bytes
         check(lib().nbm_wino23_rows(_ptr(x), B, H, W, C_, _ptr(R), st), 'nbm_wino23_rows')
     else:
-        check(lib().nbm_wino23_rows_tiles(_ptr(x), B, H, W, C_, _ptr(tiles), tiles.numel(), nb_ptr, _ptr(blk_info), _ptr(R), st),
-              'nbm_wino23_rows_tiles')
+        check(lib().nbm_wino23_rows_tiles(_ptr(x), B, H, W, C_, _ptr(tiles), tiles.numel(), nb_ptr, _ptr(blk_info), _ptr(R), int(skip_pattern),
+                                          st), 'nbm_wino23_rows_tiles')
     if prof:
         ev[1].record()
-    check(lib().nbm_wino23_conv_fused_tiles(_ptr(R), _ptr(U), None, _ptr(bias), None, 0, B, H, W, C_, N, C.c_void_p(y_ptr), _ptr(tiles),
+    check(lib().nbm_wino23_conv_fused_tiles(_ptr(R), _ptr(U), None, _ptr(bias), None, 2 if accumulate else 0, B, H, W, C_, N, C.c_void_p(y_ptr), _ptr(tiles),
                                             tiles.numel(), nb_ptr, _ptr(blk_info), st), 'nbm_wino23_conv_fused_tiles')
     if prof:
         ev[2].record()
@@ -184,11 +186,12 @@ class LazyMap:
     12 GB alive until the garbage collector runs); its consumers keep it alive and hand it back to `lazy_complete`.
     The operands stay here for as long as the map lives, so EVERY RoI pooling on the map -- not only the first -- finds the
     tiles under its windows computed (`done` counts them); the state goes when the map does (`_forget`)."""
-    __slots__ = ('x', 'U', 'bias', 'skip', 'stride', 'chunks', 'roi', 'keep', 'sparse', 'lateral', 'rois', 'done', 'vg', 'cell_gb', 'cell_gb_done', 'vx', '__weakref__')
+    __slots__ = ('x', 'U', 'bias', 'skip', 'stride', 'chunks', 'roi', 'keep', 'sparse', 'overlap', 'lateral', 'rois', 'done', 'vg', 'cell_gb', 'cell_gb_done', 'vx', '__weakref__')
 
     def __init__(self, x, U, bias, stride):
         self.x, self.U, self.bias, self.stride = x, U, bias, stride
         self.skip, self.chunks, self.keep, self.sparse, self.lateral = None, [], False, True, None
+        self.overlap = False         # dense-looking level (every tile holds a pattern pixel) whose backward pass still goes through the cells
         self.roi = []           # per RoI pooling: per chunk (tile list, pinned block count, event)
         self.rois = []          # per RoI pooling: (rois, n_roi, n_levels, level, fh, fw)
         self.done = 0
@@ -357,6 +360,9 @@ def conv3x3_winograd_lazy(x, U, bias, stride, Ucell=None, fold=None, keep=False)
         st.skip = pat.full
         st.chunks.append((b0, nb, pat))
         st.sparse = pat.frac < 0.6               # the weight gradient over the listed tiles pays off when most are not listed
+        # stride 3 / 4: no tile is free of pattern pixels, but the gradient still lives on 9 / S^2 of the pixels (+ the RoI windows):
+        # the cell transforms take that share (overlapping 5x5 patches, added class by class), the listed kernel the RoI share
+        st.overlap = bool(not st.sparse and cell_ok and CELL_BWD and 3 <= stride < 5 and N % 32 == 0)
         if cell_ok:                                  # (3x3 blocks of different cells never overlap)
             stream = _stream()
             Vx, M, K, T = _cell_operand(st, b0, nb, H, W, C_, x, n_out=N, ci=ci)
@@ -417,7 +423,7 @@ def lazy_complete(fm, rois, n_roi, fmap_hw, level=0):
     fh = (C.c_int * nl)(*[int(h) for h, _ in fmap_hw])
     fw = (C.c_int * nl)(*[int(w) for _, w in fmap_hw])
     blocks_per_img = -(-((H + 1) // 2 * ((W + 1) // 2)) // 128)
-    keep = st.keep and st.sparse                  # a backward pass will want the lists
+    keep = st.keep and (st.sparse or st.overlap)  # a backward pass will want the lists
     per_chunk = []
     for b0, nb, _ in st.chunks:
         key = (str(x.device), nb * blocks_per_img * 128)
@@ -547,10 +553,17 @@ def _cell_outgrad(st, g, ci, b0, nb):
 
 
 def cell_usable(st, H, W, C_, N):
-    return CELL_BWD and st.stride >= 5 and C_ % 32 == 0 and N % 32 == 0 and H >= 3 and W >= 3
+    return CELL_BWD and (st.stride >= 5 or st.overlap) and C_ % 32 == 0 and N % 32 == 0 and H >= 3 and W >= 3
 
 
-def conv3x3_winograd_dgrad_tiles(st, g, Ut, Ucell=None):
+def listed_backward(st):
+    """The backward pass of this demand-driven convolution can run over its pattern / RoI footprint (Fn.Conv.backward): always for
+    a sparse level; for an `overlap` level while at most one RoI pooling read the map (its RoI share is ADDED to the cell share, so a
+    tile must not be listed twice -- two poolings fall back to the dense kernels)."""
+    return st.sparse or (st.overlap and len(st.rois) <= 1)
+
+
+def conv3x3_winograd_dgrad_tiles(st, g, Ut, Ucell=None, base=None):
     """Data gradient of a demand-driven convolution (LazyMap `st`): g [B,H,W,N] is zero except on the pattern pixels and inside
     the RoI windows, so the gradient wrt the input is zero except within two pixels of the pattern blocks and one pixel of the
     windows.  Pattern share (`Ucell` = _prep.cell_weight: [25][C][N]): per stride x stride cell the full convolution of the 3x3
@@ -558,7 +571,10 @@ def conv3x3_winograd_dgrad_tiles(st, g, Ut, Ucell=None):
     transform into a zero-filled map).  RoI share: the same convolution operator (Ut = weights rotated / channel-swapped,
     F(2x2,3x3)) through the listed fused kernel on the tiles within a pixel of the RoI windows, which reads ALL of g there and
     so overwrites those tiles with their complete values.  Without `Ucell` (or NBM_CELL_BWD=0) the pattern share also goes
-    through the listed fused kernel: the static list of the tiles around the pattern (56 % of the tiles, 16 / 12 / 9 planes)."""
+    through the listed fused kernel: the static list of the tiles around the pattern (56 % of the tiles, 16 / 12 / 9 planes).
+    `st.overlap` (stride 3 / 4: the 5x5 patches of neighbouring cells overlap): the patches are ADDED, one parity class of cells per
+    launch, into `base` (the gradient another consumer of the input left, taken over in place) or zeros, and the RoI share -- g
+    with its pattern pixels read as zeros -- is added on top by the listed kernel."""
     _chk(g, name='g'), _chk(Ut, name='Ut')
     B, H, W, N = g.shape
     C_ = Ut.shape[1]
@@ -566,13 +582,19 @@ def conv3x3_winograd_dgrad_tiles(st, g, Ut, Ucell=None):
     img_bytes = H * W * C_ * 4
     blocks_per_img = -(-((H + 1) // 2 * ((W + 1) // 2)) // 128)
     cell = Ucell is not None and cell_usable(st, H, W, C_, N)
+    overlap = cell and st.stride < 5
+    if base is not None and not overlap:
+        raise ValueError('conv3x3_winograd_dgrad_tiles: `base` is only taken over by the accumulating (overlap) form')
     pool = None
-    if cell and ZERO_POOL:
+    if overlap:
+        assert len(st.rois) <= 1
+        gx = base if base is not None else torch.zeros((B, H, W, C_), device=g.device, dtype=torch.float32)
+    elif cell and ZERO_POOL:
         # persistent map (see zero_acquire): the cell patches are rewritten by every pass, only the RoI tiles have to be undone
         gx, pool = zero_acquire((B, H, W, C_), g.device, ('cell-dgrad', st.stride))
         if pool is not None and ZERO_POOL_CHECK:
             pool['check'] = lambda buf, s_=st.stride: _check_zero_outside_patches(buf, s_)
-    if pool is None:
+    if pool is None and not overlap:
         gx = torch.zeros((B, H, W, C_), device=g.device, dtype=torch.float32)
     if cell:
         assert Ucell.shape == (25, C_, N)
@@ -587,8 +609,9 @@ def conv3x3_winograd_dgrad_tiles(st, g, Ut, Ucell=None):
                 gemm_conv(vg, Ucell, M, B=1, H=T, W=1, Cin=N, N=C_, groups=25, x_gs=T * N, w_gs=C_ * N, y_gs=T * C_)
             finally:
                 ops._PROFILE_LABEL = global_label
-            check(lib().nbm_cell_dgrad_output(_ptr(M), nb, H, W, C_, st.stride, C.c_void_p(gx.data_ptr() + b0 * img_bytes), _stream()),
-                  'nbm_cell_dgrad_output')
+            for cls in (range(4) if overlap else (-1,)):
+                check(lib().nbm_cell_dgrad_output(_ptr(M), nb, H, W, C_, st.stride, C.c_void_p(gx.data_ptr() + b0 * img_bytes), cls, _stream()),
+                      'nbm_cell_dgrad_output')
         else:
             pat = wino23_pattern(nb, H, W, st.stride, g.device, dilate=1)
             _wino23_tiles_run(g[b0:b0 + nb], Ut, None, gx.data_ptr() + b0 * img_bytes, pat.tiles, None, pat.n_eff, 'wino23-dgrad',
@@ -603,7 +626,8 @@ def conv3x3_winograd_dgrad_tiles(st, g, Ut, Ucell=None):
             tiles, n_blocks = buf
             check(lib().nbm_roi_tiles(_ptr(rois[b0:b0 + nb]), _ptr(n_roi[b0:b0 + nb] if per else n_roi), nb, rois.shape[1], nl, level,
                                       fh, fw, None if cell else _ptr(pat.full), 1, _ptr(tiles), _ptr(n_blocks), per, _stream()), 'nbm_roi_tiles')
-            _wino23_tiles_run(g[b0:b0 + nb], Ut, None, gx.data_ptr() + b0 * img_bytes, tiles, n_blocks, None, 'wino23-dgrad-rois')
+            _wino23_tiles_run(g[b0:b0 + nb], Ut, None, gx.data_ptr() + b0 * img_bytes, tiles, n_blocks, None, 'wino23-dgrad-rois',
+                              skip_pattern=st.stride if overlap else 0, accumulate=overlap)
             if pool is not None:
                 tl, nbk = tiles.clone(), n_blocks.clone()          # the list buffer is shared by all chunks / levels
                 zero_note(pool, lambda p_=gx.data_ptr() + b0 * img_bytes, nb_=nb, tl_=tl, nbk_=nbk: check(

@@ -141,9 +141,14 @@ int nbm_wino23_conv_fused(const float* R, const float* U, const float* scale, co
  *                                a 3x3 convolution of those windows is non-zero);
  *                                tiles must hold B * ceil(TH * TW / 128) * 128 entries; writes *n_blocks. */
 int nbm_wino23_rows_tiles(const float* x, int B, int H, int W, int C, const int* tiles, int n_entries, const int* n_blocks,
-                          const unsigned* blk_info, float* R, void* stream);
+                          const unsigned* blk_info, float* R,
+                          int skip_pattern_stride /* S > 0: the pixels of the 3x3 / stride-S / pad-1 pattern read as zeros (x is a
+                                                     gradient map whose pattern share the cell transforms take, see below) */,
+                          void* stream);
 int nbm_wino23_conv_fused_tiles(const float* R, const float* U, const float* scale, const float* shift, const float* mask,
-                                int relu, int B, int H, int W, int C, int N, float* y, const int* tiles, int n_entries,
+                                int relu /* bit 0: ReLU; bit 1: ADD the result to y instead of storing it (a tile may then be
+                                            listed only once) */,
+                                int B, int H, int W, int C, int N, float* y, const int* tiles, int n_entries,
                                 const int* n_blocks, const unsigned* blk_info, void* stream);
 int nbm_roi_tiles(const float* rois, const int* n_roi, int B, int roi_cap, int n_levels, int level, const int* fh,
                   const int* fw, const unsigned char* skip, int dilate, int* tiles, int* n_blocks,
@@ -168,8 +173,10 @@ int nbm_wino23_outgrad_tiles(const float* g, int B, int H, int W, int N, const i
  *   nbm_cell_outgrad       g [B][H][W][N] -> Vg [25][cells][N] = E blk E^T (+ bias_grad [N] += sum of the block pixels, optional)
  *   nbm_cell_input         x [B][H][W][C] -> Vx [25][cells][C] = Vinv^T patch Vinv
  *   nbm_cell_dgrad_output  M [25][cells][C] (= Vg_xi U_xi^T, nbm_gemm_conv with groups = 25, U = E w E^T from the host)
- *                          -> the 5x5 pixels of every cell in gx [B][H][W][C] (patches do not overlap: S >= 5; other pixels
- *                          are not written)
+ *                          -> the 5x5 pixels of every cell in gx [B][H][W][C] (parity_class < 0: stored, patches do not overlap:
+ *                          S >= 5, other pixels are not written; parity_class 0..3, S >= 3: the cells with
+ *                          (oy & 1, ox & 1) == (class >> 1, class & 1) only, ADDED to gx -- four launches accumulate the
+ *                          overlapping patches of a stride-3 / 4 pattern)
  * the weight gradient's 25 TN GEMMs dU_xi = Vg_xi^T Vx_xi are nbm_conv_wgrad with groups = 25; dW = E^T dU E on the host. */
 int nbm_cell_outgrad(const float* g, int B, int H, int W, int N, int stride, float* Vg, float* bias_grad, void* stream);
 int nbm_cell_input(const float* x, int B, int H, int W, int C, int stride, float* Vx, int ld /* row pitch of Vx, >= c_off + C */,
@@ -178,7 +185,7 @@ int nbm_cell_input(const float* x, int B, int H, int W, int C, int stride, float
  * top-down merge of fpn.py:143-144 without its lateral term), 0 outside the image */
 int nbm_cell_input_up(const float* x1, const float* bias, int B, int H, int W, int C, int Hc, int Wc, int stride, float* Vx, int ld,
                       int c_off, void* stream);
-int nbm_cell_dgrad_output(const float* M, int B, int H, int W, int C, int stride, float* gx, void* stream);
+int nbm_cell_dgrad_output(const float* M, int B, int H, int W, int C, int stride, float* gx, int parity_class, void* stream);
 /* FORWARD of the pattern pixels with the same 25 products per cell (the correlation form, F(3x3,3x3)): nbm_cell_input of the
  * input, M_xi = Vx_xi U_xi^T (U = E w E^T as [25][N][C]), then blk = E^T M E + bias into the 3x3 pattern block of every cell of
  * y [B][H][W][N] (other pixels are not written). */

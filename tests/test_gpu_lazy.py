@@ -333,6 +333,63 @@ def test_data_gradient_over_the_listed_tiles_equals_the_dense_one(cell):
     assert bool((got.cpu()[(ref == 0).all(-1)] == 0).all())          # exact zeros where no gradient can arrive
 
 
+@pytest.mark.parametrize('with_base', [False, True])
+def test_overlap_level_backward_equals_the_dense_one(with_base):
+    """Stride 4 (FPN level P2): every tile holds a pattern pixel, so the level is not `sparse`, but its gradient still lives on the
+    3x3 blocks of the 4x4 cells and in the RoI windows.  `overlap` backward: data gradient = the 5x5 cell patches ADDED class by
+    class (they overlap) onto `base` (another consumer's gradient, taken over in place) + the RoI share from the listed kernel
+    with the pattern pixels masked, accumulated; weight gradient = cells + masked RoI tiles.  Both == torch."""
+    import torch.nn.functional as F
+    B, H, W, C, N, S = 2, 47, 66, 128, 64, 4
+    x = rnd('ox', B, H, W, C).cuda()
+    w = rnd('ow', N, C, 3, 3, scale=0.05).cuda()
+    b = rnd('ob', N).cuda()
+    y, st = ondemand.conv3x3_winograd_lazy(x, _prep.wino23(w), b, S, Ucell=_prep.cell_weight(w, forward=True), keep=True)
+    assert st.overlap and not st.sparse and ondemand.listed_backward(st)
+    fh = [2 * H, H, (H + 1) // 2, (H + 3) // 4, (H + 7) // 8]
+    fw = [2 * W, W, (W + 1) // 2, (W + 3) // 4, (W + 7) // 8]
+    rois_np = np.array([[[10., 12., 40., 36.], [100., 60., 131., 90.], [0., 0., 30., 22.], [200., 150., 236., 180.], [40., 40., 52., 50.],
+                         [60., 20., 160., 140.]]] * B, dtype=np.float32)
+    rois_np[1, :, [0, 2]] += 7
+    rois = torch.from_numpy(rois_np).cuda()
+    ondemand.lazy_complete(y, rois, torch.tensor([6], dtype=torch.int32, device='cuda'), list(zip(fh, fw)), level=1)
+    assert len(st.rois) == 1
+    m = torch.zeros(B, H, W, dtype=torch.bool)
+    rows, cols = torch.zeros(H, dtype=torch.bool), torch.zeros(W, dtype=torch.bool)
+    for n_, v in ((H, rows), (W, cols)):
+        for o in range((n_ - 1) // S + 1):
+            for k in range(3):
+                if 0 <= S * o - 1 + k < n_:
+                    v[S * o - 1 + k] = True
+    m |= (rows[:, None] & cols[None, :])[None]
+    n1 = 0
+    for bi in range(B):
+        for r in range(rois_np.shape[1]):
+            lvl, x1, y1, x2, y2 = window(rois_np[bi, r], fh, fw)
+            if lvl == 1:
+                n1 += 1
+                m[bi, y1:y2 + 1, x1:x2 + 1] = True
+    assert n1 >= 3 * B and not bool(m.all())
+    g = (rnd('og', B, H, W, N) * m[..., None]).cuda().contiguous()
+    base = rnd('obase', B, H, W, C).cuda() if with_base else None
+    base0 = base.clone() if with_base else None
+    got = ondemand.conv3x3_winograd_dgrad_tiles(st, g, _prep.wino23(w, transposed=True, m=2), _prep.cell_weight(w), base=base)
+    if with_base:
+        assert got.data_ptr() == base.data_ptr()                          # taken over in place
+    xr = x.permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
+    wr = w.double().cpu().requires_grad_(True)
+    F.conv2d(xr, wr, None, 1, 1).backward(g.permute(0, 3, 1, 2).double().cpu())
+    ref = xr.grad.permute(0, 2, 3, 1).float() + (base0.cpu() if with_base else 0)
+    err = (got.cpu() - ref).abs().max().item()
+    assert err < 2e-5 * ref.abs().max().item() + 1e-6, (err, ref.abs().max().item())
+    dU, gb, dUc = ondemand.conv3x3_winograd_wgrad_tiles(st, x, g, want_bias=True)
+    assert dUc is not None
+    gw = _prep.wino23_weight_grad(dU, 2) + _prep.cell_weight_grad(dUc)
+    errw = (gw.cpu() - wr.grad.float()).abs().max().item()
+    assert errw < 2e-4 * wr.grad.abs().max().item() + 1e-5, (errw, wr.grad.abs().max().item())
+    assert torch.allclose(gb.cpu(), g.sum((0, 1, 2)).cpu(), rtol=1e-4, atol=1e-4)
+
+
 def test_lateral_on_listed_pixels_equals_the_dense_lateral():
     """ondemand.conv1x1_lazy (igemm ROWS variant, pixel list) and the RoI-phase patches (tile list x 16): the written pixels equal
     the dense lateral + merge bit for bit, nothing else is written."""
