@@ -496,37 +496,52 @@ __global__ void dwconv_bwd_data_kernel(const float* __restrict__ g, int B, int H
 template <int MULT>
 __global__ void dwconv_bwd_data_scatter_kernel(const float* __restrict__ g, int B, int H, int W, int Cin, int mult_rt, int stride,
                                                const float* __restrict__ w, float* __restrict__ gx, int Ho, int Wo) {
+  // one thread = (output pixel, 4 input channels): its gradient values and the 9 taps' weights are read once, then nine 16-byte
+  // read-modify-writes (the first form took one tap per thread and re-read both for every tap: 2.5 -> 1.9 ms; this one -> see DESIGN)
   const int mult = MULT > 0 ? MULT : mult_rt;
   const int Cout = Cin * mult, C4 = Cin >> 2;
-  const long long total = (long long)B * Ho * Wo * 9 * C4;
+  const long long total = (long long)B * Ho * Wo * C4;
   f32x4* o4 = reinterpret_cast<f32x4*>(gx);
   GRID_STRIDE(i, total) {
     const int c = (int)(i % C4);
     long long t = i / C4;
-    const int tap = (int)(t % 9); t /= 9;
     const int ox = (int)(t % Wo); t /= Wo;
     const int oy = (int)(t % Ho);
     const int b = (int)(t / Ho);
-    const int r = tap / 3, s = tap - r * 3;
-    const int iy = oy * stride - 1 + r, ix = ox * stride - 1 + s;
-    if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
     const int c0 = c * 4;
     const float* gp = g + ((long long)(b * Ho + oy) * Wo + ox) * Cout + c0 * mult;
-    const float* wp = w + (long long)c0 * mult * 9 + tap;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* wp = w + (long long)c0 * mult * 9;
     if constexpr (MULT == 2) {
       const f32x4 g0 = reinterpret_cast<const f32x4*>(gp)[0], g1 = reinterpret_cast<const f32x4*>(gp)[1];
-      acc[0] += g0[0] * wp[0];  acc[0] += g0[1] * wp[9];
-      acc[1] += g0[2] * wp[18]; acc[1] += g0[3] * wp[27];
-      acc[2] += g1[0] * wp[36]; acc[2] += g1[1] * wp[45];
-      acc[3] += g1[2] * wp[54]; acc[3] += g1[3] * wp[63];
-    } else {
+      float w8[8][9];
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        for (int e = 0; e < mult; ++e) acc[k] += gp[k * mult + e] * wp[(k * mult + e) * 9];
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) w8[q][k] = wp[q * 9 + k];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int iy = oy * stride - 1 + tap / 3, ix = ox * stride - 1 + tap % 3;
+        if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc[0] += g0[0] * w8[0][tap]; acc[0] += g0[1] * w8[1][tap];
+        acc[1] += g0[2] * w8[2][tap]; acc[1] += g0[3] * w8[3][tap];
+        acc[2] += g1[0] * w8[4][tap]; acc[2] += g1[1] * w8[5][tap];
+        acc[3] += g1[2] * w8[6][tap]; acc[3] += g1[3] * w8[7][tap];
+        const long long o = (((long long)b * H + iy) * W + ix) * C4 + c;
+        o4[o] = o4[o] + acc;
+      }
+    } else {
+      for (int tap = 0; tap < 9; ++tap) {
+        const int iy = oy * stride - 1 + tap / 3, ix = ox * stride - 1 + tap % 3;
+        if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          for (int e = 0; e < mult; ++e) acc[k] += gp[k * mult + e] * wp[(k * mult + e) * 9 + tap];
+        const long long o = (((long long)b * H + iy) * W + ix) * C4 + c;
+        o4[o] = o4[o] + acc;
+      }
     }
-    const long long o = (((long long)b * H + iy) * W + ix) * C4 + c;
-    o4[o] = o4[o] + acc;
   }
 }
 
@@ -1009,7 +1024,7 @@ extern "C" int nbm_dwconv3x3_bwd_acc(const float* g, const float* w, int B, int 
   if ((H + 2 - 3) / stride + 1 != Ho || (W + 2 - 3) / stride + 1 != Wo) return NBM_EINVAL;
   if ((Cin & 3) || !nbm_aligned16(gx)) return NBM_EALIGN;
   if (stride >= 3 && (mult != 2 || nbm_aligned16(g))) {          // disjoint 3x3 blocks: scatter form
-    const dim3 sg(grid_for((long long)B * Ho * Wo * 9 * (Cin / 4)));
+    const dim3 sg(grid_for((long long)B * Ho * Wo * (Cin / 4)));
     if (mult == 2) hipLaunchKernelGGL(dwconv_bwd_data_scatter_kernel<2>, sg, dim3(TPB), 0, ST, g, B, H, W, Cin, mult, stride, w, gx, Ho, Wo);
     else hipLaunchKernelGGL(dwconv_bwd_data_scatter_kernel<0>, sg, dim3(TPB), 0, ST, g, B, H, W, Cin, mult, stride, w, gx, Ho, Wo);
     return nbm_launch_status();
