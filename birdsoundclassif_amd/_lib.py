@@ -99,6 +99,8 @@ SIGNATURES = {
     'nbm_zero_roi_windows': [_P, _I, _I, _I, _P, _P, _I, _I, _I, _P],
     'nbm_zero_pattern': [_P, _I, _I, _I, _I, _I, _P],
     'nbm_zero_tiles': [_P, _I, _I, _I, _I, _P, _I, _P, _P],
+    'nbm_tiles_gather': [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P],
+    'nbm_tiles_scatter_add': [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P],
     'nbm_proposal_iou': [_P, _P, _P, _I, _I, _I, _P, _P, _P],
     'nbm_maxpool3x3s2_bwd': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     'nbm_upsample_bilinear_bwd': [_P, _I, _I, _I, _I, _P, _I, _I, _P],
@@ -122,7 +124,7 @@ SIGNATURES = {
     'nbm_cell_outgrad': [_P, _I, _I, _I, _I, _I, _P, _P, _P],
     'nbm_cell_input': [_P, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     'nbm_cell_input_up': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P],
-    'nbm_cell_dgrad_output': [_P, _I, _I, _I, _I, _I, _P, _I, _P],
+    'nbm_cell_dgrad_output': [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P],
     'nbm_cell_output': [_P, _P, _I, _I, _I, _I, _I, _P, _P],
     'nbm_weighted_sum': [_P, _P, _P, _P, _P, _L, _P],
     'nbm_weighted_sum_bwd': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P],

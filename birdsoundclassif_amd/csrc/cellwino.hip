@@ -209,10 +209,12 @@ __global__ __launch_bounds__(256) void cell_input_up_kernel(const float* __restr
 // cls = 0..3 (S >= 3): only the cells with (oy & 1, ox & 1) == (cls >> 1, cls & 1), and the patch is ADDED to gx -- cells of one
 // parity class are 2 S >= 6 pixels apart, so four launches accumulate the overlapping patches of a stride-3 / 4 pattern without atomics
 __global__ __launch_bounds__(256) void cell_dgrad_output_kernel(const float* __restrict__ M, const CellGeom q, float* __restrict__ gx,
-                                                                int cls) {
+                                                                int cls, int ld4, int coff4, float* __restrict__ bias_grad) {
   const f32x4* m4 = reinterpret_cast<const f32x4*>(M);
   f32x4* o4 = reinterpret_cast<f32x4*>(gx);
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum = zero;                   // bias_grad (optional) += sum of the patch pixels inside the image (as in cell_outgrad_kernel)
+  int my_c = -1;
   const unsigned total = (unsigned)(q.T * q.C4);
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     const int c = (int)(i % (unsigned)q.C4);
@@ -220,6 +222,7 @@ __global__ __launch_bounds__(256) void cell_dgrad_output_kernel(const float* __r
     int b, oy, ox;
     cell_of(q, cell, b, oy, ox);
     if (cls >= 0 && (((oy & 1) << 1) | (ox & 1)) != cls) continue;
+    my_c = c;
     f32x4 t[NP][NP];                   // t[j][e] = sum_a Vinv[j][a] M[a][e]
 #pragma unroll
     for (int j = 0; j < NP; ++j)
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(256) void cell_dgrad_output_kernel(const float* __r
     for (int a = 0; a < NP; ++a)
 #pragma unroll
       for (int e = 0; e < NP; ++e) {
-        const f32x4 v = m4[((long long)(a * NP + e) * q.T + cell) * q.C4 + c];
+        const f32x4 v = m4[((long long)(a * NP + e) * q.T + cell) * ld4 + coff4 + c];
 #pragma unroll
         for (int j = 0; j < NP; ++j)
           if (CV[j][a] != 0.f) t[j][e] += CV[j][a] * v;
@@ -247,10 +250,23 @@ __global__ __launch_bounds__(256) void cell_dgrad_output_kernel(const float* __r
         for (int e = 0; e < NP; ++e)
           if (CV[l][e] != 0.f) o += CV[l][e] * t[j][e];
         const long long at = (((long long)b * q.H + y) * q.W + xx) * q.C4 + c;
+        bsum += o;
         if (cls >= 0) o += o4[at];
         o4[at] = o;
       }
     }
+  }
+  if (bias_grad) {                     // uniform
+    __shared__ float red[MAX_BIAS_N];
+    const int n = q.C4 * 4;
+    for (int k = threadIdx.x; k < n; k += 256) red[k] = 0.f;
+    __syncthreads();
+    if (my_c >= 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(&red[my_c * 4 + e], bsum[e]);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < n; k += 256) atomicAdd(bias_grad + k, red[k]);
   }
 }
 
@@ -357,13 +373,14 @@ extern "C" int nbm_cell_output(const float* M, const float* bias, int B, int H, 
   return nbm_launch_status();
 }
 
-extern "C" int nbm_cell_dgrad_output(const float* M, int B, int H, int W, int C, int stride, float* gx, int parity_class,
-                                     void* stream) {
+extern "C" int nbm_cell_dgrad_output(const float* M, int B, int H, int W, int C, int stride, float* gx, int parity_class, int ld,
+                                     int c_off, float* bias_grad, void* stream) {
   CellGeom q;
   // parity_class < 0: 5x5 patches are WRITTEN, no overlap allowed (stride >= 5); 0..3: one parity class of cells, ADDED (stride >= 3)
   if (!M || !gx || parity_class > 3 || !cell_geom(B, H, W, C, stride, q, parity_class < 0 ? 5 : 3)) return NBM_EINVAL;
+  if (ld < c_off + C || c_off < 0 || (ld & 3) || (c_off & 3) || (bias_grad && C > MAX_BIAS_N)) return NBM_EINVAL;
   if (!nbm_aligned16(M) || !nbm_aligned16(gx)) return NBM_EALIGN;
   hipLaunchKernelGGL(cell_dgrad_output_kernel, dim3(stream_grid(q.T * q.C4, q.C4)), dim3(256), 0, (hipStream_t)stream, M, q, gx,
-                     parity_class);
+                     parity_class, ld / 4, c_off / 4, bias_grad);
   return nbm_launch_status();
 }

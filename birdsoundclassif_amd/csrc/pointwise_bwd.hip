@@ -852,6 +852,33 @@ __global__ void zero_tiles_kernel(float* __restrict__ g, int H, int W, int C4, c
   }
 }
 
+// compact [n_entries][2][2][C] <-> the 2x2 tiles of a list in a map [B][H][W][C].  MODE 0: compact = map (pixels outside the image:
+// zeros); MODE 1: map += compact (every tile listed once)
+template <int MODE>
+__global__ void tiles_copy_kernel(float* __restrict__ map, int H, int W, int C4, const int* __restrict__ tiles,
+                                  const int* __restrict__ n_blocks, float* __restrict__ compact) {
+  if (n_blocks && (int)blockIdx.x >= *n_blocks) return;
+  const int TH = (H + 1) >> 1, TW = (W + 1) >> 1;
+  f32x4* m4 = reinterpret_cast<f32x4*>(map);
+  f32x4* c4 = reinterpret_cast<f32x4*>(compact);
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  for (int e = 0; e < 128; ++e) {
+    const int ent = blockIdx.x * 128 + e;
+    const int t = tiles[ent];
+    if (t < 0) continue;                       // block-uniform
+    const int b = t / (TH * TW), rem = t - b * (TH * TW);
+    const int ty = rem / TW, tx = rem - ty * TW;
+    for (int i = threadIdx.x; i < 4 * C4; i += blockDim.x) {
+      const int c = i % C4, px = i / C4;
+      const int y = 2 * ty + (px >> 1), x = 2 * tx + (px & 1);
+      const bool in = y < H && x < W;
+      const long long mi = (((long long)b * H + y) * W + x) * C4 + c, ci = ((long long)ent * 4 + px) * C4 + c;
+      if (MODE == 0) c4[ci] = in ? m4[mi] : z;
+      else if (in) m4[mi] = m4[mi] + c4[ci];
+    }
+  }
+}
+
 // ---- optimiser: squared gradient norm, then clip + AdamW (torch.optim.AdamW semantics, decoupled decay)
 __global__ void sqnorm_kernel(const float* __restrict__ g, long long n, double* __restrict__ out) {
   double acc = 0.0;
@@ -1100,6 +1127,22 @@ extern "C" int nbm_zero_tiles(float* g, int B, int H, int W, int C, const int* t
   if (!g || !tiles || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || n_entries <= 0 || (n_entries & 127)) return NBM_EINVAL;
   if (!nbm_aligned16(g)) return NBM_EALIGN;
   hipLaunchKernelGGL(zero_tiles_kernel, dim3(n_entries / 128), dim3(256), 0, ST, g, H, W, C / 4, tiles, n_blocks);
+  return nbm_launch_status();
+}
+extern "C" int nbm_tiles_gather(const float* map, int B, int H, int W, int C, const int* tiles, int n_entries, const int* n_blocks,
+                                float* compact, void* stream) {
+  if (!map || !tiles || !compact || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || n_entries <= 0 || (n_entries & 127)) return NBM_EINVAL;
+  if (!nbm_aligned16(map) || !nbm_aligned16(compact)) return NBM_EALIGN;
+  hipLaunchKernelGGL(tiles_copy_kernel<0>, dim3(n_entries / 128), dim3(256), 0, ST, const_cast<float*>(map), H, W, C / 4, tiles, n_blocks,
+                     compact);
+  return nbm_launch_status();
+}
+extern "C" int nbm_tiles_scatter_add(float* map, int B, int H, int W, int C, const int* tiles, int n_entries, const int* n_blocks,
+                                     const float* compact, void* stream) {
+  if (!map || !tiles || !compact || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || n_entries <= 0 || (n_entries & 127)) return NBM_EINVAL;
+  if (!nbm_aligned16(map) || !nbm_aligned16(compact)) return NBM_EALIGN;
+  hipLaunchKernelGGL(tiles_copy_kernel<1>, dim3(n_entries / 128), dim3(256), 0, ST, map, H, W, C / 4, tiles, n_blocks,
+                     const_cast<float*>(compact));
   return nbm_launch_status();
 }
 extern "C" int nbm_sqnorm_accum(const float* g, int64_t n, double* out, void* stream) {

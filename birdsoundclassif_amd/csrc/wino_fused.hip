@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256, BN == 128 ? 1 : 2) void wino23_fused_kernel(co
     if (t >= 0) {
       const int bi = t / p.THW, rem = t - bi * p.THW;
       const int ty = rem / p.TW, tx = rem - ty * p.TW;
-      const long long pix = ((long long)bi * p.H + 2 * ty) * p.W + 2 * tx;
+      const long long pix = (p.relu & 4) ? (long long)(bm0 + tid) * 4 : ((long long)bi * p.H + 2 * ty) * p.W + 2 * tx;
       v = (pix << 2) | (2 * ty + 1 < p.H ? 2 : 0) | (2 * tx + 1 < p.W ? 1 : 0);
     }
     row_pix[tid] = v;
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256, BN == 128 ? 1 : 2) void wino23_fused_kernel(co
           if (rp < 0) break;
           if ((rp & need) != need) continue;
           f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CP + cc * 4);
-          const long long idx = ((rp >> 2) + pp * p.W + qq) * p.N + n;
+          const long long idx = ((rp >> 2) + ((p.relu & 4) ? pp * 2 + qq : pp * p.W + qq)) * p.N + n;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = v[e] * sc[e] + sh[e];
           if (p.relu & 1) {

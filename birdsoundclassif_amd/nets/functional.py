@@ -122,7 +122,7 @@ class Conv(Function):
         sh = bias.detach() if bias is not None else shift
         ctx.wino = _winograd_ok(x, weight, kh, kw, stride, pad) and scale is None and residual is None and \
             act == ACT_NONE and alpha == 1.0 and up is None
-        ctx.lazy = None
+        ctx.lazy = ctx.lat_state = None
         if ctx.wino and lazy_stride:
             # demand-driven map (ondemand.conv3x3_winograd_lazy): the tiles a 3x3 / lazy_stride consumer reads now, the tiles under
             # the RoIs when the RoI pooling asks for them; the backward pass is the dense one (the incoming gradient is
@@ -137,6 +137,8 @@ class Conv(Function):
             # pass (if one can follow) is the cell-domain one, the only one that does not read the pattern patches of this map
             defer = not any(ctx.needs_input_grad) or (ondemand.CELL_BWD and LAZY_WGRAD and LAZY_DGRAD)
             y = ondemand.conv1x1_lazy(x, _prep.krsc(weight), sh, alpha, up, lazy_stride[0], defer=defer)
+            hit = ondemand._LAZY_LATERAL.get(y.data_ptr())
+            ctx.lat_state = hit[0] if hit is not None else None      # its consumer's backward pass may leave this node's gradients there
         elif ctx.wino:        # large 3x3 (FPN output convolutions): Winograd F(2x2,3x3), 2.25x fewer multiplies
             y = ops.conv3x3_winograd(x, _prep.wino23(weight), sh)
         else:
@@ -168,12 +170,17 @@ class Conv(Function):
             raise RuntimeError('demand-driven FPN map: a RoI pooling ran on it without recording its tile lists (the map was '
                                'produced under no_grad?) -- its gradient would be dropped')
         listed = ctx.lazy is not None and ondemand.listed_backward(ctx.lazy) and (ctx.lazy.sparse or (LAZY_DGRAD and LAZY_WGRAD))
+        # a deferred lateral whose consumer's backward pass (which ran before this node's) already produced this node's gradients
+        pre = ctx.lat_state.grads if ctx.lat_state is not None else None
+        if pre is not None and (pre['gw_cell'] is None or scale is not None or kh != 1):
+            pre = None
         if ctx.needs_input_grad[0] and listed and LAZY_DGRAD and N % 32 == 0 and N >= 64:
             # demand-driven map: the incoming gradient lives on the pattern pixels and in the RoI windows, the outgoing one
             # within a pixel of them -> the listed fused kernel on the tiles around them (F(2x2,3x3), no transforms through HBM)
             other = _STASH.pop(x.data_ptr(), None) if ctx.take_x else None       # overlap level: taken over as the accumulation base
             gx = ondemand.conv3x3_winograd_dgrad_tiles(ctx.lazy, g.view(B, H, W, N), _prep.wino23(weight, transposed=True, m=2),
-                                                       _prep.cell_weight(weight) if ondemand.CELL_BWD else None, base=other)
+                                                       _prep.cell_weight(weight) if ondemand.CELL_BWD else None, base=other,
+                                                       lateral_grads=LAZY_WGRAD and ctx.needs_input_grad[1])
         elif ctx.needs_input_grad[0] and ctx.wino and N % 32 == 0:
             # data gradient of a 3x3 / stride 1 / pad 1 convolution = the same convolution with the kernel rotated by 180
             # degrees and the channel roles swapped: Winograd again
@@ -185,9 +192,12 @@ class Conv(Function):
                 gx = ops.axpby(gx, other)
         elif ctx.needs_input_grad[0]:
             other = _STASH.pop(x.data_ptr(), None) if ctx.take_x else None
-            gx = torch.empty_like(x)
-            ops.conv_dgrad(gp, wk, gx, B=B, H=H, W=W, Cin=Cin, N=N, kh=kh, kw=kw, stride=stride, pad=pad,
-                           g_ld=gp.shape[1], w_ld=wk.shape[1], a_scale=scale, alpha=alpha, residual=other)
+            if pre is not None and other is None:     # deferred lateral: d/dt came out of the consumer's cell-domain pass
+                gx = pre['dt']
+            else:
+                gx = torch.empty_like(x)
+                ops.conv_dgrad(gp, wk, gx, B=B, H=H, W=W, Cin=Cin, N=N, kh=kh, kw=kw, stride=stride, pad=pad,
+                               g_ld=gp.shape[1], w_ld=wk.shape[1], a_scale=scale, alpha=alpha, residual=other)
             if ctx.stash_x:                           # the tensor's other consumer adds this in its own kernel
                 _STASH[x.data_ptr()] = gx
                 gx = None
@@ -202,6 +212,11 @@ class Conv(Function):
             # weight gradient in the Winograd domain: 16 TN GEMMs dU = dM^T V, mapped back with dW = G^T dU G
             dU, gb = ops.conv3x3_winograd_wgrad(x, g.view(B, H, W, N), want_bias=want_gb, m=WINO_BWD_TILE)
             gw = _prep.wino23_weight_grad(dU, WINO_BWD_TILE)
+        elif ctx.needs_input_grad[1] and pre is not None:
+            gwk = torch.zeros_like(wk)
+            gwk[:, :Cin] = pre['gw_roi'] + pre['gw_cell']
+            gw = _w_to_ref_layout(gwk, weight)
+            gb = pre['gb'] if want_gb else None
         elif ctx.needs_input_grad[1]:
             gwk = torch.zeros_like(wk)
             if want_gb:                                   # the bias gradient rides along in the weight-gradient kernel
@@ -210,7 +225,7 @@ class Conv(Function):
                            g_ld=gp.shape[1], out_ld=wk.shape[1], row_scale=scale, alpha=alpha, bias_grad=gb)
             gw = _w_to_ref_layout(gwk, weight)
         elif want_gb:
-            gb = ops.colsum(gp, N)
+            gb = pre['gb'] if pre is not None else ops.colsum(gp, N)
         if ctx.lazy is not None:
             # the map's gradient has been consumed: drop the operands the LazyMap kept for further RoI poolings, as the tape
             # drops its saved tensors (19 GB of merged map + the lateral's inputs at B = 128 would otherwise stay allocated
@@ -492,6 +507,7 @@ class MaxPool(Function):
         other = _STASH.pop(ctx.x_ptr, None) if ctx.take_x else None     # the lateral's share of d/dx, added in the kernel
         premask = PREMASK and ctx.premask and other is not None
         gx = ops.maxpool3x3s2_bwd(idx, gy.contiguous(), *ctx.hw, residual=other, mask=x if premask else None)
+        ondemand.zero_recycle(other)                  # the lateral's share may be a persistent map (ondemand.zero_acquire)
         if premask:
             _PREMASKED[ctx.x_ptr] = (gx.data_ptr(), gx._version)
         return gx, None

@@ -134,7 +134,7 @@ def wino23_pattern(B, H, W, stride, device, dilate=0):
 
 
 def _wino23_tiles_run(x, U, bias, y_ptr, tiles, n_blocks, n_listed, label, blk_info=None, dense_rows=False, skip_pattern=0,
-                      accumulate=False):
+                      accumulate=False, compact=False):
     """Rows transform + fused kernel for the listed tiles of x [B,H,W,C] -> pixels of the map at device address y_ptr.
     n_listed: executed work in 16-plane tile equivalents (None: device-side count in n_blocks).  skip_pattern = S: the pixels of the
     3x3 / stride-S pattern of x read as zeros; accumulate: the result is added to the map (every tile listed once)."""
@@ -161,7 +161,7 @@ def _wino23_tiles_run(x, U, bias, y_ptr, tiles, n_blocks, n_listed, label, blk_i
                                           st), 'nbm_wino23_rows_tiles')
     if prof:
         ev[1].record()
-    check(lib().nbm_wino23_conv_fused_tiles(_ptr(R), _ptr(U), None, _ptr(bias), None, 2 if accumulate else 0, B, H, W, C_, N, C.c_void_p(y_ptr), _ptr(tiles),
+    check(lib().nbm_wino23_conv_fused_tiles(_ptr(R), _ptr(U), None, _ptr(bias), None, (2 if accumulate else 0) | (4 if compact else 0), B, H, W, C_, N, C.c_void_p(y_ptr), _ptr(tiles),
                                             tiles.numel(), nb_ptr, _ptr(blk_info), st), 'nbm_wino23_conv_fused_tiles')
     if prof:
         ev[2].record()
@@ -233,10 +233,12 @@ class LateralState:
     3x3 convolution, reads it; `conv3x3_winograd_lazy` picks the state up and `lazy_complete` finishes the pixels under the RoI
     tiles before it convolves them.  `deferred`: not even the pattern patches were computed -- the consumer takes the lateral's
     OPERANDS into its cell-domain GEMMs instead (`conv3x3_winograd_lazy`, Ufold)."""
-    __slots__ = ('t', 'wk', 'bias', 'alpha', 'up', 'deferred', 'stride')
+    __slots__ = ('t', 'wk', 'bias', 'alpha', 'up', 'deferred', 'stride', 'ufold', 'grads')
 
     def __init__(self, t, wk, bias, alpha, up, deferred=False, stride=0):
         self.t, self.wk, self.bias, self.alpha, self.up, self.deferred, self.stride = t, wk, bias, alpha, up, deferred, stride
+        self.ufold = None            # [25][N][C + Cin] of the consumer's forward pass (deferred lateral): kept for the backward pass
+        self.grads = None            # the lateral's own gradients, when the consumer's backward pass produced them (LAT_CELL_BWD)
 
 
 ZERO_FILL = False                   # functional.py sets it when a DENSE backward kernel may read a sparse map (A/B switches off)
@@ -361,6 +363,8 @@ def conv3x3_winograd_lazy(x, U, bias, stride, Ucell=None, fold=None, keep=False)
         _lateral_pattern_pass(x, st.lateral, stride)             # this consumer cannot take the operands: the patches after all
         st.lateral.deferred = False
     Ufold = fold(st.lateral.wk, st.lateral.alpha) if st.lateral is not None and st.lateral.deferred else None
+    if Ufold is not None and st.keep:
+        st.lateral.ufold = Ufold
     img_bytes = H * W * N * 4
     chunk = lazy_chunk(x)
     for ci, b0 in enumerate(range(0, B, chunk)):
@@ -457,9 +461,19 @@ def lazy_complete(fm, rois, n_roi, fmap_hw, level=0):
         if keep:
             host = _pinned_int()
             host.copy_(n_blocks, non_blocking=True)
+            tiles_d = host_d = None
+            if st.lateral is not None and st.lateral.ufold is not None and LAT_CELL_BWD and st.stride >= 5:
+                # the data gradient's list (tiles within a pixel of the windows) now, so that its length is known on the host when
+                # the backward pass sizes the compact operands of the lateral's RoI share
+                tiles_d = torch.empty((key[1],), device=x.device, dtype=torch.int32)
+                nbd = torch.zeros((1,), device=x.device, dtype=torch.int32)
+                check(lib().nbm_roi_tiles(_ptr(rois[b0:b0 + nb]), _ptr(nr), nb, cap, nl, level, fh, fw, None, 1, _ptr(tiles_d), _ptr(nbd),
+                                          per, _stream()), 'nbm_roi_tiles')
+                host_d = _pinned_int()
+                host_d.copy_(nbd, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
-            per_chunk.append((tiles, host, ev))
+            per_chunk.append((tiles, host, ev, tiles_d, host_d))
     if keep:                                      # the data gradient lists the tiles around these windows again
         st.roi.append(per_chunk)
         st.rois.append((rois, n_roi, nl, level, fh, fw))
@@ -467,6 +481,10 @@ def lazy_complete(fm, rois, n_roi, fmap_hw, level=0):
 
 
 CELL_BWD = os.environ.get('NBM_CELL_BWD', '1') != '0'     # pattern share of both gradients through the cell transforms (cellwino.hip)
+# The deferred lateral's OWN gradients from the consumer's backward pass: its pattern share rides in the cell-domain GEMMs (the
+# folded weights [U | alpha U W] give d/dt in the transform domain, the weight-gradient GEMMs already hold d/d(alpha U W)), its RoI
+# share runs on compact [tiles x 4 pixels] operands -- instead of three dense passes over the 18.9 GB gradient of the merged map
+LAT_CELL_BWD = os.environ.get('NBM_LAT_CELL_BWD', '1') != '0'
 
 
 # ---- persistent gradient maps of a demand-driven level (training)
@@ -572,7 +590,7 @@ def listed_backward(st):
     return st.sparse or (st.overlap and len(st.rois) <= 1)
 
 
-def conv3x3_winograd_dgrad_tiles(st, g, Ut, Ucell=None, base=None):
+def conv3x3_winograd_dgrad_tiles(st, g, Ut, Ucell=None, base=None, lateral_grads=False):
     """Data gradient of a demand-driven convolution (LazyMap `st`): g [B,H,W,N] is zero except on the pattern pixels and inside
     the RoI windows, so the gradient wrt the input is zero except within two pixels of the pattern blocks and one pixel of the
     windows.  Pattern share (`Ucell` = _prep.cell_weight: [25][C][N]): per stride x stride cell the full convolution of the 3x3
@@ -607,6 +625,25 @@ def conv3x3_winograd_dgrad_tiles(st, g, Ut, Ucell=None, base=None):
         gx = torch.zeros((B, H, W, C_), device=g.device, dtype=torch.float32)
     if cell:
         assert Ucell.shape == (25, C_, N)
+    # `lateral_grads`: the deferred lateral's data / bias gradient and the RoI share of its weight gradient are produced here too
+    # (LAT_CELL_BWD above) and left in st.lateral.grads for the lateral's own backward node
+    lt = st.lateral
+    do_lat = bool(lateral_grads and LAT_CELL_BWD and cell and not overlap and lt is not None and lt.ufold is not None and
+                  all(pc[3] is not None for per_chunk in st.roi for pc in per_chunk) and len(st.roi) == len(st.rois) and
+                  len(st.rois) <= 1)          # RoI shares are ADDED: a tile listed by two poolings would count twice
+    if do_lat:
+        Cin = lt.t.shape[-1]
+        K = C_ + Cin
+        Ud = lt.ufold[:, :, :K].transpose(1, 2).contiguous()              # [25][C + Cin][N]: rows C.. = alpha W^T U, d/dt in the transform domain
+        Wl = (float(lt.alpha) * lt.wk[:, :Cin]).contiguous()              # [C][Cin]
+        dt = dt_pool = None
+        if ZERO_POOL:
+            dt, dt_pool = zero_acquire((B, H, W, Cin), g.device, ('lat-dt', st.stride))
+        if dt is None:
+            dt = torch.zeros((B, H, W, Cin), device=g.device, dtype=torch.float32)
+        gb_lat = torch.zeros((C_,), device=g.device, dtype=torch.float32)
+        gw_roi = torch.zeros((C_, Cin), device=g.device, dtype=torch.float32)
+        dt_img_bytes = H * W * Cin * 4
     for ci, (b0, nb, _) in enumerate(st.chunks):
         if cell:
             vg = _cell_outgrad(st, g, ci, b0, nb)
@@ -614,18 +651,54 @@ def conv3x3_winograd_dgrad_tiles(st, g, Ut, Ucell=None, base=None):
             M, _ = ops._wino_scratch(g.device, 25 * T * C_, 0)
             global_label = ops._PROFILE_LABEL
             ops._PROFILE_LABEL = ('cell-dgrad', H, W)
+            if do_lat:
+                M, _ = ops._wino_scratch(g.device, 25 * T * K, 0)
             try:
-                gemm_conv(vg, Ucell, M, B=1, H=T, W=1, Cin=N, N=C_, groups=25, x_gs=T * N, w_gs=C_ * N, y_gs=T * C_)
+                if do_lat:
+                    gemm_conv(vg, Ud, M, B=1, H=T, W=1, Cin=N, N=K, groups=25, x_gs=T * N, w_gs=K * N, y_gs=T * K)
+                else:
+                    gemm_conv(vg, Ucell, M, B=1, H=T, W=1, Cin=N, N=C_, groups=25, x_gs=T * N, w_gs=C_ * N, y_gs=T * C_)
             finally:
                 ops._PROFILE_LABEL = global_label
-            for cls in (range(4) if overlap else (-1,)):
-                check(lib().nbm_cell_dgrad_output(_ptr(M), nb, H, W, C_, st.stride, C.c_void_p(gx.data_ptr() + b0 * img_bytes), cls, _stream()),
-                      'nbm_cell_dgrad_output')
+            if do_lat:            # d/d(merged map) patches (+ their sum = pattern share of the lateral's bias gradient), d/dt patches
+                check(lib().nbm_cell_dgrad_output(_ptr(M), nb, H, W, C_, st.stride, C.c_void_p(gx.data_ptr() + b0 * img_bytes), -1, K, 0,
+                                                  _ptr(gb_lat), _stream()), 'nbm_cell_dgrad_output')
+                check(lib().nbm_cell_dgrad_output(_ptr(M), nb, H, W, Cin, st.stride, C.c_void_p(dt.data_ptr() + b0 * dt_img_bytes), -1, K, C_,
+                                                  None, _stream()), 'nbm_cell_dgrad_output')
+            else:
+                for cls in (range(4) if overlap else (-1,)):
+                    check(lib().nbm_cell_dgrad_output(_ptr(M), nb, H, W, C_, st.stride, C.c_void_p(gx.data_ptr() + b0 * img_bytes), cls, C_, 0,
+                                                      None, _stream()), 'nbm_cell_dgrad_output')
         else:
             pat = wino23_pattern(nb, H, W, st.stride, g.device, dilate=1)
             _wino23_tiles_run(g[b0:b0 + nb], Ut, None, gx.data_ptr() + b0 * img_bytes, pat.tiles, None, pat.n_eff, 'wino23-dgrad',
                               pat.blk_info)
-        for rois, n_roi, nl, level, fh, fw in st.rois:          # one entry per RoI pooling that read the map
+        for si, (rois, n_roi, nl, level, fh, fw) in enumerate(st.rois):          # one entry per RoI pooling that read the map
+            if do_lat:
+                # RoI share, kept apart from the pattern share: g with its pattern pixels read as zeros through the listed kernel into a
+                # COMPACT [tiles][2][2][C] operand; added to the map (the bilinear backward reads it there), and the lateral's three
+                # gradients of these pixels from compact operands (a few % of the map)
+                _, _, ev, tl, host_d = st.roi[si][ci]
+                ev.synchronize()                          # recorded during the forward pass: long done
+                n = int(host_d.item()) * 128
+                if n:
+                    tl = tl[:n]
+                    gx_p, dt_p = C.c_void_p(gx.data_ptr() + b0 * img_bytes), C.c_void_p(dt.data_ptr() + b0 * dt_img_bytes)
+                    Gc = torch.zeros((n * 4, C_), device=g.device, dtype=torch.float32)
+                    _wino23_tiles_run(g[b0:b0 + nb], Ut, None, Gc.data_ptr(), tl, None, n, 'wino23-dgrad-rois', skip_pattern=st.stride,
+                                      compact=True)
+                    check(lib().nbm_tiles_scatter_add(gx_p, nb, H, W, C_, _ptr(tl), n, None, _ptr(Gc), _stream()), 'nbm_tiles_scatter_add')
+                    tc = torch.zeros((n * 4, Cin), device=g.device, dtype=torch.float32)
+                    check(lib().nbm_tiles_gather(_ptr(lt.t[b0:b0 + nb]), nb, H, W, Cin, _ptr(tl), n, None, _ptr(tc), _stream()), 'nbm_tiles_gather')
+                    dtc = torch.matmul(Gc, Wl)
+                    check(lib().nbm_tiles_scatter_add(dt_p, nb, H, W, Cin, _ptr(tl), n, None, _ptr(dtc), _stream()), 'nbm_tiles_scatter_add')
+                    gw_roi.addmm_(Gc.t(), tc, alpha=float(lt.alpha))
+                    gb_lat += Gc.sum(0)
+                    for pl, (p_, c_) in ((pool, (gx_p, C_)), (dt_pool, (dt_p, Cin))):
+                        if pl is not None:
+                            zero_note(pl, lambda p_=p_, c_=c_, nb_=nb, tl_=tl, n_=n: check(
+                                lib().nbm_zero_tiles(p_, nb_, H, W, c_, _ptr(tl_), n_, None, _stream()), 'nbm_zero_tiles'))
+                continue
             per = ops.per_image_counts(n_roi, B)
             key = (str(g.device), nb * blocks_per_img * 128)
             buf = _ROI_TILE_BUF.get(key)
@@ -641,6 +714,10 @@ def conv3x3_winograd_dgrad_tiles(st, g, Ut, Ucell=None, base=None):
                 tl, nbk = tiles.clone(), n_blocks.clone()          # the list buffer is shared by all chunks / levels
                 zero_note(pool, lambda p_=gx.data_ptr() + b0 * img_bytes, nb_=nb, tl_=tl, nbk_=nbk: check(
                     lib().nbm_zero_tiles(C.c_void_p(p_), nb_, H, W, C_, _ptr(tl_), tl_.numel(), _ptr(nbk_), _stream()), 'nbm_zero_tiles'))
+    if do_lat:
+        if dt_pool is not None and ZERO_POOL_CHECK:
+            dt_pool['check'] = lambda buf, s_=st.stride: _check_zero_outside_patches(buf, s_)
+        lt.grads = dict(dt=dt, gb=gb_lat, gw_roi=gw_roi, gw_cell=None)
     return gx
 
 
@@ -690,7 +767,7 @@ def conv3x3_winograd_wgrad_tiles(st, x, g, want_bias=False, cell=None):
             st.vg.pop(ci, None)
         parts = []
         for per_chunk in st.roi:                    # one entry per RoI pooling that read the map
-            tiles, host, ev = per_chunk[ci]
+            tiles, host, ev = per_chunk[ci][:3]
             ev.synchronize()                        # recorded during the forward pass: long done
             n = int(host.item()) * 128
             if n:
@@ -731,5 +808,7 @@ def conv3x3_winograd_wgrad_tiles(st, x, g, want_bias=False, cell=None):
         st.vg = st.cell_gb = st.cell_gb_done = None
         if dUc.shape[2] != C_:          # deferred lateral: d/dU = d/d(first block) + alpha * d/d(second block) W^T  (second block = alpha U W)
             lt = st.lateral
+            if lt.grads is not None and lt.ufold is not None:        # ... and d/dW_lat = alpha * sum_xi U_xi^T d/d(second block)_xi
+                lt.grads['gw_cell'] = float(lt.alpha) * torch.einsum('knc,kni->ci', lt.ufold[:, :, :C_], dUc[:, :, C_:])
             dUc = (dUc[:, :, :C_] + float(lt.alpha) * torch.matmul(dUc[:, :, C_:], lt.wk[:, :dUc.shape[2] - C_].t())).contiguous()
     return dU, gb, dUc

@@ -147,7 +147,8 @@ int nbm_wino23_rows_tiles(const float* x, int B, int H, int W, int C, const int*
                           void* stream);
 int nbm_wino23_conv_fused_tiles(const float* R, const float* U, const float* scale, const float* shift, const float* mask,
                                 int relu /* bit 0: ReLU; bit 1: ADD the result to y instead of storing it (a tile may then be
-                                            listed only once) */,
+                                            listed only once); bit 2: y is COMPACT, [n_entries][2][2][N] in list order (pixels
+                                            outside the image are not written) instead of the map */,
                                 int B, int H, int W, int C, int N, float* y, const int* tiles, int n_entries,
                                 const int* n_blocks, const unsigned* blk_info, void* stream);
 int nbm_roi_tiles(const float* rois, const int* n_roi, int B, int roi_cap, int n_levels, int level, const int* fh,
@@ -185,7 +186,9 @@ int nbm_cell_input(const float* x, int B, int H, int W, int C, int stride, float
  * top-down merge of fpn.py:143-144 without its lateral term), 0 outside the image */
 int nbm_cell_input_up(const float* x1, const float* bias, int B, int H, int W, int C, int Hc, int Wc, int stride, float* Vx, int ld,
                       int c_off, void* stream);
-int nbm_cell_dgrad_output(const float* M, int B, int H, int W, int C, int stride, float* gx, int parity_class, void* stream);
+int nbm_cell_dgrad_output(const float* M, int B, int H, int W, int C, int stride, float* gx, int parity_class,
+                          int ld /* row pitch of M, >= c_off + C */, int c_off /* first channel of M read */,
+                          float* bias_grad /* optional [C]: += sum of the patch pixels written (inside the image) */, void* stream);
 /* FORWARD of the pattern pixels with the same 25 products per cell (the correlation form, F(3x3,3x3)): nbm_cell_input of the
  * input, M_xi = Vx_xi U_xi^T (U = E w E^T as [25][N][C]), then blk = E^T M E + bias into the 3x3 pattern block of every cell of
  * y [B][H][W][N] (other pixels are not written). */
@@ -416,6 +419,13 @@ int nbm_zero_roi_windows(float* g, int H, int W, int C, const float* rois /*[B][
                          int B, int n_roi, int lvl, void* stream);
 int nbm_zero_pattern(float* g, int B, int H, int W, int C, int stride, void* stream);
 int nbm_zero_tiles(float* g, int B, int H, int W, int C, const int* tiles, int n_entries, const int* n_blocks, void* stream);
+/* the 2x2 tiles of such a list <-> compact [n_entries][2][2][C] in list order (the compact output layout of
+ * nbm_wino23_conv_fused_tiles): gather reads the map (zeros outside the image), scatter_add adds the compact values into it (every
+ * tile listed once).  The RoI share of the finest level's lateral gradients runs on these compact operands. */
+int nbm_tiles_gather(const float* map, int B, int H, int W, int C, const int* tiles, int n_entries, const int* n_blocks, float* compact,
+                     void* stream);
+int nbm_tiles_scatter_add(float* map, int B, int H, int W, int C, const int* tiles, int n_entries, const int* n_blocks,
+                          const float* compact, void* stream);
 /* out[n] = sum_m g[m][n] (bias gradients) */
 int nbm_colsum(const float* g, int64_t M, int N, int ld, float* out, void* stream);
 int nbm_maxpool3x3s2_bwd(const uint8_t* idx, const float* gy, float* gx, int B, int H, int W, int C, int Ho, int Wo,

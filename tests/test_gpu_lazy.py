@@ -272,7 +272,7 @@ def test_weight_gradient_over_the_listed_tiles_equals_the_dense_one(cell):
     # pixels with a reader: the pattern pixels + every pixel of the tiles under the RoIs (re-derived from the kept RoI list)
     TH, TW = (H + 1) // 2, (W + 1) // 2
     m = ~torch.isnan(y[..., 0])                      # the map was NaN-poisoned: written == has a reader
-    tiles, host, ev = st.roi[0][0]
+    tiles, host, ev = st.roi[0][0][:3]
     ev.synchronize()
     ids = tiles[:int(host.item()) * 128]
     assert int((ids >= 0).sum()) > 0
@@ -640,7 +640,7 @@ def test_persistent_gradient_maps_are_clean_after_every_step():
                 out.append(({k: float(v) for k, v in loss.items()}, float(opt.grad_norm())))
             if pool:
                 tags = sorted(k[2][0] for k in ondemand._ZERO_POOL)
-                assert tags == ['cell-dgrad', 'roi-grad'], tags                       # both maps of level 0 came from the pool ...
+                assert tags == ['cell-dgrad', 'lat-dt', 'roi-grad'], tags             # the three maps of level 0 came from the pool ...
                 assert not any(e['busy'] for e in ondemand._ZERO_POOL.values())       # ... and were handed back by their readers
         finally:
             ondemand.ZERO_POOL, ondemand.ZERO_POOL_CHECK = True, False
@@ -655,3 +655,43 @@ def test_persistent_gradient_maps_are_clean_after_every_step():
         for k, v in l0.items():
             assert abs(v - l1[k]) <= tol * max(1.0, abs(v)), (si, k, v, l1[k])
         assert abs(n0 - n1) <= 4 * tol * n0, (si, n0, n1)
+
+
+def test_lateral_gradients_from_the_cell_domain_equal_the_dense_passes():
+    """ondemand.LAT_CELL_BWD: the finest lateral's own gradients (data, weight, bias) come out of its consumer's backward pass --
+    pattern share in the cell-domain GEMMs (folded weights), RoI share on compact operands -- instead of three dense passes over the
+    gradient of the merged map.  Every parameter gradient of a positive step equals the one of the dense passes."""
+    from birdsoundclassif_amd import train as T
+    from birdsoundclassif_amd.nets import build_model
+    args = T.default_args(device='cuda')
+    B = 2
+    img = torch.from_numpy(synth.image_batch(0, B))
+    bb, ids, lens = synth.label_batch(0, B)
+    batch = [img, img, bb, ids, lens]
+    res = {}
+    for on in (False, True):
+        model, crit = build_model(args)
+        model.load_state_dict(filler_state_dict())
+        model = model.cuda().train()
+        crit.train()
+        np.random.seed(5)
+        ondemand.LAT_CELL_BWD = on
+        try:
+            loss = T.step(model, crit, batch, 'cuda', False)
+            sum(loss[k] * crit.weight_dict[k] for k in loss if k in crit.weight_dict).backward()
+            Fn.stash_check_empty()
+        finally:
+            ondemand.LAT_CELL_BWD = True
+            ondemand.zero_pool_clear()
+        torch.cuda.synchronize()
+        res[on] = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    assert set(res[False]) == set(res[True])
+    worst = 0.0
+    for k, g in res[False].items():
+        g2 = res[True][k]
+        assert torch.isfinite(g2).all(), k
+        tol = 1e-4 * float(g.abs().max()) + 1e-7
+        err = float((g - g2).abs().max())
+        assert err <= tol, (k, err, tol)
+        worst = max(worst, err / (float(g.abs().max()) + 1e-12))
+    assert any('fpn' in k for k in res[True])
