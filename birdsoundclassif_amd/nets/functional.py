@@ -69,11 +69,41 @@ def _premasked(y, gy):
     return tag is not None and tag == (gy.data_ptr(), gy._version)
 
 
+# Early backward pass of the RPN branch (train.step, SPLIT_BACKWARD): the first-stage loss does not depend on the second stage, so its
+# gradient is propagated through the RPN head -- down to the FPN output maps, no further -- BEFORE the host waits for the RoI count:
+# those ~15 ms of kernels fill the window in which the GPU used to idle behind the host-side proposal targets.  The RPN's share of
+# d/d(FPN map) is PARKED here (data_ptr of the map -> (gradient map, the map itself)); the RoI pooling's backward pass, the map's
+# other consumer, scatters into it and hands the sum to the producer -- the mirror image of _GRAD_ACC.
+EARLY = False            # True while train.step runs that early pass
+_PARKED = {}
+_FPN_OUT = {}            # data_ptr -> FPN output map (NHWC) of this forward pass
+_FPN_UP = {}             # data_ptr of an up-sampled copy of an FPN map (the RPN's first operator on level P5) -> that map
+
+
+def fpn_out_register(maps):
+    _FPN_OUT.clear()
+    _FPN_UP.clear()
+    _PARKED.clear()
+    for m in maps:
+        _FPN_OUT[m.data_ptr()] = m
+
+
+def parked_flush():
+    """No RoI pooling consumed the parked gradients (the step ended after the first stage): propagate them into the FPN now."""
+    items = [(m, g) for (g, m, _) in _PARKED.values()]
+    _PARKED.clear()
+    if items:
+        torch.autograd.backward([m for m, _ in items], [g for _, g in items])
+
+
 def stash_reset():
     """Start of a forward pass: forget the registrations (and any gradient) of earlier passes."""
     _STASH.clear()
     _STASH_OK.clear()
     _PREMASKED.clear()
+    _PARKED.clear()
+    _FPN_OUT.clear()
+    _FPN_UP.clear()
     ondemand.zero_pool_new_pass()
 
 
@@ -518,7 +548,10 @@ class UpsampleAdd(Function):
     def forward(ctx, src, add, Ho, Wo):
         ctx.hw = src.shape[1:3]
         ctx.has_add = add is not None
-        return ops.upsample_bilinear_add(src, Ho, Wo, add=add)
+        y = ops.upsample_bilinear_add(src, Ho, Wo, add=add)
+        if add is None and src.data_ptr() in _FPN_OUT:
+            _FPN_UP[y.data_ptr()] = _FPN_OUT[src.data_ptr()]
+        return y
 
     @staticmethod
     @once_differentiable
@@ -546,6 +579,32 @@ class DwConv(Function):
         # first (later node) and leaves its scatter map in _GRAD_ACC: add this gradient into it on the few pixels a tap reaches
         # and return nothing -- instead of a dense write here, and a dense add by autograd (12.6 GB maps at level 0).  The
         # producer's backward pass waits for both consumers either way.
+        if EARLY and ctx.needs_input_grad[0] and x.data_ptr() in _FPN_UP and GRAD_SHARE:
+            # level P5: the RPN up-samples the map first (layers.py:35-37); the early pass does not reach that node (it lies on no
+            # path to an RPN parameter), so its transpose is applied here and the result parked under the FPN map
+            fm = _FPN_UP[x.data_ptr()]
+            gx, gw, gb = ops.dwconv3x3_bwd(x, gy, weight.detach(), mult, stride, need_gx=True, need_gw=True, has_bias=has_bias)
+            _PARKED[fm.data_ptr()] = (ops.upsample_bilinear_bwd(gx, fm.shape[1], fm.shape[2]), fm, None)
+            return None, gw, gb, None, None
+        if EARLY and ctx.needs_input_grad[0] and x.data_ptr() in _FPN_OUT and GRAD_SHARE:
+            # early pass of the RPN branch: this gradient is the FIRST share of d/d(FPN map); park it for the RoI pooling's backward
+            # pass (a persistent map for the demand-driven level, see ondemand.zero_acquire; the taps' 3x3 blocks are its footprint)
+            st = ondemand.lazy_state(x)
+            acc = e = None
+            if (ondemand.ZERO_POOL and LAZY_DGRAD and LAZY_WGRAD and ondemand.CELL_BWD and st is not None and st.sparse and st.keep and
+                    st.stride >= 5 and stride >= 3):
+                acc, e = ondemand.zero_acquire(tuple(x.shape), x.device, ('map-grad', st.stride))
+                if acc is not None:
+                    ondemand.zero_note(e, lambda b_=acc, s_=tuple(x.shape), st_=st.stride: ops.zero_pattern(b_, st_))
+            if acc is None and stride >= 3:
+                acc = torch.zeros_like(x)
+            if acc is not None:
+                ops.dwconv3x3_bwd_acc(gy, weight.detach(), mult, stride, acc)
+                _, gw, gb = ops.dwconv3x3_bwd(x, gy, weight.detach(), mult, stride, need_gx=False, need_gw=True, has_bias=has_bias)
+            else:
+                acc, gw, gb = ops.dwconv3x3_bwd(x, gy, weight.detach(), mult, stride, need_gx=True, need_gw=True, has_bias=has_bias)
+            _PARKED[x.data_ptr()] = (acc, _FPN_OUT[x.data_ptr()], e)
+            return None, gw, gb, None, None
         ref = _GRAD_ACC.pop(x.data_ptr(), None) if ctx.needs_input_grad[0] else None
         acc = ref() if ref is not None else None          # weak: alive only while autograd still holds the RoI pooling's map
         if acc is not None and acc.shape == x.shape:
@@ -658,11 +717,15 @@ class RoiPool(Function):
     @once_differentiable
     def backward(ctx, gpool, _gpe, _glvl):
         rois, level = ctx.saved_tensors
-        gf = ops.roi_pool_bwd(gpool.contiguous(), rois, level, ctx.shapes, pooled=ctx.pooled)
+        # the RPN branch's share, if its early backward pass parked one (train.step): scatter into it
+        bases = {i: _PARKED.pop(ptr) for i, ptr in enumerate(ctx.fm_ptrs) if ptr in _PARKED}
+        gf = ops.roi_pool_bwd(gpool.contiguous(), rois, level, ctx.shapes, pooled=ctx.pooled,
+                              bases={i: (g, e) for i, (g, _, e) in bases.items()})
         _GRAD_ACC.clear()
         if GRAD_SHARE:                         # the other consumer of each map may add its gradient here (Fn.DwConv.backward)
-            for ptr, g in zip(ctx.fm_ptrs, gf):
-                _GRAD_ACC[ptr] = weakref.ref(g)
+            for i, (ptr, g) in enumerate(zip(ctx.fm_ptrs, gf)):
+                if i not in bases:
+                    _GRAD_ACC[ptr] = weakref.ref(g)
         return (None, None, None, None, None, None, *gf)
 
 

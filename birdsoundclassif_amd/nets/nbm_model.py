@@ -60,8 +60,11 @@ class NbmModel(nn.Module):
         if getattr(self.args, 'sandwich_attn', False):
             return materialize(self.attn[1](self.fpn(self.attn[0](features))))
         if lazy and self._lazy_strides():
-            return self.fpn(self.attn(features), lazy_strides=self._lazy_strides())
-        return self.fpn(self.attn(features))
+            out = self.fpn(self.attn(features), lazy_strides=self._lazy_strides())
+        else:
+            out = self.fpn(self.attn(features))
+        Fn.fpn_out_register(out)               # the early backward pass of the RPN branch parks its gradients by these maps (train.step)
+        return out
 
     def forward_first_stage(self, samples, host_work=None, lazy=False):
         """samples [B,1,H,W] f32 on the GPU -> {'rois','rpn_cls_scores','rpn_bbox_reg','fpn_out'} (nbm_model.py:39-54).

@@ -844,7 +844,7 @@ def bn_train_bwd(g2d, x2d, mean, invstd, w):
     return gx, gw, gb
 
 
-def roi_pool_bwd(gpool, rois, level, fmap_shapes, pooled=None):
+def roi_pool_bwd(gpool, rois, level, fmap_shapes, pooled=None, bases=None):
     """gpool [B*R,2,2,C] -> list of zero-initialised-then-accumulated gradient maps (NHWC) for the FPN levels.
     `pooled` {level index: stride of the RPN's depthwise convolution on that map}: those maps come from the persistent pool of
     `ondemand.zero_acquire` (demand-driven levels: the consumer of the gradient recycles them) instead of a fresh fill."""
@@ -853,9 +853,19 @@ def roi_pool_bwd(gpool, rois, level, fmap_shapes, pooled=None):
     gf = []
     for i, s in enumerate(fmap_shapes):
         buf = None
+        if bases and i in bases:             # another consumer's share of this map's gradient (Fn._PARKED): scatter into it
+            base, e = bases[i]
+            if e is not None:                # a persistent map: the RoI windows join its footprint
+                from . import ondemand
+                ondemand.zero_note(e, lambda b_=base, s_=s, i_=i: check(lib().nbm_zero_roi_windows(
+                    _ptr(b_), s_[1], s_[2], s_[3], _ptr(rois), _ptr(level), B, R, i_, _stream()), 'nbm_zero_roi_windows'))
+                if ondemand.ZERO_POOL_CHECK:
+                    e['check'] = _check_all_zero
+            gf.append(base)
+            continue
         if pooled and i in pooled:
             from . import ondemand
-            buf, e = ondemand.zero_acquire(s, gpool.device, ('roi-grad', i, pooled[i]))
+            buf, e = ondemand.zero_acquire(s, gpool.device, ('map-grad', pooled[i]))
         if buf is not None:
             # footprints: the RoI windows of this level, and the 3x3 blocks the strided taps add to (Fn.DwConv.backward)
             ondemand.zero_note(e, lambda b_=buf, s_=s, i_=i: check(lib().nbm_zero_roi_windows(
@@ -874,6 +884,11 @@ def roi_pool_bwd(gpool, rois, level, fmap_shapes, pooled=None):
     check(lib().nbm_roi_pool_bwd(ptrs, fh, fw, n, C_, _ptr(_chk(rois)), _ptr(level), B, R, _ptr(_chk(gpool)), _stream()),
           'nbm_roi_pool_bwd')
     return gf
+
+
+def zero_pattern(buf, stride):
+    B, H, W, C_ = buf.shape
+    check(lib().nbm_zero_pattern(_ptr(buf), B, H, W, C_, int(stride), _stream()), 'nbm_zero_pattern')
 
 
 def _check_all_zero(buf):

@@ -222,8 +222,14 @@ def build_optimizer(model, args):
     return optimizer, lr_scheduler
 
 
-def step(model, criterion, batch, device, negative_sample):
-    """One forward + loss evaluation (reference train.py:220-257)."""
+# The first-stage loss is back-propagated through the RPN head while the host is still busy with the proposal targets (see
+# functional.EARLY): the GPU used to idle ~12 ms per step behind that sync.  Needs `optimizer.zero_grad()` BEFORE `step` (train_one_step
+# does that); the first-stage losses come back detached (their gradient is already in the parameters / parked at the FPN maps).
+SPLIT_BACKWARD = os.environ.get('NBM_SPLIT_BACKWARD', '1') != '0'
+
+
+def step(model, criterion, batch, device, negative_sample, early_backward=False):
+    """One forward + loss evaluation (reference train.py:220-257).  `early_backward` (train_one_step): see SPLIT_BACKWARD."""
     img, neg_img, bb_coord, bird_ids, lengths = batch
     img, neg_img = img.to(device), neg_img.to(device)
     # Boxes and class ids are consumed by the host-side target layers (NumPy RNG, like the reference's `.cpu().numpy()`
@@ -240,6 +246,8 @@ def step(model, criterion, batch, device, negative_sample):
             if rois is not None and hasattr(criterion, 'precompute_proposal_iou'):
                 criterion.precompute_proposal_iou(rois, bb_coord, lengths)      # device IoU + D2H, queued right behind the proposals
             criterion.precompute_first_stage_loss(cls, reg, bb_coord, lengths)
+            if early_backward and SPLIT_BACKWARD and torch.is_grad_enabled():
+                _early_rpn_backward(model, criterion)
         host_work.wants_rois = True
     # lazy=True: the finest FPN map is computed where it is read; it goes straight into forward_second_stage below
     out_first_stage = model.forward_first_stage(inpt, host_work, lazy=True)
@@ -260,6 +268,29 @@ def step(model, criterion, batch, device, negative_sample):
     if not negative_sample:
         loss.update(criterion.loss_cardinality(out_second_stage['bbox_classes'], proposal_tgt_out['labels']))
     return loss
+
+
+def _early_rpn_backward(model, criterion):
+    """Queue the backward pass of the (pre-queued) first-stage loss through the RPN head now, before the host waits for the RoI
+    count: gradients of the RPN parameters accumulate, the shares of d/d(FPN maps) are parked (functional._PARKED) for the RoI pooling's
+    backward pass -- or `parked_flush`, if the step ends after the first stage."""
+    from .nets import functional as Fn
+    pre = criterion._pre_loss
+    w = criterion.weight_dict
+    keys = [k for k in pre if k in w and pre[k].requires_grad]
+    rpn = getattr(getattr(model, 'head', None), 'rpn', None)
+    if not keys or rpn is None or not Fn.GRAD_SHARE or not Fn._FPN_OUT:
+        return
+    params = [p for p in rpn.parameters() if p.requires_grad]
+    loss = sum(pre[k] * w[k] for k in keys)
+    Fn.EARLY = True
+    try:
+        torch.autograd.backward(loss, inputs=params)       # stops at the RPN's first operators: they park d/d(FPN map) themselves
+    finally:
+        Fn.EARLY = False
+    if len(Fn._PARKED) != len(Fn._FPN_OUT):
+        raise RuntimeError('early RPN backward: not every FPN map received its share (functional._PARKED)')
+    criterion._pre_loss = {k: (v.detach() if k in keys else v) for k, v in pre.items()}
 
 
 def allreduce_grads(optimizer_or_model):
@@ -321,12 +352,14 @@ def allreduce_grads(optimizer_or_model):
 
 def train_one_step(model, criterion, optimizer, batch, max_norm, device, negative_sample):
     """reference train.py:205-217."""
-    loss_dict = step(model, criterion, batch, device, negative_sample)
+    from .nets import functional as Fn
+    optimizer.zero_grad()                  # before the step: part of the backward pass runs inside it (SPLIT_BACKWARD)
+    loss_dict = step(model, criterion, batch, device, negative_sample, early_backward=True)
     weight_dict = criterion.weight_dict
     losses = sum(loss_dict[k] * weight_dict[k] for k in loss_dict.keys() if k in weight_dict)
-    optimizer.zero_grad()
-    losses.backward()
-    from .nets import functional as Fn
+    if losses.requires_grad:
+        losses.backward()
+    Fn.parked_flush()                      # the step ended after the first stage: the RPN branch's gradients still have to reach the FPN
     Fn.stash_check_empty()                 # a handed-over gradient that nobody picked up would be a silently dropped gradient
     allreduce_grads(optimizer if isinstance(optimizer, FusedAdamW) else model)
     if isinstance(optimizer, FusedAdamW):

@@ -640,7 +640,7 @@ def test_persistent_gradient_maps_are_clean_after_every_step():
                 out.append(({k: float(v) for k, v in loss.items()}, float(opt.grad_norm())))
             if pool:
                 tags = sorted(k[2][0] for k in ondemand._ZERO_POOL)
-                assert tags == ['cell-dgrad', 'lat-dt', 'roi-grad'], tags             # the three maps of level 0 came from the pool ...
+                assert tags == ['cell-dgrad', 'lat-dt', 'map-grad'], tags             # the three maps of level 0 came from the pool ...
                 assert not any(e['busy'] for e in ondemand._ZERO_POOL.values())       # ... and were handed back by their readers
         finally:
             ondemand.ZERO_POOL, ondemand.ZERO_POOL_CHECK = True, False
