@@ -444,20 +444,30 @@ __global__ __launch_bounds__(256, BM > 128 ? 1 : STAGES == 1 ? 3 : 2) void igemm
 // global memory into MFMA operand registers (lane (row, half h) holds k = 16 h .. 16 h + 15 of every 32-wide chunk: the same K
 // order as the tiled kernel, so the sums are bit-identical), multiplies against all N channels, and sends the 32 x N tile out through
 // a private 32 x 32 LDS patch (16-byte residual loads / stores, 128-byte row segments) -- no workgroup barrier after the prologue.
-// Measured at B = 64 (scripts/stream1x1_probe.py, tiled -> streaming, outputs bit-identical): 64 -> 256 + residual + ReLU 1.20 -> 1.05 ms,
-// 64 -> 64 0.28 -> 0.21, 256 -> 64 0.68 -> 0.63; 64 -> 256 without residual 0.78 -> 0.78 (left on the tiled kernel); the detect step
-// 73.4 -> 72.75 ms.  Accumulation groups of 8 blocks (8 spilled registers) or 12 waves per workgroup (28-74 spilled) were slower.
+// Measured at B = 64 (scripts/stream1x1_probe.py, tiled -> streaming, outputs bit-identical): 64 -> 256 + residual + ReLU 1.17-1.20 -> 0.90 ms
+// (1.05 before the group's residual rows were requested ahead of its MFMAs), 64 -> 64 0.28 -> 0.20, 256 -> 64 0.68 -> 0.62; 64 -> 256
+// without residual 0.78 -> 0.78 (left on the tiled kernel).  Groups of 2 blocks 0.97; 12 waves per workgroup spill (25-74 registers):
+// 0.91.  What stays: 256 -> 64 takes 0.62 ms where its loads alone take 0.26 (6 TB/s), loads + stores 0.39 and its MFMAs 0.32 -- the
+// phases ADD although every wave now has eight chunk loads in flight during its MFMAs (vmcnt(28) in front of every chunk): with the
+// matrix pipe and HBM both near their limits the part does not sustain both (the tiled kernels show the same sum).
 struct StreamParams {
   const float* x; const float* w; float* y; const float* scale; const float* shift; const float* residual;
   int M, x_ld, w_ld, y_ld, res_ld, m_tiles; float alpha; int act;
 };
 constexpr int SPITCH = 36;
-// NTG: 32-wide channel blocks per accumulation group (the activation rows stay in registers for all groups); WAVES per workgroup
+// NTG: 32-wide channel blocks per accumulation group; WAVES per workgroup.  Two schedules, both aimed at keeping every wave's memory
+// requests in flight WHILE it multiplies (ablation of the first version, 256 -> 64 at B = 64: 0.64 ms; without the MFMAs 0.39 = 5 TB/s;
+// without loads and stores 0.26: the phases of a wave simply added up):
+//  * K32 <= 2 (K = 64, up to 256 output channels): the rows of the NEXT tile are requested before the MFMAs (`an`), and each group's
+//    residual rows before the group's MFMAs, so the epilogue finds them in registers;
+//  * K32 > 2 (K = 256, 64 output channels): all accumulators live at once, K chunks outermost -- the registers of chunk kc are
+//    reloaded with the next tile's chunk kc right after its MFMAs were issued: 8 chunk loads in flight per wave at all times, no
+//    second register set.
 template <int K32, int NT, int NTG, int WAVES>
 __global__ __launch_bounds__(WAVES * 64, 1) void stream1x1_kernel(const StreamParams p) {
   constexpr int K = K32 * 32, N = NT * 32, WP = K + 4;
-  constexpr bool PREFETCH = K32 <= 2;
-  static_assert(NT % NTG == 0, "groups");
+  constexpr bool CHUNKED = K32 > 2;
+  static_assert(NT % NTG == 0 && (!CHUNKED || NTG == NT), "groups");
   __shared__ __attribute__((aligned(16))) float Ws[N * WP];
   __shared__ __attribute__((aligned(16))) float Stg[WAVES][32 * SPITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
@@ -468,70 +478,92 @@ __global__ __launch_bounds__(WAVES * 64, 1) void stream1x1_kernel(const StreamPa
   __syncthreads();
   float* stg = Stg[wave];
   const int er = lane >> 3, ec = (lane & 7) * 4;            // epilogue: 8 rows x 8 chunks of 4 channels per pass
-  f32x4 a[K32][4], an[PREFETCH ? K32 : 1][4];
-  auto load_a = [&](int tile, f32x4 (*dst)[4]) {
+  f32x4 a[K32][4], an[CHUNKED ? 1 : K32][4];
+  auto row_ptr = [&](int tile) {
     int m = tile * 32 + li;
     m = m < p.M ? m : p.M - 1;
-    const float* xp = p.x + (long long)m * p.x_ld + 16 * lh;
+    return p.x + (long long)m * p.x_ld + 16 * lh;
+  };
+  auto load_chunk = [&](const float* xp, int kc, f32x4* dst) {
 #pragma unroll
-    for (int kc = 0; kc < K32; ++kc)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) dst[kc][q] = *reinterpret_cast<const f32x4*>(xp + kc * 32 + 4 * q);
+    for (int q = 0; q < 4; ++q) dst[q] = *reinterpret_cast<const f32x4*>(xp + kc * 32 + 4 * q);
   };
   const int step = gridDim.x * WAVES;
   int tile = blockIdx.x * WAVES + wave;
-  if (PREFETCH && tile < p.m_tiles) load_a(tile, an);
+  if (tile < p.m_tiles) {
+    const float* xp = row_ptr(tile);
+#pragma unroll
+    for (int kc = 0; kc < K32; ++kc) load_chunk(xp, kc, CHUNKED ? a[kc] : an[kc]);
+  }
   for (; tile < p.m_tiles; tile += step) {
-    if constexpr (PREFETCH) {
+    const bool more = tile + step < p.m_tiles;
+    const float* xn = row_ptr(more ? tile + step : tile);
+    if constexpr (!CHUNKED) {
 #pragma unroll
       for (int kc = 0; kc < K32; ++kc)
 #pragma unroll
         for (int q = 0; q < 4; ++q) a[kc][q] = an[kc][q];
-      if (tile + step < p.m_tiles) load_a(tile + step, an);
-    } else {
-      load_a(tile, a);
+#pragma unroll
+      for (int kc = 0; kc < K32; ++kc) load_chunk(xn, kc, an[kc]);       // unconditional (see below): after the last tile, its own rows again
     }
     const int m0 = tile * 32;
-    // the residual rows of the block that goes out next are requested one block ahead: their latency hides behind the previous
-    // block's LDS round trip and stores (and, for the first block of a group, behind the group's MFMAs)
-    f32x4 rq[4], rn[4];
-    auto load_res = [&](int jn, f32x4* dst) {
+    f32x4 rq[NTG][4];
+    auto load_res = [&](int jj, f32x4* dst) {
       if (!p.residual) return;
 #pragma unroll
       for (int pass = 0; pass < 4; ++pass) {
         const int m = m0 + pass * 8 + er;
-        dst[pass] = *reinterpret_cast<const f32x4*>(p.residual + (long long)(m < p.M ? m : p.M - 1) * p.res_ld + jn * 32 + ec);
+        dst[pass] = *reinterpret_cast<const f32x4*>(p.residual + (long long)(m < p.M ? m : p.M - 1) * p.res_ld + jj * 32 + ec);
       }
     };
-    load_res(0, rn);
 #pragma unroll
     for (int g = 0; g < NT / NTG; ++g) {
+#pragma unroll
+      for (int j = 0; j < NTG; ++j) load_res(g * NTG + j, rq[j]);          // in flight during this group's MFMAs
       f32x16 acc[NTG];
 #pragma unroll
       for (int j = 0; j < NTG; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-#pragma unroll
-      for (int j = 0; j < NTG; ++j) {
-        const float* wb = Ws + ((g * NTG + j) * 32 + li) * WP + 16 * lh;
+      if constexpr (CHUNKED) {
 #pragma unroll
         for (int kc = 0; kc < K32; ++kc) {
-          f32x4 b[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) b[q] = *reinterpret_cast<const f32x4*>(wb + kc * 32 + 4 * q);
+          for (int j = 0; j < NTG; ++j) {
+            const float* wb = Ws + (j * 32 + li) * WP + 16 * lh + kc * 32;
+            f32x4 b[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 4; ++q) b[q] = *reinterpret_cast<const f32x4*>(wb + 4 * q);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kc][q][e], b[q][e], acc[j], 0, 0, 0);
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kc][q][e], b[q][e], acc[j], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);       // keep the reload HERE (the scheduler sank all eight behind the last MFMA)
+          load_chunk(xn, kc, a[kc]);       // the next tile's chunk (or, after the last tile, this one's again: no branch, so the
+                                           // compiler counts the loads in flight exactly) into the registers just consumed
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NTG; ++j) {
+          const float* wb = Ws + ((g * NTG + j) * 32 + li) * WP + 16 * lh;
+#pragma unroll
+          for (int kc = 0; kc < K32; ++kc) {
+            f32x4 b[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b[q] = *reinterpret_cast<const f32x4*>(wb + kc * 32 + 4 * q);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kc][q][e], b[q][e], acc[j], 0, 0, 0);
+          }
         }
       }
       // epilogue, one 32 x 32 block at a time through this wave's LDS patch (same arithmetic as the tiled kernel's)
 #pragma unroll
       for (int j = 0; j < NTG; ++j) {
         const int jj = g * NTG + j;
-#pragma unroll
-        for (int pass = 0; pass < 4; ++pass) rq[pass] = rn[pass];
-        if (jj + 1 < NT) load_res(jj + 1, rn);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
         for (int e = 0; e < 16; ++e) stg[((e & 3) + 8 * (e >> 2) + 4 * lh) * SPITCH + li] = acc[j][e];
@@ -547,7 +579,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void stream1x1_kernel(const StreamPa
           f32x4 v = *reinterpret_cast<const f32x4*>(stg + r * SPITCH + ec);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = (v[e] * p.alpha) * sc[e] + sh[e] + 0.f;
-          if (p.residual) { v[0] += rq[pass][0]; v[1] += rq[pass][1]; v[2] += rq[pass][2]; v[3] += rq[pass][3]; }
+          if (p.residual) { v[0] += rq[j][pass][0]; v[1] += rq[j][pass][1]; v[2] += rq[j][pass][2]; v[3] += rq[j][pass][3]; }
           if (p.act == NBM_ACT_RELU) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
