@@ -471,9 +471,12 @@ __global__ __launch_bounds__(WAVES * 64, 1) void stream1x1_kernel(const StreamPa
   __shared__ __attribute__((aligned(16))) float Ws[N * WP];
   __shared__ __attribute__((aligned(16))) float Stg[WAVES][32 * SPITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
+  // blockIdx.y = slice of N output channels (layers whose whole weight matrix does not fit LDS: every slice streams the rows again --
+  // through L2, the slices of a tile run side by side -- and owns its columns of the output / residual)
+  const int n_off = blockIdx.y * N;
   for (int i = tid; i < N * (K / 4); i += WAVES * 64) {
     const int n = i / (K / 4), c = i - n * (K / 4);
-    *reinterpret_cast<f32x4*>(Ws + n * WP + c * 4) = *reinterpret_cast<const f32x4*>(p.w + (long long)n * p.w_ld + c * 4);
+    *reinterpret_cast<f32x4*>(Ws + n * WP + c * 4) = *reinterpret_cast<const f32x4*>(p.w + (long long)(n_off + n) * p.w_ld + c * 4);
   }
   __syncthreads();
   float* stg = Stg[wave];
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void stream1x1_kernel(const StreamPa
 #pragma unroll
       for (int pass = 0; pass < 4; ++pass) {
         const int m = m0 + pass * 8 + er;
-        dst[pass] = *reinterpret_cast<const f32x4*>(p.residual + (long long)(m < p.M ? m : p.M - 1) * p.res_ld + jj * 32 + ec);
+        dst[pass] = *reinterpret_cast<const f32x4*>(p.residual + (long long)(m < p.M ? m : p.M - 1) * p.res_ld + n_off + jj * 32 + ec);
       }
     };
 #pragma unroll
@@ -568,7 +571,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void stream1x1_kernel(const StreamPa
 #pragma unroll
         for (int e = 0; e < 16; ++e) stg[((e & 3) + 8 * (e >> 2) + 4 * lh) * SPITCH + li] = acc[j][e];
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const int n = jj * 32 + ec;
+        const int n = n_off + jj * 32 + ec;
         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
         if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
         if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
@@ -598,9 +601,11 @@ __global__ __launch_bounds__(WAVES * 64, 1) void stream1x1_kernel(const StreamPa
 }
 
 template <int K32, int NT, int NTG, int WAVES, int WG_PER_CU>
-int launch_stream(const StreamParams& p, hipStream_t st) {
+int launch_stream(const StreamParams& p, hipStream_t st, int slices = 1) {
   const int wgs = (p.m_tiles + WAVES - 1) / WAVES;
-  hipLaunchKernelGGL((stream1x1_kernel<K32, NT, NTG, WAVES>), dim3(wgs < 256 * WG_PER_CU ? wgs : 256 * WG_PER_CU), dim3(WAVES * 64), 0, st, p);
+  int gx = 256 * WG_PER_CU / slices;                    // the persistent grid is shared by the slices
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL((stream1x1_kernel<K32, NT, NTG, WAVES>), dim3(wgs < gx ? wgs : gx, slices), dim3(WAVES * 64), 0, st, p);
   return nbm_launch_status();
 }
 
@@ -683,6 +688,12 @@ extern "C" int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream) {
     if (k32 == 2 && nt == 8 && d->residual) return launch_stream<2, 8, 4, 8, 1>(sp, st);
     if (k32 == 2 && nt == 2) return launch_stream<2, 2, 2, 8, 2>(sp, st);
     if (k32 == 8 && nt == 2) return launch_stream<8, 2, 2, 8, 1>(sp, st);
+    // wider layers in slices of N (experiment switch NBM_STREAM_SLICED, default on)
+    static const int sliced = getenv("NBM_STREAM_SLICED") ? atoi(getenv("NBM_STREAM_SLICED")) : 1;
+    if (sliced && d->residual) {
+      if (k32 == 4 && nt % 4 == 0 && nt <= 32) return launch_stream<4, 4, 4, 8, 1>(sp, st, nt / 4);      // 128 -> 512: 4 slices of 128
+      if (k32 == 8 && nt % 2 == 0 && nt <= 64) return launch_stream<8, 2, 2, 8, 1>(sp, st, nt / 2);      // 256 -> 1024: 16 slices of 64
+    }
   }
   if (d->N > 64) {
     p.n_tiles = (d->N + 127) / 128;

@@ -75,10 +75,10 @@ def test_conv_igemm(cfg):
 
 
 @pytest.mark.parametrize('cfg', [(64, 256, True, 'relu'), (64, 64, False, 'relu'), (256, 64, True, 'none'), (256, 64, False, 'silu'),
-                                 (64, 64, True, 'leaky')])
+                                 (64, 64, True, 'leaky'), (128, 512, True, 'relu'), (256, 1024, True, 'relu'), (256, 128, True, 'none')])
 def test_streaming_1x1_equals_the_tiled_kernel_bit_for_bit(cfg, monkeypatch):
-    """The 1x1 layers whose weights fit LDS (ResNet layer1) go through stream1x1_kernel (csrc/igemm.hip) once the map is large
-    enough: same K order, same epilogue arithmetic -> the SAME BITS as the tiled kernel (NBM_STREAM1X1=0), incl. a ragged last
+    """The 1x1 layers whose weights fit LDS (ResNet layer1; wider ones in slices of N: 128 -> 512, 256 -> 1024) go through
+    stream1x1_kernel (csrc/igemm.hip) once the map is large enough: same K order, same epilogue arithmetic -> the SAME BITS as the tiled kernel (NBM_STREAM1X1=0), incl. a ragged last
     32-row tile, and both within fp32 tolerance of torch."""
     K, N, with_res, act = cfg
     B, H, W = 2, 67, 63                                    # M = 8442: not a multiple of 32, above the streaming threshold
