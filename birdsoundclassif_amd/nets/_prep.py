@@ -62,8 +62,11 @@ def wino23(weight, transposed=False, m=2, scale=None):
 
     def make():
         return ops.wino_weight(weight.detach().contiguous(), transposed, m, None if scale is None else scale.detach().contiguous())
-    tag = ('wino', m, transposed) if scale is None else ('wino', m, transposed, scale.data_ptr(), scale._version)
-    return _cached(weight, tag, make)
+    # ONE entry per (weight, m, transposed, scaled?): the scale's identity is part of the entry's VERSION, not of its key -- the
+    # FrozenBN affine is a fresh tensor every forward pass, so a key holding its data_ptr added a 36-plane copy per layer and step
+    # that nothing evicted (60-130 MB per training step: scripts/soak.py)
+    extra = () if scale is None else (scale.data_ptr(), scale._version)
+    return _cached(weight, ('wino', m, transposed, scale is not None), make, extra=extra)
 
 
 def wino23_weight_grad(dU, m=2, row_scale=None):
@@ -142,18 +145,19 @@ def bn_affine(weight, bias, mean, var, eps, conv_bias=None):
         if conv_bias is not None:
             shift = shift + conv_bias.detach() * scale
         return scale.contiguous(), shift.contiguous()
-    # any of the five tensors changing must invalidate: fold their versions into the tag
-    tag = ('bn', weight._version, bias._version, mean._version, var._version,
-           None if conv_bias is None else conv_bias._version, mean.data_ptr())
-    return _cached(weight, tag, make)
+    # any of the five tensors changing must invalidate: their versions are part of the entry's version (`extra`), NOT of its key -- a
+    # key that changes with every update would leave one stale entry per update behind
+    extra = (weight._version, bias._version, mean._version, var._version, None if conv_bias is None else conv_bias._version,
+             mean.data_ptr(), var.data_ptr(), bias.data_ptr())
+    return _cached(weight, ('bn', conv_bias is not None), make, extra=extra)
 
 
 def cat_rows(tag, *tensors):
     """Concatenate several [Ni, K] weight matrices (or [Ni] biases) along dim 0, cached on the first."""
     def make():
         return torch.cat([t.detach().reshape(t.shape[0], -1) if t.dim() > 1 else t.detach() for t in tensors], 0).contiguous()
-    vtag = (tag,) + tuple(t._version for t in tensors)
-    return _cached(tensors[0], vtag, make)
+    extra = tuple(v for t in tensors for v in (t.data_ptr(), t._version))
+    return _cached(tensors[0], ('cat', tag), make, extra=extra)
 
 
 def clear():
