@@ -1,6 +1,6 @@
 """Soak: N training steps in the reference's 9 positive : 1 negative schedule at B = 128; prints losses every 10 steps, memory at the end.
 Checks that nothing drifts (NaN), leaks (allocated / reserved memory) or trips the hand-over checks over many steps."""
-import sys, os, time, torch, numpy as np
+import sys, os, time, resource, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from birdsoundclassif_amd import synth
 from birdsoundclassif_amd.nets import build_model
@@ -27,8 +27,9 @@ for it in range(N):
     if it % 10 in (0, 9) or it == N - 1:
         vals = {k: round(float(v), 4) for k, v in loss.items()}
         assert all(np.isfinite(v) for v in vals.values()), (it, vals)
-        mem.append((torch.cuda.memory_allocated() / 2 ** 30, torch.cuda.memory_reserved() / 2 ** 30))
-        print(f'step {it:4d} neg={int(neg)} {vals}  allocated {mem[-1][0]:.1f} GiB reserved {mem[-1][1]:.1f} GiB', flush=True)
+        mem.append((torch.cuda.memory_allocated() / 2 ** 30, torch.cuda.memory_reserved() / 2 ** 30, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2 ** 20))
+        print(f'step {it:4d} neg={int(neg)} {vals}  allocated {mem[-1][0]:.1f} GiB reserved {mem[-1][1]:.1f} GiB host max RSS {mem[-1][2]:.2f} GiB', flush=True)
 torch.cuda.synchronize()
 print(f'{N} steps, {1e3 * (time.perf_counter() - t0) / N:.1f} ms / step incl. the printing syncs; max allocated {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB')
 assert mem[-1][0] < mem[len(mem) // 2][0] + 1.0, 'allocated memory keeps growing'
+assert mem[-1][2] < mem[len(mem) // 2][2] + 0.3, 'host memory keeps growing'

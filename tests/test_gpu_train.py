@@ -621,3 +621,29 @@ def test_premasked_gradient_handover(third_consumer, monkeypatch):
         assert len(stem_masks) == 1, calls                        # autograd summed a third share in: masked by the producer
     else:
         assert not stem_masks, calls                              # complete and masked inside maxpool_bwd: no extra pass
+
+
+def test_prepared_weight_cache_does_not_grow_with_training_steps():
+    """Regression (scripts/soak.py): cache entries keyed by a per-step tensor identity (the FrozenBN scale handed to the Winograd
+    data-gradient weights) or by version counters were never evicted -- one 36-plane weight copy per ResNet 3x3 layer and step.
+    The number of prepared copies and the device memory held between steps must not depend on the number of steps."""
+    from birdsoundclassif_amd import train as T
+    from birdsoundclassif_amd.nets import build_model, _prep
+    args = T.default_args(device='cuda')
+    model, crit = build_model(args)
+    model.load_state_dict(filler_state_dict())
+    model = model.cuda().train()
+    crit.train()
+    opt, _ = T.build_optimizer(model, args)
+    B = 2
+    img = torch.from_numpy(synth.image_batch(0, B))
+    bb, ids, lens = synth.label_batch(0, B)
+    batch = [img, img, bb, ids, lens]
+    np.random.seed(3)
+    seen = []
+    for it in range(6):
+        T.train_one_step(model, crit, opt, batch, args.clip_max_norm, 'cuda', negative_sample=(it == 3))
+        torch.cuda.synchronize()
+        seen.append((len(_prep._cache), torch.cuda.memory_allocated()))
+    assert seen[5][0] == seen[2][0], seen
+    assert seen[5][1] <= seen[2][1] + (8 << 20), seen
