@@ -82,11 +82,15 @@ def train_bench(rank, world, dist, batch, steps, warmup, mix_steps=10):
 
     for _ in range(warmup):
         train_one_step(model, crit, opt, data, args.clip_max_norm, 'cuda', negative_sample=False)
+    # first with the instruments on (HIP events around every data- / weight-gradient launch, FLOP counters: ~600 event records and a
+    # few dozen small copies per step): roofline of the weight-gradient kernels, executed FLOPs -- and three more steps for the
+    # allocator to settle (the persistent gradient maps, the kept operands and the pinned rings appear during the first steps)
     ops.FLOPS = [0.0]                      # executed MFMA FLOPs of every GEMM launch (Winograd-domain counts where that path runs)
-    ops.PROFILE_BWD = []                   # live HIP events around every data- / weight-gradient launch
-    dt, loss = timed([False] * steps)
+    ops.PROFILE_BWD = []
+    dt_instr, _ = timed([False] * steps)
     exec_gflop_per_clip = ops.flops_total() / (steps * batch) / 1e9
     prof, ops.PROFILE_BWD, ops.FLOPS = ops.PROFILE_BWD, None, None
+    dt, loss = timed([False] * steps)      # the figure of this leg: nothing attached
     # dominant backward kernel: igemm_tn_kernel<128,0,0> (weight gradients); its largest launches are the 36
     # Winograd F(4x4,3x3)-domain TN GEMMs of fpn.out_convs.4 (groups = 36, one launch per batch chunk)
     wg = {}
@@ -111,7 +115,7 @@ def train_bench(rank, world, dist, batch, steps, warmup, mix_steps=10):
                     'largest_launches': [{'B,H,W,Cin,N,k,stride,groups': list(t[1:]), 'ms': sum(wg[t]) / len(wg[t]),
                                           'launches': len(wg[t]), 'executed_TFLOPs': gflop(t) * len(wg[t]) / sum(wg[t])} for t in top],
                     'traffic': None, 'traffic_note': 'FETCH_SIZE / WRITE_SIZE / MFMA-busy of this kernel: profiles/r02_pmc_wgrad.json'}
-    pos = {'ms_per_step': dt / steps * 1e3, 'clips_per_s': world * batch * steps / dt}
+    pos = {'ms_per_step': dt / steps * 1e3, 'clips_per_s': world * batch * steps / dt, 'ms_per_step_instrumented': dt_instr / steps * 1e3}
     # the reference's schedule: one negative step in ten
     mix = None
     if mix_steps:
@@ -126,7 +130,8 @@ def train_bench(rank, world, dist, batch, steps, warmup, mix_steps=10):
     v = pos['clips_per_s']
     exec_tflops = v / world * exec_gflop_per_clip / 1e3
     return {'value': v, 'unit': 'clips/s', 'batch_per_gpu': batch, 'global_batch': world * batch, 'steps': steps,
-            'ms_per_step': pos['ms_per_step'], 'parallelism': f'dp{world}',
+            'ms_per_step': pos['ms_per_step'], 'ms_per_step_with_the_instruments_on': pos['ms_per_step_instrumented'],
+            'parallelism': f'dp{world}',
             'executed_GFLOP_per_clip': exec_gflop_per_clip, 'executed_TFLOPs_per_gpu': exec_tflops,
             'executed_frac_of_mfma_peak': exec_tflops / FP32_MFMA_PEAK_TFLOPS,
             'direct_conv_equivalent_GFLOP_per_clip': TRAIN_GFLOP_PER_CLIP,
