@@ -80,11 +80,10 @@ def train_bench(rank, world, dist, batch, steps, warmup, mix_steps=10):
             dt = float(t.item())
         return dt, loss
 
-    for _ in range(warmup):
-        train_one_step(model, crit, opt, data, args.clip_max_norm, 'cuda', negative_sample=False)
+    for _ in range(warmup + 3):            # + 3: the persistent gradient maps, kept operands and pinned rings appear during the first
+        train_one_step(model, crit, opt, data, args.clip_max_norm, 'cuda', negative_sample=False)      # steps (scripts/steptimes.py)
     # first with the instruments on (HIP events around every data- / weight-gradient launch, FLOP counters: ~600 event records and a
-    # few dozen small copies per step): roofline of the weight-gradient kernels, executed FLOPs -- and three more steps for the
-    # allocator to settle (the persistent gradient maps, the kept operands and the pinned rings appear during the first steps)
+    # few dozen small copies per step): roofline of the weight-gradient kernels, executed FLOPs
     ops.FLOPS = [0.0]                      # executed MFMA FLOPs of every GEMM launch (Winograd-domain counts where that path runs)
     ops.PROFILE_BWD = []
     dt_instr, _ = timed([False] * steps)
