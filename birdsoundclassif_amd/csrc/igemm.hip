@@ -65,6 +65,12 @@ struct IgemmParams {
 // LDS reads and half the barriers per MFMA, 110 KB of LDS -> ONE workgroup = one wave per SIMD) -- 2048 -> 3072 @24576: 2.34 ms
 // against 2.23 (132 vs 138.5 TF/s), 1024 -> 1536 @98304: 2.50 / 2.30, 1024 -> 256 @24x64: 0.42 / 0.39, small grids far worse
 // (512 -> 2048 @12x32: 0.60 / 0.44).  The second co-resident wave per SIMD is worth more than the larger tile.
+// A PERSISTENT form of this kernel (512 workgroups walk their XCD's chunk of tiles; address set-up and the first operand loads of the
+// next tile issued before the epilogue of the current one; 189 VGPRs) was built to hide the per-tile ramp (~1.9 K-steps by a fit over
+// three shapes) and measured 2 % SLOWER everywhere: 24576 x 3072 x 2048 134.3 -> 131.2 TF/s, 98304 x 1536 x 1024 135.7 -> 133.0,
+// 98304 x 1024 x 512 128.5 -> 125.3, 393216 x 128 x 512 121.6 -> 119.1 (scripts/blas_compare.py).  With two workgroups per CU the
+// ramp of one is already covered by the other; what the vendor library gains on these shapes comes from stream-K (no partial round
+// of workgroups), not from pipelining across tiles.  Not kept.
 template <int BM, int BN, int WM, int WN, int AMODE, int EPI, int STAGES = 2, bool ROWS = false>
 __global__ __launch_bounds__(256, BM > 128 ? 1 : STAGES == 1 ? 3 : 2) void igemm_kernel(const IgemmParams p) {
   constexpr int MT = WM / 32, NT = WN / 32;
