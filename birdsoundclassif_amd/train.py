@@ -250,6 +250,8 @@ def step(model, criterion, batch, device, negative_sample, early_backward=False)
                 _early_rpn_backward(model, criterion)
         host_work.wants_rois = True
     # lazy=True: the finest FPN map is computed where it is read; it goes straight into forward_second_stage below
+    # (also in a negative step, whose 1000 RoIs per image list nearly every tile: 620-660 ms against 757 ms with dense maps at B = 128,
+    # scripts/negstep_ab.py)
     out_first_stage = model.forward_first_stage(inpt, host_work, lazy=True)
     loss.update(criterion.first_stage_loss(out_first_stage['rpn_cls_scores'], out_first_stage['rpn_bbox_reg'],
                                            bb_coord, lengths, negative_sample))
