@@ -295,6 +295,20 @@ def _early_rpn_backward(model, criterion):
     criterion._pre_loss = {k: (v.detach() if k in keys else v) for k, v in pre.items()}
 
 
+_CONTROL_GROUP = {}
+
+
+def _control_group(dist):
+    """Process group for small HOST tensors: the default group itself under gloo, a gloo group created once (collectively, at the
+    first data-parallel step) beside an RCCL default group."""
+    if dist.get_backend() != 'nccl':
+        return None
+    key = id(dist.group.WORLD)
+    if key not in _CONTROL_GROUP:
+        _CONTROL_GROUP[key] = dist.new_group(backend='gloo')
+    return _CONTROL_GROUP[key]
+
+
 def allreduce_grads(optimizer_or_model):
     """Data-parallel exchange step (NEW capability): average the fp32 gradients of all ranks -- one
     collective per flat gradient buffer (RCCL all-reduce over xGMI when the backend is nccl; gloo in the CPU tests).
@@ -304,8 +318,7 @@ def allreduce_grads(optimizer_or_model):
     failure paths of `step` ("RPN failed", proposal batch cannot be filled -- data dependent, reference train.py:232-247)
     leave the second-stage parameters without a gradient on one rank only; that rank must still apply the averaged
     gradient and advance its Adam step count like its peers, or the replicas drift apart for good.  The bitmap has ~400
-    int32 entries and goes through the SAME process group as the gradients (a device tensor under RCCL: one small
-    host <-> device round trip per step, 0.01 % of a 0.73 s step; a host tensor under gloo)."""
+    int32 entries and is a HOST tensor reduced over gloo in either case (`_control_group`)."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return
@@ -313,12 +326,10 @@ def allreduce_grads(optimizer_or_model):
     if hasattr(optimizer_or_model, 'flat_grads'):
         bufs = optimizer_or_model.flat_grads()
         bits = optimizer_or_model.touched_bitmap()
-        if dist.get_backend() == 'nccl':
-            dev_bits = bits.to(bufs[0].device)
-            dist.all_reduce(dev_bits, op=dist.ReduceOp.MAX)
-            bits = dev_bits.cpu()
-        else:
-            dist.all_reduce(bits, op=dist.ReduceOp.MAX)
+        # the bitmap is host data and decides host control flow: it travels through a gloo group of its own (a host tensor over
+        # loopback / TCP, ~0.1 ms), NOT through RCCL -- a device round trip here is a stream synchronisation per step, i.e. the
+        # host loses its run-ahead and the anchor targets of the next step (160 ms of NumPy at B = 128) stop being hidden
+        dist.all_reduce(bits, op=dist.ReduceOp.MAX, group=_control_group(dist))
         optimizer_or_model.set_touched_bitmap(bits)
     else:
         # plain module (torch optimiser; the gloo CPU tests): EVERY trainable parameter in module order, zeros where this rank

@@ -34,7 +34,13 @@ def test_rccl_one_rank_group_runs_the_collectives_of_the_exchange_step():
         dist.barrier()
         torch.cuda.synchronize()
         assert torch.equal(flat, ref) and bits.tolist() == [0, 1, 1, 0, 1] and float(t) == 0.125 and int(one.item()) == 1
-        from birdsoundclassif_amd.train import allreduce_grads
+        # the touched bitmap of the data-parallel step travels as a HOST tensor through a gloo group created beside the RCCL one
+        from birdsoundclassif_amd.train import allreduce_grads, _control_group
+        ctl = _control_group(dist)
+        assert ctl is not None and _control_group(dist) is ctl                        # created once
+        hbits = torch.tensor([0, 1, 1, 0, 1], dtype=torch.int32)
+        dist.all_reduce(hbits, op=dist.ReduceOp.MAX, group=ctl)
+        assert hbits.tolist() == [0, 1, 1, 0, 1]
         m = torch.nn.Linear(4, 3).cuda()
         m(torch.ones(2, 4, device='cuda')).sum().backward()
         g = m.weight.grad.clone()
