@@ -10,6 +10,11 @@ python3 $R/scripts/trainlayers.py 128 > $O/train_layers.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-dense-reference --bulk-files 0 > $O/bench_under_rocprof.log 2>&1
 find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/bench_kernel_stats.csv \;
 rm -rf $O/stats
+# the detect leg alone (the training forward launches the same kernel templates at B = 128: their durations must not mix into the
+# average that is compared with bench.py's live figure for the dominant kernel)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/dstats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-dense-reference --no-train --bulk-files 0 > $O/detect_under_rocprof.log 2>&1
+find $O/dstats -name "*kernel_stats.csv" -exec cp {} $O/detect_kernel_stats.csv \;
+rm -rf $O/dstats
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tstats -- python3 $R/scripts/trainbench.py 128 3 > $O/train_under_rocprof.log 2>&1
 find $O/tstats -name "*kernel_stats.csv" -exec cp {} $O/train_kernel_stats.csv \;
 rm -rf $O/tstats
