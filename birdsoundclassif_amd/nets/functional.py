@@ -84,6 +84,8 @@ def fpn_out_register(maps):
     _FPN_OUT.clear()
     _FPN_UP.clear()
     _PARKED.clear()
+    if not torch.is_grad_enabled():        # inference: nothing will be parked, and the registry must not keep 8 GB of maps alive
+        return
     for m in maps:
         _FPN_OUT[m.data_ptr()] = m
 
@@ -92,6 +94,8 @@ def parked_flush():
     """No RoI pooling consumed the parked gradients (the step ended after the first stage): propagate them into the FPN now."""
     items = [(m, g) for (g, m, _) in _PARKED.values()]
     _PARKED.clear()
+    _FPN_OUT.clear()                       # end of the step: the registry lets go of the maps
+    _FPN_UP.clear()
     if items:
         torch.autograd.backward([m for m, _ in items], [g for _, g in items])
 
