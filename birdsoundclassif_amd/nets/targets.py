@@ -122,6 +122,11 @@ class ProposalTargetLayer(nn.Module):
         B, gmax = len(lengths), max(lengths)
         idx = np.cumsum([0] + list(lengths))
         gt_pad = np.full((B, gmax, 4), -1, dtype=_F)
+        if min(lengths) > 0:                 # every image has rows: one masked assignment, one segmented maximum
+            lens = np.asarray(lengths)
+            gt_pad[np.arange(gmax)[None, :] < lens[:, None]] = gt_c
+            batched = bool((np.maximum.reduceat(gt_c.max(axis=1), idx[:-1]) > -1).all())
+            return gt_pad, batched
         for b, (i0, i1) in enumerate(zip(idx[:-1], idx[1:])):
             gt_pad[b, :i1 - i0] = gt_c[i0:i1]
         batched = all(gt_c[i0:i1].max() > -1 for i0, i1 in zip(idx[:-1], idx[1:]))
@@ -189,6 +194,9 @@ class ProposalTargetLayer(nn.Module):
                 fg_mask = mx_m > fg_t
                 bg_mask = (hi_t > mx_m) & (mx_m >= lo_t)
             keep_all = np.zeros((B, nb), dtype=np.int64)
+            # the candidate lists of ALL images from two nonzero() calls (row-major: already grouped by image, ascending inside)
+            fg_cols, bg_cols = np.nonzero(fg_mask)[1], np.nonzero(bg_mask)[1]
+            fg_end, bg_end = np.cumsum(fg_mask.sum(axis=1)), np.cumsum(bg_mask.sum(axis=1))
         else:
             out_r = np.zeros((B, nb, 4), dtype=_F)
             out_l = np.zeros((B, nb), dtype=_F)
@@ -196,7 +204,8 @@ class ProposalTargetLayer(nn.Module):
         for b, (i0, i1) in enumerate(zip(idx[:-1], idx[1:])):
             if batched:
                 n_rows = int(n_all[b])
-                fg, bg = np.flatnonzero(fg_mask[b]), np.flatnonzero(bg_mask[b])
+                fg = fg_cols[(fg_end[b - 1] if b else 0):fg_end[b]]
+                bg = bg_cols[(bg_end[b - 1] if b else 0):bg_end[b]]
             else:
                 gt = gt_c[i0:i1]
                 allr = np.concatenate([rois_c[b], gt], axis=0) if gt.max() > -1 else rois_c[b]
