@@ -29,6 +29,8 @@ struct BwdParams {
   const float* row_scale;    // TN: per-n multiplier of dW rows or null
   const float* residual;     // NN: added to dX (gradient accumulation) or null
   const float* mask;         // NN: forward output of the producer; dX is zeroed where mask <= 0 (ReLU) or null
+  const float* residual2;    // NN: a HALF-resolution map [B][ceil(H/2)][ceil(W/2)][Cin] added at the pixels with even iy and ix, or null
+  int res2_ld;
   long long g_gs, w_gs, x_gs, out_gs, res_gs;
   int B, H, W, Cin, N, kh, kw, stride, pad, Ho, Wo;
   int g_ld, w_ld, x_ld, out_ld, res_ld, mask_ld;
@@ -319,6 +321,15 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
           const f32x4 q = *reinterpret_cast<const f32x4*>(rg + (long long)m * p.res_ld + c);
           v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3];
         }
+        if (p.residual2) {          // the data gradient of a 1x1 / stride-2 shortcut, kept at its own (half) resolution
+          const int hw = p.H * p.W, b_ = (int)(m / hw), rem_ = (int)(m - (long long)b_ * hw);
+          const int iy_ = rem_ / p.W, ix_ = rem_ - iy_ * p.W;
+          if (!((iy_ | ix_) & 1)) {
+            const long long m2 = ((long long)b_ * ((p.H + 1) >> 1) + (iy_ >> 1)) * ((p.W + 1) >> 1) + (ix_ >> 1);
+            const f32x4 q = *reinterpret_cast<const f32x4*>(p.residual2 + m2 * p.res2_ld + c);
+            v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3];
+          }
+        }
         if (p.mask) {
           const f32x4 q = *reinterpret_cast<const f32x4*>(p.mask + (long long)m * p.mask_ld + c);
 #pragma unroll
@@ -342,6 +353,12 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
         const long long m = out_pixel(q);
         float v = acc[i][j][e] * p.alpha;
         if (rg) v += rg[(long long)m * p.res_ld + c];
+        if (p.residual2) {
+          const int hw = p.H * p.W, b_ = (int)(m / hw), rem_ = (int)(m - (long long)b_ * hw);
+          const int iy_ = rem_ / p.W, ix_ = rem_ - iy_ * p.W;
+          if (!((iy_ | ix_) & 1))
+            v += p.residual2[(((long long)b_ * ((p.H + 1) >> 1) + (iy_ >> 1)) * ((p.W + 1) >> 1) + (ix_ >> 1)) * p.res2_ld + c];
+        }
         if (p.mask && !(p.mask[(long long)m * p.mask_ld + c] > 0.f)) v = 0.f;
         og[(long long)m * p.out_ld + c] = v;
       }
@@ -618,6 +635,7 @@ static int fill_common(const nbm_bwd_desc* d, BwdParams& p) {
     return NBM_EINVAL;
   p.g = d->g; p.w = d->w; p.x = d->x; p.out = d->out;
   p.a_scale = d->a_scale; p.row_scale = d->row_scale; p.residual = d->residual; p.mask = d->mask;
+  p.residual2 = d->residual2; p.res2_ld = d->res2_ld;
   p.g_gs = d->g_gs; p.w_gs = d->w_gs; p.x_gs = d->x_gs; p.out_gs = d->out_gs; p.res_gs = d->res_gs;
   p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.N = d->N; p.kh = d->kh; p.kw = d->kw;
   p.stride = d->stride; p.pad = d->pad; p.Ho = d->Ho; p.Wo = d->Wo;
@@ -637,6 +655,7 @@ extern "C" int nbm_conv_dgrad(const nbm_bwd_desc* d, void* stream) {
       !nbm_aligned16(d->g) || !nbm_aligned16(d->w) || (d->a_scale && !nbm_aligned16(d->a_scale)))
     return NBM_EALIGN;
   if (d->out_ld < d->Cin || (d->residual && d->res_ld < d->Cin) || (d->mask && d->mask_ld < d->Cin)) return NBM_EINVAL;
+  if (d->residual2 && (d->stride != 1 || d->groups != 1 || d->res2_ld < d->Cin)) return NBM_EINVAL;
   if (d->a_scale && (d->N & 31)) return NBM_EINVAL;
   // the gather window of one 128-row tile (+ one image boundary) must stay inside the 2 GB buffer resource
   {
@@ -649,7 +668,8 @@ extern "C" int nbm_conv_dgrad(const nbm_bwd_desc* d, void* stream) {
   p.w_row = d->w_ld;
   p.vec_epi = ((d->out_ld & 3) == 0 && (d->out_gs & 3) == 0 && nbm_aligned16(d->out) &&
                (!d->residual || ((d->res_ld & 3) == 0 && (d->res_gs & 3) == 0 && nbm_aligned16(d->residual))) &&
-               (!d->mask || ((d->mask_ld & 3) == 0 && nbm_aligned16(d->mask)))) ? 1 : 0;
+               (!d->mask || ((d->mask_ld & 3) == 0 && nbm_aligned16(d->mask))) &&
+               (!d->residual2 || ((d->res2_ld & 3) == 0 && nbm_aligned16(d->residual2)))) ? 1 : 0;
   p.m_tiles = (p.M + 127) / 128;
   if (d->stride == 2) {                  // group the M tiles by parity class (see igemm_nn_kernel)
     p.phased = 1;

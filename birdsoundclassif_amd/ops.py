@@ -631,8 +631,9 @@ def _bwd_desc(g, *, B, H, W, Cin, N, kh, kw, stride, pad, g_ld, groups=1, alpha=
 
 
 def conv_dgrad(g, w, out, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, g_ld=None, w_ld=None, out_ld=None,
-               a_scale=None, residual=None, mask=None, alpha=1.0, groups=1, g_gs=0, w_gs=0, out_gs=0, res_gs=0):
-    """Raw nbm_conv_dgrad: out[B*H*W][Cin] = gather(g)[..][N] x W (see include/nbm_hip.h)."""
+               a_scale=None, residual=None, mask=None, alpha=1.0, groups=1, g_gs=0, w_gs=0, out_gs=0, res_gs=0, residual2=None):
+    """Raw nbm_conv_dgrad: out[B*H*W][Cin] = gather(g)[..][N] x W (see include/nbm_hip.h).  `residual2` [B, ceil(H/2), ceil(W/2),
+    Cin]: added at the pixels with even row and column (a stride-2 shortcut's data gradient at its own resolution)."""
     d = _bwd_desc(g, B=B, H=H, W=W, Cin=Cin, N=N, kh=kh, kw=kw, stride=stride, pad=pad,
                   g_ld=N if g_ld is None else g_ld, groups=groups, alpha=alpha)
     d.w, d.out = w.data_ptr(), out.data_ptr()
@@ -643,6 +644,10 @@ def conv_dgrad(g, w, out, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, g_ld=
     d.res_ld = Cin if residual is not None else 0
     d.mask = mask.data_ptr() if mask is not None else None
     d.mask_ld = Cin if mask is not None else 0
+    if residual2 is not None:
+        if groups != 1 or tuple(residual2.shape) != (B, (H + 1) // 2, (W + 1) // 2, Cin) or kh != 1 or stride != 1:
+            raise ValueError('conv_dgrad: residual2 must be [B, ceil(H/2), ceil(W/2), Cin] of a 1x1 / stride-1 data gradient')
+        d.residual2, d.res2_ld = _chk(residual2, name='residual2').data_ptr(), Cin
     d.g_gs, d.w_gs, d.out_gs, d.res_gs = g_gs, w_gs, out_gs, res_gs
     if FLOPS is not None:          # executed: the stride-2 kernels visit only the taps that reach each parity class
         FLOPS[0] += 2.0 * B * d.Ho * d.Wo * N * kh * kw * Cin * groups

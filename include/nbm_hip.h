@@ -387,6 +387,10 @@ typedef struct nbm_bwd_desc {
   int g_ld, w_ld, x_ld, out_ld, res_ld, mask_ld;
   float alpha;
   float* bias_grad;      /* wgrad: [groups][N], += sum_m g[m][n] (the bias gradient rides along; zeroed by the caller) or NULL */
+  const float* residual2;/* dgrad (groups == 1): a HALF-resolution map [B][ceil(H/2)][ceil(W/2)][Cin] (pitch res2_ld), added to dX at
+                            the pixels with even iy and ix -- the data gradient of the block's 1x1 / stride-2 shortcut
+                            (torchvision Bottleneck.downsample), which is non-zero only there -- or NULL                    */
+  int res2_ld;
 } nbm_bwd_desc;
 
 /* dX[b][iy][ix][c] = alpha * sum_{r,s,n} g[b][(iy+pad-r)/stride][(ix+pad-s)/stride][n] * a_scale[n] * W[n][r][s][c]
