@@ -215,13 +215,18 @@ __global__ __launch_bounds__(256) void cell_dgrad_output_kernel(const float* __r
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   f32x4 bsum = zero;                   // bias_grad (optional) += sum of the patch pixels inside the image (as in cell_outgrad_kernel)
   int my_c = -1;
-  const unsigned total = (unsigned)(q.T * q.C4);
+  // cls >= 0: the threads enumerate the cells of that parity class only (a quarter of the grid: no idle waves)
+  const int cy = cls >= 0 ? cls >> 1 : 0, cx = cls >= 0 ? cls & 1 : 0;
+  const int OHc = cls >= 0 ? (q.OH - cy + 1) >> 1 : q.OH, OWc = cls >= 0 ? (q.OW - cx + 1) >> 1 : q.OW;
+  const unsigned total = (unsigned)((long long)q.B * OHc * OWc * q.C4);
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
     const int c = (int)(i % (unsigned)q.C4);
-    const unsigned cell = i / (unsigned)q.C4;
-    int b, oy, ox;
-    cell_of(q, cell, b, oy, ox);
-    if (cls >= 0 && (((oy & 1) << 1) | (ox & 1)) != cls) continue;
+    unsigned rest = i / (unsigned)q.C4;
+    int ox = (int)(rest % (unsigned)OWc); rest /= (unsigned)OWc;
+    int oy = (int)(rest % (unsigned)OHc);
+    const int b = (int)(rest / (unsigned)OHc);
+    if (cls >= 0) { oy = 2 * oy + cy; ox = 2 * ox + cx; }
+    const unsigned cell = ((unsigned)b * q.OH + oy) * q.OW + ox;
     my_c = c;
     f32x4 t[NP][NP];                   // t[j][e] = sum_a Vinv[j][a] M[a][e]
 #pragma unroll
