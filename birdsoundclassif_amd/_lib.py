@@ -103,7 +103,8 @@ SIGNATURES = {
     'nbm_tiles_scatter_add': [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P],
     'nbm_proposal_iou': [_P, _P, _P, _I, _I, _I, _P, _P, _P],
     'nbm_maxpool3x3s2_bwd': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
-    'nbm_upsample_bilinear_bwd': [_P, _I, _I, _I, _I, _P, _I, _I, _P],
+    'nbm_upsample_bilinear_bwd': [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P],
+    'nbm_tiles_upsample_bilinear_bwd_add': [_P, _I, _I, _I, _I, _P, _I, _P, _P, _I, _I, _P],
     'nbm_png_unfilter_gray8': [_P, _L, _I, _I, _I, _P, _L, _P, _P],
     'nbm_image_half_std_u8': [_P, _L, _I, _L, _P, _P],
     'nbm_randn_fill': [_U64, _L, _P, _P],

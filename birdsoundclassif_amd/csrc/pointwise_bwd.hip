@@ -291,8 +291,11 @@ __global__ void maxpool_bwd_kernel(const uint8_t* __restrict__ idx, const float*
 }
 
 // gradient of bilinear(align_corners) up-sampling wrt the coarse map, gather form
+// `pat` = S > 0: gy is known to be zero outside the 5x5 patches around the 3x3 / stride-S pattern (the data gradient of a
+// demand-driven level's output convolution, pattern share only) -- fine rows / columns outside the patch bands never enter the
+// per-axis lists, i.e. the test is paid once per axis and thread, not once per load (the per-load form was the slower one above)
 __global__ void upsample_bwd_kernel(const float* __restrict__ gy, int B, int Hi, int Wi, int C4, float* __restrict__ gsrc,
-                                    int Ho, int Wo, float sh, float sw) {
+                                    int Ho, int Wo, float sh, float sw, int pat) {
   const f32x4* g4 = reinterpret_cast<const f32x4*>(gy);
   f32x4* o4 = reinterpret_cast<f32x4*>(gsrc);
   // grid = (ceil(Wi * C4 / 256), Hi, B): 32-bit index arithmetic only (the 64-bit div / mod chain of a flat index cost more than
@@ -317,6 +320,7 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ gy, int B, int Hi,
       int lo = sh > 0.f ? (int)floorf((Y - 1) / sh) - 1 : 0, hi = sh > 0.f ? (int)ceilf((Y + 1) / sh) + 1 : Ho - 1;
       lo = max(lo, 0); hi = min(hi, Ho - 1);
       for (int oy = lo; oy <= hi; ++oy) {
+        if (pat && ((oy + 2) % pat >= 5 || (oy + 2) / pat > (Ho - 1) / pat)) continue;
         const float fy = sh * oy;
         const int y0 = (int)fy, y1 = y0 + (y0 < Hi - 1 ? 1 : 0);
         const float ly = fminf(fmaxf(fy - y0, 0.f), 1.f);
@@ -331,6 +335,7 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ gy, int B, int Hi,
       lo = sw > 0.f ? (int)floorf((X - 1) / sw) - 1 : 0; hi = sw > 0.f ? (int)ceilf((X + 1) / sw) + 1 : Wo - 1;
       lo = max(lo, 0); hi = min(hi, Wo - 1);
       for (int ox = lo; ox <= hi; ++ox) {
+        if (pat && ((ox + 2) % pat >= 5 || (ox + 2) / pat > (Wo - 1) / pat)) continue;
         const float fx = sw * ox;
         const int x0 = (int)fx, x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
         const float lx = fminf(fmaxf(fx - x0, 0.f), 1.f);
@@ -879,6 +884,37 @@ __global__ void tiles_copy_kernel(float* __restrict__ map, int H, int W, int C4,
   }
 }
 
+// The same bilinear backward in scatter form for the 2x2 tiles of a list held as compact [n_entries][2][2][C] values (the RoI
+// share of a demand-driven level's data gradient): every fine pixel adds its four weighted shares into the coarse map.
+__global__ void tiles_upsample_bwd_add_kernel(const float* __restrict__ compact, int Ho, int Wo, int C, const int* __restrict__ tiles,
+                                              const int* __restrict__ n_blocks, float* __restrict__ gsrc, int Hi, int Wi, float sh,
+                                              float sw) {
+  if (n_blocks && (int)blockIdx.x >= *n_blocks) return;
+  const int TH = (Ho + 1) >> 1, TW = (Wo + 1) >> 1;
+  for (int e = 0; e < 128; ++e) {
+    const int ent = blockIdx.x * 128 + e;
+    const int t = tiles[ent];
+    if (t < 0) continue;                       // block-uniform
+    const int b = t / (TH * TW), rem = t - b * (TH * TW);
+    const int ty = rem / TW, tx = rem - ty * TW;
+    for (int i = threadIdx.x; i < 4 * C; i += blockDim.x) {
+      const int c = i % C, px = i / C;
+      const int oy = 2 * ty + (px >> 1), ox = 2 * tx + (px & 1);
+      if (oy >= Ho || ox >= Wo) continue;
+      const float g = compact[((long long)ent * 4 + px) * C + c];
+      const float fy = sh * oy, fx = sw * ox;
+      const int y0 = (int)fy, y1 = y0 + (y0 < Hi - 1 ? 1 : 0), x0 = (int)fx, x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
+      const float ly = fminf(fmaxf(fy - y0, 0.f), 1.f), lx = fminf(fmaxf(fx - x0, 0.f), 1.f);
+      float* row0 = gsrc + ((long long)(b * Hi + y0) * Wi) * C + c;
+      float* row1 = gsrc + ((long long)(b * Hi + y1) * Wi) * C + c;
+      atomicAdd(row0 + (long long)x0 * C, (1.f - ly) * (1.f - lx) * g);
+      atomicAdd(row0 + (long long)x1 * C, (1.f - ly) * lx * g);
+      atomicAdd(row1 + (long long)x0 * C, ly * (1.f - lx) * g);
+      atomicAdd(row1 + (long long)x1 * C, ly * lx * g);
+    }
+  }
+}
+
 // ---- optimiser: squared gradient norm, then clip + AdamW (torch.optim.AdamW semantics, decoupled decay)
 __global__ void sqnorm_kernel(const float* __restrict__ g, long long n, double* __restrict__ out) {
   double acc = 0.0;
@@ -990,14 +1026,25 @@ extern "C" int nbm_maxpool3x3s2_bwd(const uint8_t* idx, const float* gy, float* 
   return nbm_launch_status();
 }
 extern "C" int nbm_upsample_bilinear_bwd(const float* gy, int B, int Hi, int Wi, int C, float* gsrc, int Ho, int Wo,
-                                         void* stream) {
+                                         int pattern_stride, void* stream) {
   if (!gy || !gsrc || B <= 0 || C <= 0 || (C & 3) || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return NBM_EINVAL;
+  if (pattern_stride < 0 || (pattern_stride > 0 && pattern_stride < 5)) return NBM_EINVAL;      // the 5x5 patches must be disjoint
   if (!nbm_aligned16(gy) || !nbm_aligned16(gsrc)) return NBM_EALIGN;
   const float sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
   const float sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
   if (Hi > 65535 || B > 65535) return NBM_EUNSUPPORTED;
   hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)(((long long)Wi * (C / 4) + 255) / 256), Hi, B), dim3(256), 0, ST, gy, B, Hi,
-                     Wi, C / 4, gsrc, Ho, Wo, sh, sw);
+                     Wi, C / 4, gsrc, Ho, Wo, sh, sw, pattern_stride);
+  return nbm_launch_status();
+}
+extern "C" int nbm_tiles_upsample_bilinear_bwd_add(const float* compact, int B, int Ho, int Wo, int C, const int* tiles, int n_entries,
+                                                   const int* n_blocks, float* gsrc, int Hi, int Wi, void* stream) {
+  if (!compact || !tiles || !gsrc || B <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || n_entries <= 0 || (n_entries & 127))
+    return NBM_EINVAL;
+  const float sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
+  const float sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+  hipLaunchKernelGGL(tiles_upsample_bwd_add_kernel, dim3(n_entries / 128), dim3(256), 0, ST, compact, Ho, Wo, C, tiles, n_blocks, gsrc,
+                     Hi, Wi, sh, sw);
   return nbm_launch_status();
 }
 extern "C" int nbm_softmax_rows_bwd(const float* p, const float* gp, float* out, int64_t rows, int cols, float alpha,

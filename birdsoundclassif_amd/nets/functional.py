@@ -63,6 +63,8 @@ _STASH_OK = {}           # data_ptr -> shape of the tensors whose OTHER consumer
 _PREMASKED = {}
 PREMASK = True           # module switch for A/B measurements (scripts/trainloop.py)
 HALF_RES_SHORTCUT = True  # Bottleneck.backward: a stride-2 shortcut's data gradient stays at half resolution (A/B switch)
+UPBWD_SPLIT_READ = True   # the finest lateral's node reads a split gradient (ondemand.UPBWD_SPLIT) as it is; False: it puts the RoI share
+                          # into the map first and reads that densely (A/B switch, and the fallback's test)
 
 
 def _premasked(y, gy):
@@ -207,8 +209,18 @@ class Conv(Function):
         listed = ctx.lazy is not None and ondemand.listed_backward(ctx.lazy) and (ctx.lazy.sparse or (LAZY_DGRAD and LAZY_WGRAD))
         # a deferred lateral whose consumer's backward pass (which ran before this node's) already produced this node's gradients
         pre = ctx.lat_state.grads if ctx.lat_state is not None else None
+        raw = pre
         if pre is not None and (pre['gw_cell'] is None or scale is not None or kh != 1):
             pre = None
+        share = None
+        if raw is not None and raw.get('up_share') is not None:
+            # the consumer kept the RoI share of this node's incoming gradient out of the map (ondemand.UPBWD_SPLIT).  Good when all this
+            # node computes from gy is the bilinear backward below; if a dense kernel is going to read gy, the share goes in first
+            if UPBWD_SPLIT_READ and pre is not None and gy.data_ptr() == raw['gx_ptr'] and not (ctx.take_x and x.data_ptr() in _STASH):
+                share = raw['up_share']
+            else:
+                raw['complete'](gy)
+            raw['up_share'] = None
         if ctx.needs_input_grad[0] and listed and LAZY_DGRAD and N % 32 == 0 and N >= 64:
             # demand-driven map: the incoming gradient lives on the pattern pixels and in the RoI windows, the outgoing one
             # within a pixel of them -> the listed fused kernel on the tiles around them (F(2x2,3x3), no transforms through HBM)
@@ -269,7 +281,8 @@ class Conv(Function):
         gres = g if (ctx.has_res and ctx.needs_input_grad[5]) else None
         gup = None
         if ctx.up_hw is not None and ctx.needs_input_grad[12]:        # fused top-down merge: d/d(coarse map)
-            gup = ops.upsample_bilinear_bwd(g, *ctx.up_hw)
+            gup = (ops.upsample_bilinear_bwd(g, *ctx.up_hw) if share is None else
+                   ops.upsample_bilinear_bwd(g, *ctx.up_hw, pattern_stride=raw['pat_stride'], tiles_share=share))
             if ctx.stash_up:                          # the coarse map's output convolution adds it in its data-gradient epilogue
                 _STASH[ctx.up_ptr] = gup
                 gup = None

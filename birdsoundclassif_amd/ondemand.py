@@ -207,8 +207,8 @@ class LazyMap:
     def __del__(self):          # the pinned counters go back to the pool
         try:
             for per_chunk in self.roi:
-                for _, host, _ in per_chunk:
-                    _PINNED_FREE.append(host)
+                for entry in per_chunk:         # (tiles, host, event, dilated tiles, its host counter or None)
+                    _PINNED_FREE.extend(h for h in (entry[1], entry[4] if len(entry) > 4 else None) if h is not None)
         except Exception:       # interpreter shutdown
             pass
 
@@ -485,6 +485,10 @@ CELL_BWD = os.environ.get('NBM_CELL_BWD', '1') != '0'     # pattern share of bot
 # folded weights [U | alpha U W] give d/dt in the transform domain, the weight-gradient GEMMs already hold d/d(alpha U W)), its RoI
 # share runs on compact [tiles x 4 pixels] operands -- instead of three dense passes over the 18.9 GB gradient of the merged map
 LAT_CELL_BWD = os.environ.get('NBM_LAT_CELL_BWD', '1') != '0'
+# ... and then the only reader left of d/d(merged map) is the bilinear backward of the top-down merge: the RoI share stays in its
+# compact form (nbm_tiles_upsample_bilinear_bwd_add) and the map holds the pattern patches only, which lets that reader skip the rows
+# and columns between the patches (nbm_upsample_bilinear_bwd(pattern_stride): 61 % of 18.9 GB at B = 128)
+UPBWD_SPLIT = os.environ.get('NBM_UPBWD_SPLIT', '1') != '0'
 
 
 # ---- persistent gradient maps of a demand-driven level (training)
@@ -644,6 +648,8 @@ def conv3x3_winograd_dgrad_tiles(st, g, Ut, Ucell=None, base=None, lateral_grads
         gb_lat = torch.zeros((C_,), device=g.device, dtype=torch.float32)
         gw_roi = torch.zeros((C_, Cin), device=g.device, dtype=torch.float32)
         dt_img_bytes = H * W * Cin * 4
+        split = bool(UPBWD_SPLIT and st.stride >= 5)
+        shares = []                  # split: (compact RoI share of d/d(merged map), its tile list, first image, images) per chunk
     for ci, (b0, nb, _) in enumerate(st.chunks):
         if cell:
             vg = _cell_outgrad(st, g, ci, b0, nb)
@@ -687,14 +693,17 @@ def conv3x3_winograd_dgrad_tiles(st, g, Ut, Ucell=None, base=None, lateral_grads
                     Gc = torch.zeros((n * 4, C_), device=g.device, dtype=torch.float32)
                     _wino23_tiles_run(g[b0:b0 + nb], Ut, None, Gc.data_ptr(), tl, None, n, 'wino23-dgrad-rois', skip_pattern=st.stride,
                                       compact=True)
-                    check(lib().nbm_tiles_scatter_add(gx_p, nb, H, W, C_, _ptr(tl), n, None, _ptr(Gc), _stream()), 'nbm_tiles_scatter_add')
+                    if split:
+                        shares.append((Gc, tl, b0, nb))
+                    else:
+                        check(lib().nbm_tiles_scatter_add(gx_p, nb, H, W, C_, _ptr(tl), n, None, _ptr(Gc), _stream()), 'nbm_tiles_scatter_add')
                     tc = torch.zeros((n * 4, Cin), device=g.device, dtype=torch.float32)
                     check(lib().nbm_tiles_gather(_ptr(lt.t[b0:b0 + nb]), nb, H, W, Cin, _ptr(tl), n, None, _ptr(tc), _stream()), 'nbm_tiles_gather')
                     dtc = torch.matmul(Gc, Wl)
                     check(lib().nbm_tiles_scatter_add(dt_p, nb, H, W, Cin, _ptr(tl), n, None, _ptr(dtc), _stream()), 'nbm_tiles_scatter_add')
                     gw_roi.addmm_(Gc.t(), tc, alpha=float(lt.alpha))
                     gb_lat += Gc.sum(0)
-                    for pl, (p_, c_) in ((pool, (gx_p, C_)), (dt_pool, (dt_p, Cin))):
+                    for pl, (p_, c_) in ((None if split else pool, (gx_p, C_)), (dt_pool, (dt_p, Cin))):
                         if pl is not None:
                             zero_note(pl, lambda p_=p_, c_=c_, nb_=nb, tl_=tl, n_=n: check(
                                 lib().nbm_zero_tiles(p_, nb_, H, W, c_, _ptr(tl_), n_, None, _stream()), 'nbm_zero_tiles'))
@@ -717,7 +726,18 @@ def conv3x3_winograd_dgrad_tiles(st, g, Ut, Ucell=None, base=None, lateral_grads
     if do_lat:
         if dt_pool is not None and ZERO_POOL_CHECK:
             dt_pool['check'] = lambda buf, s_=st.stride: _check_zero_outside_patches(buf, s_)
-        lt.grads = dict(dt=dt, gb=gb_lat, gw_roi=gw_roi, gw_cell=None)
+        lt.grads = dict(dt=dt, gb=gb_lat, gw_roi=gw_roi, gw_cell=None, up_share=None)
+        if split:
+            def complete(gy, shares=shares, pool=pool):
+                """A dense kernel is going to read d/d(merged map) after all: the RoI share goes into the map."""
+                for Gc_, tl_, b0_, nb_ in shares:
+                    p_ = C.c_void_p(gy.data_ptr() + b0_ * img_bytes)
+                    check(lib().nbm_tiles_scatter_add(p_, nb_, H, W, C_, _ptr(tl_), tl_.numel(), None, _ptr(Gc_), _stream()),
+                          'nbm_tiles_scatter_add')
+                    if pool is not None and pool['buf'].data_ptr() == gy.data_ptr():
+                        zero_note(pool, lambda p_=p_, nb_=nb_, tl_=tl_: check(
+                            lib().nbm_zero_tiles(p_, nb_, H, W, C_, _ptr(tl_), tl_.numel(), None, _stream()), 'nbm_zero_tiles'))
+            lt.grads.update(up_share=shares, pat_stride=st.stride, gx_ptr=gx.data_ptr(), complete=complete)
     return gx
 
 

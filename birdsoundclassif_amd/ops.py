@@ -769,11 +769,20 @@ def maxpool3x3s2_bwd(idx, gy, H, W, residual=None, mask=None):
     return gx
 
 
-def upsample_bilinear_bwd(gy, Hi, Wi):
+def upsample_bilinear_bwd(gy, Hi, Wi, pattern_stride=0, tiles_share=()):
+    """d/d(coarse map) of the bilinear top-down merge.  `pattern_stride` = S: gy is zero outside the 5x5 patches around the 3x3 /
+    stride-S pattern, only those are read; `tiles_share`: (compact [n][2][2][C], tile list, first image, images) entries whose
+    bilinear backward is ADDED on top (the RoI share of a demand-driven level's gradient, kept out of gy -- ondemand.UPBWD_SPLIT)."""
     B, Ho, Wo, C_ = gy.shape
     gs = torch.empty((B, Hi, Wi, C_), device=gy.device, dtype=torch.float32)
-    check(lib().nbm_upsample_bilinear_bwd(_ptr(_chk(gy)), B, Hi, Wi, C_, _ptr(gs), Ho, Wo, _stream()),
+    check(lib().nbm_upsample_bilinear_bwd(_ptr(_chk(gy)), B, Hi, Wi, C_, _ptr(gs), Ho, Wo, int(pattern_stride), _stream()),
           'nbm_upsample_bilinear_bwd')
+    for compact, tiles, b0, nb in tiles_share:
+        if compact.shape != (tiles.numel() * 4, C_) or b0 < 0 or b0 + nb > B:
+            raise ValueError('upsample_bilinear_bwd: compact operand / tile list / image range do not fit the map')
+        check(lib().nbm_tiles_upsample_bilinear_bwd_add(_ptr(_chk(compact)), nb, Ho, Wo, C_, _ptr(tiles), tiles.numel(), None,
+                                                        C.c_void_p(gs.data_ptr() + b0 * Hi * Wi * C_ * 4), Hi, Wi, _stream()),
+              'nbm_tiles_upsample_bilinear_bwd_add')
     return gs
 
 

@@ -448,8 +448,16 @@ int nbm_mha_small_bwd(const float* q, const float* k, const float* v, const floa
                       int go_ld, float* gq, float* gk, float* gv, int gq_ld, int gk_ld, int gv_ld, float* workspace, int S,
                       int N, int nhead, int hd, int64_t seq_stride, int64_t batch_stride, const int32_t* n_valid,
                       float scale, void* stream);
-/* gradient of the bilinear (align_corners) up-sampling of fpn.py:143-144 wrt the coarse map [B][Hi][Wi][C], gather form */
-int nbm_upsample_bilinear_bwd(const float* gy, int B, int Hi, int Wi, int C, float* gsrc, int Ho, int Wo, void* stream);
+/* gradient of the bilinear (align_corners) up-sampling of fpn.py:143-144 wrt the coarse map [B][Hi][Wi][C], gather form.
+ * pattern_stride = S >= 5: the caller guarantees that gy [B][Ho][Wo][C] is zero outside the 5x5 patches around the 3x3 / stride-S /
+ * pad-1 pattern (rows and columns o*S - 2 .. o*S + 2): those rows / columns are not read (61 % of the map at S = 8); 0: every
+ * pixel is read.  nbm_tiles_upsample_bilinear_bwd_add: the same operator in scatter form for the 2x2 tiles of a list (layout of
+ * nbm_roi_tiles, ids relative to [B][Ho][Wo]) held as compact [n_entries][2][2][C] values (nbm_wino23_conv_fused_tiles), ADDED
+ * into gsrc with fp32 atomics -- the RoI share of the same gradient, a few % of the map. */
+int nbm_upsample_bilinear_bwd(const float* gy, int B, int Hi, int Wi, int C, float* gsrc, int Ho, int Wo, int pattern_stride,
+                              void* stream);
+int nbm_tiles_upsample_bilinear_bwd_add(const float* compact, int B, int Ho, int Wo, int C, const int* tiles, int n_entries,
+                                        const int* n_blocks, float* gsrc, int Hi, int Wi, void* stream);
 int nbm_softmax_rows_bwd(const float* p, const float* gp, float* out, int64_t rows, int cols, float alpha, void* stream);
 int nbm_pair_softmax_bwd(const float* y, const float* gy, float* gx, int64_t n_pairs, void* stream);
 /* depthwise 3x3 gradients: gx (may be NULL), gw [Cout][9] and gb [Cout] (gw NULL = skip both) */

@@ -660,7 +660,10 @@ def test_persistent_gradient_maps_are_clean_after_every_step():
 def test_lateral_gradients_from_the_cell_domain_equal_the_dense_passes():
     """ondemand.LAT_CELL_BWD: the finest lateral's own gradients (data, weight, bias) come out of its consumer's backward pass --
     pattern share in the cell-domain GEMMs (folded weights), RoI share on compact operands -- instead of three dense passes over the
-    gradient of the merged map.  Every parameter gradient of a positive step equals the one of the dense passes."""
+    gradient of the merged map.  Every parameter gradient of a positive step equals the one of the dense passes.  Also with the
+    variants of what the bilinear backward of the top-down merge reads (ondemand.UPBWD_SPLIT): the RoI share from its compact form
+    + the pattern patches only (default); the share scattered into the map by the producer (split off); by the lateral's node
+    (the fallback a dense reader of that gradient takes)."""
     from birdsoundclassif_amd import train as T
     from birdsoundclassif_amd.nets import build_model
     args = T.default_args(device='cuda')
@@ -669,29 +672,34 @@ def test_lateral_gradients_from_the_cell_domain_equal_the_dense_passes():
     bb, ids, lens = synth.label_batch(0, B)
     batch = [img, img, bb, ids, lens]
     res = {}
-    for on in (False, True):
+    for mode in ('dense', 'split', 'split-off', 'split-completed-by-the-reader'):
         model, crit = build_model(args)
         model.load_state_dict(filler_state_dict())
         model = model.cuda().train()
         crit.train()
         np.random.seed(5)
-        ondemand.LAT_CELL_BWD = on
+        ondemand.LAT_CELL_BWD = mode != 'dense'
+        ondemand.UPBWD_SPLIT = mode != 'split-off'
+        Fn.UPBWD_SPLIT_READ = mode != 'split-completed-by-the-reader'
+        ondemand.ZERO_POOL_CHECK = True
         try:
             loss = T.step(model, crit, batch, 'cuda', False)
             sum(loss[k] * crit.weight_dict[k] for k in loss if k in crit.weight_dict).backward()
             Fn.stash_check_empty()
         finally:
-            ondemand.LAT_CELL_BWD = True
+            ondemand.LAT_CELL_BWD = ondemand.UPBWD_SPLIT = Fn.UPBWD_SPLIT_READ = True
+            ondemand.ZERO_POOL_CHECK = False
             ondemand.zero_pool_clear()
         torch.cuda.synchronize()
-        res[on] = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
-    assert set(res[False]) == set(res[True])
-    worst = 0.0
-    for k, g in res[False].items():
-        g2 = res[True][k]
-        assert torch.isfinite(g2).all(), k
-        tol = 1e-4 * float(g.abs().max()) + 1e-7
-        err = float((g - g2).abs().max())
-        assert err <= tol, (k, err, tol)
-        worst = max(worst, err / (float(g.abs().max()) + 1e-12))
-    assert any('fpn' in k for k in res[True])
+        res[mode] = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    for mode in res:
+        if mode == 'dense':
+            continue
+        assert set(res['dense']) == set(res[mode])
+        for k, g in res['dense'].items():
+            g2 = res[mode][k]
+            assert torch.isfinite(g2).all(), (mode, k)
+            tol = 1e-4 * float(g.abs().max()) + 1e-7
+            err = float((g - g2).abs().max())
+            assert err <= tol, (mode, k, err, tol)
+    assert any('fpn' in k for k in res['split'])

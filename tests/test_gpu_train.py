@@ -647,3 +647,46 @@ def test_prepared_weight_cache_does_not_grow_with_training_steps():
         seen.append((len(_prep._cache), torch.cuda.memory_allocated()))
     assert seen[5][0] == seen[2][0], seen
     assert seen[5][1] <= seen[2][1] + (8 << 20), seen
+
+
+@pytest.mark.parametrize('geom', [(2, 188, 512, 94, 256, 32, 8), (3, 47, 66, 24, 33, 8, 8), (1, 25, 33, 13, 17, 16, 5), (2, 24, 64, 12, 32, 4, 8)])
+def test_bilinear_backward_reads_the_pattern_patches_only_and_takes_a_tile_share(geom):
+    """nbm_upsample_bilinear_bwd(pattern_stride): on a gradient that is zero outside the 5x5 patches of the stride-S pattern the
+    pruned gather equals the full one bit for bit (the rows / columns it leaves out contribute exact zeros);
+    nbm_tiles_upsample_bilinear_bwd_add: the scatter form on a compact tile operand equals scattering the tiles into a map and
+    gathering from that (different summation order: 1e-6)."""
+    from birdsoundclassif_amd.ops import _ptr, _stream, check, lib
+    B, Ho, Wo, Hi, Wi, C_, S = geom
+    gen = torch.Generator().manual_seed(11)
+
+    def band(n):
+        i = torch.arange(n)
+        return ((i + 2) % S < 5) & ((i + 2) // S < (n - 1) // S + 1)
+    inside = (band(Ho)[:, None] & band(Wo)[None, :]).float()
+    g = (torch.randn((B, Ho, Wo, C_), generator=gen) * inside[None, :, :, None]).cuda().contiguous()
+    full = ops.upsample_bilinear_bwd(g, Hi, Wi)
+    pruned = ops.upsample_bilinear_bwd(g, Hi, Wi, pattern_stride=S)
+    assert torch.equal(full, pruned)
+    # a pixel outside the patches is NOT read by the pruned form (that is the point of it)
+    g2 = g.clone()
+    for axis, n in ((1, Ho), (2, Wo)):
+        out = torch.nonzero(~band(n)).flatten()
+        if out.numel():                           # (S = 5: the bands are contiguous, only the rows past the last cell are outside)
+            g2.index_fill_(axis, out.cuda(), float('nan'))
+    assert torch.equal(ops.upsample_bilinear_bwd(g2, Hi, Wi, pattern_stride=S), full)
+    # tile share
+    TH, TW = (Ho + 1) // 2, (Wo + 1) // 2
+    ids = torch.randperm(B * TH * TW, generator=gen)[:max(1, B * TH * TW // 7)].sort().values.int()
+    n = -(-ids.numel() // 128) * 128 + 128                        # one block of padding only
+    tiles = torch.full((n,), -1, dtype=torch.int32)
+    tiles[:ids.numel()] = ids
+    tiles = tiles.cuda()
+    compact = torch.randn((n * 4, C_), generator=gen).cuda()
+    dense = torch.zeros_like(g)
+    check(lib().nbm_tiles_scatter_add(_ptr(dense), B, Ho, Wo, C_, _ptr(tiles), n, None, _ptr(compact), _stream()), 'scatter')
+    ref = ops.upsample_bilinear_bwd(dense + g, Hi, Wi)
+    got = ops.upsample_bilinear_bwd(g, Hi, Wi, pattern_stride=S, tiles_share=[(compact, tiles, 0, B)])
+    err = float((ref - got).abs().max())
+    assert err <= 1e-5 * max(1.0, float(ref.abs().max())), err
+    with pytest.raises(ValueError):
+        ops.upsample_bilinear_bwd(g, Hi, Wi, tiles_share=[(compact[:-4], tiles, 0, B)])

@@ -87,3 +87,21 @@ def test_committed_bench_line_carries_the_contract_fields():
         assert k in c, k
     assert c['kind'] in ('port', 'reference')
     assert abs(line['value'] - 64 * 1000.0 / line['ms_per_step']) < 1e-6 * line['value']
+
+
+def test_pinned_counters_return_to_the_pool_when_the_map_dies():
+    """Every (RoI pooling, chunk) entry of a LazyMap holds one pinned counter, two when the dilated list of a deferred lateral
+    exists: all of them go back to ondemand._PINNED_FREE when the map's state is dropped (a pool that never refills allocates pinned
+    memory -- a stream stall -- every few training steps)."""
+    import gc
+    import torch
+    before = len(ondemand._PINNED_FREE)
+    st = ondemand.LazyMap(None, None, None, 8)
+    hosts = [torch.zeros(1, dtype=torch.int32) for _ in range(5)]
+    st.roi.append([(None, hosts[0], None, None, None), (None, hosts[1], None, 'tiles_d', hosts[2])])
+    st.roi.append([(None, hosts[3], None), (None, hosts[4], None, None, None)])          # the 3-tuples of the older layout too
+    del st
+    gc.collect()
+    got = ondemand._PINNED_FREE[before:]
+    assert len(got) == 5 and {id(h) for h in got} == {id(h) for h in hosts}
+    del ondemand._PINNED_FREE[before:]
