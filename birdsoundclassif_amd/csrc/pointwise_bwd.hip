@@ -290,6 +290,88 @@ __global__ void maxpool_bwd_kernel(const uint8_t* __restrict__ idx, const float*
   }
 }
 
+// Contributors of coarse index P along one axis (scale s = (n_coarse - 1) / (n_fine - 1), fine index o -> s * o): the fine
+// indices with P - 1 < s * o < P + 1, at most ceil(2 / s) <= NF of them, starting at `lo` = the first o with s * o > P - 1.  Fixed slots
+// (index lo + k, weight 0 when the slot does not contribute or lies outside the pattern bands) instead of compacted lists: no
+// dynamically indexed registers, ~40 VALU instructions per axis.
+template <int NF>
+__device__ __forceinline__ void upbwd_axis(int P, float s, float inv_s, int n_fine, int n_coarse, int pat, float inv_pat, int last_cell,
+                                           int& lo, float (&w)[NF]) {
+  lo = max((int)((float)(P - 1) * inv_s), 0);
+  while (lo > 0 && s * (float)(lo - 1) > (float)(P - 1)) --lo;          // float rounding of the estimate: settle on the exact first index
+  while (lo < n_fine && s * (float)lo <= (float)(P - 1)) ++lo;
+#pragma unroll
+  for (int k = 0; k < NF; ++k) {
+    const int o = lo + k;
+    const float f = s * (float)o;
+    const int p0 = (int)f, p1 = p0 + (p0 < n_coarse - 1 ? 1 : 0);
+    const float l = fminf(fmaxf(f - (float)p0, 0.f), 1.f);
+    float wv = (p0 == P ? 1.f - l : 0.f) + (p1 == P ? l : 0.f);
+    bool ok = o < n_fine;
+    if (pat) {                                                           // (o + 2) % pat < 5 and the cell exists: exact for o < 2^20
+      const int q = o + 2, cell = (int)(((float)q + 0.5f) * inv_pat);
+      ok = ok && (q - cell * pat) < 5 && cell <= last_cell;
+    }
+    w[k] = ok ? wv : 0.f;
+  }
+}
+
+// The same operator for scales with at most NF contributors per axis (2 / s <= NF: every level of the pyramid, s ~ 1/2).  What bounded the
+// general kernel below was neither bandwidth nor latency but VALU issue: ~650 VALU + ~450 SALU instructions per wave to build its
+// compacted lists (rocprofv3 --pmc SQ_INSTS_VALU on scripts/upbwd_probe.py: 3.0e9 per launch x 4 cycles per wave64 instruction / 1024
+// SIMDs = 5.0 ms, the measured time -- which is why reading 39 % of the bytes did not make it faster).  Here: fixed slots, the row
+// slots in scalar registers (Y = blockIdx.y), every load of a thread in flight at once.
+template <int NF, int V>
+__global__ __launch_bounds__(256) void upsample_bwd_fast_kernel(const float* __restrict__ gy, int Hi, int Wi, int C4, float* __restrict__ gsrc,
+                                                                int Ho, int Wo, float sh, float sw, int pat) {
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(gy);
+  f32x4* o4 = reinterpret_cast<f32x4*>(gsrc);
+  const int lanes = C4 / V;                        // a thread owns V channel vectors of its pixel: c, c + lanes, ...
+  const int xc = blockIdx.x * 256 + threadIdx.x;
+  if (xc >= Wi * lanes) return;
+  const int X = xc / lanes, c = xc - X * lanes;
+  const int Y = blockIdx.y, b = blockIdx.z;
+  const float inv_pat = pat ? 1.f / (float)pat : 0.f;
+  int ylo, xlo;
+  float wy[NF], wx[NF];
+  upbwd_axis<NF>(Y, sh, 1.f / sh, Ho, Hi, pat, inv_pat, pat ? (Ho - 1) / pat : 0, ylo, wy);
+  upbwd_axis<NF>(X, sw, 1.f / sw, Wo, Wi, pat, inv_pat, pat ? (Wo - 1) / pat : 0, xlo, wx);
+  ylo = __builtin_amdgcn_readfirstlane(ylo);
+  float wyu[NF];
+#pragma unroll
+  for (int a = 0; a < NF; ++a) wyu[a] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wy[a])));
+#pragma unroll 1
+  for (int v = 0; v < V; ++v) {
+    const int cc = c + v * lanes;
+    const f32x4* base = g4 + ((long long)(b * Ho + ylo) * Wo + xlo) * C4 + cc;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // two groups of rows (3 + 2): the loads of a group are all in flight together, and 15 instead of 25 vectors in registers keep
+    // 6 waves per SIMD resident (all 25: 110 VGPRs, 4 waves -- measured slower)
+#pragma unroll
+    for (int a0 = 0; a0 < NF; a0 += 3) {
+      f32x4 g[3][NF];
+#pragma unroll
+      for (int a = a0; a < a0 + 3 && a < NF; ++a)
+        if (wyu[a] != 0.f) {                                             // workgroup-uniform
+#pragma unroll
+          for (int e = 0; e < NF; ++e)
+            if (wx[e] != 0.f) g[a - a0][e] = base[((long long)a * Wo + e) * C4];
+        }
+#pragma unroll
+      for (int a = a0; a < a0 + 3 && a < NF; ++a)
+        if (wyu[a] != 0.f) {
+#pragma unroll
+          for (int e = 0; e < NF; ++e)
+            if (wx[e] != 0.f) {
+              const float w = wyu[a] * wx[e];
+              acc[0] += w * g[a - a0][e][0]; acc[1] += w * g[a - a0][e][1]; acc[2] += w * g[a - a0][e][2]; acc[3] += w * g[a - a0][e][3];
+            }
+        }
+    }
+    o4[((long long)(b * Hi + Y) * Wi + X) * C4 + cc] = acc;
+  }
+}
+
 // gradient of bilinear(align_corners) up-sampling wrt the coarse map, gather form
 // `pat` = S > 0: gy is known to be zero outside the 5x5 patches around the 3x3 / stride-S pattern (the data gradient of a
 // demand-driven level's output convolution, pattern share only) -- fine rows / columns outside the patch bands never enter the
@@ -862,13 +944,13 @@ __global__ void zero_tiles_kernel(float* __restrict__ g, int H, int W, int C4, c
 template <int MODE>
 __global__ void tiles_copy_kernel(float* __restrict__ map, int H, int W, int C4, const int* __restrict__ tiles,
                                   const int* __restrict__ n_blocks, float* __restrict__ compact) {
-  if (n_blocks && (int)blockIdx.x >= *n_blocks) return;
+  if (n_blocks && (int)(blockIdx.x >> 4) >= *n_blocks) return;       // 8 list entries per workgroup, 16 workgroups per 128-entry block
   const int TH = (H + 1) >> 1, TW = (W + 1) >> 1;
   f32x4* m4 = reinterpret_cast<f32x4*>(map);
   f32x4* c4 = reinterpret_cast<f32x4*>(compact);
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  for (int e = 0; e < 128; ++e) {
-    const int ent = blockIdx.x * 128 + e;
+  for (int e = 0; e < 8; ++e) {
+    const int ent = blockIdx.x * 8 + e;
     const int t = tiles[ent];
     if (t < 0) continue;                       // block-uniform
     const int b = t / (TH * TW), rem = t - b * (TH * TW);
@@ -889,10 +971,11 @@ __global__ void tiles_copy_kernel(float* __restrict__ map, int H, int W, int C4,
 __global__ void tiles_upsample_bwd_add_kernel(const float* __restrict__ compact, int Ho, int Wo, int C, const int* __restrict__ tiles,
                                               const int* __restrict__ n_blocks, float* __restrict__ gsrc, int Hi, int Wi, float sh,
                                               float sw) {
-  if (n_blocks && (int)blockIdx.x >= *n_blocks) return;
+  // 8 list entries per workgroup (a list of a few 10 000 tiles is only a few hundred 128-entry blocks: too few workgroups for 256 CUs)
+  if (n_blocks && (int)(blockIdx.x >> 4) >= *n_blocks) return;
   const int TH = (Ho + 1) >> 1, TW = (Wo + 1) >> 1;
-  for (int e = 0; e < 128; ++e) {
-    const int ent = blockIdx.x * 128 + e;
+  for (int e = 0; e < 8; ++e) {
+    const int ent = blockIdx.x * 8 + e;
     const int t = tiles[ent];
     if (t < 0) continue;                       // block-uniform
     const int b = t / (TH * TW), rem = t - b * (TH * TW);
@@ -1033,8 +1116,20 @@ extern "C" int nbm_upsample_bilinear_bwd(const float* gy, int B, int Hi, int Wi,
   const float sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
   const float sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
   if (Hi > 65535 || B > 65535) return NBM_EUNSUPPORTED;
-  hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)(((long long)Wi * (C / 4) + 255) / 256), Hi, B), dim3(256), 0, ST, gy, B, Hi,
-                     Wi, C / 4, gsrc, Ho, Wo, sh, sw, pattern_stride);
+  const int C4 = C / 4;
+  const dim3 grid((unsigned)(((long long)Wi * C4 + 255) / 256), Hi, B);
+  constexpr int NF = 5;
+  if (sh > 0.f && sw > 0.f && 2.f / sh <= NF - 0.05f && 2.f / sw <= NF - 0.05f && Ho < (1 << 20) && Wo < (1 << 20)) {
+    // V channel vectors per thread: what bounds these launches is the number of waves (4.6 M of them at B = 128 took 5.1-5.4 ms
+    // whether they read 23.7 or 12.1 GB and whether they issued 650 or 250 VALU instructions each)
+    const int V = 1;
+    const dim3 gv((unsigned)(((long long)Wi * (C4 / V) + 255) / 256), Hi, B);
+    if (V == 3) hipLaunchKernelGGL((upsample_bwd_fast_kernel<NF, 3>), gv, dim3(256), 0, ST, gy, Hi, Wi, C4, gsrc, Ho, Wo, sh, sw, pattern_stride);
+    else if (V == 2) hipLaunchKernelGGL((upsample_bwd_fast_kernel<NF, 2>), gv, dim3(256), 0, ST, gy, Hi, Wi, C4, gsrc, Ho, Wo, sh, sw, pattern_stride);
+    else hipLaunchKernelGGL((upsample_bwd_fast_kernel<NF, 1>), gv, dim3(256), 0, ST, gy, Hi, Wi, C4, gsrc, Ho, Wo, sh, sw, pattern_stride);
+  } else {
+    hipLaunchKernelGGL(upsample_bwd_kernel, grid, dim3(256), 0, ST, gy, B, Hi, Wi, C4, gsrc, Ho, Wo, sh, sw, pattern_stride);
+  }
   return nbm_launch_status();
 }
 extern "C" int nbm_tiles_upsample_bilinear_bwd_add(const float* compact, int B, int Ho, int Wo, int C, const int* tiles, int n_entries,
@@ -1043,7 +1138,7 @@ extern "C" int nbm_tiles_upsample_bilinear_bwd_add(const float* compact, int B, 
     return NBM_EINVAL;
   const float sh = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
   const float sw = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
-  hipLaunchKernelGGL(tiles_upsample_bwd_add_kernel, dim3(n_entries / 128), dim3(256), 0, ST, compact, Ho, Wo, C, tiles, n_blocks, gsrc,
+  hipLaunchKernelGGL(tiles_upsample_bwd_add_kernel, dim3(n_entries / 8), dim3(256), 0, ST, compact, Ho, Wo, C, tiles, n_blocks, gsrc,
                      Hi, Wi, sh, sw);
   return nbm_launch_status();
 }
@@ -1180,7 +1275,7 @@ extern "C" int nbm_tiles_gather(const float* map, int B, int H, int W, int C, co
                                 float* compact, void* stream) {
   if (!map || !tiles || !compact || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || n_entries <= 0 || (n_entries & 127)) return NBM_EINVAL;
   if (!nbm_aligned16(map) || !nbm_aligned16(compact)) return NBM_EALIGN;
-  hipLaunchKernelGGL(tiles_copy_kernel<0>, dim3(n_entries / 128), dim3(256), 0, ST, const_cast<float*>(map), H, W, C / 4, tiles, n_blocks,
+  hipLaunchKernelGGL(tiles_copy_kernel<0>, dim3(n_entries / 8), dim3(256), 0, ST, const_cast<float*>(map), H, W, C / 4, tiles, n_blocks,
                      compact);
   return nbm_launch_status();
 }
@@ -1188,7 +1283,7 @@ extern "C" int nbm_tiles_scatter_add(float* map, int B, int H, int W, int C, con
                                      const float* compact, void* stream) {
   if (!map || !tiles || !compact || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || n_entries <= 0 || (n_entries & 127)) return NBM_EINVAL;
   if (!nbm_aligned16(map) || !nbm_aligned16(compact)) return NBM_EALIGN;
-  hipLaunchKernelGGL(tiles_copy_kernel<1>, dim3(n_entries / 128), dim3(256), 0, ST, map, H, W, C / 4, tiles, n_blocks,
+  hipLaunchKernelGGL(tiles_copy_kernel<1>, dim3(n_entries / 8), dim3(256), 0, ST, map, H, W, C / 4, tiles, n_blocks,
                      const_cast<float*>(compact));
   return nbm_launch_status();
 }
