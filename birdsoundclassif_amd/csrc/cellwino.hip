@@ -173,19 +173,28 @@ __global__ __launch_bounds__(256) void cell_input_up_kernel(const float* __restr
       const float fy = sh * (yin ? y : 0);
       const int y0 = (int)fy, y1 = y0 + (y0 < Hc - 1 ? 1 : 0);
       const float ly = fminf(fmaxf(fy - y0, 0.f), 1.f), hy = 1.f - ly;
+      // The 20 loads of a patch row go out together, before the first interpolation: no branch around them (a pixel outside the image
+      // reads a clamped address and is zeroed afterwards) -- behind one, the four loads of every patch pixel waited for those of the
+      // pixel before, 25 dependent round trips per thread
+      f32x4 v00[NP], v01[NP], v10[NP], v11[NP];
+      float lxs[NP];
 #pragma unroll
       for (int l = 0; l < NP; ++l) {
-        const int xx = q.S * ox - 2 + l;
-        f32x4 v = zero;
-        if (yin && (unsigned)xx < (unsigned)q.W) {
-          const float fx = sw * xx;
-          const int x0 = (int)fx, x1i = x0 + (x0 < Wc - 1 ? 1 : 0);
-          const float lx = fminf(fmaxf(fx - x0, 0.f), 1.f), hx = 1.f - lx;
-          const f32x4 v00 = s4[((rb + y0) * Wc + x0) * q.C4 + c], v01 = s4[((rb + y0) * Wc + x1i) * q.C4 + c];
-          const f32x4 v10 = s4[((rb + y1) * Wc + x0) * q.C4 + c], v11 = s4[((rb + y1) * Wc + x1i) * q.C4 + c];
+        const float fx = sw * min(max(q.S * ox - 2 + l, 0), q.W - 1);
+        const int x0 = (int)fx, x1i = x0 + (x0 < Wc - 1 ? 1 : 0);
+        lxs[l] = fminf(fmaxf(fx - x0, 0.f), 1.f);
+        v00[l] = s4[((rb + y0) * Wc + x0) * q.C4 + c]; v01[l] = s4[((rb + y0) * Wc + x1i) * q.C4 + c];
+        v10[l] = s4[((rb + y1) * Wc + x0) * q.C4 + c]; v11[l] = s4[((rb + y1) * Wc + x1i) * q.C4 + c];
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = (hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e])) + bv[e];
-        }
+      for (int l = 0; l < NP; ++l) {
+        const bool ok = yin && (unsigned)(q.S * ox - 2 + l) < (unsigned)q.W;
+        const float lx = lxs[l], hx = 1.f - lx;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          v[e] = ok ? (hy * (hx * v00[l][e] + lx * v01[l][e]) + ly * (hx * v10[l][e] + lx * v11[l][e])) + bv[e] : 0.f;
 #pragma unroll
         for (int a = 0; a < NP; ++a)
           if (CV[j][a] != 0.f) t[a][l] += CV[j][a] * v;

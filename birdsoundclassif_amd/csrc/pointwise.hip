@@ -283,27 +283,36 @@ __global__ void dwconv3x3_vec_kernel(const float* __restrict__ x, int B, int H, 
       w_chunk = c4;
     }
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // all nine taps in flight before the first is used (clamped address, zeroed outside the image): a bounds branch in front of
+    // every load makes them go out one at a time, nine memory latencies per output vector (see dwconv_bwd_weight_vec_kernel)
+    float xv[9][NIN];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      const int iy = oy * stride - 1 + r;
-      if ((unsigned)iy >= (unsigned)H) continue;
+      const int iyc = min(max(oy * stride - 1 + r, 0), H - 1);
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
-        const int ix = ox * stride - 1 + s;
-        if ((unsigned)ix >= (unsigned)W) continue;
-        const float* xp = x + ((long long)(b * H + iy) * W + ix) * Cin + ci0;
-        float xv[NIN];
+        const int ixc = min(max(ox * stride - 1 + s, 0), W - 1);
+        const float* xp = x + ((long long)(b * H + iyc) * W + ixc) * Cin + ci0;
+        float* v = xv[r * 3 + s];
         if constexpr (NIN == 4) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(xp);
-          xv[0] = v[0]; xv[1] = v[1]; xv[2] = v[2]; xv[3] = v[3];
+          const f32x4 q = *reinterpret_cast<const f32x4*>(xp);
+          v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
         } else if constexpr (NIN == 2) {
-          const float2 v = *reinterpret_cast<const float2*>(xp);
-          xv[0] = v.x; xv[1] = v.y;
+          const float2 q = *reinterpret_cast<const float2*>(xp);
+          v[0] = q.x; v[1] = q.y;
         } else {
-          xv[0] = *xp;
+          v[0] = *xp;
         }
+      }
+    }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] += xv[j / MULT] * wr[j][r * 3 + s];
+    for (int r = 0; r < 3; ++r) {
+      const bool oky = (unsigned)(oy * stride - 1 + r) < (unsigned)H;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const bool ok = oky && (unsigned)(ox * stride - 1 + s) < (unsigned)W;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += (ok ? xv[r * 3 + s][j / MULT] : 0.f) * wr[j][r * 3 + s];
       }
     }
     f32x4 out = {acc[0], acc[1], acc[2], acc[3]};

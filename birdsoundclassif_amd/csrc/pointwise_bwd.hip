@@ -696,36 +696,47 @@ __global__ __launch_bounds__(256) void dwconv_bwd_weight_vec_kernel(const float*
     for (int e = 0; e < 10; ++e) acc[j][e] = 0.f;
   if (o0 < Cout) {
     const int ci0 = o0 / MULT;
-    const long long npix = (long long)B * Ho * Wo;
-    for (long long pix = blockIdx.x * 4ll + sub; pix < npix; pix += (long long)gridDim.x * 4) {
-      long long t = pix;
-      const int ox = (int)(t % Wo); t /= Wo;
-      const int oy = (int)(t % Ho);
-      const int b = (int)(t / Ho);
-      const f32x4 gv = *reinterpret_cast<const f32x4*>(g + pix * Cout + o0);
+    const int npix = B * Ho * Wo;                       // < 2^31: checked by the host
+    for (int pix = blockIdx.x * 4 + sub; pix < npix; pix += gridDim.x * 4) {
+      int t = pix;
+      const int ox = t % Wo; t /= Wo;
+      const int oy = t % Ho;
+      const int b = t / Ho;
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(g + (long long)pix * Cout + o0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[j][9] += gv[j];
+      // all nine taps are loaded before the first one is used (clamped address, value zeroed outside the image): behind a bounds
+      // branch each, the loads went out one at a time -- ten memory latencies per pixel and stream, which is what these launches cost
+      float xv[9][NIN];
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         const int iy = oy * stride - 1 + r;
-        if ((unsigned)iy >= (unsigned)H) continue;
+        const int iyc = min(max(iy, 0), H - 1);
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
           const int ix = ox * stride - 1 + s;
-          if ((unsigned)ix >= (unsigned)W) continue;
-          const float* xp = x + ((long long)(b * H + iy) * W + ix) * Cin + ci0;
-          float xv[NIN];
+          const int ixc = min(max(ix, 0), W - 1);
+          const float* xp = x + ((long long)(b * H + iyc) * W + ixc) * Cin + ci0;
+          float* v = xv[r * 3 + s];
           if constexpr (NIN == 4) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(xp);
-            xv[0] = v[0]; xv[1] = v[1]; xv[2] = v[2]; xv[3] = v[3];
+            const f32x4 q = *reinterpret_cast<const f32x4*>(xp);
+            v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
           } else if constexpr (NIN == 2) {
-            const float2 v = *reinterpret_cast<const float2*>(xp);
-            xv[0] = v.x; xv[1] = v.y;
+            const float2 q = *reinterpret_cast<const float2*>(xp);
+            v[0] = q.x; v[1] = q.y;
           } else {
-            xv[0] = *xp;
+            v[0] = *xp;
           }
+        }
+      }
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[j][r * 3 + s] += gv[j] * xv[j / MULT];
+      for (int r = 0; r < 3; ++r) {
+        const bool oky = (unsigned)(oy * stride - 1 + r) < (unsigned)H;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const bool ok = oky && (unsigned)(ox * stride - 1 + s) < (unsigned)W;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j][r * 3 + s] += gv[j] * (ok ? xv[r * 3 + s][j / MULT] : 0.f);
         }
       }
     }
@@ -1172,9 +1183,11 @@ extern "C" int nbm_dwconv3x3_bwd(const float* x, const float* g, const float* w,
     hipError_t e = hipMemsetAsync(gw, 0, sizeof(float) * Cout * 9, ST);
     if (e == hipSuccess && gb) e = hipMemsetAsync(gb, 0, sizeof(float) * Cout, ST);
     if (e != hipSuccess) return (int)e;
-    dim3 grid(grid_for((long long)B * Ho * Wo, 4, 512), (Cout + 63) / 64);
+    // 192 workgroup columns: every workgroup ends with 2560 atomics on the same 5120 addresses, and that tail grows with the grid
+    // (B = 128, 24 x 64 outputs, 512 channels: 64 -> 0.75, 128 -> 0.48, 192 -> 0.44, 256 -> 0.47, 512 -> 0.63, 1024 -> 0.86 ms)
+    dim3 grid(grid_for((long long)B * Ho * Wo, 4, 192), (Cout + 63) / 64);
     const bool vec = (mult == 1 || mult == 2 || mult == 4) && (Cout & 3) == 0 && (Cin % (4 / mult)) == 0 && nbm_aligned16(g) &&
-                     nbm_aligned16(x);
+                     nbm_aligned16(x) && (long long)B * Ho * Wo < (1ll << 31) - 4ll * 65536;
     if (vec) {
       const dim3 gv(grid.x, (Cout + 255) / 256);
       if (mult == 1) hipLaunchKernelGGL(dwconv_bwd_weight_vec_kernel<1>, gv, dim3(256), 0, ST, x, g, B, H, W, Cin, stride, gw, gb, Ho, Wo);

@@ -39,13 +39,23 @@ __global__ __launch_bounds__(256) void stem7x7_kernel(const StemParams p) {
 
   // ---- stage: 7 input rows x 261 columns (zeros outside the image), folded weights
   const int ix0 = 2 * ox0 - 3;
-  for (int i = tid; i < 7 * SP; i += 256) {
+  // (all loads of a thread go out before the first LDS write: clamped addresses, zeros selected afterwards -- with a bounds branch
+  // around each load they were eight dependent round trips in front of 56 MFMAs)
+  constexpr int NST = (7 * SP + 255) / 256;
+  float stv[NST];
+#pragma unroll
+  for (int k = 0; k < NST; ++k) {
+    const int i = min(tid + 256 * k, 7 * SP - 1);
+    const int r = i / SP, c = i - r * SP;
+    const int iy = min(max(2 * oy - 3 + r, 0), p.H - 1), ix = min(max(ix0 + c, 0), p.W - 1);
+    stv[k] = p.img[((long long)b * p.H + iy) * p.W + ix];
+  }
+#pragma unroll
+  for (int k = 0; k < NST; ++k) {
+    const int i = tid + 256 * k;
     const int r = i / SP, c = i - r * SP;
     const int iy = 2 * oy - 3 + r, ix = ix0 + c;
-    float v = 0.f;
-    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c < 261)
-      v = p.img[((long long)b * p.H + iy) * p.W + ix];
-    img_s[i] = v;
+    if (i < 7 * SP) img_s[i] = ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c < 261) ? stv[k] : 0.f;
   }
   for (int i = tid; i < KK * 64 / 4; i += 256)
     reinterpret_cast<f32x4*>(w_s)[i] = reinterpret_cast<const f32x4*>(p.weff)[i];
@@ -158,20 +168,36 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(const StemWgradParams p
     const int oy = rowi % p.Ho, b = rowi / p.Ho;
     const int ox0 = tx * 128, ix0 = 2 * ox0 - 3;
     __syncthreads();                                     // the previous strip's operands are consumed
-    for (int i = tid; i < 7 * SP; i += 256) {
+    // all 16 global loads of a thread in flight together (clamped addresses, zeros selected afterwards), as in stem7x7_kernel
+    constexpr int NST = (7 * SP + 255) / 256;
+    float stv[NST];
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+      const int i = min(tid + 256 * k, 7 * SP - 1);
       const int rr = i / SP, c = i - rr * SP;
-      const int iy = 2 * oy - 3 + rr, ix = ix0 + c;
-      float v = 0.f;
-      if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c < 261) v = p.img[((long long)b * p.H + iy) * p.W + ix];
-      img_s[i] = v;
+      const int iy = min(max(2 * oy - 3 + rr, 0), p.H - 1), ix = min(max(ix0 + c, 0), p.W - 1);
+      stv[k] = p.img[((long long)b * p.H + iy) * p.W + ix];
     }
     const float* gsrc = p.g + (((long long)b * p.Ho + oy) * p.Wo + ox0) * 64;
     const int npx = min(128, p.Wo - ox0);
-    for (int i = tid; i < 128 * 16; i += 256) {
-      const int px = i >> 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (px < npx) v = *reinterpret_cast<const f32x4*>(gsrc + (long long)i * 4);
-      reinterpret_cast<f32x4*>(g_s)[i] = v;
+    f32x4 gv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = tid + 256 * k;
+      gv[k] = *reinterpret_cast<const f32x4*>(gsrc + (long long)(min(i >> 4, npx - 1) * 16 + (i & 15)) * 4);
+    }
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+      const int i = tid + 256 * k;
+      const int rr = i / SP, c = i - rr * SP;
+      const int iy = 2 * oy - 3 + rr, ix = ix0 + c;
+      if (i < 7 * SP) img_s[i] = ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c < 261) ? stv[k] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = tid + 256 * k;
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+      reinterpret_cast<f32x4*>(g_s)[i] = (i >> 4) < npx ? gv[k] : zero4;
     }
     __syncthreads();
 #pragma unroll 8

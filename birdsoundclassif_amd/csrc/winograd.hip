@@ -302,6 +302,20 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restr
     if (bias) bv = reinterpret_cast<const f32x2*>(bias)[c];
     if (scale) sv = reinterpret_cast<const f32x2*>(scale)[c];
     const f32x2* mk = reinterpret_cast<const f32x2*>(mask);
+    const f32x2* rs = reinterpret_cast<const f32x2*>(residual);
+    // the mask / residual values of all 16 pixels are requested up front (clamped addresses): loaded inside the loop below, behind its
+    // bounds tests, they were up to 32 dependent round trips per thread
+    f32x2 mq[4][4], rq[4][4];
+    if (mk || rs) {                                              // uniform
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          const long long idc = (((long long)b * H + min(4 * ty + p, H - 1)) * W + min(4 * tx + o, W - 1)) * N2 + c;
+          if (mk) mq[p][o] = mk[idc];
+          if (rs) rq[p][o] = rs[idc];
+        }
+    }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int oy = 4 * ty + p;
@@ -314,8 +328,12 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(const float* __restr
 #pragma unroll
         for (int q = 0; q < 6; ++q) acc += s[p][q] * W43_AT[o][q];
         const long long idx = (((long long)b * H + oy) * W + ox) * N2 + c;
-        f32x2 v = wino_epilogue(acc, sv, bv, relu, mk, idx);
-        if (residual) v += reinterpret_cast<const f32x2*>(residual)[idx];      // gradient of another consumer of the same tensor
+        f32x2 v = wino_epilogue(acc, sv, bv, relu, (const f32x2*)nullptr, idx);
+        if (mk) {
+          if (!(mq[p][o][0] > 0.f)) v[0] = 0.f;
+          if (!(mq[p][o][1] > 0.f)) v[1] = 0.f;
+        }
+        if (rs) v += rq[p][o];                                   // gradient of another consumer of the same tensor
         y2[idx] = v;
       }
     }
