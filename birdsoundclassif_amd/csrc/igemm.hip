@@ -349,9 +349,22 @@ __global__ __launch_bounds__(256, BM > 128 ? 1 : STAGES == 1 ? 3 : 2) void igemm
         if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
         if (p.shift && !p.shift_per_row) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
       }
+      constexpr int NR = (HROWS + RPP - 1) / RPP;      // tile rows a thread finishes
 #pragma unroll
       for (int half = 0; half < HALVES; ++half) {
       if (half) __syncthreads();
+      // the residual values of this thread's rows are requested before the accumulators go through LDS: loaded inside the row loop
+      // (behind its `m >= M` exit) they were NR dependent round trips at the end of every tile
+      f32x4 rq[NR];
+      const bool pre = !ROWS && rg && n < p.N;
+      if (pre) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+          long long m = bm0 + half * HROWS + rr + k * RPP;
+          m = m < p.M ? m : p.M - 1;
+          rq[k] = *reinterpret_cast<const f32x4*>(rg + m * p.res_ld + n);
+        }
+      }
       if (HALVES == 1 || wm0 == half * HROWS) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
@@ -363,8 +376,10 @@ __global__ __launch_bounds__(256, BM > 128 ? 1 : STAGES == 1 ? 3 : 2) void igemm
       }
       __syncthreads();
       if (n < p.N) {
-#pragma unroll 4
-        for (int r = rr; r < HROWS; r += RPP) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+          const int r = rr + k * RPP;
+          if (r >= HROWS) break;
           long long m = bm0 + half * HROWS + r;
           if (m >= p.M) break;
           if constexpr (ROWS) {
@@ -376,7 +391,7 @@ __global__ __launch_bounds__(256, BM > 128 ? 1 : STAGES == 1 ? 3 : 2) void igemm
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = (v[e] * p.alpha) * sc[e] + sh[e] + rs;
           if (rg) {
-            const f32x4 q = *reinterpret_cast<const f32x4*>(rg + (long long)m * p.res_ld + n);
+            const f32x4 q = pre ? rq[k] : *reinterpret_cast<const f32x4*>(rg + (long long)m * p.res_ld + n);
             v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3];
           }
           if (p.up) {       // same arithmetic as upsample_add_kernel (pointwise.hip): interp first, then + lateral
