@@ -295,9 +295,23 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
     constexpr int CH = BN / 4, RPP = 256 / CH;
     const int cc = tid % CH, rr = tid / CH;
     const int c = bn0 + cc * 4;
+    constexpr int NR = (HROWS + RPP - 1) / RPP;                 // tile rows a thread finishes
 #pragma unroll
     for (int half = 0; half < HALVES; ++half) {
       if (HALVES > 1 && half) __syncthreads();                  // the previous half has been read
+      // residual / mask values of this thread's rows: requested before the accumulators go through LDS (inside the row loop, behind
+      // its exit test, they were 2 NR dependent round trips at the end of every tile -- igemm.hip)
+      f32x4 rq[NR], mq[NR];
+      const bool pre = c < p.Cin && (rg || p.mask);
+      if (pre) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+          const int qq = min(q0 + half * HROWS + rr + k * RPP, rows_here - 1);
+          const long long m = out_pixel(qq);
+          if (rg) rq[k] = *reinterpret_cast<const f32x4*>(rg + m * p.res_ld + c);
+          if (p.mask) mq[k] = *reinterpret_cast<const f32x4*>(p.mask + m * p.mask_ld + c);
+        }
+      }
       if (HALVES == 1 || wm0 == half * HROWS) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -309,8 +323,10 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
       }
       __syncthreads();
       if (c >= p.Cin) continue;
-#pragma unroll 4
-      for (int rl = rr; rl < HROWS; rl += RPP) {
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        const int rl = rr + k * RPP;
+        if (rl >= HROWS) break;
         const int r = half * HROWS + rl;
         if (q0 + r >= rows_here) break;
         const long long m = out_pixel(q0 + r);
@@ -318,7 +334,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
         if (rg) {
-          const f32x4 q = *reinterpret_cast<const f32x4*>(rg + (long long)m * p.res_ld + c);
+          const f32x4 q = rq[k];
           v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3];
         }
         if (p.residual2) {          // the data gradient of a 1x1 / stride-2 shortcut, kept at its own (half) resolution
@@ -331,7 +347,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
           }
         }
         if (p.mask) {
-          const f32x4 q = *reinterpret_cast<const f32x4*>(p.mask + (long long)m * p.mask_ld + c);
+          const f32x4 q = mq[k];
 #pragma unroll
           for (int e = 0; e < 4; ++e) if (!(q[e] > 0.f)) v[e] = 0.f;
         }
