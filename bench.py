@@ -229,6 +229,10 @@ def parse_args(argv=None):
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=64)
+    ap.add_argument('--spin-up', dest='spin_up', type=int, default=20,
+                    help='untimed steps BEFORE the --warmup steps: the card takes ~20 steps (1.5 s) from idle to its steady clocks -- '
+                         'scripts/detectloop.py: first block of 20 steps after 5 warm-up steps 1.5-3 %% slower than the next ones; '
+                         'reported as spin_up_steps in the line')
     ap.add_argument('--min-score', type=float, default=0.2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--train-batch', type=int, default=128)
@@ -420,6 +424,8 @@ def main(argv=None):
             dist.barrier()
             torch.cuda.synchronize()
 
+    for _ in range(a.spin_up):                                 # idle -> steady clocks (see --spin-up); not part of W, not timed
+        step()
     for _ in range(a.warmup):
         step()
     sync_all()
@@ -577,7 +583,7 @@ def main(argv=None):
             train = {'error': f'{type(exc).__name__}: {exc}'[:500]}
     if rank == 0:
         line = {'metric': 'clips/sec (3 s @ 22.05 kHz) detect fwd', 'value': world * B * a.steps / dt, 'unit': 'clips/s',
-                'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': dt / a.steps * 1e3,
+                'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'spin_up_steps': a.spin_up, 'ms_per_step': dt / a.steps * 1e3,
                 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                 'config': {'workload': 'BASELINE.json configs[1]: 1xMI355X inference, batch=64 synthetic 3 s clips '
                                        '(PCM16 @22.05 kHz resident in HBM) through the HIP STFT front end + detector '

@@ -394,6 +394,9 @@ __global__ __launch_bounds__(256, BM > 128 ? 1 : STAGES == 1 ? 3 : 2) void igemm
             const f32x4 q = pre ? rq[k] : *reinterpret_cast<const f32x4*>(rg + (long long)m * p.res_ld + n);
             v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3];
           }
+          // (NEGATIVE: the rows in groups of 2 / 4 with the four gathered vectors of a whole group requested first -- 4: spills at the
+          // 256-register cap; 2: 242 registers, the merge laterals 3.039 / 1.376 / 0.621 ms against 3.042 / 1.364 / 0.621: what these
+          // launches wait for is not the gather's latency)
           if (p.up) {       // same arithmetic as upsample_add_kernel (pointwise.hip): interp first, then + lateral
 #pragma clang fp contract(off)   // like torch's CPU upsample_bilinear2d: no fused multiply-adds in the coordinates or the
                                  // blend (the compiler fused `scale * o - floor` in one instantiation of this kernel and not in
