@@ -446,6 +446,68 @@ def main(argv=None):
     dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
     ops.PROFILE_ONLY = None
+    # ---- the headline: the SAME step (front end + detector + device post-processing, same kernels, same batch semantics) captured
+    # once in a hipGraph and replayed -- no Python between the ~300 launches of a step.  The eager loop above (HIP events around
+    # the dominant kernel's launches) stays in the line as `eager_with_events`: it carries the roofline measurement, and it is
+    # bound by the HOST on boxes with slower cores (75.3 ms eager against 69.4 ms per replayed batch in one and the same run)
+    eager = {'ms_per_step': dt / a.steps * 1e3, 'clips_per_s_per_gpu': B * a.steps / dt, 'detections_per_step': n_det / a.steps}
+    graph_note, gd = None, None
+    try:
+        from birdsoundclassif_amd.bulk import GraphedDetector
+        gd = GraphedDetector(model, B, pcm.shape[1], 22050, min_score=a.min_score, independent=False)
+        gd.pcm.copy_(pcm)
+    except Exception as exc:
+        graph_note = f'hipGraph capture failed ({type(exc).__name__}: {exc}); value is the eager loop'[:300]
+    if dist is not None:                                       # every rank replays, or none does (the loop below holds barriers)
+        flag = torch.tensor([0.0 if gd is None else 1.0], device='cuda')
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag.item()) == 0.0 and gd is not None:
+            gd, graph_note = None, 'hipGraph capture failed on another rank; value is the eager loop'
+    try:
+        if gd is None:
+            raise RuntimeError(graph_note)
+        last_copy = [None]
+
+        def launch_g():
+            with torch.cuda.stream(gd.stream):
+                if last_copy[0] is not None:
+                    gd.stream.wait_event(last_copy[0])          # the static outputs are overwritten: the previous D2H must be done
+                gd.replay()
+                ready = torch.cuda.Event()
+                ready.record(gd.stream)
+            det_h = torch.empty(gd.det.shape, dtype=gd.det.dtype, pin_memory=True)
+            n_h = torch.empty(gd.n_det.shape, dtype=gd.n_det.dtype, pin_memory=True)
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(ready)
+                det_h.copy_(gd.det, non_blocking=True)
+                n_h.copy_(gd.n_det, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(copy_stream)
+            last_copy[0] = done
+            return gd.det, gd.n_det, det_h, n_h, done
+
+        for _ in range(a.warmup):
+            finish(launch_g())
+        sync_all()
+        t0 = time.perf_counter()
+        n_det_g, pending = 0, None
+        for _ in range(a.steps):
+            cur = launch_g()
+            if pending is not None:
+                out = finish(pending)
+                n_det_g += sum(len(v['bbox_coord']) for d in out for v in d.values())
+            pending = cur
+        out = finish(pending)
+        n_det_g += sum(len(v['bbox_coord']) for d in out for v in d.values())
+        sync_all()
+        dt_g = time.perf_counter() - t0
+        if n_det_g != n_det:
+            raise RuntimeError(f'the replayed steps returned {n_det_g} detections, the eager ones {n_det}')
+        dt = dt_g
+        del gd
+    except Exception as exc:                                   # the eager figure stays the headline
+        if graph_note is None:
+            graph_note = f'hipGraph replay failed ({type(exc).__name__}: {exc}); value is the eager loop'[:300]
     ops.PROFILE = []                                           # one extra, untimed step with events around every GEMM-type launch
     ops.FLOPS = [0.0]                                          # ... and the executed-MFMA-FLOP counter of every GEMM launch
     step()
@@ -588,7 +650,9 @@ def main(argv=None):
                 'config': {'workload': 'BASELINE.json configs[1]: 1xMI355X inference, batch=64 synthetic 3 s clips '
                                        '(PCM16 @22.05 kHz resident in HBM) through the HIP STFT front end + detector '
                                        'forward + device post-processing, detections returned to the host',
-                           'batch_per_gpu': B, 'min_score': a.min_score, 'detections_per_step': n_det / a.steps},
+                           'batch_per_gpu': B, 'min_score': a.min_score, 'detections_per_step': n_det / a.steps,
+                           'launch': 'hipGraph replay of the captured step' if graph_note is None else graph_note},
+                'eager_with_events': eager,
                 'roofline': roof, 'frontend': frontend, 'dense_finest_map': dense_ref, 'bulk_inference': bulk_leg,
                 'train_step': train, **dist_info}
         if world == 1 and not a.no_cpu_baseline:
