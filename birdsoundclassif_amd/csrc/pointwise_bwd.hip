@@ -321,55 +321,80 @@ __device__ __forceinline__ void upbwd_axis(int P, float s, float inv_s, int n_fi
 // compacted lists (rocprofv3 --pmc SQ_INSTS_VALU on scripts/upbwd_probe.py: 3.0e9 per launch x 4 cycles per wave64 instruction / 1024
 // SIMDs = 5.0 ms, the measured time -- which is why reading 39 % of the bytes did not make it faster).  Here: fixed slots, the row
 // slots in scalar registers (Y = blockIdx.y), every load of a thread in flight at once.
-template <int NF, int V>
+// SHARE (C4 >= 32: a workgroup covers <= 9 coarse columns of one coarse row): the slots of the row and of those columns are computed
+// ONCE per workgroup -- one lane each, in the first wave -- and handed out through LDS, instead of ~240 VALU instructions in every
+// thread.
+template <int NF, bool SHARE>
 __global__ __launch_bounds__(256) void upsample_bwd_fast_kernel(const float* __restrict__ gy, int Hi, int Wi, int C4, float* __restrict__ gsrc,
                                                                 int Ho, int Wo, float sh, float sw, int pat) {
   const f32x4* g4 = reinterpret_cast<const f32x4*>(gy);
   f32x4* o4 = reinterpret_cast<f32x4*>(gsrc);
-  const int lanes = C4 / V;                        // a thread owns V channel vectors of its pixel: c, c + lanes, ...
   const int xc = blockIdx.x * 256 + threadIdx.x;
-  if (xc >= Wi * lanes) return;
-  const int X = xc / lanes, c = xc - X * lanes;
+  const bool active = xc < Wi * C4;
+  const int X = min(xc / C4, Wi - 1), c = xc - (xc / C4) * C4;
   const int Y = blockIdx.y, b = blockIdx.z;
   const float inv_pat = pat ? 1.f / (float)pat : 0.f;
   int ylo, xlo;
-  float wy[NF], wx[NF];
-  upbwd_axis<NF>(Y, sh, 1.f / sh, Ho, Hi, pat, inv_pat, pat ? (Ho - 1) / pat : 0, ylo, wy);
-  upbwd_axis<NF>(X, sw, 1.f / sw, Wo, Wi, pat, inv_pat, pat ? (Wo - 1) / pat : 0, xlo, wx);
-  ylo = __builtin_amdgcn_readfirstlane(ylo);
-  float wyu[NF];
+  float wyu[NF], wx[NF];
+  if constexpr (SHARE) {
+    constexpr int MAXX = 10;                         // 256 / 32 + 2
+    __shared__ int s_lo[1 + MAXX];
+    __shared__ float s_w[1 + MAXX][NF];
+    const int x_first = (blockIdx.x * 256) / C4;
+    const int t = threadIdx.x;
+    if (t < 1 + MAXX) {
+      int lo;
+      float w[NF];
+      if (t == 0) upbwd_axis<NF>(Y, sh, 1.f / sh, Ho, Hi, pat, inv_pat, pat ? (Ho - 1) / pat : 0, lo, w);
+      else upbwd_axis<NF>(min(x_first + t - 1, Wi - 1), sw, 1.f / sw, Wo, Wi, pat, inv_pat, pat ? (Wo - 1) / pat : 0, lo, w);
+      s_lo[t] = lo;
 #pragma unroll
-  for (int a = 0; a < NF; ++a) wyu[a] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wy[a])));
-#pragma unroll 1
-  for (int v = 0; v < V; ++v) {
-    const int cc = c + v * lanes;
-    const f32x4* base = g4 + ((long long)(b * Ho + ylo) * Wo + xlo) * C4 + cc;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    // two groups of rows (3 + 2): the loads of a group are all in flight together, and 15 instead of 25 vectors in registers keep
-    // 6 waves per SIMD resident (all 25: 110 VGPRs, 4 waves -- measured slower)
-#pragma unroll
-    for (int a0 = 0; a0 < NF; a0 += 3) {
-      f32x4 g[3][NF];
-#pragma unroll
-      for (int a = a0; a < a0 + 3 && a < NF; ++a)
-        if (wyu[a] != 0.f) {                                             // workgroup-uniform
-#pragma unroll
-          for (int e = 0; e < NF; ++e)
-            if (wx[e] != 0.f) g[a - a0][e] = base[((long long)a * Wo + e) * C4];
-        }
-#pragma unroll
-      for (int a = a0; a < a0 + 3 && a < NF; ++a)
-        if (wyu[a] != 0.f) {
-#pragma unroll
-          for (int e = 0; e < NF; ++e)
-            if (wx[e] != 0.f) {
-              const float w = wyu[a] * wx[e];
-              acc[0] += w * g[a - a0][e][0]; acc[1] += w * g[a - a0][e][1]; acc[2] += w * g[a - a0][e][2]; acc[3] += w * g[a - a0][e][3];
-            }
-        }
+      for (int k = 0; k < NF; ++k) s_w[t][k] = w[k];
     }
-    o4[((long long)(b * Hi + Y) * Wi + X) * C4 + cc] = acc;
+    __syncthreads();
+    if (!active) return;
+    ylo = s_lo[0];
+    xlo = s_lo[1 + X - x_first];
+#pragma unroll
+    for (int k = 0; k < NF; ++k) { wyu[k] = s_w[0][k]; wx[k] = s_w[1 + X - x_first][k]; }
+  } else {
+    if (!active) return;
+    float wy[NF];
+    upbwd_axis<NF>(Y, sh, 1.f / sh, Ho, Hi, pat, inv_pat, pat ? (Ho - 1) / pat : 0, ylo, wy);
+    upbwd_axis<NF>(X, sw, 1.f / sw, Wo, Wi, pat, inv_pat, pat ? (Wo - 1) / pat : 0, xlo, wx);
+#pragma unroll
+    for (int a = 0; a < NF; ++a) wyu[a] = wy[a];
   }
+  ylo = __builtin_amdgcn_readfirstlane(ylo);
+#pragma unroll
+  for (int a = 0; a < NF; ++a) wyu[a] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, wyu[a])));
+  const f32x4* base = g4 + ((long long)(b * Ho + ylo) * Wo + xlo) * C4 + c;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  // two groups of rows (3 + 2): the loads of a group are all in flight together, and 15 instead of 25 vectors in registers keep
+  // 6 waves per SIMD resident (all 25: 110 VGPRs, 4 waves -- measured slower; 3 channel vectors per thread: 9.2 ms, three dependent
+  // round trips per wave)
+#pragma unroll
+  for (int a0 = 0; a0 < NF; a0 += 3) {
+    f32x4 g[3][NF];
+#pragma unroll
+    for (int a = a0; a < a0 + 3 && a < NF; ++a)
+      if (wyu[a] != 0.f) {                                               // workgroup-uniform
+#pragma unroll
+        for (int e = 0; e < NF; ++e)
+          if (wx[e] != 0.f) g[a - a0][e] = base[((long long)a * Wo + e) * C4];
+      }
+#pragma unroll
+    for (int a = a0; a < a0 + 3 && a < NF; ++a)
+      if (wyu[a] != 0.f) {
+#pragma unroll
+        for (int e = 0; e < NF; ++e)
+          if (wx[e] != 0.f) {
+            const float w = wyu[a] * wx[e];
+            acc[0] += w * g[a - a0][e][0]; acc[1] += w * g[a - a0][e][1]; acc[2] += w * g[a - a0][e][2]; acc[3] += w * g[a - a0][e][3];
+          }
+      }
+  }
+  o4[((long long)(b * Hi + Y) * Wi + X) * C4 + c] = acc;
 }
 
 // gradient of bilinear(align_corners) up-sampling wrt the coarse map, gather form
@@ -1131,13 +1156,8 @@ extern "C" int nbm_upsample_bilinear_bwd(const float* gy, int B, int Hi, int Wi,
   const dim3 grid((unsigned)(((long long)Wi * C4 + 255) / 256), Hi, B);
   constexpr int NF = 5;
   if (sh > 0.f && sw > 0.f && 2.f / sh <= NF - 0.05f && 2.f / sw <= NF - 0.05f && Ho < (1 << 20) && Wo < (1 << 20)) {
-    // V channel vectors per thread: what bounds these launches is the number of waves (4.6 M of them at B = 128 took 5.1-5.4 ms
-    // whether they read 23.7 or 12.1 GB and whether they issued 650 or 250 VALU instructions each)
-    const int V = 1;
-    const dim3 gv((unsigned)(((long long)Wi * (C4 / V) + 255) / 256), Hi, B);
-    if (V == 3) hipLaunchKernelGGL((upsample_bwd_fast_kernel<NF, 3>), gv, dim3(256), 0, ST, gy, Hi, Wi, C4, gsrc, Ho, Wo, sh, sw, pattern_stride);
-    else if (V == 2) hipLaunchKernelGGL((upsample_bwd_fast_kernel<NF, 2>), gv, dim3(256), 0, ST, gy, Hi, Wi, C4, gsrc, Ho, Wo, sh, sw, pattern_stride);
-    else hipLaunchKernelGGL((upsample_bwd_fast_kernel<NF, 1>), gv, dim3(256), 0, ST, gy, Hi, Wi, C4, gsrc, Ho, Wo, sh, sw, pattern_stride);
+    if (C4 >= 32) hipLaunchKernelGGL((upsample_bwd_fast_kernel<NF, true>), grid, dim3(256), 0, ST, gy, Hi, Wi, C4, gsrc, Ho, Wo, sh, sw, pattern_stride);
+    else hipLaunchKernelGGL((upsample_bwd_fast_kernel<NF, false>), grid, dim3(256), 0, ST, gy, Hi, Wi, C4, gsrc, Ho, Wo, sh, sw, pattern_stride);
   } else {
     hipLaunchKernelGGL(upsample_bwd_kernel, grid, dim3(256), 0, ST, gy, B, Hi, Wi, C4, gsrc, Ho, Wo, sh, sw, pattern_stride);
   }
