@@ -27,9 +27,12 @@ for it in range(N):
     if it % 10 in (0, 9) or it == N - 1:
         vals = {k: round(float(v), 4) for k, v in loss.items()}
         assert all(np.isfinite(v) for v in vals.values()), (it, vals)
-        mem.append((torch.cuda.memory_allocated() / 2 ** 30, torch.cuda.memory_reserved() / 2 ** 30, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2 ** 20))
+        mem.append((torch.cuda.memory_allocated() / 2 ** 30, torch.cuda.memory_reserved() / 2 ** 30, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2 ** 20, neg))
         print(f'step {it:4d} neg={int(neg)} {vals}  allocated {mem[-1][0]:.1f} GiB reserved {mem[-1][1]:.1f} GiB host max RSS {mem[-1][2]:.2f} GiB', flush=True)
 torch.cuda.synchronize()
 print(f'{N} steps, {1e3 * (time.perf_counter() - t0) / N:.1f} ms / step incl. the printing syncs; max allocated {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB')
-assert mem[-1][0] < mem[len(mem) // 2][0] + 1.0, 'allocated memory keeps growing'
-assert mem[-1][2] < mem[len(mem) // 2][2] + 0.3, 'host memory keeps growing'
+for kind in (False, True):           # like with like: a negative step leaves 2.7 GiB more allocated than a positive one
+    m = [e for e in mem if e[3] == kind]
+    if len(m) >= 4:
+        assert m[-1][0] < m[len(m) // 2][0] + 1.0, 'allocated memory keeps growing'
+        assert m[-1][2] < m[len(m) // 2][2] + 0.3, 'host memory keeps growing'
