@@ -515,6 +515,8 @@ __global__ void dwconv_bwd_data_kernel(const float* __restrict__ g, int B, int H
   f32x4* o4 = reinterpret_cast<f32x4*>(gx);
   // MULT == 2: the 72 weights of this thread's 4 input channels in registers (its channel chunk is fixed when the item stride is
   // a multiple of C4): the per-tap scalar weight loads were what this kernel spent its time on
+  // (NEGATIVE, end of round 3: the taps enumerated statically for strides 1 / 2 with the six loads of a filter row issued together and
+  // the absent taps dropped afterwards -- 2.04 -> 2.49 ms for the three launches of a step: at stride 2 only 2.25 of the 9 taps exist)
   // (HOIST is only instantiated for strides <= 2: with larger strides most pixels are reached by no tap at all and preloading 72
   // weights per thread measured 1.8x slower; the register array also costs occupancy, hence a separate instantiation)
   float wr[HOIST ? 8 : 1][9];
