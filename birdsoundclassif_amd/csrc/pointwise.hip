@@ -207,10 +207,32 @@ __global__ void upsample_add_kernel(const float* __restrict__ src, int B, int Hi
 }
 
 // one wave per row; 4 rows per 256-thread block
+constexpr int SOFTMAX_REG = 24;         // rows of up to 1536 columns (the attention maps of a 24 x 64 level) are held in registers
 __global__ void softmax_rows_kernel(float* __restrict__ x, long long rows, int cols, long long ld) {
   const int lane = threadIdx.x & 63;
   for (long long row = blockIdx.x * 4ll + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * 4) {
     float* r = x + row * ld;
+    if (cols <= 64 * SOFTMAX_REG) {
+      // the row stays in registers (same element -> lane mapping, same order of the sum: bit-identical): one read and one write of
+      // the map instead of three reads and two writes; all loads of the lane in flight together
+      float v[SOFTMAX_REG];
+#pragma unroll
+      for (int j = 0; j < SOFTMAX_REG; ++j) v[j] = r[min(lane + 64 * j, cols - 1)];
+      float m = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < SOFTMAX_REG; ++j)
+        if (lane + 64 * j < cols) m = fmaxf(m, v[j]);
+      m = nbm_wave_max(m);
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < SOFTMAX_REG; ++j)
+        if (lane + 64 * j < cols) { v[j] = expf(v[j] - m); s += v[j]; }
+      s = nbm_wave_sum(s);
+#pragma unroll
+      for (int j = 0; j < SOFTMAX_REG; ++j)
+        if (lane + 64 * j < cols) r[lane + 64 * j] = v[j] / s;
+      continue;
+    }
     float m = -INFINITY;
     for (int c = lane; c < cols; c += 64) m = fmaxf(m, r[c]);
     m = nbm_wave_max(m);

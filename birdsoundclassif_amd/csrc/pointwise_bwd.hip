@@ -481,6 +481,25 @@ __global__ void softmax_bwd_kernel(const float* __restrict__ p, const float* __r
   for (long long row = blockIdx.x * 4ll + (threadIdx.x >> 6); row < rows; row += (long long)gridDim.x * 4) {
     const float* pr = p + row * cols;
     const float* gr = gp + row * cols;
+    constexpr int REG = 24;                 // rows of up to 1536 columns in registers: p and g are read once (pointwise.hip, softmax_rows_kernel)
+    if (cols <= 64 * REG) {
+      float pv[REG], gv[REG];
+#pragma unroll
+      for (int j = 0; j < REG; ++j) {
+        const int c = min(lane + 64 * j, cols - 1);
+        pv[j] = pr[c]; gv[j] = gr[c];
+      }
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < REG; ++j)
+        if (lane + 64 * j < cols) s += pv[j] * gv[j];
+      s = nbm_wave_sum(s);
+      float* o = out + row * cols;
+#pragma unroll
+      for (int j = 0; j < REG; ++j)
+        if (lane + 64 * j < cols) o[lane + 64 * j] = pv[j] * (gv[j] - s) * alpha;
+      continue;
+    }
     float s = 0.f;
     for (int c = lane; c < cols; c += 64) s += pr[c] * gr[c];
     s = nbm_wave_sum(s);
