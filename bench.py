@@ -68,19 +68,25 @@ def train_bench(rank, world, dist, batch, steps, warmup, mix_steps=10):
             torch.cuda.synchronize()
 
     def timed(schedule):
-        sync_all()
-        t0 = time.perf_counter()
-        for negative in schedule:
-            loss = train_one_step(model, crit, opt, data, args.clip_max_norm, 'cuda', negative_sample=negative)
-        sync_all()
-        dt = time.perf_counter() - t0
+        import gc
+        gc.collect()
+        gc.disable()                       # like timeit: a generation-2 collection inside a 3-5 step window is +30-90 ms on one step
+        try:
+            sync_all()
+            t0 = time.perf_counter()
+            for negative in schedule:
+                loss = train_one_step(model, crit, opt, data, args.clip_max_norm, 'cuda', negative_sample=negative)
+            sync_all()
+            dt = time.perf_counter() - t0
+        finally:
+            gc.enable()
         if dist is not None:
             t = torch.tensor([dt], device='cuda', dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, loss
 
-    for _ in range(warmup + 3):            # + 3: the persistent gradient maps, kept operands and pinned rings appear during the first
+    for _ in range(warmup + 6):            # + 6: the persistent gradient maps, kept operands and pinned rings appear during the first
         train_one_step(model, crit, opt, data, args.clip_max_norm, 'cuda', negative_sample=False)      # steps (scripts/steptimes.py)
     # first with the instruments on (HIP events around every data- / weight-gradient launch, FLOP counters: ~600 event records and a
     # few dozen small copies per step): roofline of the weight-gradient kernels, executed FLOPs
@@ -124,6 +130,11 @@ def train_bench(rank, world, dist, batch, steps, warmup, mix_steps=10):
         dtm, _ = timed([(i % 10) == 9 for i in range(mix_steps)])
         mix = {'steps': mix_steps, 'negative_every': 10, 'ms_per_step': dtm / mix_steps * 1e3,
                'clips_per_s': world * batch * mix_steps / dtm}
+    if os.environ.get('NBM_BENCH_MEMLOG') == '1':
+        st = torch.cuda.memory_stats()
+        print(f'bench: train leg: alloc retries {st.get("num_alloc_retries")}, ooms {st.get("num_ooms")}, peak allocated '
+              f'{torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB, peak reserved {torch.cuda.max_memory_reserved() / 2 ** 30:.1f} GiB',
+              file=sys.stderr, flush=True)
     del model, opt
     torch.cuda.empty_cache()
     v = pos['clips_per_s']
@@ -236,7 +247,7 @@ def parse_args(argv=None):
     ap.add_argument('--min-score', type=float, default=0.2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--train-batch', type=int, default=128)
-    ap.add_argument('--train-steps', type=int, default=3)
+    ap.add_argument('--train-steps', type=int, default=5)
     ap.add_argument('--no-train', action='store_true')
     ap.add_argument('--no-dense-reference', dest='no_dense_reference', action='store_true')
     ap.add_argument('--bulk-files', type=int, default=2048,
@@ -428,6 +439,9 @@ def main(argv=None):
         step()
     for _ in range(a.warmup):
         step()
+    import gc
+    gc.collect()
+    gc.disable()                                               # timed regions run without the cyclic collector (as timeit does)
     sync_all()
     ops.PROFILE = []                                           # live HIP-event timing of the dominant kernel's launches only:
     ops.PROFILE_ONLY = 'deepk'                                 # events around all ~250 launches cost the step 2.5 %
@@ -444,6 +458,7 @@ def main(argv=None):
     n_det += sum(len(v['bbox_coord']) for d in out for v in d.values())
     sync_all()
     dt = time.perf_counter() - t0
+    gc.enable()
     prof, ops.PROFILE = ops.PROFILE, None
     ops.PROFILE_ONLY = None
     # ---- the headline: the SAME step (front end + detector + device post-processing, same kernels, same batch semantics) captured
@@ -488,6 +503,8 @@ def main(argv=None):
 
         for _ in range(a.warmup):
             finish(launch_g())
+        gc.collect()
+        gc.disable()
         sync_all()
         t0 = time.perf_counter()
         n_det_g, pending = 0, None
@@ -501,11 +518,13 @@ def main(argv=None):
         n_det_g += sum(len(v['bbox_coord']) for d in out for v in d.values())
         sync_all()
         dt_g = time.perf_counter() - t0
+        gc.enable()
         if n_det_g != n_det:
             raise RuntimeError(f'the replayed steps returned {n_det_g} detections, the eager ones {n_det}')
         dt = dt_g
         del gd
     except Exception as exc:                                   # the eager figure stays the headline
+        gc.enable()
         if graph_note is None:
             graph_note = f'hipGraph replay failed ({type(exc).__name__}: {exc}); value is the eager loop'[:300]
     ops.PROFILE = []                                           # one extra, untimed step with events around every GEMM-type launch
@@ -638,14 +657,19 @@ def main(argv=None):
     train = None
     if not a.no_train:
         del model
+        import gc
+        gc.collect()                              # the captured graphs of the detect / bulk legs own private pools: let them go
         torch.cuda.empty_cache()
+        if os.environ.get('NBM_BENCH_MEMLOG') == '1':
+            print(f'bench: before the train leg: allocated {torch.cuda.memory_allocated() / 2 ** 30:.1f} GiB, reserved '
+                  f'{torch.cuda.memory_reserved() / 2 ** 30:.1f} GiB', file=sys.stderr, flush=True)
         try:
             train = train_bench(rank, world, dist, a.train_batch, a.train_steps, 2)     # 2 warm-up steps: allocator, lists, pinned ring
         except Exception as exc:                  # the detect line above is the contract metric: never lose it
             train = {'error': f'{type(exc).__name__}: {exc}'[:500]}
     if rank == 0:
         line = {'metric': 'clips/sec (3 s @ 22.05 kHz) detect fwd', 'value': world * B * a.steps / dt, 'unit': 'clips/s',
-                'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'spin_up_steps': a.spin_up, 'ms_per_step': dt / a.steps * 1e3,
+                'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'spin_up_steps': a.spin_up, 'gc_disabled_in_timed_regions': True, 'ms_per_step': dt / a.steps * 1e3,
                 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                 'config': {'workload': 'BASELINE.json configs[1]: 1xMI355X inference, batch=64 synthetic 3 s clips '
                                        '(PCM16 @22.05 kHz resident in HBM) through the HIP STFT front end + detector '
