@@ -15,6 +15,11 @@ Prints ONE JSON line on rank 0, carrying `roofline` (dominant kernel: the deep-K
 kernel, all its launches of a step timed live with HIP events on the launch stream), `bulk_inference` (configs[4] on this
 rank's shard: wav files -> txt files end to end), `train_step` (configs[2] / [3]) and `cpu_baseline` (the oracle port on the
 host cores, bounded sample, N=1 only).  `python bench.py --gpus N` starts its N ranks itself (see launch_ranks).
+
+Order of the detect leg: `--spin-up` untimed steps (idle -> steady clocks), W warm-up steps, K eager steps with HIP events around
+the dominant kernel's launches (-> `roofline`, `eager_with_events`), then the same step captured in a hipGraph: W warm-up replays and
+K TIMED replays = `value` / `ms_per_step` (falls back to the eager figure, with a note in `config.launch`, if the capture fails).
+Timed regions run with Python's cyclic garbage collector disabled, as `timeit` does (`gc_disabled_in_timed_regions`).
 """
 import argparse
 import json
