@@ -252,7 +252,10 @@ def parse_args(argv=None):
     ap.add_argument('--min-score', type=float, default=0.2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--train-batch', type=int, default=128)
-    ap.add_argument('--train-steps', type=int, default=5)
+    ap.add_argument('--train-steps', type=int, default=8,
+                    help='timed steps of the train leg (every timed region starts with an empty GPU queue: the host side of its first step '
+                         '-- 160 ms of anchor targets at B = 128 -- is not hidden behind a previous step; 2-3 steps measured 470-500 ms / step '
+                         'where 5-8 measure 427)')
     ap.add_argument('--no-train', action='store_true')
     ap.add_argument('--no-dense-reference', dest='no_dense_reference', action='store_true')
     ap.add_argument('--bulk-files', type=int, default=2048,
