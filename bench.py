@@ -33,12 +33,29 @@ sys.path.insert(0, ROOT)
 import numpy as np   # noqa: E402
 import torch         # noqa: E402
 
-PMC_DOMINANT = 'r03_pmc_dominant.json'    # committed rocprofv3 --pmc passes of `python bench.py` (scripts/pmc_dominant.py)
+PMC_DOMINANT = 'r04_pmc_dominant.json'    # committed rocprofv3 --pmc passes of `python bench.py` (scripts/pmc_dominant.py)
+PMC_WGRAD = 'r04_pmc_wgrad.json'          # ... of scripts/trainbench.py: the weight-gradient kernels (scripts/r04_profiles.sh)
+PMC_DGRAD = 'r04_pmc_dgrad.json'          # ... the data-gradient kernels
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 FP64_MFMA_PEAK_TFLOPS = 78.6           # v_mfma_f64_16x16x4_f64: half the fp32 rate on this part (64 cycles / 2048 FLOP / SIMD)
 FPN0_GFLOP_PER_CLIP = 170.322          # fpn.out_convs.4, 3x3 384->256 @188x512
 FWD_GFLOP_PER_CLIP = 325.56            # SURVEY.md §6 (conv + addmm + bmm, forward)
 TRAIN_GFLOP_PER_CLIP = 993.45          # SURVEY.md §6 (fwd + bwd, positive step)
+
+
+def pmc_traffic(name, same_workload):
+    """`traffic` (HBM bytes per launch, 2 x FETCH_SIZE + WRITE_SIZE) of a kernel family from THIS round's committed rocprofv3 --pmc
+    passes (counters cannot be read live), or null with the reason."""
+    path = os.path.join(ROOT, 'profiles', name)
+    try:
+        pj = json.load(open(path))
+    except Exception as exc:
+        return {'traffic': None, 'traffic_note': f'profiles/{name} not readable ({type(exc).__name__}): no PMC pass of this round for this kernel'}
+    if not same_workload:
+        return {'traffic': None, 'traffic_note': f'profiles/{name} was taken at another batch size'}
+    return {'traffic': pj.get('traffic_bytes_per_launch'), 'traffic_unit': 'bytes/launch (2*FETCH_SIZE + WRITE_SIZE, mean over the launches)',
+            'mfma_busy_frac_pmc': pj.get('mfma_busy_frac'),
+            'traffic_note': f'profiles/{name}: separate rocprofv3 --pmc passes of scripts/trainbench.py (same step, same batch), not measured in this run'}
 
 
 def train_bench(rank, world, dist, batch, steps, warmup, mix_steps=10):
@@ -72,6 +89,8 @@ def train_bench(rank, world, dist, batch, steps, warmup, mix_steps=10):
             dist.barrier()
             torch.cuda.synchronize()
 
+    dt_local = [0.0]
+
     def timed(schedule):
         import gc
         gc.collect()
@@ -81,6 +100,8 @@ def train_bench(rank, world, dist, batch, steps, warmup, mix_steps=10):
             t0 = time.perf_counter()
             for negative in schedule:
                 loss = train_one_step(model, crit, opt, data, args.clip_max_norm, 'cuda', negative_sample=negative)
+            torch.cuda.synchronize()
+            dt_local[0] = time.perf_counter() - t0     # this rank's own time (before the closing barrier)
             sync_all()
             dt = time.perf_counter() - t0
         finally:
@@ -100,7 +121,26 @@ def train_bench(rank, world, dist, batch, steps, warmup, mix_steps=10):
     dt_instr, _ = timed([False] * steps)
     exec_gflop_per_clip = ops.flops_total() / (steps * batch) / 1e9
     prof, ops.PROFILE_BWD, ops.FLOPS = ops.PROFILE_BWD, None, None
+    from birdsoundclassif_amd import train as T
+    T.exchange_stats_reset(dist is not None)
     dt, loss = timed([False] * steps)      # the figure of this leg: nothing attached
+    # data parallel: what the exchange cost THIS rank, and how far the ranks' own step times are apart (all-gathered below)
+    exch = T.exchange_stats_summary()
+    T.exchange_stats_reset(False)
+    per_rank = None
+    if dist is not None:
+        mine = torch.tensor([dt_local[0] / steps * 1e3, exch['exchange_ms'] if exch else 0.0, exch['control_ms'] if exch else 0.0,
+                             float(exch['overlapped_steps']) if exch else 0.0], device='cuda', dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        rows = [t.tolist() for t in allr]
+        per_rank = {'ms_per_step': [r[0] for r in rows], 'ms_per_step_min': min(r[0] for r in rows), 'ms_per_step_max': max(r[0] for r in rows),
+                    'exchange_ms': [r[1] for r in rows], 'control_ms': [r[2] for r in rows],
+                    'overlapped_steps': [int(r[3]) for r in rows], 'timed_steps': steps,
+                    'note': 'per rank, means over the timed steps: ms_per_step = the rank\'s own wall time between the two barriers; '
+                            'exchange_ms = HIP events from the start of the first flat-buffer all-reduce (inside the backward pass when '
+                            'overlapped) to the end of the last; control_ms = host wall time of the touched-bitmap all-reduce over gloo '
+                            '(includes waiting for the slowest rank\'s host)'}
     # dominant backward kernel: igemm_tn_kernel<128,0,0> (weight gradients); its largest launches are the 36
     # Winograd F(4x4,3x3)-domain TN GEMMs of fpn.out_convs.4 (groups = 36, one launch per batch chunk)
     wg = {}
@@ -124,8 +164,62 @@ def train_bench(rank, world, dist, batch, steps, warmup, mix_steps=10):
                     'all_wgrad_ms_per_step': all_ms / steps,
                     'largest_launches': [{'B,H,W,Cin,N,k,stride,groups': list(t[1:]), 'ms': sum(wg[t]) / len(wg[t]),
                                           'launches': len(wg[t]), 'executed_TFLOPs': gflop(t) * len(wg[t]) / sum(wg[t])} for t in top],
-                    'traffic': None, 'traffic_note': 'FETCH_SIZE / WRITE_SIZE / MFMA-busy of this kernel: profiles/r02_pmc_wgrad.json'}
+                    **pmc_traffic(PMC_WGRAD, batch == 128)}
+    dg = {}
+    for tag, e0, e1 in prof:
+        if tag[0] == 'dgrad':
+            dg.setdefault(tag, []).append(e0.elapsed_time(e1))
+    dgrad_roof = None
+    if dg:
+        def dgflop(t):
+            _, b, H, W, Cin, N, k, stride, groups = t
+            return 2.0 * b * ((H - 1) // stride + 1) * ((W - 1) // stride + 1) * N * Cin * k * k * groups / 1e9
+        d_ms = sum(sum(v) for v in dg.values())
+        d_gf = sum(dgflop(t) * len(v) for t, v in dg.items())
+        d_n = sum(len(v) for v in dg.values())
+        dtop = sorted(dg, key=lambda t: -sum(dg[t]))[:4]
+        dgrad_roof = {'bound': 'mfma', 'kernel': 'igemm_nn_kernel<BN,STAGES>: every data-gradient launch of a step (NN GEMMs on the KRSC weights)',
+                      'achieved': d_gf / d_ms, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': d_gf / d_ms / FP32_MFMA_PEAK_TFLOPS,
+                      'avg_launch_ms': d_ms / d_n, 'launches': d_n, 'all_dgrad_ms_per_step': d_ms / steps,
+                      'largest_launches': [{'B,H,W,Cin,N,k,stride,groups': list(t[1:]), 'ms': sum(dg[t]) / len(dg[t]), 'launches': len(dg[t]),
+                                            'executed_TFLOPs': dgflop(t) * len(dg[t]) / sum(dg[t])} for t in dtop],
+                      **pmc_traffic(PMC_DGRAD, batch == 128)}
     pos = {'ms_per_step': dt / steps * 1e3, 'clips_per_s': world * batch * steps / dt, 'ms_per_step_instrumented': dt_instr / steps * 1e3}
+    # SURVEY 8d (ii), second figure: the same step with the front end fused in -- PCM16 clips resident in HBM -> 2x up-sample -> STFT-dB
+    # -> normalise / window (the detect leg's front end) -> images -> training step.  The reference trains from PNG spectrograms
+    # (image_dataset.py:43-44), so the headline of this leg stays the image-fed step.
+    with_fe = None
+    try:
+        from birdsoundclassif_amd.nbm_datasets.prepare_dataset import SpectrogramFrontEnd
+        fe = SpectrogramFrontEnd('cuda')
+        pcm = torch.from_numpy(np.tile(synth.clip_batch_pcm16(rank * 8, 8), (-(-batch // 8), 1))[:batch].copy()).cuda()
+
+        def fe_step():
+            with torch.no_grad():
+                im, _ = fe(pcm, 22050)
+            d2 = [im[:, 0], neg, data[2], data[3], data[4]]
+            return train_one_step(model, crit, opt, d2, args.clip_max_norm, 'cuda', negative_sample=False)
+        fe_step()
+        import gc
+        gc.collect()
+        gc.disable()
+        try:
+            sync_all()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fe_step()
+            sync_all()
+            dtf = time.perf_counter() - t0
+        finally:
+            gc.enable()
+        if dist is not None:
+            t = torch.tensor([dtf], device='cuda', dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtf = float(t.item())
+        with_fe = {'ms_per_step': dtf / steps * 1e3, 'clips_per_s': world * batch * steps / dtf, 'steps': steps,
+                   'what': 'PCM16 (3 s @ 22.05 kHz, resident in HBM) -> HIP front end -> images -> the same positive training step'}
+    except Exception as exc:                      # informational figure: never lose the leg over it
+        with_fe = {'error': f'{type(exc).__name__}: {exc}'[:300]}
     # the reference's schedule: one negative step in ten
     mix = None
     if mix_steps:
@@ -146,7 +240,10 @@ def train_bench(rank, world, dist, batch, steps, warmup, mix_steps=10):
     exec_tflops = v / world * exec_gflop_per_clip / 1e3
     return {'value': v, 'unit': 'clips/s', 'batch_per_gpu': batch, 'global_batch': world * batch, 'steps': steps,
             'ms_per_step': pos['ms_per_step'], 'ms_per_step_with_the_instruments_on': pos['ms_per_step_instrumented'],
-            'parallelism': f'dp{world}',
+            'parallelism': f'dp{world}', 'per_rank': per_rank,
+            'exchange': None if world == 1 else ('one all-reduce (AVG) per flat gradient buffer; the non-backbone buffer starts inside the backward '
+                                                 'pass (hook on the backbone\'s last tap), the backbone buffer after it' if T.DP_OVERLAP else
+                                                 'one all-reduce (AVG) per flat gradient buffer, after the backward pass'),
             'executed_GFLOP_per_clip': exec_gflop_per_clip, 'executed_TFLOPs_per_gpu': exec_tflops,
             'executed_frac_of_mfma_peak': exec_tflops / FP32_MFMA_PEAK_TFLOPS,
             'direct_conv_equivalent_GFLOP_per_clip': TRAIN_GFLOP_PER_CLIP,
@@ -156,7 +253,7 @@ def train_bench(rank, world, dist, batch, steps, warmup, mix_steps=10):
                     'with a reader, forward and weight gradient); direct_conv_equivalent = SURVEY 993.45 GFLOP/clip '
                     'and is NOT a roofline figure',
             'reference_schedule_9_positive_1_negative': mix,
-            'roofline_backward': bwd_roof,
+            'roofline_backward': bwd_roof, 'roofline_backward_data_gradients': dgrad_roof, 'with_front_end': with_fe,
             'final_loss': {k: float(x.detach()) if torch.is_tensor(x) else float(x) for k, x in loss.items()},
             'workload': 'BASELINE.json configs[2]/[3]: positive training step (fwd + bwd + clip + AdamW), fp32'}
 
@@ -207,7 +304,7 @@ def bulk_bench(model, rank, world, dist, n_files, batch, min_score, headline_cli
         shutil.rmtree(root, ignore_errors=True)
 
 
-def cpu_baseline(n_clips=16, batch=4, threads=32):
+def cpu_baseline(n_clips=16, batch=4, threads=32, threads8_clips=8):
     """Oracle port (numpy front end + pure-torch detector) on the host cores; bounded sample (~10-20 s).
     32 torch threads: measured fastest on the GPU box (8: 1.36, 16: 1.43, 32: 1.81, 64: 1.13, 128: 0.54 clips/s for
     the detector alone); one untimed warm-up batch."""
@@ -234,9 +331,23 @@ def cpu_baseline(n_clips=16, batch=4, threads=32):
             run(1000 + s, batch)
             done += batch
         dt = time.perf_counter() - t0
-    return {'value': done / dt, 'unit': 'clips/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{done} synthetic 3 s clips in batches of {batch}: oracle front end (numpy float64 FFT, 1 thread) + '
-                      f'oracle detector forward (torch CPU fp32, {threads} threads), {dt:.1f} s'}
+    res = {'value': done / dt, 'unit': 'clips/s', 'cores': threads, 'kind': 'port',
+           'sample': f'{done} synthetic 3 s clips in batches of {batch}: oracle front end (numpy float64 FFT, 1 thread) + '
+                     f'oracle detector forward (torch CPU fp32, {threads} threads), {dt:.1f} s'}
+    # the 8-thread figure (comparable with the survey container's 8 cores, BASELINE.md 2: ~1.1 clips/s), same code
+    if threads != 8 and threads8_clips > 0:
+        torch.set_num_threads(8)
+        with torch.no_grad():
+            run(900, 2)
+            t0 = time.perf_counter()
+            d8 = 0
+            for s0 in range(0, threads8_clips, batch):
+                run(1000 + s0, batch)
+                d8 += batch
+            dt8 = time.perf_counter() - t0
+        res['threads8'] = {'value': d8 / dt8, 'unit': 'clips/s', 'cores': 8, 'sample': f'{d8} of the same clips, torch.set_num_threads(8), {dt8:.1f} s'}
+        torch.set_num_threads(threads)
+    return res
 
 
 def parse_args(argv=None):
@@ -270,6 +381,15 @@ def free_port():
         return s.getsockname()[1]
 
 
+def host_threads_per_rank(world):
+    """Host threads one rank may use: usable cores (affinity mask where the platform has one) / ranks on this host, at least 1."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 1
+    return max(1, cores // max(1, world))
+
+
 def launch_ranks(n, argv, script=None, timeout=None):
     """`python bench.py --gpus N` without torchrun: start N rank processes of this script (one per GPU; RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* in their environment) BEFORE this process has made any GPU call -- it never makes one: it only
@@ -280,6 +400,11 @@ def launch_ranks(n, argv, script=None, timeout=None):
     env = dict(os.environ)
     env.update(WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()), NBM_BENCH_LAUNCHER='self')
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    # N ranks share one host: cap every rank's host thread pools (torch intra-op / OpenMP / MKL: the NumPy target layers and the
+    # CPU side of torch each default to ALL cores) at cores / N, so that 8 ranks do not run 8 x 128 threads on 128 cores
+    per_rank = host_threads_per_rank(n)
+    for k in ('OMP_NUM_THREADS', 'MKL_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'NBM_HOST_THREADS'):
+        env.setdefault(k, str(per_rank))
     procs = []
     for r in range(n):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
@@ -342,7 +467,11 @@ def dist_setup(a):
     if not dry:
         torch.cuda.set_device(dev)
     dist, backend, seen, devices = None, None, 1, [dev]
+    host_threads = None
     if world > 1:
+        # under torchrun the launcher above did not run: cap this rank's host thread pools here (same rule)
+        host_threads = int(os.environ.get('NBM_HOST_THREADS') or host_threads_per_rank(int(os.environ.get('LOCAL_WORLD_SIZE', world))))
+        torch.set_num_threads(host_threads)
         import datetime
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -363,7 +492,13 @@ def dist_setup(a):
         devices = [int(v) - 1 for v in idx.tolist()]
         if seen != world:
             raise SystemExit(f'the {backend} all-reduce saw {seen} ranks, expected {world}')
+        # the gloo group for host-side control data of the training exchange (touched bitmap), created collectively NOW -- not
+        # inside the first training step (train.init_control_group)
+        from birdsoundclassif_amd.train import init_control_group
+        control = init_control_group(dist)
     info = {'backend': backend, 'ranks_seen': seen, 'rank_devices': devices,
+            'host_threads_per_rank': host_threads,
+            'control_group': None if world == 1 else ('gloo beside the RCCL group' if control is not None else 'the default (gloo) group'),
             'launcher': os.environ.get('NBM_BENCH_LAUNCHER', 'torchrun' if 'TORCHELASTIC_RUN_ID' in os.environ else 'external' if world > 1 else 'none')}
     return rank, world, local, dist, info
 
@@ -389,7 +524,8 @@ def main(argv=None):
         if dist is not None:
             dist.barrier()
         if rank == 0:
-            print(json.dumps({'metric': 'dry run (launcher test)', 'n_gpus': world, **dist_info}), flush=True)
+            print(json.dumps({'metric': 'dry run (launcher test)', 'n_gpus': world, **dist_info,
+                              'torch_threads': torch.get_num_threads(), 'OMP_NUM_THREADS': os.environ.get('OMP_NUM_THREADS')}), flush=True)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -592,12 +728,15 @@ def main(argv=None):
                    if len(tag) == 9 and isinstance(tag[8], tuple) and tag[8][0] in ('wino23', 'wino23-rois'))
     roof = None
     traffic = None                      # HBM bytes per launch of the dominant kernel: PMC counters cannot be read live;
+    traffic_why = None
     try:                                # the value comes from the committed rocprofv3 --pmc passes of this same command
         pj = json.load(open(os.path.join(ROOT, 'profiles', PMC_DOMINANT)))
         if B == 64 and pj.get('lazy_finest') == bool(ondemand.LAZY_FINEST) and pj.get('kernel_family') == 'igemm deep-K':
             traffic = pj['traffic_bytes_per_launch']
-    except Exception:
-        traffic = None
+        else:
+            traffic_why = 'batch / on-demand mode differ from that profile'
+    except Exception as exc:
+        traffic, traffic_why = None, f'profiles/{PMC_DOMINANT} not readable ({type(exc).__name__})'
     if deep:
         per = [(tag, ms, gemm_gflop(tag)) for tag, ms in deep]
         gflop, ms = sum(g for _, _, g in per), sum(m for _, m, _ in per)
@@ -616,7 +755,8 @@ def main(argv=None):
                 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS,
                 'traffic': traffic, 'traffic_unit': 'bytes/launch (2*FETCH_SIZE + WRITE_SIZE, mean over the launches)',
                 'traffic_source': f'profiles/{PMC_DOMINANT}: separate rocprofv3 --pmc passes of this command, NOT measured in this run '
-                                  '(counters cannot be read live); null when batch / on-demand mode differ from that profile',
+                                  '(counters cannot be read live); null when batch / on-demand mode differ from that profile'
+                                  + (f' -- null here: {traffic_why}' if traffic_why else ''),
                 'avg_launch_ms': ms / len(per), 'launches': len(per), 'launches_per_step': len(per) / a.steps,
                 'executed_GFLOP_per_launch': gflop / len(per), 'ms_per_step': ms / a.steps,
                 'largest_launches': [{'what': k, 'ms': v[0] / v[2], 'launches_per_step': v[2] / a.steps, 'executed_TFLOPs': v[1] / v[0],

@@ -83,12 +83,38 @@ _FPN_OUT = {}            # data_ptr -> FPN output map (NHWC) of this forward pas
 _FPN_UP = {}             # data_ptr of an up-sampled copy of an FPN map (the RPN's first operator on level P5) -> that map
 
 
-def fpn_out_register(maps):
+# ---- one training pass in flight per process.  The registries above are keyed by `data_ptr()` of tensors that are alive for the whole
+# pass (saved tensors / parked maps), so keys of two passes never collide; what CAN go wrong is ORDER: a forward pass that starts while
+# an earlier pass still has gradients parked (its RPN branch was back-propagated early) or stashed (its backward pass is half-way) used
+# to wipe them silently -- the earlier pass then lost a share of d/d(FPN map).  Now:
+#   * a forward pass under `no_grad` (validation between two training steps, reference train.py:362-377; `detect`) registers nothing and
+#     touches nothing here;
+#   * a grad-enabled forward pass gets a token owned by its model; starting one while `_PARKED` / `_STASH` still hold gradients of the
+#     previous token raises instead of dropping them (gradient accumulation over two forwards, two models interleaved inside a step);
+#   * the early backward pass and `parked_flush` must belong to the token of the forward pass that registered the FPN maps;
+#   * every backward pass validates itself: the first node that stashes / consumes a hand-over queues an engine callback that runs
+#     `stash_check_empty` when the engine finishes -- also for callers that use `step()` + their own `backward()`.
+_PASS = {'token': 0, 'owner': None}
+
+
+def pass_token():
+    return _PASS['token']
+
+
+def _owner_name(ref):
+    o = ref() if ref is not None else None
+    return type(o).__name__ + f'@{id(o):#x}' if o is not None else 'a model that no longer exists'
+
+
+def fpn_out_register(maps, token=None):
+    if token is not None and token != _PASS['token']:
+        raise RuntimeError('FPN maps registered by a forward pass that is no longer the current one (functional._PASS): another '
+                           'grad-enabled forward pass started in between')
+    if not torch.is_grad_enabled():        # inference: nothing will be parked, and the registry must not keep 8 GB of maps alive
+        return
     _FPN_OUT.clear()
     _FPN_UP.clear()
     _PARKED.clear()
-    if not torch.is_grad_enabled():        # inference: nothing will be parked, and the registry must not keep 8 GB of maps alive
-        return
     for m in maps:
         _FPN_OUT[m.data_ptr()] = m
 
@@ -103,15 +129,44 @@ def parked_flush():
         torch.autograd.backward([m for m, _ in items], [g for _, g in items])
 
 
-def stash_reset():
-    """Start of a forward pass: forget the registrations (and any gradient) of earlier passes."""
-    _STASH.clear()
+def stash_reset(owner=None):
+    """Start of a forward pass of `owner` (NbmModel._fpn_nhwc) -> the pass token (0 under no_grad: such a pass registers nothing --
+    `ctx.needs_input_grad` is all False -- and leaves a training pass in flight alone)."""
+    if not torch.is_grad_enabled():
+        return 0
+    if _PARKED or _STASH:
+        what = ', '.join(f'{len(d)} {n}' for d, n in ((_PARKED, 'parked RPN share(s) of d/d(FPN map)'), (_STASH, 'stashed gradient(s)')) if d)
+        raise RuntimeError(f'a grad-enabled forward pass started while the previous one (token {_PASS["token"]}, {_owner_name(_PASS["owner"])}) '
+                           f'still holds {what}: its backward pass has not finished.  One forward / backward pair in flight per process '
+                           '(gradient accumulation: finish each micro-batch with backward(); two models: finish one step before the '
+                           'other starts; to abandon the pending pass call functional.pass_abandon())')
     _STASH_OK.clear()
     _PREMASKED.clear()
-    _PARKED.clear()
     _FPN_OUT.clear()
     _FPN_UP.clear()
     ondemand.zero_pool_new_pass()
+    _PASS['token'] += 1
+    _PASS['owner'] = weakref.ref(owner) if owner is not None else None
+    return _PASS['token']
+
+
+def pass_abandon():
+    """Drop whatever the current pass parked / stashed (an exception ended its step; a caller decided not to back-propagate it)."""
+    _STASH.clear()
+    _PARKED.clear()
+    _STASH_OK.clear()
+    _PREMASKED.clear()
+    _FPN_OUT.clear()
+    _FPN_UP.clear()
+    _GRAD_ACC.clear()
+    ondemand.zero_pool_new_pass()
+
+
+def pass_check_owner(model, what):
+    o = _PASS['owner']() if _PASS['owner'] is not None else None
+    if o is not None and model is not None and o is not model:
+        raise RuntimeError(f'{what}: the pass in flight (token {_PASS["token"]}) belongs to {_owner_name(_PASS["owner"])}, not to '
+                           f'{type(model).__name__}@{id(model):#x} -- two models interleaved inside one step')
 
 
 def stash_accept(t, needs_grad):
@@ -133,6 +188,22 @@ def stash_check_empty():
         n = len(_STASH)
         _STASH.clear()
         raise RuntimeError(f'{n} stashed gradient(s) were never picked up by their second consumer (functional._STASH)')
+
+
+_END_CHECK = [False]
+
+
+def _end_of_backward():
+    _END_CHECK[0] = False
+    stash_check_empty()
+
+
+def arm_end_of_backward_check():
+    """Called from inside a backward node that leaves a gradient in `_STASH`: when the engine finishes THIS backward run, nothing may
+    be left there (queued once per run; an exception raised in the callback reaches the caller of `backward()`)."""
+    if not _END_CHECK[0]:
+        _END_CHECK[0] = True
+        torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
 
 
 def _winograd_ok(x, weight, kh, kw, stride, pad):
@@ -247,6 +318,7 @@ class Conv(Function):
                                g_ld=gp.shape[1], w_ld=wk.shape[1], a_scale=scale, alpha=alpha, residual=other)
             if ctx.stash_x:                           # the tensor's other consumer adds this in its own kernel
                 _STASH[x.data_ptr()] = gx
+                arm_end_of_backward_check()
                 gx = None
         want_gb = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] and listed and LAZY_WGRAD:
@@ -285,6 +357,7 @@ class Conv(Function):
                    ops.upsample_bilinear_bwd(g, *ctx.up_hw, pattern_stride=raw['pat_stride'], tiles_share=share))
             if ctx.stash_up:                          # the coarse map's output convolution adds it in its data-gradient epilogue
                 _STASH[ctx.up_ptr] = gup
+                arm_end_of_backward_check()
                 gup = None
         if gres is None:
             ondemand.zero_recycle(gy)   # a persistent gradient map (ondemand.zero_acquire): this node was its last reader

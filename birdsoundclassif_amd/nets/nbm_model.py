@@ -50,8 +50,14 @@ class NbmModel(nn.Module):
         if samples.dim() != 4 or samples.shape[1] != self.args.inpt_channels:
             raise ValueError(f'expected [B,{self.args.inpt_channels},H,W], got {tuple(samples.shape)}')
         x = samples.permute(0, 2, 3, 1).contiguous()
-        Fn.stash_reset()                       # gradient hand-over registrations are per forward pass (functional._STASH)
+        token = Fn.stash_reset(self)           # gradient hand-over registrations are per forward pass, owned by this model (functional._PASS)
         features, _ = self.backbone(x)
+        if torch.is_grad_enabled() and features[-1].requires_grad:
+            # data-parallel training: when autograd hands the gradient of the LAST tap to the backbone, every non-backbone gradient is
+            # final -- the exchange of that flat buffer starts there, beside the backbone's backward kernels (train.DP_OVERLAP)
+            from .. import train as _train
+            if _train.exchange_armed():
+                features[-1].register_hook(_train.backbone_boundary_hook)
         if getattr(self.args, 'add_posenc', False):                       # nbm_model.py:45-46
             pe = self.backbone[1]
             features = [Fn.AddConst.apply(f, pe(f)) for f in features]
@@ -63,7 +69,7 @@ class NbmModel(nn.Module):
             out = self.fpn(self.attn(features), lazy_strides=self._lazy_strides())
         else:
             out = self.fpn(self.attn(features))
-        Fn.fpn_out_register(out)               # the early backward pass of the RPN branch parks its gradients by these maps (train.step)
+        Fn.fpn_out_register(out, token or None)  # the early backward pass of the RPN branch parks its gradients by these maps (train.step)
         return out
 
     def forward_first_stage(self, samples, host_work=None, lazy=False):

@@ -283,6 +283,7 @@ def _early_rpn_backward(model, criterion):
     rpn = getattr(getattr(model, 'head', None), 'rpn', None)
     if not keys or rpn is None or not Fn.GRAD_SHARE or not Fn._FPN_OUT:
         return
+    Fn.pass_check_owner(model, 'early RPN backward')
     params = [p for p in rpn.parameters() if p.requires_grad]
     loss = sum(pre[k] * w[k] for k in keys)
     Fn.EARLY = True
@@ -296,17 +297,129 @@ def _early_rpn_backward(model, criterion):
 
 
 _CONTROL_GROUP = {}
+# Per-rank timings of the last data-parallel exchange (bench.py reports them; reset by `exchange_stats_reset`):
+#   control_ms   host wall time of the touched-bitmap all-reduce over the gloo control group (includes waiting for the slowest rank's HOST)
+#   exchange_ms  device time between the first and the last flat-buffer all-reduce of the step finishing, HIP events on the launch stream
+#                (CPU tensors: host wall time); with the overlapped form this window runs beside the backbone's backward kernels
+#   overlapped   1 when the non-backbone buffer's all-reduce was started from inside the backward pass (see DP_OVERLAP)
+EXCHANGE_STATS = None
 
 
-def _control_group(dist):
-    """Process group for small HOST tensors: the default group itself under gloo, a gloo group created once (collectively, at the
-    first data-parallel step) beside an RCCL default group."""
-    if dist.get_backend() != 'nccl':
+def exchange_stats_reset(enabled=True):
+    global EXCHANGE_STATS
+    EXCHANGE_STATS = {'steps': 0, 'control_ms': [], 'exchange_events': [], 'exchange_ms_host': [], 'overlapped': 0} if enabled else None
+
+
+def exchange_stats_summary():
+    """-> dict of means over the recorded steps (synchronises the recorded events), or None."""
+    st = EXCHANGE_STATS
+    if not st or not st['steps']:
+        return None
+    ms = [a.elapsed_time(b) for a, b in st['exchange_events']] + list(st['exchange_ms_host'])
+    n = st['steps']
+    return {'steps': n, 'control_ms': sum(st['control_ms']) / max(1, len(st['control_ms'])),
+            'exchange_ms': sum(ms) / max(1, len(ms)), 'overlapped_steps': st['overlapped']}
+
+
+def _device_backend(dist):
+    """Backend of the default process group ('nccl' = RCCL on ROCm).  A function of its own so that the CPU test can force the
+    RCCL-side control flow (separate gloo control group) over a gloo default group."""
+    return dist.get_backend()
+
+
+def init_control_group(dist=None):
+    """Create the process group for small HOST tensors NOW -- collectively, on every rank, right after `init_process_group` (train
+    `__main__`, `bench.dist_setup`): the default group itself under gloo (returns None), a gloo group beside an RCCL default group.
+    Creating it lazily inside the first training step would put a collective `new_group` behind data-dependent control flow."""
+    if dist is None:
+        import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or _device_backend(dist) != 'nccl':
         return None
     key = id(dist.group.WORLD)
     if key not in _CONTROL_GROUP:
         _CONTROL_GROUP[key] = dist.new_group(backend='gloo')
     return _CONTROL_GROUP[key]
+
+
+def _control_group(dist):
+    """The group of `init_control_group` (created there; a caller that skipped the eager call still gets it here, at the first
+    data-parallel step, where every rank arrives)."""
+    return init_control_group(dist)
+
+
+def _flat_allreduce(dist, buf, world, async_op=False):
+    """Average one flat fp32 gradient buffer over the ranks.  -> work handle (async_op) or None."""
+    if dist.get_backend() == 'nccl':
+        return dist.all_reduce(buf, op=dist.ReduceOp.AVG, async_op=async_op)          # RCCL averages in the collective itself
+    w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=async_op)
+    if async_op:
+        return (w, buf, world)
+    buf.div_(world)
+    return None
+
+
+def _flat_wait(handle):
+    if handle is None:
+        return
+    if isinstance(handle, tuple):
+        w, buf, world = handle
+        w.wait()
+        buf.div_(world)
+    else:
+        handle.wait()
+
+
+# Overlap of the exchange with the backward pass (SURVEY 8e: "bucketed in reverse-autograd order, overlapped with backward"), in the
+# two buckets the optimiser already has: the NON-backbone flat buffer (FPN, attention, RPN, RCNN head: ~20 M gradients, 80 MB) is
+# final when autograd hands the gradient of the backbone's LAST tap (c5) to the backbone -- every node of the heads, the FPN
+# (top-down chain: the coarsest lateral runs last) and the attention pyramid was created after every backbone node and c5's gradient
+# is the sum of their shares -- so `NbmModel._fpn_nhwc` puts a tensor hook on that tap and the hook starts the first all-reduce
+# (async; RCCL's stream waits for the kernels queued so far) while the backbone's backward kernels (~40 % of the backward pass) are
+# still to run.  The backbone buffer follows after `backward()`.  The ORDER of collectives is the same on every rank whatever its
+# control flow (buffer 0, then buffer 1; a rank whose hook never fired -- no backward pass at all -- starts buffer 0 afterwards).
+DP_OVERLAP = os.environ.get('NBM_DP_OVERLAP', '1') != '0'
+_PENDING = {}            # id(optimizer) -> {'handles': [...], 'started': int, 't0': event | float}
+
+
+def _dist_active():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def exchange_begin(optimizer):
+    """Called by `train_one_step` before the step: arms the overlapped exchange for this optimiser (FusedAdamW + world > 1 only)."""
+    _PENDING.pop(id(optimizer), None)
+    if DP_OVERLAP and hasattr(optimizer, 'flat_grads') and _dist_active():
+        _PENDING[id(optimizer)] = {'handles': [], 'started': 0, 't0': None, 'opt': optimizer}
+
+
+def _mark_t0(st, like):
+    if st['t0'] is None:
+        if like.is_cuda:
+            st['t0'] = torch.cuda.Event(enable_timing=True)
+            st['t0'].record()
+        else:
+            import time
+            st['t0'] = time.perf_counter()
+
+
+def backbone_boundary_hook(grad):
+    """Tensor hook on the backbone's last tap (registered by NbmModel._fpn_nhwc while an exchange is armed): every non-backbone
+    gradient is final -> start the all-reduce of flat buffer 0 beside the backbone's backward pass."""
+    import torch.distributed as dist
+    for st in _PENDING.values():
+        if st['started'] == 0:
+            bufs = st['opt'].flat_grads()
+            _mark_t0(st, bufs[0])
+            st['handles'].append(_flat_allreduce(dist, bufs[0], dist.get_world_size(), async_op=True))
+            st['started'] = 1
+            if EXCHANGE_STATS is not None:
+                EXCHANGE_STATS['overlapped'] += 1
+    return None
+
+
+def exchange_armed():
+    return bool(_PENDING)
 
 
 def allreduce_grads(optimizer_or_model):
@@ -318,19 +431,41 @@ def allreduce_grads(optimizer_or_model):
     failure paths of `step` ("RPN failed", proposal batch cannot be filled -- data dependent, reference train.py:232-247)
     leave the second-stage parameters without a gradient on one rank only; that rank must still apply the averaged
     gradient and advance its Adam step count like its peers, or the replicas drift apart for good.  The bitmap has ~400
-    int32 entries and is a HOST tensor reduced over gloo in either case (`_control_group`)."""
+    int32 entries and is a HOST tensor reduced over gloo in either case (`_control_group`).
+
+    When `exchange_begin` armed the overlapped form, buffer 0's all-reduce may already be in flight (started by
+    `backbone_boundary_hook` inside the backward pass); this call starts whatever has not been started, in buffer order, and waits."""
+    import time
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return
     world = dist.get_world_size()
+    stats = EXCHANGE_STATS
     if hasattr(optimizer_or_model, 'flat_grads'):
         bufs = optimizer_or_model.flat_grads()
+        st = _PENDING.pop(id(optimizer_or_model), None) or {'handles': [], 'started': 0, 't0': None}
+        _mark_t0(st, bufs[0])
+        for b in bufs[st['started']:]:                    # same order on every rank: buffer 0 (unless the hook started it), buffer 1
+            st['handles'].append(_flat_allreduce(dist, b, world, async_op=True))
         bits = optimizer_or_model.touched_bitmap()
         # the bitmap is host data and decides host control flow: it travels through a gloo group of its own (a host tensor over
         # loopback / TCP, ~0.1 ms), NOT through RCCL -- a device round trip here is a stream synchronisation per step, i.e. the
         # host loses its run-ahead and the anchor targets of the next step (160 ms of NumPy at B = 128) stop being hidden
+        tc = time.perf_counter()
         dist.all_reduce(bits, op=dist.ReduceOp.MAX, group=_control_group(dist))
         optimizer_or_model.set_touched_bitmap(bits)
+        control_ms = (time.perf_counter() - tc) * 1e3
+        for h in st['handles']:
+            _flat_wait(h)                                  # RCCL: the compute stream waits for the collective (no host block)
+        if stats is not None:
+            stats['steps'] += 1
+            stats['control_ms'].append(control_ms)
+            if bufs[0].is_cuda:
+                t1 = torch.cuda.Event(enable_timing=True)
+                t1.record()
+                stats['exchange_events'].append((st['t0'], t1))
+            else:
+                stats['exchange_ms_host'].append((time.perf_counter() - st['t0']) * 1e3)
     else:
         # plain module (torch optimiser; the gloo CPU tests): EVERY trainable parameter in module order, zeros where this rank
         # has no gradient, plus one flag per parameter -- so that all ranks reduce buffers of the same length whatever soft
@@ -354,26 +489,25 @@ def allreduce_grads(optimizer_or_model):
                 else:
                     p.grad.copy_(avg)
             off += n
-        return
-    for b in bufs:
-        if dist.get_backend() == 'nccl':
-            dist.all_reduce(b, op=dist.ReduceOp.AVG)          # RCCL averages in the collective itself
-        else:
-            dist.all_reduce(b, op=dist.ReduceOp.SUM)
-            b.div_(world)
 
 
 def train_one_step(model, criterion, optimizer, batch, max_norm, device, negative_sample):
     """reference train.py:205-217."""
     from .nets import functional as Fn
     optimizer.zero_grad()                  # before the step: part of the backward pass runs inside it (SPLIT_BACKWARD)
-    loss_dict = step(model, criterion, batch, device, negative_sample, early_backward=True)
-    weight_dict = criterion.weight_dict
-    losses = sum(loss_dict[k] * weight_dict[k] for k in loss_dict.keys() if k in weight_dict)
-    if losses.requires_grad:
-        losses.backward()
-    Fn.parked_flush()                      # the step ended after the first stage: the RPN branch's gradients still have to reach the FPN
-    Fn.stash_check_empty()                 # a handed-over gradient that nobody picked up would be a silently dropped gradient
+    exchange_begin(optimizer)              # data parallel: arm the overlapped exchange (no-op for one rank / a torch optimiser)
+    try:
+        loss_dict = step(model, criterion, batch, device, negative_sample, early_backward=True)
+        weight_dict = criterion.weight_dict
+        losses = sum(loss_dict[k] * weight_dict[k] for k in loss_dict.keys() if k in weight_dict)
+        if losses.requires_grad:
+            losses.backward()
+        Fn.parked_flush()                  # the step ended after the first stage: the RPN branch's gradients still have to reach the FPN
+        Fn.stash_check_empty()             # a handed-over gradient that nobody picked up would be a silently dropped gradient
+    except BaseException:
+        _PENDING.pop(id(optimizer), None)
+        Fn.pass_abandon()                  # whatever this step parked / stashed dies with it: the next step starts clean
+        raise
     allreduce_grads(optimizer if isinstance(optimizer, FusedAdamW) else model)
     if isinstance(optimizer, FusedAdamW):
         optimizer.step(max_norm=max_norm)
@@ -583,4 +717,5 @@ if __name__ == '__main__':
         # ranks > 0 wait in the next all-reduce while rank 0 validates and runs the test-set detection: give the
         # collective watchdog room for that instead of its 10-minute default
         _dist.init_process_group('nccl', timeout=datetime.timedelta(hours=2), device_id=torch.device('cuda', _lr))
+        init_control_group(_dist)          # the gloo group for host-side control data, created collectively before any step
     main(_args)

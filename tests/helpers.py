@@ -108,3 +108,45 @@ def assert_rois_equal_up_to_near_ties(got, ref, ref_scores, eps=2e-7, what='RoIs
     if flips:
         print(f'{what}: {len(flips)} one-pixel rounding flip(s): {flips}')
     return flips
+
+
+def preround_corners(bbox_reg, args):
+    """Box corners BEFORE `.round()` (reference nets_utils.py:169-186), fp32, in the reference's operation order:
+    bbox_reg [B, 4*A*levels, h, w] (NCHW-shaped) -> [B, h*w*A*levels, 4] (K-major / anchor-minor like the proposal layer)."""
+    from birdsoundclassif_amd.nets.util.nets_utils import generate_anchors_frcnn, get_anchor_shifts_frcnn
+    reg = bbox_reg.detach().float().cpu()
+    B, _, h, w = reg.shape
+    a = generate_anchors_frcnn(base_size=args.base_size, ratios=args.ratios, scales=2 ** np.arange(args.n_layers))
+    sh = get_anchor_shifts_frcnn(w, h, args.anchor_stride)
+    anchors = torch.from_numpy((a + sh).reshape(-1, 4).astype(np.float32))
+    d = reg.permute(0, 2, 3, 1).reshape(B, -1, 4)
+    wa = anchors[:, 2] - anchors[:, 0] + 1
+    ha = anchors[:, 3] - anchors[:, 1] + 1
+    xa = anchors[:, 0] + 0.5 * wa
+    ya = anchors[:, 1] + 0.5 * ha
+    x = d[..., 0] * wa + xa
+    y = d[..., 1] * ha + ya
+    ww = torch.exp(d[..., 2]) * wa
+    hh = torch.exp(d[..., 3]) * ha
+    return torch.stack([x - 0.5 * ww, y - 0.5 * hh, x + 0.5 * ww, y + 0.5 * hh], -1)
+
+
+def assert_flips_are_half_pixel_ties(flips, bbox_reg, args, margin=1e-4):
+    """Every one-pixel flip reported by `assert_rois_equal_up_to_near_ties` must be a proposal whose corner sits within `margin` of
+    x.5 BEFORE the reference's `.round()` (nets_utils.py:186): only then can fp32 reassociation noise (1e-5 on O(100) coordinates)
+    put it on either side.  The pre-round value is recomputed from the product's own RPN regression output."""
+    if not flips:
+        return
+    pre = preround_corners(bbox_reg, args)
+    lim = torch.tensor([args.img_width - 1, args.img_height - 1, args.img_width - 1, args.img_height - 1], dtype=torch.float32)
+    for (b, rank, got, ref) in flips:
+        got, ref = torch.tensor(got), torch.tensor(ref)
+        j = int((got != ref).nonzero()[0])
+        half = 0.5 * float(got[j] + ref[j])
+        boxes = torch.minimum(pre[b].round().clamp(min=0), lim)
+        cand = (boxes == got).all(-1).nonzero().flatten()
+        assert len(cand) > 0, f'flip {(b, rank)}: no anchor decodes to the product RoI {got.tolist()}'
+        dist = (pre[b][cand, j] - half).abs().min()
+        assert float(dist) < margin, (f'flip {(b, rank)} coordinate {j}: pre-round value is {float(dist):.2e} away from {half} '
+                                      f'(margin {margin}): not a rounding tie')
+        print(f'flip image {b} rank {rank} coordinate {j}: pre-round value within {float(dist):.2e} of {half}')

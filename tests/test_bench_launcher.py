@@ -28,6 +28,11 @@ def test_self_launch_two_ranks():
     d = _line(r.stdout)
     assert d['n_gpus'] == 2 and d['ranks_seen'] == 2 and d['backend'] == 'gloo' and d['rank_devices'] == [0, 1]
     assert d['launcher'] == 'self'
+    # N ranks on one host: every rank's host thread pools are capped at cores / N (launcher: environment; rank: torch.set_num_threads),
+    # and the control group of the training exchange exists before any step (under gloo it is the default group itself)
+    cores = len(os.sched_getaffinity(0))
+    assert d['host_threads_per_rank'] == max(1, cores // 2) == d['torch_threads'] and d['OMP_NUM_THREADS'] == str(max(1, cores // 2))
+    assert d['control_group'] == 'the default (gloo) group'
 
 
 def test_same_script_under_torchrun():
@@ -40,6 +45,7 @@ def test_same_script_under_torchrun():
     assert r.returncode == 0, r.stderr[-2000:]
     d = _line(r.stdout)
     assert d['n_gpus'] == 2 and d['ranks_seen'] == 2 and d['launcher'] == 'torchrun'
+    assert d['host_threads_per_rank'] == d['torch_threads'] == max(1, len(os.sched_getaffinity(0)) // 2)
 
 
 def test_a_failing_rank_fails_the_launch():

@@ -135,7 +135,12 @@ class TwoStage(torch.nn.Module):
         self.backbone_like = torch.nn.Linear(8, 6)             # second parameter group (lr_backbone)
 
     def loss(self, x, second_stage):
-        h = self.first(x) + self.backbone_like(x)
+        hb = self.backbone_like(x)                             # created first, like the backbone's nodes: its backward runs last
+        if torch.is_grad_enabled():
+            from birdsoundclassif_amd import train
+            if train.exchange_armed():                         # what NbmModel._fpn_nhwc does with the backbone's last tap
+                hb.register_hook(train.backbone_boundary_hook)
+        h = self.first(x) + hb
         l1 = (h ** 2).mean()
         return l1 + (self.second(torch.tanh(h)) ** 2).mean() if second_stage else l1
 
@@ -145,11 +150,21 @@ def _groups(m):
             {'params': list(m.backbone_like.parameters()), 'lr': 1e-3}]
 
 
-def _fused_worker(rank, world, port, out):
+def _fused_worker(rank, world, port, out, force_rccl_control_flow=False, overlap=False):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     patch_cpu_optimizer()
+    from birdsoundclassif_amd import train
     from birdsoundclassif_amd.train import FusedAdamW, allreduce_grads
+    train.DP_OVERLAP = overlap
+    ctl = None
+    if force_rccl_control_flow:
+        # the branch a GPU job takes: the default group is RCCL, so the touched bitmap travels through a gloo group of its own,
+        # created EAGERLY right after init_process_group (train.__main__ / bench.dist_setup) -- forced here over a gloo default group
+        train._device_backend = lambda d: 'nccl'
+        ctl = train.init_control_group(dist)
+        assert ctl is not None and ctl is not dist.group.WORLD and train._control_group(dist) is ctl
+    train.exchange_stats_reset()
     m = TwoStage()
     ref = TwoStage()                                           # single-process torch AdamW on the averaged gradients
     opt = FusedAdamW(_groups(m), lr=1e-2, weight_decay=1e-2)
@@ -160,7 +175,12 @@ def _fused_worker(rank, world, port, out):
     for it, stages in enumerate(plan):
         x = [torch.full((4, 8), 0.1 * (r + 1) + 0.05 * it) + torch.arange(8.0) * 0.01 for r in range(world)]
         opt.zero_grad()
-        m.loss(x[rank], stages[rank]).backward()
+        train.exchange_begin(opt)
+        if it == 2 and rank == 1 and overlap:
+            with torch.no_grad():                              # a rank without any backward pass: its hook never fires, the
+                m.loss(x[rank], stages[rank])                  # collectives still go out in the same order
+        else:
+            m.loss(x[rank], stages[rank]).backward()
         allreduce_grads(opt)
         opt.step(max_norm=0.05)
         # reference: average of the per-rank gradients (a rank that skipped the second stage contributes zeros); a
@@ -170,7 +190,8 @@ def _fused_worker(rank, world, port, out):
         for r in range(world):
             for p_ in ref.parameters():
                 p_.grad = None
-            ref.loss(x[r], stages[r]).backward()
+            if not (it == 2 and r == 1 and overlap):
+                ref.loss(x[r], stages[r]).backward()
             grads.append([None if p_.grad is None else p_.grad.clone() for p_ in ref.parameters()])
         for i, p_ in enumerate(ref.parameters()):
             gs = [g[i] for g in grads if g[i] is not None]
@@ -190,6 +211,12 @@ def _fused_worker(rank, world, port, out):
     ok = ok and all(torch.equal(lst[0], t) for t in lst)
     # second-stage parameters stepped twice (steps 0 and 1), the others three times
     exp = [3, 3, 2, 2, 3, 3]
+    st = train.exchange_stats_summary()
+    ok = ok and st is not None and st['steps'] == 3 and st['control_ms'] >= 0 and st['exchange_ms'] >= 0
+    if overlap:                                                # the hook started buffer 0's all-reduce inside every backward pass
+        ok = ok and st['overlapped_steps'] == (2 if rank == 1 else 3)
+    else:
+        ok = ok and st['overlapped_steps'] == 0
     out[rank] = bool(ok) and steps.tolist() == exp
     dist.destroy_process_group()
 
@@ -200,6 +227,20 @@ def test_fused_adamw_flat_path_world2_with_a_soft_failure_on_one_rank():
     with mp.Manager() as mgr:
         out = mgr.dict()
         mp.spawn(_fused_worker, args=(world, port, out), nprocs=world, join=True)
+        assert dict(out) == {0: True, 1: True}
+
+
+def test_rccl_side_control_flow_forced_over_gloo_with_the_overlapped_exchange():
+    """the control flow a multi-GPU job takes -- eager gloo control group beside the (here: pretended) RCCL
+    default group, touched-bitmap MAX-reduce through it, `set_touched_bitmap`, and the overlapped exchange (buffer 0's all-reduce
+    started by the backbone-boundary hook inside the backward pass, buffer 1 after it) -- with a soft failure on one rank per step
+    and one step in which rank 1 has no backward pass at all.  Same parameters and step counts on both ranks, equal to a
+    single-process AdamW on the averaged gradients."""
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_fused_worker, args=(world, port, out, True, True), nprocs=world, join=True)
         assert dict(out) == {0: True, 1: True}
 
 

@@ -9,7 +9,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from birdsoundclassif_amd import synth                                     # noqa: E402
-from helpers import assert_rois_equal_up_to_near_ties, check_packed, dets_to_rows, filler_state_dict, load_golden   # noqa: E402
+from helpers import (assert_flips_are_half_pixel_ties, assert_rois_equal_up_to_near_ties, check_packed, dets_to_rows,   # noqa: E402
+                     filler_state_dict, load_golden)
 from oracle import frontend_ref as FR, nets_ref as O                       # noqa: E402
 
 
@@ -193,6 +194,14 @@ def test_forward_matches_reference_golden(model):
     assert tuple(o['rois'].shape) == tuple(ref_rois.shape)
     n_bad = int((o['rois'].cpu().numpy() != ref_rois).any(-1).sum())
     assert n_bad == 0, f'{n_bad} RoIs differ from the reference'
+    # the TIMED path (FPN levels 0 / 1 on demand: the RPN reads their pattern pixels through the cell transforms) must give
+    # the reference's RoIs bit for bit too -- an RoI that flips without producing a detection would be invisible further down
+    with torch.no_grad():
+        ol = model.forward_first_stage(x, lazy=True)
+    n_bad = int((ol['rois'].cpu().numpy() != ref_rois).any(-1).sum())
+    assert n_bad == 0, f'{n_bad} RoIs of the on-demand (lazy) path differ from the reference'
+    check_packed(g, 'rpn_cls_scores', ol['rpn_cls_scores'], atol=1e-4)
+    check_packed(g, 'rpn_bbox_reg', ol['rpn_bbox_reg'], atol=1e-4)
     with torch.no_grad():
         s = model.forward_second_stage(o['fpn_out'], o['rois'], training=True)
     check_packed(g, 'bbox_reg', s['bbox_reg'], atol=1e-4)
@@ -344,7 +353,11 @@ def test_composition_flags_vs_reference_golden(tag, kw):
         ref_scores = torch.from_numpy(g[f'{tag}.roi_scores.full'].reshape(g[f'{tag}.roi_scores.shape']))
         # (and at most one corner per image that round() put on the other side of x.5 -- seen once in the suite: posenc, image 1,
         # x2 = 226 vs 227; reported, and the second stage is then checked stage-wise on the reference's RoIs)
-        flips = assert_rois_equal_up_to_near_ties(o['rois'], ref_rois, ref_scores, what=f'{tag} RoIs', max_pixel_flips=1)
+        # -- tolerated for `posenc` ONLY, and only when the product's own pre-round coordinate is within 1e-4 of x.5 (diagnosis in
+        # DESIGN 2 / scripts/posenc_flip.py: which reassociation crosses x.5); every other variant must match pixel for pixel
+        flips = assert_rois_equal_up_to_near_ties(o['rois'], ref_rois, ref_scores, what=f'{tag} RoIs',
+                                                  max_pixel_flips=1 if tag == 'posenc' else 0)
+        assert_flips_are_half_pixel_ties(flips, o['rpn_bbox_reg'], args)
         # detections: the same (image, class, box) rows as the reference, scores within 1e-4
         dets = m.forward_second_stage(o['fpn_out'], ref_rois.cuda(), min_score=0.2, training=False) if flips else m(x, min_score=0.2)
         rows, ref = dets_to_rows(dets), g[f'{tag}.dets_min0.2']

@@ -40,6 +40,8 @@ def test_config1_b64_inference_equals_b8_equals_oracle():
         peak = torch.cuda.max_memory_allocated() / 2 ** 30
         o8 = model.forward_first_stage(img8)
         o64 = model.forward_first_stage(img64)
+        l8 = model.forward_first_stage(img8, lazy=True)['rois']           # the TIMED path: FPN levels 0 / 1 on demand
+        l64 = model.forward_first_stage(img64, lazy=True)['rois']
     # every copy inside the 64-batch == the 8-batch, bit for bit (classes, boxes AND scores: same kernels, same data)
     assert torch.equal(n64.view(8, 8), n8.expand(8, 8))
     assert int(n8.sum()) > 0
@@ -55,6 +57,9 @@ def test_config1_b64_inference_equals_b8_equals_oracle():
         ref1 = O.forward_first_stage(sd, cfg, x)
         ref = O.forward(sd, cfg, x, min_score=0.05)
     assert_rois_equal_up_to_near_ties(o8['rois'], ref1['rois'], ref1['roi_scores'])
+    # ... and so are the RoIs of the on-demand path (the one `detect` / the bench / training run), at both batch sizes
+    assert_rois_equal_up_to_near_ties(l8, ref1['rois'], ref1['roi_scores'], what='RoIs of the on-demand path')
+    assert torch.equal(l64.view(8, 8, *l8.shape[1:]), l8.expand(8, *l8.shape))
     got = dets_to_rows(model.head.fast_rcnn.dets_to_dicts(det8.cpu(), n8.cpu(), model.args.num_classes))
     want = dets_to_rows(ref)
     assert got.shape == want.shape and len(got) > 0

@@ -465,6 +465,21 @@ def test_detections_do_not_change_and_no_unwritten_pixel_is_read(model, B):
     assert float((det0[..., 5] - det1[..., 5]).abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize('B,seed', [(2, 0), (5, 70), (3, 31)])
+def test_rois_of_the_on_demand_path_equal_the_dense_path_bit_for_bit(model, B, seed):
+    """The RPN reads FPN levels 0 / 1 of the on-demand path through the cell transforms (F(3x3,3x3): within 1e-5 of the dense map,
+    DESIGN 4c).  Every RoI -- also the ones that never become a detection -- must nevertheless be the dense path's: same boxes, same
+    order, same count; RPN outputs within 1e-5."""
+    x = torch.from_numpy(synth.image_batch(seed, B))[:, None].cuda()
+    with torch.no_grad():
+        a = model.forward_first_stage(x)
+        b = model.forward_first_stage(x, lazy=True)
+    assert a['rois'].shape == b['rois'].shape and a['rois'].shape[1] > 0
+    assert torch.equal(a['rois'], b['rois'])
+    assert float((a['rpn_cls_scores'] - b['rpn_cls_scores']).abs().max()) < 1e-5
+    assert float((a['rpn_bbox_reg'] - b['rpn_bbox_reg']).abs().max()) < 2e-5
+
+
 def test_independent_detection_equals_one_image_per_call(model):
     """detect(..., independent=True) on a batch == detect() on each image alone, bit for bit (bulk inference: the reference CLI
     runs one file per model call).  Image 2 is blank: its proposal counts differ from its launch-mates'."""

@@ -48,3 +48,43 @@ def test_rccl_one_rank_group_runs_the_collectives_of_the_exchange_step():
         assert torch.equal(m.weight.grad, g)
     finally:
         dist.destroy_process_group()
+
+
+def _two_ranks(overlap):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    env.update(WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), NBM_DP_OVERLAP='1' if overlap else '0',
+               OMP_NUM_THREADS='4', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, 'tests', 'dp_gpu_worker.py')], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE if r == 0 else None, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
+    line = [ln for ln in outs[0][0].splitlines() if ln.startswith('{')]
+    assert len(line) == 1, outs[0][0]
+    return json.loads(line[0])
+
+
+def test_two_ranks_share_the_gpu_overlapped_exchange():
+    """Two data-parallel ranks of the REAL model on the one GPU of the box (gloo; functional only): the overlapped exchange -- the
+    non-backbone buffer's all-reduce started by the hook on the backbone's last tap inside the backward pass -- fires in every step,
+    leaves both replicas bit-identical, and averages to the same gradients as the serial exchange (up to the atomic-order noise of
+    the weight-gradient kernels between two runs)."""
+    import numpy as np
+    a = _two_ranks(overlap=True)
+    b = _two_ranks(overlap=False)
+    assert a['overlap'] is True and b['overlap'] is False
+    assert a['stats']['steps'] == 2 and a['stats']['overlapped_steps'] == 2, a['stats']
+    assert b['stats']['steps'] == 2 and b['stats']['overlapped_steps'] == 0, b['stats']
+    assert a['replicas_identical'] and b['replicas_identical']
+    ga, gb = np.array(a['grad_samples']), np.array(b['grad_samples'])
+    scale = np.abs(gb).max()
+    assert scale > 0 and np.abs(ga - gb).max() < 1e-4 * scale, (np.abs(ga - gb).max(), scale)
+    for x, y in zip(a['grad_norms'], b['grad_norms']):
+        assert abs(x - y) < 1e-4 * y, (a['grad_norms'], b['grad_norms'])

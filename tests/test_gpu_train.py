@@ -690,3 +690,94 @@ def test_bilinear_backward_reads_the_pattern_patches_only_and_takes_a_tile_share
     assert err <= 1e-5 * max(1.0, float(ref.abs().max())), err
     with pytest.raises(ValueError):
         ops.upsample_bilinear_bwd(g, Hi, Wi, tiles_share=[(compact[:-4], tiles, 0, B)])
+
+
+def _train_setup(seed=0):
+    from birdsoundclassif_amd.nets import build_model
+    from birdsoundclassif_amd.train import default_args, build_optimizer
+    args = default_args(device='cuda')
+    model, crit = build_model(args)
+    model.load_state_dict(filler_state_dict(seed))
+    model = model.cuda().train()
+    crit.train()
+    opt, _ = build_optimizer(model, args)
+    x = torch.from_numpy(synth.image_batch(0, 2)).cuda()
+    bb, ids, lengths = synth.label_batch(0, 2)
+    return args, model, crit, opt, [x, x, bb, ids, lengths]
+
+
+def test_one_training_pass_in_flight_two_models_interleaved_raise():
+    """the gradient hand-over registries (functional._PARKED / _STASH) serve ONE forward / backward pair at a time.  A
+    second grad-enabled forward pass -- of another model, or of the same one (gradient accumulation over two forwards) -- that starts
+    while the first pass still has its RPN share parked raises instead of silently dropping that share."""
+    from birdsoundclassif_amd import train as T
+    args, a, crit_a, opt_a, batch = _train_setup()
+    _, b, crit_b, opt_b, _ = _train_setup(1)
+    np.random.seed(3)
+    opt_a.zero_grad()
+    loss = T.step(a, crit_a, batch, 'cuda', negative_sample=False, early_backward=True)     # forward of A: the RPN branch is back-propagated
+    if T.SPLIT_BACKWARD and Fn.GRAD_SHARE:
+        # the early pass parked the RPN's share of d/d(FPN map) on every level; the RoI pooling's backward pass has not run yet:
+        # nothing may start a new grad-enabled pass now
+        assert len(Fn._PARKED) == 5
+        with pytest.raises(RuntimeError, match='still holds'):
+            b.forward_first_stage(batch[0][:, None], lazy=True)
+        with pytest.raises(RuntimeError, match='still holds'):
+            a.forward_first_stage(batch[0][:, None], lazy=True)
+        assert len(Fn._PARKED) == 5              # the refused passes dropped nothing
+    # ... while a forward pass under no_grad (validation between two training steps, reference train.py:362-377) is harmless:
+    with torch.no_grad():
+        b.eval()
+        b.detect(batch[0][:, None], min_score=0.2)
+        b.train()
+    wd = crit_a.weight_dict
+    sum(loss[k] * wd[k] for k in loss if k in wd).backward()
+    Fn.parked_flush()
+    Fn.stash_check_empty()
+    got = {n: p.grad.clone() for n, p in a.named_parameters() if p.grad is not None}
+    # reference: the same step of the same model, nothing in between
+    _, a2, crit_a2, opt_a2, _ = _train_setup()
+    np.random.seed(3)
+    opt_a2.zero_grad()
+    loss2 = T.step(a2, crit_a2, batch, 'cuda', negative_sample=False, early_backward=True)
+    sum(loss2[k] * wd[k] for k in loss2 if k in wd).backward()
+    Fn.parked_flush()
+    Fn.stash_check_empty()
+    for n, p in a2.named_parameters():
+        if p.grad is None:
+            assert n not in got or float(got[n].abs().max()) == 0.0, n
+            continue
+        scale = float(p.grad.abs().max()) + 1e-12
+        assert float((got[n] - p.grad).abs().max()) <= 2e-4 * scale + 1e-9, n
+    # the pass is closed: both models may start a new one
+    b.forward_first_stage(batch[0][:, None], lazy=True)
+    Fn.pass_abandon()
+
+
+def test_early_backward_of_another_models_pass_raises():
+    from birdsoundclassif_amd import train as T
+    args, a, crit_a, opt_a, batch = _train_setup()
+    _, b, crit_b, opt_b, _ = _train_setup(1)
+    if not T.SPLIT_BACKWARD:
+        pytest.skip('NBM_SPLIT_BACKWARD=0')
+    np.random.seed(3)
+    # b's forward pass is the one in flight; an early RPN backward issued for `a` must not park its gradients under b's maps
+    o = b.forward_first_stage(batch[0][:, None], lazy=True)
+    crit_a._pre_loss = {'first_class_loss': o['rpn_cls_scores'].sum() * 0 + 1.0}
+    with pytest.raises(RuntimeError, match='two models interleaved'):
+        T._early_rpn_backward(a, crit_a)
+    Fn.pass_abandon()
+
+
+def test_a_backward_pass_that_leaves_a_stashed_gradient_raises_by_itself():
+    """every backward pass validates itself (engine callback queued by the node that stashes): a caller that runs its own
+    `backward()` on a sub-graph -- so that the second consumer never runs -- gets a RuntimeError from `backward()`, not a dropped share."""
+    x = rnd('sx', 2, 8, 8, 64).cuda().requires_grad_(True)
+    w1 = rnd('sw1', 64, 64, 1, 1, scale=0.1).cuda().requires_grad_(True)
+    h = Fn.conv(x, w1, None)                     # producer of the shared tensor
+    Fn.stash_reset()
+    Fn.stash_accept(h, True)                     # a second consumer announced itself in the forward pass ...
+    y = Fn.Conv.apply(h, w1, None, None, None, None, 1, 1, 1, 0, Fn.ACT_NONE, 1.0)
+    with pytest.raises(RuntimeError, match='never picked up'):
+        y.sum().backward()                       # ... but only the first consumer's branch is back-propagated
+    assert not Fn._STASH
