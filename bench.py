@@ -350,6 +350,13 @@ def cpu_baseline(n_clips=16, batch=4, threads=32, threads8_clips=8):
     return res
 
 
+def graph_replay_agreed(dist, ok_here):
+    """Multi-rank detect leg: did EVERY rank finish its timed replays?  (MIN over the ranks of a success flag.)"""
+    flag = torch.tensor([1.0 if ok_here else 0.0], device='cuda')
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return float(flag.item()) > 0.0
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -622,9 +629,8 @@ def main(argv=None):
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if float(flag.item()) == 0.0 and gd is not None:
             gd, graph_note = None, 'hipGraph capture failed on another rank; value is the eager loop'
-    try:
-        if gd is None:
-            raise RuntimeError(graph_note)
+    dt_g = None
+    if gd is not None:
         last_copy = [None]
 
         def launch_g():
@@ -645,32 +651,47 @@ def main(argv=None):
             last_copy[0] = done
             return gd.det, gd.n_det, det_h, n_h, done
 
-        for _ in range(a.warmup):
-            finish(launch_g())
+        # Every rank passes BOTH barriers below whatever happens to it in between (a rank-local exception used to leave that rank two
+        # barriers short and its peers waiting for the collective timeout): failures are noted, the barriers are unconditional.
+        ok = True
+        try:
+            for _ in range(a.warmup):
+                finish(launch_g())
+        except Exception as exc:
+            ok, graph_note = False, f'hipGraph replay failed in the warm-up ({type(exc).__name__}: {exc}); value is the eager loop'[:300]
         gc.collect()
         gc.disable()
-        sync_all()
-        t0 = time.perf_counter()
-        n_det_g, pending = 0, None
-        for _ in range(a.steps):
-            cur = launch_g()
-            if pending is not None:
-                out = finish(pending)
-                n_det_g += sum(len(v['bbox_coord']) for d in out for v in d.values())
-            pending = cur
-        out = finish(pending)
-        n_det_g += sum(len(v['bbox_coord']) for d in out for v in d.values())
-        sync_all()
-        dt_g = time.perf_counter() - t0
-        gc.enable()
-        if n_det_g != n_det:
-            raise RuntimeError(f'the replayed steps returned {n_det_g} detections, the eager ones {n_det}')
+        try:
+            sync_all()
+            t0 = time.perf_counter()
+            if ok:
+                try:
+                    n_det_g, pending = 0, None
+                    for _ in range(a.steps):
+                        cur = launch_g()
+                        if pending is not None:
+                            out = finish(pending)
+                            n_det_g += sum(len(v['bbox_coord']) for d in out for v in d.values())
+                        pending = cur
+                    out = finish(pending)
+                    n_det_g += sum(len(v['bbox_coord']) for d in out for v in d.values())
+                    if n_det_g != n_det:
+                        raise RuntimeError(f'the replayed steps returned {n_det_g} detections, the eager ones {n_det}')
+                except Exception as exc:
+                    ok, graph_note = False, f'hipGraph replay failed ({type(exc).__name__}: {exc}); value is the eager loop'[:300]
+            sync_all()
+            if ok:
+                dt_g = time.perf_counter() - t0
+        finally:
+            gc.enable()
+            gd = None                                          # the captured graph owns a private pool: let it go before the other legs
+        # graph and eager times are never mixed in the MAX-reduce: every rank reports its replayed time, or every rank its eager one
+        if dist is not None and not graph_replay_agreed(dist, dt_g is not None):
+            if dt_g is not None:
+                graph_note = 'hipGraph replay failed on another rank; value is the eager loop'
+            dt_g = None
+    if dt_g is not None:
         dt = dt_g
-        del gd
-    except Exception as exc:                                   # the eager figure stays the headline
-        gc.enable()
-        if graph_note is None:
-            graph_note = f'hipGraph replay failed ({type(exc).__name__}: {exc}); value is the eager loop'[:300]
     ops.PROFILE = []                                           # one extra, untimed step with events around every GEMM-type launch
     ops.FLOPS = [0.0]                                          # ... and the executed-MFMA-FLOP counter of every GEMM launch
     step()

@@ -43,8 +43,15 @@ def main(argv=None):
             rest.extend(group)
             continue
         batch = min(args.bulk_batch, -(-len(group) // 8) * 8)
-        bulk.detect_files(model, group, batch=batch, min_score=args.min_score, bird_dict=bird_dict, write_txt=True,
-                          keep_results=False)
+        try:
+            bulk.detect_files(model, group, batch=batch, min_score=args.min_score, bird_dict=bird_dict, write_txt=True,
+                              keep_results=False)
+        except (ValueError, NotImplementedError, OSError) as exc:
+            # a file whose header disagrees with its data, a truncated or changing file, a decode the bulk reader does not do: the
+            # per-file driver (= the reference's behaviour) takes the whole group (it rewrites the txt files the bulk route finished)
+            print(f'bulk route gave up on a group of {len(group)} clips ({type(exc).__name__}: {exc}); they go through the per-file driver')
+            rest.extend(group)
+            continue
         done += len(group)
         print(f'{done} / {len(files)} processed~ (bulk route: {len(group)} clips of {key[1]} samples @ {key[0]} Hz)')
     for wav_path in sorted(rest):

@@ -33,17 +33,27 @@ class SetCriterion(nn.Module):
 
     def _upload(self, name, arr, dev):
         """Small host array -> device through a persistent pinned staging buffer, asynchronously: a pageable `.to(device)` is a
-        stream-ordered blocking copy, i.e. the host would wait for every kernel queued in front of it.  The buffer is reused
-        every step: the step's host sync on the RoI count lies between two uses."""
+        stream-ordered blocking copy, i.e. the host would wait for every kernel queued in front of it.  The staging buffer of a
+        name is reused every step, so every copy out of it is followed by an event, and the host waits for THAT event (the copy
+        of the previous step: long done, the wait returns at once) before it overwrites the buffer -- on the soft-failure paths of a
+        step no other host sync separates two uses."""
         if dev.type != 'cuda':
             return torch.from_numpy(arr).to(dev)
         t = torch.from_numpy(np.ascontiguousarray(arr))
-        buf = self._pinned.get(name)
-        if buf is None or buf.numel() < t.numel() or buf.dtype != t.dtype:
-            buf = self._pinned[name] = torch.empty((max(t.numel(), 8192),), dtype=t.dtype).pin_memory()
+        slot = self._pinned.get(name)
+        if slot is None or slot[0].numel() < t.numel() or slot[0].dtype != t.dtype:
+            if slot is not None and slot[1] is not None:
+                slot[1].synchronize()               # the old buffer's last copy must be out before the buffer is dropped
+            slot = self._pinned[name] = [torch.empty((max(t.numel(), 8192),), dtype=t.dtype).pin_memory(), None]
+        buf, ev = slot
+        if ev is not None:
+            ev.synchronize()
         view = buf[:t.numel()].view(t.shape)
         view.copy_(t)
-        return view.to(dev, non_blocking=True)
+        out = view.to(dev, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record()
+        return out
 
     def precompute_first_stage_loss(self, labels_pred, bbox_reg, gt_bbox, lengths):
         """Positive step: anchor targets (host) AND the first-stage loss kernels, queued behind the first-stage forward while the
