@@ -102,6 +102,7 @@ SIGNATURES = {
     'nbm_tiles_gather': [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P],
     'nbm_tiles_scatter_add': [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P],
     'nbm_proposal_iou': [_P, _P, _P, _I, _I, _I, _P, _P, _P],
+    'nbm_anchor_targets': [_P, _I, _P, _P, _I, _I, _F, _F, _P, _P, _P, _P],
     'nbm_maxpool3x3s2_bwd': [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     'nbm_upsample_bilinear_bwd': [_P, _I, _I, _I, _I, _P, _I, _I, _I, _P],
     'nbm_tiles_upsample_bilinear_bwd_add': [_P, _I, _I, _I, _I, _P, _I, _P, _P, _I, _I, _P],
@@ -123,6 +124,9 @@ SIGNATURES = {
     'nbm_wino23_input_tiles': [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P],
     'nbm_wino23_outgrad_tiles': [_P, _I, _I, _I, _I, _P, _I, _P, _P, _P, _I, _P],
     'nbm_cell_outgrad': [_P, _I, _I, _I, _I, _I, _P, _P, _P],
+    'nbm_cell_weight': [_P, _I, _I, _P, _I, _P, _I, _P],
+    'nbm_cell_weight_fold': [_P, _P, _I, _I, _I, _I, _F, _P, _I, _P, _I, _P],
+    'nbm_cell_weight_grad': [_P, _I, _I, _I, _P, _P],
     'nbm_cell_input': [_P, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     'nbm_cell_input_up': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     'nbm_cell_dgrad_output': [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P],

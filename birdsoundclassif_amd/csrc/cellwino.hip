@@ -330,6 +330,108 @@ __global__ __launch_bounds__(256) void cell_output_kernel(const float* __restric
   }
 }
 
+// ---- kernel side of the cell transforms (was: float64 torch.einsum calls = Tensile GEMMs on the training path).  Float64
+// arithmetic, ONE rounding to fp32 -- the transformed kernels carry every pattern pixel of the forward pass.
+__device__ __forceinline__ void cell_e_w_et(const double g[3][3], double u[NP][NP]) {
+  double t[NP][3];                     // E g
+#pragma unroll
+  for (int a = 0; a < NP; ++a)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) t[a][s] = (double)CE[a][0] * g[0][s] + (double)CE[a][1] * g[1][s] + (double)CE[a][2] * g[2][s];
+#pragma unroll
+  for (int a = 0; a < NP; ++a)
+#pragma unroll
+    for (int b = 0; b < NP; ++b) u[a][b] = (double)CE[b][0] * t[a][0] + (double)CE[b][1] * t[a][1] + (double)CE[b][2] * t[a][2];
+}
+
+// w [N][C][3][3] -> U = E w E^T.  U_nc (optional): [25][N][ld] at column 0 (B operand of the forward plane GEMMs);
+// U_cn (optional): [25][ldt rows >= C][N] rows 0..C-1 (B operand of the data-gradient plane GEMMs).
+__global__ __launch_bounds__(256) void cell_weight_kernel(const float* __restrict__ w, int N, int C, float* __restrict__ U_nc, int ld,
+                                                          float* __restrict__ U_cn, int ldt) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * C) return;
+  const int n = i / C, c = i - n * C;
+  double g[3][3], u[NP][NP];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int s2 = 0; s2 < 3; ++s2) g[r][s2] = (double)w[(long long)i * 9 + r * 3 + s2];
+  cell_e_w_et(g, u);
+#pragma unroll
+  for (int a = 0; a < NP; ++a)
+#pragma unroll
+    for (int b = 0; b < NP; ++b) {
+      const int xi = a * NP + b;
+      if (U_nc) U_nc[((long long)xi * N + n) * ld + c] = (float)u[a][b];
+      if (U_cn) U_cn[((long long)xi * ldt + c) * N + n] = (float)u[a][b];
+    }
+}
+
+// The deferred lateral folded into the consumer's kernels: [alpha U W_lat] with U = E w E^T ([25][N][C]) and W_lat [C][Cin] (row pitch
+// wl_ld) -> columns C .. C + Cin - 1 of U_nc [25][N][ld] and rows C .. C + Cin - 1 of U_cn [25][ldt][N].  Thread = (n, k):
+// P[r][s] = sum_c w[n][c][r][s] W_lat[c][k] in float64 (the transform is linear, so E (sum_c ...) E^T = sum_c (E w E^T) W), then E P E^T.
+__global__ __launch_bounds__(256) void cell_weight_fold_kernel(const float* __restrict__ w, const float* __restrict__ wl, int wl_ld, int N,
+                                                               int C, int Cin, float alpha, float* __restrict__ U_nc, int ld,
+                                                               float* __restrict__ U_cn, int ldt) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * Cin) return;
+  const int n = i / Cin, k = i - n * Cin;
+  double g[3][3], u[NP][NP];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int s2 = 0; s2 < 3; ++s2) g[r][s2] = 0.0;
+  const float* wn = w + (long long)n * C * 9;
+  for (int c = 0; c < C; ++c) {
+    const double l = (double)wl[(long long)c * wl_ld + k];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s2 = 0; s2 < 3; ++s2) g[r][s2] += (double)wn[c * 9 + r * 3 + s2] * l;
+  }
+  cell_e_w_et(g, u);
+#pragma unroll
+  for (int a = 0; a < NP; ++a)
+#pragma unroll
+    for (int b = 0; b < NP; ++b) {
+      const int xi = a * NP + b;
+      const float v = (float)((double)alpha * u[a][b]);
+      if (U_nc) U_nc[((long long)xi * N + n) * ld + C + k] = v;
+      if (U_cn) U_cn[((long long)xi * ldt + C + k) * N + n] = v;
+    }
+}
+
+// dU [25][N][ld] (columns 0..C-1) -> dW [N][C][3][3] = E^T dU E (float64, one rounding): the gradient wrt the checkpoint-layout kernel
+__global__ __launch_bounds__(256) void cell_weight_grad_kernel(const float* __restrict__ dU, int N, int C, int ld, float* __restrict__ dW) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * C) return;
+  const int n = i / C, c = i - n * C;
+  double t[3][NP];                     // t[r][b] = sum_a E[a][r] dU[a][b]
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int b = 0; b < NP; ++b) t[r][b] = 0.0;
+#pragma unroll
+  for (int a = 0; a < NP; ++a)
+#pragma unroll
+    for (int b = 0; b < NP; ++b) {
+      const double v = (double)dU[((long long)(a * NP + b) * N + n) * ld + c];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+        if (CE[a][r] != 0.f) t[r][b] += (double)CE[a][r] * v;
+    }
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int s2 = 0; s2 < 3; ++s2) {
+      double o = 0.0;
+#pragma unroll
+      for (int b = 0; b < NP; ++b)
+        if (CE[b][s2] != 0.f) o += (double)CE[b][s2] * t[r][b];
+      dW[(long long)i * 9 + r * 3 + s2] = (float)o;
+    }
+}
+
 // S >= 3: the 3x3 blocks of different cells are disjoint; the 5x5 patches may overlap (read-only) unless they are written
 inline bool cell_geom(int B, int H, int W, int C, int S, CellGeom& q, int min_S = 3) {
   if (B <= 0 || H < 3 || W < 3 || C <= 0 || (C & 3) || S < min_S) return false;
@@ -396,5 +498,27 @@ extern "C" int nbm_cell_dgrad_output(const float* M, int B, int H, int W, int C,
   if (!nbm_aligned16(M) || !nbm_aligned16(gx)) return NBM_EALIGN;
   hipLaunchKernelGGL(cell_dgrad_output_kernel, dim3(stream_grid(q.T * q.C4, q.C4)), dim3(256), 0, (hipStream_t)stream, M, q, gx,
                      parity_class, ld / 4, c_off / 4, bias_grad);
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_cell_weight(const float* w, int N, int C, float* U_nc, int ld, float* U_cn, int ldt, void* stream) {
+  if (!w || (!U_nc && !U_cn) || N <= 0 || C <= 0 || (U_nc && ld < C) || (U_cn && ldt < C)) return NBM_EINVAL;
+  hipLaunchKernelGGL(cell_weight_kernel, dim3((unsigned)((N * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, N, C, U_nc, ld, U_cn,
+                     ldt);
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_cell_weight_fold(const float* w, const float* w_lat, int wl_ld, int N, int C, int Cin, float alpha, float* U_nc, int ld,
+                                    float* U_cn, int ldt, void* stream) {
+  if (!w || !w_lat || (!U_nc && !U_cn) || N <= 0 || C <= 0 || Cin <= 0 || wl_ld < Cin || (U_nc && ld < C + Cin) || (U_cn && ldt < C + Cin))
+    return NBM_EINVAL;
+  hipLaunchKernelGGL(cell_weight_fold_kernel, dim3((unsigned)((N * Cin + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, w_lat, wl_ld, N,
+                     C, Cin, alpha, U_nc, ld, U_cn, ldt);
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_cell_weight_grad(const float* dU, int N, int C, int ld, float* dW, void* stream) {
+  if (!dU || !dW || N <= 0 || C <= 0 || ld < C) return NBM_EINVAL;
+  hipLaunchKernelGGL(cell_weight_grad_kernel, dim3((unsigned)((N * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dU, N, C, ld, dW);
   return nbm_launch_status();
 }

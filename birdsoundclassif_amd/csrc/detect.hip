@@ -509,6 +509,72 @@ __global__ void proposal_iou_kernel(const float* __restrict__ rois, const float*
   asg[(size_t)b * (R + G) + j] = arg;
 }
 
+// AnchorTargetLayer, arithmetic half (reference layers.py:150-179, nets_utils.py:103-126): IoU of the image's ground-truth boxes with
+// every anchor that lies inside the image, best overlap / first best box per anchor, best overlap per box, and the label each anchor
+// has BEFORE the random subsampling: 0 if best < neg_t, 1 if best >= pos_t or the anchor is a best anchor (ties included) of a box
+// whose best overlap is > 0, else -1.  One workgroup per image; the IoU uses the reference's fp32 operations in its order (no
+// contraction in this file, correctly rounded division), evaluated twice with the same code, so `ov == gmx` means what it means on
+// the host.  A NaN or negative overlap (degenerate box) raises the image's flag: the host then recomputes that image with NumPy.
+constexpr int ANCHOR_MAXG = 256;
+__device__ __forceinline__ float anchor_ov(const float* a, const float* q) {
+  const float area_a = (a[2] - a[0] + 1.f) * (a[3] - a[1] + 1.f);
+  float xi = fminf(a[2], q[2]) - fmaxf(a[0], q[0]) + 1.f;
+  xi = fmaxf(xi, 0.f);
+  float yi = fminf(a[3], q[3]) - fmaxf(a[1], q[1]) + 1.f;
+  yi = fmaxf(yi, 0.f);
+  const float inter = xi * yi;
+  const float area_g = (q[2] - q[0] + 1.f) * (q[3] - q[1] + 1.f);
+  const float den = (area_a + area_g) - inter;
+  return __fdiv_rn(inter, den);
+}
+
+__global__ __launch_bounds__(1024) void anchor_targets_kernel(const float* __restrict__ anchors, int n_in, const float* __restrict__ gt,
+                                                              const int* __restrict__ n_gt, int G, float neg_t, float pos_t,
+                                                              signed char* __restrict__ lab, short* __restrict__ amx,
+                                                              int* __restrict__ flag) {
+  __shared__ float sg[ANCHOR_MAXG * 4];
+  __shared__ int gmx[ANCHOR_MAXG];          // float bits of the best overlap of every box (overlaps are >= +0: integer order == float order)
+  __shared__ int bad;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int ng = min(n_gt[b], G);
+  for (int i = tid; i < ng * 4; i += 1024) sg[i] = gt[(size_t)b * G * 4 + i];
+  for (int i = tid; i < ng; i += 1024) gmx[i] = 0;
+  if (tid == 0) bad = 0;
+  __syncthreads();
+  for (int a = tid; a < n_in; a += 1024) {
+    float an[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) an[e] = anchors[(size_t)a * 4 + e];
+    for (int g = 0; g < ng; ++g) {
+      const float ov = anchor_ov(an, sg + 4 * g);
+      if (!(ov >= 0.f)) bad = 1;             // NaN or negative: benign race, every writer stores 1
+      else if (ov > 0.f) atomicMax(&gmx[g], __float_as_int(ov));
+    }
+  }
+  __syncthreads();
+  for (int a = tid; a < n_in; a += 1024) {
+    float an[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) an[e] = anchors[(size_t)a * 4 + e];
+    float best = 0.f;
+    int arg = 0;
+    bool top = false;
+    for (int g = 0; g < ng; ++g) {
+      const float ov = anchor_ov(an, sg + 4 * g);
+      if (g == 0 || ov > best) { best = ov; arg = g; }       // numpy max / argmax: the first strictly greater value
+      const float gm = __int_as_float(gmx[g]);
+      top = top || (gm > 0.f && ov == gm);
+    }
+    signed char l = -1;
+    if (best < neg_t) l = 0;
+    if (best >= pos_t) l = 1;
+    if (top) l = 1;
+    lab[(size_t)b * n_in + a] = l;
+    amx[(size_t)b * n_in + a] = (short)arg;
+  }
+  if (tid == 0) flag[b] = bad;
+}
+
 }  // namespace
 
 extern "C" int nbm_rpn_decode(const float* cls, const float* reg, const float* anchors, int B, int KA,
@@ -613,5 +679,15 @@ extern "C" int nbm_proposal_iou(const float* rois, const float* gt, const int* n
   if (!rois || !gt || !n_gt || !mx || !asg || B <= 0 || R < 0 || G <= 0 || B > 65535) return NBM_EINVAL;
   hipLaunchKernelGGL(proposal_iou_kernel, dim3((R + G + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, rois, gt, n_gt, B, R, G,
                      mx, asg);
+  return nbm_launch_status();
+}
+
+// AnchorTargetLayer: labels before subsampling + first best box of every inside anchor -- see nbm_hip.h.
+extern "C" int nbm_anchor_targets(const float* anchors, int n_in, const float* gt, const int* n_gt, int B, int G, float neg_t,
+                                  float pos_t, signed char* lab, short* amx, int* flag, void* stream) {
+  if (!anchors || !gt || !n_gt || !lab || !amx || !flag || n_in <= 0 || B <= 0 || G <= 0) return NBM_EINVAL;
+  if (G > ANCHOR_MAXG) return NBM_EUNSUPPORTED;
+  hipLaunchKernelGGL(anchor_targets_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, anchors, n_in, gt, n_gt, G, neg_t, pos_t, lab,
+                     amx, flag);
   return nbm_launch_status();
 }

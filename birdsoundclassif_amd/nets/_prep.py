@@ -75,51 +75,32 @@ def wino23_weight_grad(dU, m=2, row_scale=None):
     return ops.wino_weight_grad(dU, m, row_scale)
 
 
-_CELL_E = [[1.0, 0.0, 0.0], [1.0, 1.0, 1.0], [1.0, -1.0, 1.0], [1.0, 2.0, 4.0], [1.0, -2.0, 4.0]]     # csrc/cellwino.hip: points 0, 1, -1, 2, -2
-
-
-_CELL_E_DEV = {}
-
-
-def _cell_e(device):
-    """Uploaded once per device: a per-call torch.tensor(..., device=cuda) is a pageable H2D copy = a stream sync in the middle of
-    a step (the host loses its run-ahead: 125 ms per training step when this sat in the forward pass)."""
-    key = str(device)
-    if key not in _CELL_E_DEV:
-        _CELL_E_DEV[key] = torch.tensor(_CELL_E, dtype=torch.float64, device=device)
-    return _CELL_E_DEV[key]
-
-
 def cell_weight(weight, forward=False):
-    """Kernel side of the cell transforms (csrc/cellwino.hip): [Cout, Cin, 3, 3] -> U [25][Cin][Cout] = (E w E^T)[a][b] -- the B
-    operand of the 25 data-gradient GEMMs M_xi = Vg_xi U_xi^T; `forward`: [25][Cout][Cin], the B operand of the forward GEMMs
-    M_xi = Vx_xi U_xi^T.  float64 on the device, rounded once; cached per weight version."""
-    def make():
-        E = _cell_e(weight.device)
-        u = torch.einsum('ar,bs,ncrs->abnc' if forward else 'ar,bs,ncrs->abcn', E, E, weight.detach().double())
-        return u.reshape(25, *u.shape[2:]).float().contiguous()
-    return _cached(weight, ('cell', forward), make)
+    """Kernel side of the cell transforms (csrc/cellwino.hip, `nbm_cell_weight`): [Cout, Cin, 3, 3] -> U [25][Cin][Cout] =
+    (E w E^T)[a][b] -- the B operand of the 25 data-gradient GEMMs M_xi = Vg_xi U_xi^T; `forward`: [25][Cout][Cin], the B operand of
+    the forward GEMMs M_xi = Vx_xi U_xi^T.  float64 on the device, rounded once; cached per weight version."""
+    from .. import ops
+    return _cached(weight, ('cell', forward), lambda: ops.cell_weight(weight.detach().contiguous(), forward=forward))
 
 
-def cell_weight_folded(w_out, wk_lat, alpha):
+def cell_weight_folded(w_out, wk_lat, alpha, transposed=False):
     """B operand of the cell-domain plane GEMMs of a demand-driven 3x3 convolution whose lateral was deferred
     (ondemand.conv1x1_lazy(defer=True)): [25][N][C + Cin] = [ U | alpha * U W_lat ] with U = E w_out E^T ([25][N][C]) and
-    W_lat = wk_lat[:, :Cin] the lateral's KRSC weights [C][Cin] -- the merged map x = alpha * W_lat t + b + up(x1) never exists
-    on the pattern patches: its transform is [transform(up(x1) + b) | transform(t)]."""
-    def make():
-        E = _cell_e(w_out.device)
-        u = torch.einsum('ar,bs,ncrs->abnc', E, E, w_out.detach().double())                  # [5,5,N,C]
-        wl = wk_lat.detach().double()                                                         # [C, Cin (+ padding)]
-        uf = torch.cat([u, float(alpha) * torch.einsum('abnc,ck->abnk', u, wl)], dim=-1)
-        return uf.reshape(25, uf.shape[2], uf.shape[3]).float().contiguous()
-    return _cached(w_out, ('cellfold', float(alpha)), make, extra=(wk_lat.data_ptr(), wk_lat._version, tuple(wk_lat.shape)))
+    W_lat = wk_lat the lateral's KRSC weights [C][Cin] -- the merged map x = alpha * W_lat t + b + up(x1) never exists
+    on the pattern patches: its transform is [transform(up(x1) + b) | transform(t)].  `transposed`: the same values as
+    [25][C + Cin][N], the B operand of the data-gradient GEMMs (rows C.. give d/dt in the transform domain).  Both layouts come out
+    of one pair of launches (`nbm_cell_weight` + `nbm_cell_weight_fold`) and share the cache entry."""
+    from .. import ops
+    pair = _cached(w_out, ('cellfold', float(alpha)),
+                   lambda: ops.cell_weight(w_out.detach().contiguous(), lateral=wk_lat.detach(), alpha=alpha, both=True),
+                   extra=(wk_lat.data_ptr(), wk_lat._version, tuple(wk_lat.shape)))
+    return pair[1] if transposed else pair[0]
 
 
 def cell_weight_grad(dU):
-    """dU [25][N][C] (gradient wrt the transformed kernel) -> dW [N, C, 3, 3] = E^T dU E."""
-    E = _cell_e(dU.device)
-    N, C_ = dU.shape[1:]
-    return torch.einsum('at,bs,abnc->ncts', E, E, dU.double().view(5, 5, N, C_)).float()
+    """dU [25][N][C] (gradient wrt the transformed kernel) -> dW [N, C, 3, 3] = E^T dU E (`nbm_cell_weight_grad`)."""
+    from .. import ops
+    return ops.cell_weight_grad(dU)
 
 
 def stem_fold(w1, w_init, b_init):

@@ -62,11 +62,56 @@ class SetCriterion(nn.Module):
         the result."""
         self._pre_loss = self.first_stage_loss(labels_pred, bbox_reg, gt_bbox, lengths, False)
 
+    @torch.no_grad()
+    def start_anchor_targets(self, gt_bbox, lengths, device):
+        """Top of a positive step (train.step), BEFORE the forward pass is queued: the arithmetic half of the AnchorTargetLayer -- IoU
+        of every inside anchor with the image's boxes, best box, thresholds, best-anchor ties (nbm_anchor_targets) -- on a side stream
+        of its own, results on their way to pinned host memory.  It depends on the labels only, so it neither waits for the queued
+        GPU work of the previous step nor delays this one; `first_stage_loss` hands the result to the layer, which then only draws."""
+        from .. import ops
+        self._pre_anchor = None
+        device = torch.device(device)
+        if device.type != 'cuda' or not len(lengths) or min(lengths) < 1 or max(lengths) > 256:
+            return
+        layer = self.anchor_target_layer
+        gt_c = np.ascontiguousarray(gt_bbox.detach().float().cpu().numpy(), dtype=np.float32)
+        B, G = len(lengths), max(lengths)
+        gt_pad = np.full((B, G, 4), -1, dtype=np.float32)
+        lens = np.asarray(lengths)
+        gt_pad[np.arange(G)[None, :] < lens[:, None]] = gt_c
+        side = self.__dict__.get('_side_stream')
+        if side is None:
+            side = self.__dict__['_side_stream'] = torch.cuda.Stream(device=device, priority=-1)
+        anc = self.__dict__.get('_anchors_dev')
+        if anc is None or anc.device != device:
+            anc = self.__dict__['_anchors_dev'] = layer.anchors.to(device).contiguous()
+            torch.cuda.current_stream(device).synchronize()           # once: the constant is there before the side stream reads it
+        with torch.cuda.stream(side):
+            lab, amx, flag = ops.anchor_targets(anc, self._upload('agt_pad', gt_pad, device), self._upload('an_gt', lens.astype(np.int32), device),
+                                                self.config.rpn_neg_label, self.config.rpn_pos_label)
+            host = []
+            for name, t in (('alab', lab), ('aamx', amx), ('aflag', flag)):
+                buf = self._pinned.get('d2h_' + name)
+                if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+                    buf = self._pinned['d2h_' + name] = torch.empty(t.shape, dtype=t.dtype).pin_memory()
+                buf.copy_(t, non_blocking=True)
+                host.append(buf)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self._pre_anchor = (host, ev, (lab, amx, flag), [int(v) for v in lengths])       # the device tensors stay alive until consumed
+
+    def _take_anchor_pre(self, lengths):
+        pre, self._pre_anchor = getattr(self, '_pre_anchor', None), None
+        if pre is None or pre[3] != [int(v) for v in lengths]:
+            return None
+        pre[1].synchronize()                     # a few hundred microseconds of GPU work queued before the forward pass: long done
+        return tuple(t.numpy() for t in pre[0])
+
     def precompute_first_stage_targets(self, gt_bbox, lengths):
         """Run the AnchorTargetLayer (host, NumPy RNG) ahead of the forward pass so that it overlaps with the GPU work
         still queued from the previous step; `first_stage_loss` consumes the result.  Same RNG call order as computing
         it inside the loss (anchor targets are always drawn before proposal targets)."""
-        self._pre = self.anchor_target_layer(gt_bbox, lengths, device='cpu')
+        self._pre = self.anchor_target_layer(gt_bbox, lengths, device='cpu', pre=self._take_anchor_pre(lengths))
 
     def first_stage_loss(self, labels_pred, bbox_reg, gt_bbox=None, lengths=None, neg_sample=False):
         """labels_pred [B,2A',h,w] softmaxed, bbox_reg [B,4A',h,w] (reference nbm_model.py:102-164)."""
@@ -87,7 +132,8 @@ class SetCriterion(nn.Module):
         if self._pre is not None:
             (labels, reg_targets), self._pre = self._pre, None
         else:
-            labels, reg_targets = self.anchor_target_layer(gt_bbox, lengths, device='cpu')   # host (NumPy RNG)
+            labels, reg_targets = self.anchor_target_layer(gt_bbox, lengths, device='cpu',      # host (NumPy RNG draws); the IoU half
+                                                           pre=self._take_anchor_pre(lengths))  # may come from the device
         lab_np = labels.permute(0, 2, 3, 1).reshape(-1).numpy()
         keep_np = np.nonzero(lab_np != -1)[0]
         lab_k = lab_np[keep_np]

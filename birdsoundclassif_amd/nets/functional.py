@@ -237,7 +237,7 @@ class Conv(Function):
             # zero wherever nothing was read)
             y, ctx.lazy = ondemand.conv3x3_winograd_lazy(x, _prep.wino23(weight), sh, lazy_stride[0],
                                                          _prep.cell_weight(weight, forward=True) if ondemand.CELL_FWD else None,
-                                                         fold=lambda wk, alpha: _prep.cell_weight_folded(weight, wk, alpha),
+                                                         fold=lambda wk, alpha, transposed=False: _prep.cell_weight_folded(weight, wk, alpha, transposed),
                                                          keep=lazy_stride[1])
         elif lazy_stride and kh == 1:
             # the lateral 1x1 (+ top-down merge) in front of a demand-driven 3x3: only the pixels that convolution reads

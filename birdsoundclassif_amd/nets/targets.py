@@ -67,29 +67,42 @@ class AnchorTargetLayer(nn.Module):
         self.anchors = torch.from_numpy(self.anchors_np)
         self.all_anchors = allanc
 
-    def forward(self, gt_bbox, lengths, device=None):
-        """-> (labels [B,A,h,w] int64 in {-1,0,1}, reg_targets [B,4A,h,w] f32) on `device`."""
+    def _host_labels(self, o, cfg):
+        """Labels of one image's inside anchors BEFORE the subsampling + first best box, from its IoU block o [n_in, n] (the
+        reference's own arithmetic, layers.py:162-179)."""
+        neg_t, pos_t = _F(cfg.rpn_neg_label), _F(cfg.rpn_pos_label)
+        mx, amx = o.max(axis=1), o.argmax(axis=1)
+        gmx = o.max(axis=0)
+        lb = np.full((o.shape[0],), -1, dtype=np.int64)
+        lb[mx < neg_t] = 0
+        lb[mx >= pos_t] = 1
+        if gmx.max() > 0:                                         # every GT keeps its best anchor(s), ties included
+            pos = np.nonzero(gmx > 0)[0]
+            lb[np.nonzero(o[:, pos] == gmx[pos])[0]] = 1
+        return lb, amx
+
+    def forward(self, gt_bbox, lengths, device=None, pre=None):
+        """-> (labels [B,A,h,w] int64 in {-1,0,1}, reg_targets [B,4A,h,w] f32) on `device`.
+        `pre` (optional, from `SetCriterion.start_anchor_targets`): (lab int8 [B,n_in], amx int16 [B,n_in], flag int32 [B]) host
+        arrays -- the IoU / arg-max / threshold half already done on the device (nbm_anchor_targets); the draws stay here, in the
+        reference's order (fg then bg, image by image)."""
         cfg = self.config
         device = gt_bbox.device if device is None else device
         gt = _f32(gt_bbox)
         B, n_in = len(lengths), len(self.inds_inside)
         h, w = cfg.top_size
-        ov = box_iou_incl(self.anchors_np, gt)                       # [n_in, sum N]
-        labels = np.full((B, n_in), -1, dtype=np.int64)
-        matched = np.zeros((B, n_in, 4), dtype=_F)                   # GT box assigned to every anchor
         idx = np.cumsum([0] + list(lengths))
-        neg_t, pos_t = _F(cfg.rpn_neg_label), _F(cfg.rpn_pos_label)
+        if pre is not None and (pre[0].shape != (B, n_in) or len(pre[2]) != B):
+            pre = None
+        ov = box_iou_incl(self.anchors_np, gt) if pre is None else None      # [n_in, sum N]
+        labels = np.full((B, n_in), -1, dtype=np.int64)
+        amx_all = np.zeros((B, n_in), dtype=np.int64)
+        num_fg = int(cfg.rpn_fg_fraction * cfg.rpn_batchsize)
         for b, (i0, i1) in enumerate(zip(idx[:-1], idx[1:])):
-            o = ov[:, i0:i1]
-            mx, amx = o.max(axis=1), o.argmax(axis=1)
-            gmx = o.max(axis=0)
-            lb = labels[b]
-            lb[mx < neg_t] = 0
-            lb[mx >= pos_t] = 1
-            if gmx.max() > 0:                                         # every GT keeps its best anchor(s), ties included
-                pos = np.nonzero(gmx > 0)[0]
-                lb[np.nonzero(o[:, pos] == gmx[pos])[0]] = 1
-            num_fg = int(cfg.rpn_fg_fraction * cfg.rpn_batchsize)
+            if pre is not None and not pre[2][b]:
+                lb, amx = pre[0][b].astype(np.int64), pre[1][b]
+            else:                                                     # host arithmetic (no device results, or a degenerate box: NaN)
+                lb, amx = self._host_labels(ov[:, i0:i1] if ov is not None else box_iou_incl(self.anchors_np, gt[i0:i1]), cfg)
             fg = np.nonzero(lb == 1)[0]
             if len(fg) > num_fg:
                 lb[np.random.choice(fg, len(fg) - num_fg, replace=False)] = -1
@@ -97,14 +110,24 @@ class AnchorTargetLayer(nn.Module):
             bg = np.nonzero(lb == 0)[0]
             if len(bg) > num_bg:
                 lb[np.random.choice(bg, len(bg) - num_bg, replace=False)] = -1
-            matched[b] = gt[i0:i1][amx]
-        # one vectorised encode for the whole batch (a per-image torch.log would wake the whole CPU thread pool B times)
-        tgt = box_encode(np.tile(self.anchors_np, (B, 1)), matched.reshape(-1, 4)).reshape(B, n_in, 4)
-        tgt = np.maximum(labels, 0)[..., None].astype(_F) * tgt
+            labels[b] = lb
+            amx_all[b] = amx + i0                                     # row of `gt` assigned to every anchor
         all_l = np.full((B, len(self.all_anchors)), -1, dtype=np.int64)
         all_l[:, self.inds_inside] = labels
         all_t = np.zeros((B, len(self.all_anchors), 4), dtype=_F)
-        all_t[:, self.inds_inside] = tgt
+        gw, gh = gt[:, 2] - gt[:, 0] + _F(1), gt[:, 3] - gt[:, 1] + _F(1)
+        if len(gt) and bool((gw > 0).all() and (gh > 0).all()):
+            # targets are label-masked (`max(label, 0) * target`): with proper boxes every target is finite, so only the <= 8
+            # foreground anchors of an image carry a value -- encode those rows alone (the batch-wide encode of 15 089 x B rows was a
+            # third of this layer's host time)
+            bb, aa = np.nonzero(labels == 1)
+            if len(bb):
+                all_t[bb, self.inds_inside[aa]] = box_encode(self.anchors_np[aa], gt[amx_all[bb, aa]])
+        else:
+            # a degenerate box: 0 * inf = NaN must come out exactly where the reference produces it -- the full encode
+            matched = gt[amx_all.reshape(-1)].reshape(B, n_in, 4)
+            tgt = box_encode(np.tile(self.anchors_np, (B, 1)), matched.reshape(-1, 4)).reshape(B, n_in, 4)
+            all_t[:, self.inds_inside] = np.maximum(labels, 0)[..., None].astype(_F) * tgt
         return (torch.from_numpy(all_l).view(B, h, w, self.A).permute(0, 3, 1, 2).to(device),
                 torch.from_numpy(all_t).view(B, h, w, self.A * 4).permute(0, 3, 1, 2).to(device))
 

@@ -233,11 +233,12 @@ class LateralState:
     3x3 convolution, reads it; `conv3x3_winograd_lazy` picks the state up and `lazy_complete` finishes the pixels under the RoI
     tiles before it convolves them.  `deferred`: not even the pattern patches were computed -- the consumer takes the lateral's
     OPERANDS into its cell-domain GEMMs instead (`conv3x3_winograd_lazy`, Ufold)."""
-    __slots__ = ('t', 'wk', 'bias', 'alpha', 'up', 'deferred', 'stride', 'ufold', 'grads')
+    __slots__ = ('t', 'wk', 'bias', 'alpha', 'up', 'deferred', 'stride', 'ufold', 'ufold_t', 'grads')
 
     def __init__(self, t, wk, bias, alpha, up, deferred=False, stride=0):
         self.t, self.wk, self.bias, self.alpha, self.up, self.deferred, self.stride = t, wk, bias, alpha, up, deferred, stride
         self.ufold = None            # [25][N][C + Cin] of the consumer's forward pass (deferred lateral): kept for the backward pass
+        self.ufold_t = None          # ... and the same values as [25][C + Cin][N] (B operand of the data-gradient GEMMs)
         self.grads = None            # the lateral's own gradients, when the consumer's backward pass produced them (LAT_CELL_BWD)
 
 
@@ -365,6 +366,7 @@ def conv3x3_winograd_lazy(x, U, bias, stride, Ucell=None, fold=None, keep=False)
     Ufold = fold(st.lateral.wk, st.lateral.alpha) if st.lateral is not None and st.lateral.deferred else None
     if Ufold is not None and st.keep:
         st.lateral.ufold = Ufold
+        st.lateral.ufold_t = fold(st.lateral.wk, st.lateral.alpha, transposed=True)      # same cache entry, [25][C + Cin][N]
     img_bytes = H * W * N * 4
     chunk = lazy_chunk(x)
     for ci, b0 in enumerate(range(0, B, chunk)):
@@ -638,8 +640,8 @@ def conv3x3_winograd_dgrad_tiles(st, g, Ut, Ucell=None, base=None, lateral_grads
     if do_lat:
         Cin = lt.t.shape[-1]
         K = C_ + Cin
-        Ud = lt.ufold[:, :, :K].transpose(1, 2).contiguous()              # [25][C + Cin][N]: rows C.. = alpha W^T U, d/dt in the transform domain
-        Wl = (float(lt.alpha) * lt.wk[:, :Cin]).contiguous()              # [C][Cin]
+        Ud = lt.ufold_t                                                   # [25][C + Cin][N]: rows C.. = alpha W^T U, d/dt in the transform domain
+        assert Ud is not None and tuple(Ud.shape) == (25, K, N)
         dt = dt_pool = None
         if ZERO_POOL:
             dt, dt_pool = zero_acquire((B, H, W, Cin), g.device, ('lat-dt', st.stride))
@@ -699,10 +701,12 @@ def conv3x3_winograd_dgrad_tiles(st, g, Ut, Ucell=None, base=None, lateral_grads
                         check(lib().nbm_tiles_scatter_add(gx_p, nb, H, W, C_, _ptr(tl), n, None, _ptr(Gc), _stream()), 'nbm_tiles_scatter_add')
                     tc = torch.zeros((n * 4, Cin), device=g.device, dtype=torch.float32)
                     check(lib().nbm_tiles_gather(_ptr(lt.t[b0:b0 + nb]), nb, H, W, Cin, _ptr(tl), n, None, _ptr(tc), _stream()), 'nbm_tiles_gather')
-                    dtc = torch.matmul(Gc, Wl)
+                    # the lateral's three gradients on the compact rows, through the library's own NN / TN GEMMs (was: torch.matmul /
+                    # addmm_ / sum = vendor GEMMs on the training path): d/dt = alpha Gc W_lat, dW_lat += alpha Gc^T t, db += colsum(Gc)
+                    dtc = torch.empty((n * 4, Cin), device=g.device, dtype=torch.float32)
+                    ops.conv_dgrad(Gc, lt.wk, dtc, B=1, H=n * 4, W=1, Cin=Cin, N=C_, g_ld=C_, w_ld=lt.wk.shape[1], alpha=float(lt.alpha))
                     check(lib().nbm_tiles_scatter_add(dt_p, nb, H, W, Cin, _ptr(tl), n, None, _ptr(dtc), _stream()), 'nbm_tiles_scatter_add')
-                    gw_roi.addmm_(Gc.t(), tc, alpha=float(lt.alpha))
-                    gb_lat += Gc.sum(0)
+                    conv_wgrad(Gc, tc, gw_roi, B=1, H=n * 4, W=1, Cin=Cin, N=C_, alpha=float(lt.alpha), bias_grad=gb_lat)
                     for pl, (p_, c_) in ((None if split else pool, (gx_p, C_)), (dt_pool, (dt_p, Cin))):
                         if pl is not None:
                             zero_note(pl, lambda p_=p_, c_=c_, nb_=nb, tl_=tl, n_=n: check(
@@ -828,7 +832,16 @@ def conv3x3_winograd_wgrad_tiles(st, x, g, want_bias=False, cell=None):
         st.vg = st.cell_gb = st.cell_gb_done = None
         if dUc.shape[2] != C_:          # deferred lateral: d/dU = d/d(first block) + alpha * d/d(second block) W^T  (second block = alpha U W)
             lt = st.lateral
+            K, Cin = dUc.shape[2], dUc.shape[2] - C_
+            d2 = dUc[:, :, C_:]                                           # [25][N][Cin] view, row pitch K
             if lt.grads is not None and lt.ufold is not None:        # ... and d/dW_lat = alpha * sum_xi U_xi^T d/d(second block)_xi
-                lt.grads['gw_cell'] = float(lt.alpha) * torch.einsum('knc,kni->ci', lt.ufold[:, :, :C_], dUc[:, :, C_:])
-            dUc = (dUc[:, :, :C_] + float(lt.alpha) * torch.matmul(dUc[:, :, C_:], lt.wk[:, :dUc.shape[2] - C_].t())).contiguous()
+                # one TN GEMM over the 25 N rows: out [C][Cin] = alpha * U2d^T d2 (was: torch.einsum -> vendor GEMM)
+                gwc = torch.zeros((C_, Cin), device=x.device, dtype=torch.float32)
+                conv_wgrad(lt.ufold, d2, gwc, B=1, H=25 * N, W=1, Cin=Cin, N=C_, g_ld=K, x_ld=K, alpha=float(lt.alpha))
+                lt.grads['gw_cell'] = gwc
+            # dU = d/d(first block) + alpha * d/d(second block) W_lat^T: an NT GEMM with the first block as its residual
+            dU1 = torch.empty((25, N, C_), device=x.device, dtype=torch.float32)
+            gemm_conv(d2, lt.wk, dU1, B=1, H=25 * N, W=1, Cin=Cin, N=C_, x_ld=K, w_ld=lt.wk.shape[1], residual=dUc, res_ld=K,
+                      alpha=float(lt.alpha))
+            dUc = dU1
     return dU, gb, dUc

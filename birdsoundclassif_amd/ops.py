@@ -249,6 +249,37 @@ def wino_weight_grad(dU, m=2, row_scale=None):
     return dW
 
 
+def cell_weight(weight, forward=True, lateral=None, alpha=1.0, both=False):
+    """Kernel side of the cell transforms (csrc/cellwino.hip, float64 on the device, one rounding): [N,C,3,3] -> U = E w E^T as
+    [25][N][K] (`forward`: B operand of the forward plane GEMMs) or [25][K][N] (data-gradient GEMMs); `both`: (forward, transposed).
+    `lateral` = KRSC weights [C][Cin] of a deferred lateral 1x1: K = C + Cin, the extra columns / rows hold alpha * U W_lat."""
+    _chk(weight, name='weight')
+    N, C_ = weight.shape[:2]
+    assert tuple(weight.shape[2:]) == (3, 3)
+    Cin = 0
+    if lateral is not None:
+        _chk(lateral, name='lateral')
+        assert lateral.shape[0] == C_
+        Cin = lateral.shape[1]
+    K = C_ + Cin
+    Unc = torch.empty((25, N, K), device=weight.device, dtype=torch.float32) if (forward or both) else None
+    Ucn = torch.empty((25, K, N), device=weight.device, dtype=torch.float32) if (not forward or both) else None
+    check(lib().nbm_cell_weight(_ptr(weight), N, C_, _ptr(Unc), K, _ptr(Ucn), K, _stream()), 'nbm_cell_weight')
+    if lateral is not None:
+        check(lib().nbm_cell_weight_fold(_ptr(weight), _ptr(lateral), lateral.stride(0), N, C_, Cin, float(alpha), _ptr(Unc), K,
+                                         _ptr(Ucn), K, _stream()), 'nbm_cell_weight_fold')
+    return (Unc, Ucn) if both else (Unc if forward else Ucn)
+
+
+def cell_weight_grad(dU):
+    """dU [25, N, K >= C] (columns beyond C ignored when `dU` is a [..., :C] view) -> dW [N, C, 3, 3] = E^T dU E."""
+    assert dU.dim() == 3 and dU.shape[0] == 25 and dU.stride(2) == 1 and dU.stride(0) == dU.shape[1] * dU.stride(1)
+    _, N, C_ = dU.shape
+    dW = torch.empty((N, C_, 3, 3), device=dU.device, dtype=torch.float32)
+    check(lib().nbm_cell_weight_grad(_ptr(dU), N, C_, dU.stride(1), _ptr(dW), _stream()), 'nbm_cell_weight_grad')
+    return dW
+
+
 def conv3x3_winograd_wgrad(x, g, want_bias=False, m=2):
     """Weight gradient of a 3x3 / s1 / p1 convolution in the Winograd domain: x [B,H,W,C] (forward input), g [B,H,W,N]
     (gradient wrt the output) -> (dU [(m+2)^2,N,C] with dU[xi] = dM[xi]^T V[xi], bias gradient [N] or None).  The caller
@@ -522,6 +553,23 @@ def proposal_iou(rois, gt, n_gt):
     asg = torch.empty((B, R + G), device=rois.device, dtype=torch.int32)
     check(lib().nbm_proposal_iou(_ptr(rois), _ptr(gt), _ptr(n_gt), B, R, G, _ptr(mx), _ptr(asg), _stream()), 'nbm_proposal_iou')
     return mx, asg
+
+
+def anchor_targets(anchors, gt, n_gt, neg_t, pos_t):
+    """anchors [n_in,4] (inside the image), gt [B,G,4] (padded), n_gt int32 [B] -> (lab int8 [B,n_in]: the label of every anchor
+    before the random subsampling, amx int16 [B,n_in]: first best box, flag int32 [B]: recompute on the host): reference
+    layers.py:150-179."""
+    _chk(anchors, name='anchors'), _chk(gt, name='gt')
+    B, G = gt.shape[:2]
+    n_in = anchors.shape[0]
+    if n_gt.dtype != torch.int32 or n_gt.numel() != B:
+        raise ValueError('anchor_targets: n_gt must be int32 [B]')
+    lab = torch.empty((B, n_in), device=gt.device, dtype=torch.int8)
+    amx = torch.empty((B, n_in), device=gt.device, dtype=torch.int16)
+    flag = torch.empty((B,), device=gt.device, dtype=torch.int32)
+    check(lib().nbm_anchor_targets(_ptr(anchors), n_in, _ptr(gt), _ptr(n_gt), B, G, float(neg_t), float(pos_t), _ptr(lab), _ptr(amx),
+                                   _ptr(flag), _stream()), 'nbm_anchor_targets')
+    return lab, amx, flag
 
 
 def per_image_counts(n, B):

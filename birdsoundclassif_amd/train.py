@@ -228,6 +228,10 @@ def build_optimizer(model, args):
 SPLIT_BACKWARD = os.environ.get('NBM_SPLIT_BACKWARD', '1') != '0'
 
 
+# The IoU / arg-max / threshold half of the AnchorTargetLayer on the device (nbm_anchor_targets); the NumPy draws stay on the host.
+ANCHOR_TARGETS_ON_DEVICE = os.environ.get('NBM_ANCHOR_DEVICE', '1') != '0'
+
+
 def step(model, criterion, batch, device, negative_sample, early_backward=False):
     """One forward + loss evaluation (reference train.py:220-257).  `early_backward` (train_one_step): see SPLIT_BACKWARD."""
     img, neg_img, bb_coord, bird_ids, lengths = batch
@@ -239,6 +243,8 @@ def step(model, criterion, batch, device, negative_sample, early_backward=False)
     loss = {}
     inpt = (neg_img if negative_sample else img)[:, None]
     host_work = None
+    if not negative_sample and hasattr(criterion, 'start_anchor_targets') and ANCHOR_TARGETS_ON_DEVICE:
+        criterion.start_anchor_targets(bb_coord, lengths, inpt.device)       # labels only: queued on a side stream before the forward pass
     if not negative_sample and hasattr(criterion, 'precompute_first_stage_loss'):
         # AnchorTargetLayer (host, NumPy RNG) runs while the GPU executes the first-stage forward queued before it, and the
         # first-stage loss kernels are queued behind that forward pass before the host waits for the RoI count

@@ -180,6 +180,18 @@ int nbm_wino23_outgrad_tiles(const float* g, int B, int H, int W, int N, const i
  *                          overlapping patches of a stride-3 / 4 pattern)
  * the weight gradient's 25 TN GEMMs dU_xi = Vg_xi^T Vx_xi are nbm_conv_wgrad with groups = 25; dW = E^T dU E on the host. */
 int nbm_cell_outgrad(const float* g, int B, int H, int W, int N, int stride, float* Vg, float* bias_grad, void* stream);
+/* Kernel side of the same algorithm (float64 arithmetic on the device, one rounding; replaces the reference-side autograd of
+ * fpn.py:137,145's weights through torch.einsum):
+ *   nbm_cell_weight       w [N][C][3][3] (checkpoint layout) -> U = E w E^T as U_nc [25][N][ld] (columns 0..C-1: B operand of the
+ *                         FORWARD plane GEMMs) and / or U_cn [25][ldt][N] (rows 0..C-1: B operand of the data-gradient GEMMs); either
+ *                         pointer may be NULL
+ *   nbm_cell_weight_fold  the deferred lateral (fpn.py:143-144: x = alpha W_lat t + b + up(x1)) folded into those operands:
+ *                         alpha U W_lat, W_lat [C][Cin] with row pitch wl_ld, -> columns C..C+Cin-1 of U_nc / rows C..C+Cin-1 of U_cn
+ *   nbm_cell_weight_grad  dU [25][N][ld] (columns 0..C-1) -> dW [N][C][3][3] = E^T dU E */
+int nbm_cell_weight(const float* w, int N, int C, float* U_nc, int ld, float* U_cn, int ldt, void* stream);
+int nbm_cell_weight_fold(const float* w, const float* w_lat, int wl_ld, int N, int C, int Cin, float alpha, float* U_nc, int ld,
+                         float* U_cn, int ldt, void* stream);
+int nbm_cell_weight_grad(const float* dU, int N, int C, int ld, float* dW, void* stream);
 int nbm_cell_input(const float* x, int B, int H, int W, int C, int stride, float* Vx, int ld /* row pitch of Vx, >= c_off + C */,
                    int c_off /* channel offset written */, void* stream);
 /* the same transform of patches that are not in memory: pixel = bilinear_align_corners(x1 [B][Hc][Wc][C])[pixel] + bias[C] (the
@@ -359,10 +371,18 @@ int nbm_rcnn_post(const float* rois, const int* n_roi, int B, int roi_cap, const
                   float nms_thresh, float min_score, int proposal_number, float* det, int* n_det,
                   int per_image /* n_roi[b] */, void* stream);
 
-/* Training, ProposalTargetLayer (layers.py:320-330, nets_utils.py:103-126): rows j < R = proposals rois[b][j], rows R + i = the
+/* Training, AnchorTargetLayer (layers.py:150-179, nets_utils.py:103-126): IoU (inclusive-pixel convention, the reference's fp32
+ * operations in its order) of every anchor inside the image with the n_gt[b] boxes of gt[b]; amx[b][a] = index of the FIRST best box,
+ * lab[b][a] = the anchor's label BEFORE the random subsampling (0: best overlap < neg_t; 1: best overlap >= pos_t, or the anchor is a
+ * best anchor -- ties included -- of a box whose best overlap is > 0; else -1); flag[b] != 0: a NaN / negative overlap occurred
+ * (degenerate box), the caller recomputes that image on the host.  The NumPy RNG draws stay on the host (layers.py:183-197).
+ * nbm_proposal_iou below: ProposalTargetLayer (layers.py:320-330, nets_utils.py:103-126): rows j < R = proposals rois[b][j], rows R + i = the
  * image's own ground-truth boxes gt[b][i] (the reference appends them to the proposals); for every row the IoU (inclusive-pixel
  * convention, the reference's fp32 operations in its order) with the n_gt[b] <= G boxes of gt[b]: mx[b][j] = best overlap,
  * asg[b][j] = index of the FIRST best box.  The thresholds and the NumPy RNG draws stay on the host (layers.py:332-376). */
+int nbm_anchor_targets(const float* anchors /*[n_in][4]: the anchors inside the image*/, int n_in, const float* gt /*[B][G][4]*/,
+                       const int* n_gt /*[B]*/, int B, int G /* <= 256 */, float neg_t, float pos_t, signed char* lab /*[B][n_in]*/,
+                       short* amx /*[B][n_in]*/, int* flag /*[B]*/, void* stream);
 int nbm_proposal_iou(const float* rois /*[B][R][4]*/, const float* gt /*[B][G][4]*/, const int* n_gt /*[B]*/, int B, int R, int G,
                      float* mx /*[B][R+G]*/, int* asg /*[B][R+G]*/, void* stream);
 

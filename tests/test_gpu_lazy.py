@@ -156,7 +156,7 @@ def test_finest_level_without_its_merged_map(shape):
     try:
         x = ondemand.conv1x1_lazy(t, _prep.krsc(wl), bl, alpha, up, S, defer=True)
         y, st = ondemand.conv3x3_winograd_lazy(x, _prep.wino23(wo), bo, S, _prep.cell_weight(wo, forward=True),
-                                               fold=lambda wk, a: _prep.cell_weight_folded(wo, wk, a))
+                                               fold=lambda wk, a, transposed=False: _prep.cell_weight_folded(wo, wk, a, transposed))
     finally:
         ondemand.LAZY_POISON = False
     assert st.lateral is not None and st.lateral.deferred and bool(torch.isnan(x).all())
@@ -718,3 +718,31 @@ def test_lateral_gradients_from_the_cell_domain_equal_the_dense_passes():
             err = float((g - g2).abs().max())
             assert err <= tol, (mode, k, err, tol)
     assert any('fpn' in k for k in res['split'])
+
+
+def test_cell_weight_kernels_equal_the_float64_einsum():
+    """`nbm_cell_weight` / `nbm_cell_weight_fold` / `nbm_cell_weight_grad` (csrc/cellwino.hip: the kernel side of the cell transforms,
+    float64 arithmetic, one rounding) against the float64 `torch.einsum` restatement they replaced on the training path: U = E w E^T in
+    both operand layouts, the folded lateral [U | alpha U W_lat], and dW = E^T dU E -- equal after the one rounding to fp32 (up to an
+    ulp where the float64 sums associate differently)."""
+    from birdsoundclassif_amd import ops
+    E = torch.tensor([[1.0, 0.0, 0.0], [1.0, 1.0, 1.0], [1.0, -1.0, 1.0], [1.0, 2.0, 4.0], [1.0, -2.0, 4.0]], dtype=torch.float64).cuda()
+    N, C_, Cin, alpha = 96, 160, 64, 0.75
+    w = (torch.from_numpy(synth.normal('cw', N * C_ * 9).astype(np.float32)).view(N, C_, 3, 3) * 0.05).cuda()
+    wl = (torch.from_numpy(synth.normal('cwl', C_ * Cin).astype(np.float32)).view(C_, Cin) * 0.1).cuda()
+    u = torch.einsum('ar,bs,ncrs->abnc', E, E, w.double()).reshape(25, N, C_)
+    got_f, got_t = ops.cell_weight(w, forward=True), ops.cell_weight(w, forward=False)
+    ulp = 1.2e-7 * float(u.abs().max())
+    assert float((got_f - u.float()).abs().max()) <= ulp and torch.equal(got_t, got_f.transpose(1, 2).contiguous())
+    uf = torch.cat([u, alpha * torch.einsum('knc,ci->kni', u, wl.double())], dim=-1)          # [25][N][C + Cin]
+    f_nc, f_cn = ops.cell_weight(w, lateral=wl, alpha=alpha, both=True)
+    assert tuple(f_nc.shape) == (25, N, C_ + Cin) and tuple(f_cn.shape) == (25, C_ + Cin, N)
+    assert torch.equal(f_nc[:, :, :C_], got_f) and torch.equal(f_cn, f_nc.transpose(1, 2).contiguous())
+    ref = uf[:, :, C_:].float()
+    assert float((f_nc[:, :, C_:] - ref).abs().max()) <= 2e-7 * float(ref.abs().max())
+    dU = torch.from_numpy(synth.normal('cdu', 25 * N * (C_ + Cin)).astype(np.float32)).view(25, N, C_ + Cin).cuda()
+    ref_w = torch.einsum('at,bs,abnc->ncts', E, E, dU[:, :, :C_].double().reshape(5, 5, N, C_)).float()
+    got_w = ops.cell_weight_grad(dU[:, :, :C_])                   # a column view of the wider operand (row pitch C + Cin)
+    assert got_w.shape == ref_w.shape and float((got_w - ref_w).abs().max()) <= 2e-7 * float(ref_w.abs().max())
+    got_w2 = ops.cell_weight_grad(dU[:, :, :C_].contiguous())
+    assert torch.equal(got_w, got_w2)

@@ -66,3 +66,47 @@ def test_precomputed_iou_path_equals_host_path():
         for a, b in zip(ref, got):
             assert (a is None and b is None) or torch.equal(a, b)
         assert np.array_equal(s_ref[1], s_got[1]) and s_ref[2] == s_got[2]
+
+
+def _anchor_pre_from_numpy(layer, gt, lens, args, poison=()):
+    """What SetCriterion.start_anchor_targets hands over, computed with the reference-order NumPy arithmetic."""
+    n_in, idx = len(layer.inds_inside), np.cumsum([0] + list(lens))
+    lab, amx, flag = np.zeros((len(lens), n_in), np.int8), np.zeros((len(lens), n_in), np.int16), np.zeros(len(lens), np.int32)
+    for b in range(len(lens)):
+        lb, a = layer._host_labels(targets.box_iou_incl(layer.anchors_np, gt[idx[b]:idx[b + 1]]), args)
+        lab[b], amx[b] = lb, a
+        if b in poison:                                  # the device raised the image's flag: whatever it wrote must be ignored
+            lab[b], amx[b], flag[b] = 1, 0, 1
+    return lab, amx, flag
+
+
+def test_anchor_targets_with_device_half_equal_the_all_host_layer():
+    """AnchorTargetLayer (reference layers.py:102-216) with its IoU / arg-max / threshold half handed over (`pre`, what
+    nbm_anchor_targets computes): same labels (i.e. same NumPy draws, same stream position) and same regression targets as the all-host
+    layer; an image whose flag is raised (degenerate box on the device) is recomputed on the host."""
+    args = default_args(device='cpu')
+    layer = targets.AnchorTargetLayer(args)
+    for seed, B in enumerate([8, 3, 16]):
+        bbs, lens = [], []
+        for i in range(B):
+            bb, _, l = synth.label_batch((i + seed) % 8, 1)
+            bbs.append(bb); lens += l
+        gt = torch.cat(bbs)
+        np.random.seed(seed)
+        l0, t0 = layer(gt, lens, device='cpu')
+        s0 = np.random.get_state()
+        pre = _anchor_pre_from_numpy(layer, gt.numpy().astype(np.float32), lens, args, poison=(1,) if seed == 2 else ())
+        np.random.seed(seed)
+        l1, t1 = layer(gt, lens, device='cpu', pre=pre)
+        s1 = np.random.get_state()
+        assert torch.equal(l0, l1) and torch.equal(t0, t1) and int((l0 == 1).sum()) > 0
+        assert s0[0] == s1[0] and np.array_equal(s0[1], s1[1]) and s0[2:] == s1[2:]
+    # a degenerate box (x2 < x1 - 1): the masked targets are NaN where the reference's are -- both paths take the full encode
+    gt_bad = gt.clone()
+    gt_bad[0] = torch.tensor([50., 40., 20., 90.])
+    np.random.seed(9)
+    l0, t0 = layer(gt_bad, lens, device='cpu')
+    pre = _anchor_pre_from_numpy(layer, gt_bad.numpy().astype(np.float32), lens, args)
+    np.random.seed(9)
+    l1, t1 = layer(gt_bad, lens, device='cpu', pre=pre)
+    assert torch.equal(l0, l1) and torch.equal(torch.isnan(t0), torch.isnan(t1)) and torch.equal(torch.nan_to_num(t0), torch.nan_to_num(t1))
