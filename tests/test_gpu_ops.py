@@ -455,8 +455,9 @@ def test_anchor_targets_bit_exact_and_criterion_handover():
         want, s_ref = layer(gt_t, lens, device='cpu'), np.random.get_state()
         assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
         assert np.array_equal(s_ref[1], s_got[1]) and s_ref[2] == s_got[2]
-    # degenerate box: the flag of that image (only) is raised
-    gt_pad[2, 0] = np.array([50., 40., 20., 90.], np.float32)
+    # degenerate box of area -289 = minus the area of the 17 x 17 anchors: 0 / 0 = NaN there -> the flag of that image (only) is raised
+    gt_pad[2, 0] = np.array([100., 10., 82., 26.], np.float32)
+    assert np.isnan(targets.box_iou_incl(layer.anchors_np, gt_pad[2, :1])).any()
     _, _, flag = ops.anchor_targets(anc, torch.from_numpy(gt_pad).cuda(), torch.tensor(lens, dtype=torch.int32).cuda(),
                                     args.rpn_neg_label, args.rpn_pos_label)
     f = flag.cpu().numpy()

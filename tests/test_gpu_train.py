@@ -743,12 +743,15 @@ def test_one_training_pass_in_flight_two_models_interleaved_raise():
     sum(loss2[k] * wd[k] for k in loss2 if k in wd).backward()
     Fn.parked_flush()
     Fn.stash_check_empty()
+    gmax = max(float(p.grad.abs().max()) for p in a2.parameters() if p.grad is not None)
     for n, p in a2.named_parameters():
         if p.grad is None:
             assert n not in got or float(got[n].abs().max()) == 0.0, n
             continue
-        scale = float(p.grad.abs().max()) + 1e-12
-        assert float((got[n] - p.grad).abs().max()) <= 2e-4 * scale + 1e-9, n
+        # per-parameter scale, with a floor for gradients that are mathematically zero (the attention's key bias: softmax does not
+        # see it) and hold the atomic-order noise of two runs
+        scale = float(p.grad.abs().max())
+        assert float((got[n] - p.grad).abs().max()) <= 2e-4 * scale + 1e-6 * gmax, n
     # the pass is closed: both models may start a new one
     b.forward_first_stage(batch[0][:, None], lazy=True)
     Fn.pass_abandon()
