@@ -34,8 +34,11 @@ from .nbm_datasets.prepare_dataset import SpectrogramFrontEnd, read_wav_pcm16
 class GraphedDetector:
     """Captures `front end -> model.detect` for a fixed (batch, n_samples, sample rate) and replays it."""
 
-    def __init__(self, model, batch, n_samples, sr, min_score=0.2, nms_thresh=0.3, device='cuda', independent=False):
-        self.model, self.batch, self.sr = model.eval(), batch, sr
+    def __init__(self, model, batch, n_samples, sr, min_score=0.2, nms_thresh=0.3, device='cuda', independent=False, lane=0):
+        """`lane`: detectors of different lanes may replay CONCURRENTLY (each on its own stream): their steps share nothing that a kernel
+        writes (ops.lane).  Two lanes in flight fill each other's kernel tails -- `detect_files(lanes=2)`, bench.py."""
+        from . import ops
+        self.model, self.batch, self.sr, self.lane = model.eval(), batch, sr, int(lane)
         self.fe = SpectrogramFrontEnd(device)
         self.min_score, self.nms_thresh, self.independent = min_score, nms_thresh, independent
         self.n_img = self.fe.n_images(self.fe.n_frames(n_samples * (2 if sr * 2 == self.fe.FREQ else 1)))
@@ -43,8 +46,8 @@ class GraphedDetector:
             raise NotImplementedError('GraphedDetector handles clips that fit one 1024-column window (<= 3.06 s)')
         self.pcm = torch.zeros((batch, n_samples), dtype=torch.int16, device=device)        # static graph input
         self.stream = torch.cuda.Stream()
-        with torch.no_grad(), torch.cuda.stream(self.stream):
-            for _ in range(2):                                   # warm-up: fills every weight / anchor / table cache
+        with torch.no_grad(), torch.cuda.stream(self.stream), ops.lane(self.lane):
+            for _ in range(2):                                   # warm-up: fills every weight / anchor / table cache, sizes this lane's scratch
                 self._run()
             self.stream.synchronize()
             self.graph = torch.cuda.CUDAGraph()
@@ -155,25 +158,38 @@ def txt_path(wav_path):
 
 
 def detect_files(model, files, batch=64, min_score=0.2, bird_dict=None, write_txt=True, depth=5, keep_results=True,
-                 independent=True, stats=None, detector=None):
+                 independent=True, stats=None, detector=None, lanes=None):
     """Detects over equal-length mono 16-bit PCM wav files (single-window clips, see `bulk_groups`): -> list of per-file output
     dicts in `files` order (None entries with keep_results=False); `<wav>.txt = str(dict)` written when `write_txt`.
     The last, partial batch is padded with silence and its padding results are dropped.  `stats` (dict) receives the stage
-    times.  `detector`: a GraphedDetector to reuse (same batch / clip length / rate)."""
+    times.  `detector`: a GraphedDetector (or a list of them, one per lane) to reuse (same batch / clip length / rate).
+    `lanes` (default: len(detector list), else NBM_BULK_LANES, else 2 when the shard has at least 4 batches): batches alternate between
+    that many captured steps, each replayed on its own stream, so that two batches are in flight on the GPU together -- the tail of
+    one step's kernels is filled by the other's (profiles/r04_two_lanes.txt)."""
     if not files:
         return []
     _, _, sr, _, n, _ = wav_header(files[0])
-    det = detector or GraphedDetector(model, batch, n, sr, min_score=min_score, independent=independent)
-    if (det.batch, det.pcm.shape[1], det.sr) != (batch, n, sr):
-        raise ValueError('the GraphedDetector handed in was captured for another batch / clip length / sample rate')
+    n_batches = -(-len(files) // batch)
+    dets = list(detector) if isinstance(detector, (list, tuple)) else ([detector] if detector is not None else [])
+    if lanes is None:
+        lanes = len(dets) if dets else int(os.environ.get('NBM_BULK_LANES', '2' if n_batches >= 4 else '1'))
+    lanes = max(1, int(lanes))
+    while len(dets) < lanes:
+        dets.append(GraphedDetector(model, batch, n, sr, min_score=min_score, independent=independent, lane=len(dets)))
+    dets = dets[:lanes]
+    if len({d.lane for d in dets}) != len(dets):
+        raise ValueError('the GraphedDetectors of one loop must have been captured in different lanes')
+    det = dets[0]
+    for d in dets:
+        if (d.batch, d.pcm.shape[1], d.sr) != (batch, n, sr):
+            raise ValueError('the GraphedDetector handed in was captured for another batch / clip length / sample rate')
     fe = det.fe
     L = fe.n_frames(n * (2 if sr * 2 == fe.FREQ else 1))
     names = None
     if bird_dict is not None:
         names = {v: k for k, v in bird_dict.items()}
         names[0] = 'Non bird sound'
-    n_batches = -(-len(files) // batch)
-    depth = max(3, depth)
+    depth = max(3, depth, 2 * lanes + 1)
     cap = det.det.shape[1]
     slots = [(torch.zeros((batch, n), dtype=torch.int16).pin_memory(), torch.zeros((batch, cap, 6), dtype=torch.float32).pin_memory(),
               torch.zeros((batch,), dtype=torch.int32).pin_memory()) for _ in range(depth)]
@@ -236,22 +252,24 @@ def detect_files(model, files, batch=64, min_score=0.2, bird_dict=None, write_tx
     inflight = []
     t_wait_in = 0.0
     try:
-        with torch.no_grad(), torch.cuda.stream(det.stream):
-            for _ in range(n_batches):
+        with torch.no_grad():
+            for k in range(n_batches):
                 t0 = time.perf_counter()
                 item = ready_q.get()
                 t_wait_in += time.perf_counter() - t0
                 if item is None or err:
                     break
                 i, s, cnt = item
-                det.pcm.copy_(slots[s][0], non_blocking=True)
-                det.replay()
-                slots[s][1].copy_(det.det, non_blocking=True)
-                slots[s][2].copy_(det.n_det, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(det.stream)
+                d = dets[k % lanes]                # this lane's previous batch (k - lanes) was copied out behind its replay, on the same stream
+                with torch.cuda.stream(d.stream):
+                    d.pcm.copy_(slots[s][0], non_blocking=True)
+                    d.replay()
+                    slots[s][1].copy_(d.det, non_blocking=True)
+                    slots[s][2].copy_(d.n_det, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(d.stream)
                 inflight.append((i, s, cnt, ev))
-                if len(inflight) >= 2:             # the GPU has the next batch queued: now wait for the previous one
+                if len(inflight) >= 2 * lanes:     # every lane has its next batch queued: now wait for the oldest one
                     i0, s0, c0, e0 = inflight.pop(0)
                     e0.synchronize()
                     done_q.put((i0, s0, c0))
@@ -267,5 +285,5 @@ def detect_files(model, files, batch=64, min_score=0.2, bird_dict=None, write_tx
         raise err[0]
     if stats is not None:
         stats.update(wall_s=time.perf_counter() - t_start, reader_busy_s=t_read[0], writer_busy_s=t_write[0],
-                     gpu_loop_waited_for_input_s=t_wait_in, batches=n_batches, depth=depth)
+                     gpu_loop_waited_for_input_s=t_wait_in, batches=n_batches, depth=depth, lanes=lanes)
     return out

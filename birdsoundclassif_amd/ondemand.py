@@ -441,7 +441,7 @@ def lazy_complete(fm, rois, n_roi, fmap_hw, level=0):
     keep = st.keep and (st.sparse or st.overlap)  # a backward pass will want the lists
     per_chunk = []
     for b0, nb, _ in st.chunks:
-        key = (str(x.device), nb * blocks_per_img * 128)
+        key = (str(x.device), nb * blocks_per_img * 128, ops.LANE)
         nr = n_roi[b0:b0 + nb] if per else n_roi
         if keep:                                  # the backward pass reads the list again: a buffer of its own
             tiles = torch.empty((key[1],), device=x.device, dtype=torch.int32)
@@ -713,7 +713,7 @@ def conv3x3_winograd_dgrad_tiles(st, g, Ut, Ucell=None, base=None, lateral_grads
                                 lib().nbm_zero_tiles(p_, nb_, H, W, c_, _ptr(tl_), n_, None, _stream()), 'nbm_zero_tiles'))
                 continue
             per = ops.per_image_counts(n_roi, B)
-            key = (str(g.device), nb * blocks_per_img * 128)
+            key = (str(g.device), nb * blocks_per_img * 128, ops.LANE)
             buf = _ROI_TILE_BUF.get(key)
             if buf is None:
                 buf = _ROI_TILE_BUF[key] = (torch.empty((key[1],), device=g.device, dtype=torch.int32),

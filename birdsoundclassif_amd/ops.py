@@ -144,6 +144,25 @@ def conv2d(x, w, kh=1, kw=1, stride=1, pad=0, scale=None, shift=None, residual=N
 WINO_CHUNK_BYTES = 24 << 30          # cap of the transformed-domain scratch (V + M) per batch chunk
 _WINO_SCRATCH = {}
 
+# Lanes: independent detect loops that may be IN FLIGHT TOGETHER on one GPU (two captured steps replayed on two streams fill each
+# other's kernel tails: bulk.GraphedDetector(lane=k)).  Everything a step allocates through torch is its own; what is shared
+# process-wide and WRITTEN by kernels -- the persistent transformed-domain scratch here, the RoI tile-list buffers of ondemand.py -- is
+# keyed by the lane that is current while the step is issued (warm-up and capture of a lane's graph run under `with ops.lane(k)`).
+LANE = 0
+
+
+class lane:
+    def __init__(self, k):
+        self.k = int(k)
+
+    def __enter__(self):
+        global LANE
+        self.prev, LANE = LANE, self.k
+
+    def __exit__(self, *exc):
+        global LANE
+        LANE = self.prev
+
 
 def _wino_scratch(device, n_v, n_m):
     """Two views (V: n_v floats, M: n_m floats) of ONE persistent per-device scratch allocation.  Every Winograd call on
@@ -152,12 +171,16 @@ def _wino_scratch(device, n_v, n_m):
     what the largest call so far needed (<= WINO_CHUNK_BYTES by construction of the batch chunks) and grows geometrically:
     a B = 1 detect process holds 0.4 GB, not the 24 GB a B = 64 step uses."""
     need = n_v + n_m
-    buf = _WINO_SCRATCH.get(device)
+    key = (device, LANE)
+    buf = _WINO_SCRATCH.get(key)
     if buf is None or buf.numel() < need:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('the persistent Winograd scratch would have to grow during a graph capture (the warm-up steps of the '
+                               'capture must run the same shapes under the same ops.lane)')
         have = 0 if buf is None else buf.numel()
-        _WINO_SCRATCH[device] = buf = None          # release before growing
+        _WINO_SCRATCH[key] = buf = None          # release before growing
         size = min(max(need, 2 * have), max(need, WINO_CHUNK_BYTES // 4))
-        buf = _WINO_SCRATCH[device] = torch.empty((size,), device=device, dtype=torch.float32)
+        buf = _WINO_SCRATCH[key] = torch.empty((size,), device=device, dtype=torch.float32)
     return buf[:n_v], buf[n_v:need]
 
 

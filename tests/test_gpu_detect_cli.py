@@ -164,3 +164,49 @@ def test_graphed_bulk_detection_matches_per_file_driver(tmp_path):
     a = det.det.clone(), det.n_det.clone()
     det.replay(); torch.cuda.synchronize()
     assert torch.equal(a[0], det.det) and torch.equal(a[1], det.n_det)
+
+
+def test_two_lanes_in_flight_give_the_single_lane_results(tmp_path):
+    """`detect_files(lanes=2)`: batches alternate between two captured steps that replay CONCURRENTLY on two streams (each lane has its
+    own persistent scratch and tile-list buffers, ops.lane).  The results must be those of the one-lane loop, file by file, bit for bit
+    -- a buffer shared between the lanes would show up as corrupted detections here."""
+    from birdsoundclassif_amd import bulk, ops
+    from birdsoundclassif_amd.nets import build_model
+    from birdsoundclassif_amd.train import default_args
+    model, _ = build_model(default_args(device='cuda'))
+    model.load_state_dict(filler_state_dict())
+    model = model.cuda().eval()
+    files = []
+    for i in range(44):                               # 11 batches of 4, the last lanes' batches differ in content
+        p = str(tmp_path / f'c{i}.wav')
+        synth.write_wav(p, synth.clip_pcm16(400 + i % 13), 22050)
+        files.append(p)
+    one = bulk.detect_files(model, files, batch=4, min_score=0.05, write_txt=False, lanes=1)
+    stats = {}
+    two = bulk.detect_files(model, files, batch=4, min_score=0.05, write_txt=False, lanes=2, stats=stats)
+    assert stats['lanes'] == 2 and len(one) == len(two) == 44
+    assert sum(len(v['scores']) for r in one for v in r.values()) > 0
+    assert one == two
+    # the lanes really own different scratch buffers
+    keys = [k for k in ops._WINO_SCRATCH if isinstance(k, tuple)]
+    assert {k[1] for k in keys} >= {0, 1}
+    ptrs = {ops._WINO_SCRATCH[k].data_ptr() for k in keys}
+    assert len(ptrs) == len(keys)
+    # direct: the same input through both lanes' graphs at the same time, 6 times
+    dets = [bulk.GraphedDetector(model, 4, 66150, 22050, min_score=0.05, lane=k) for k in range(2)]
+    pcm = [torch.from_numpy(synth.clip_batch_pcm16(300 + 4 * k, 4)) for k in range(2)]
+    ref = []
+    for k in range(2):
+        dets[k].pcm.copy_(pcm[k])
+        with torch.cuda.stream(dets[k].stream):
+            dets[k].replay()
+        torch.cuda.synchronize()
+        ref.append((dets[k].det.clone(), dets[k].n_det.clone()))
+    for _ in range(6):
+        for k in range(2):
+            with torch.cuda.stream(dets[k].stream):
+                dets[k].replay()
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert torch.equal(ref[k][0], dets[k].det) and torch.equal(ref[k][1], dets[k].n_det)
+    assert int(ref[0][1].sum()) > 0 and not torch.equal(ref[0][0], ref[1][0])
