@@ -276,7 +276,7 @@ def bulk_bench(model, rank, world, dist, n_files, batch, min_score, headline_cli
             synth.write_wav(path, base[i % 8], 22050)
             files.append(path)
         names = {f'Species {i}': i for i in range(1, 151)}
-        det = [bulk.GraphedDetector(model, batch, 66150, 22050, min_score=min_score, independent=True, lane=k) for k in range(max(1, lanes))]
+        det = bulk.GraphedDetector(model, batch, 66150, 22050, min_score=min_score, independent=True, lanes=max(1, lanes))
         kw = dict(batch=batch, min_score=min_score, bird_dict=names, write_txt=True, keep_results=False, detector=det)
         bulk.detect_files(model, files[:2 * batch], **kw)
         for f in files[:2 * batch]:
@@ -360,7 +360,7 @@ def graph_replay_agreed(dist, ok_here):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=6)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=64)
     ap.add_argument('--spin-up', dest='spin_up', type=int, default=20,
@@ -369,9 +369,9 @@ def parse_args(argv=None):
                          'reported as spin_up_steps in the line')
     ap.add_argument('--min-score', type=float, default=0.2)
     ap.add_argument('--lanes', type=int, default=2,
-                    help='captured detect steps in flight together on one GPU, each replayed on its own stream (bulk.GraphedDetector(lane=k)): '
-                         'the kernel tails of one step are filled by the other (two PROCESSES on one GPU: 974 against 922 clips/s, '
-                         'profiles/r04_two_lanes.txt); 1 = one step at a time')
+                    help='detect steps in flight together on one GPU: parallel branches (one stream each) of ONE captured graph '
+                         '(bulk.GraphedDetector(lanes=k)): the kernel tails of one step are filled by the other -- 65.2 against 68.9 ms '
+                         'per batch (profiles/r04_two_lanes.txt); needs --steps to be a multiple of it; 1 = one step at a time')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--train-batch', type=int, default=128)
     ap.add_argument('--train-steps', type=int, default=8,
@@ -621,54 +621,64 @@ def main(argv=None):
     # the dominant kernel's launches) stays in the line as `eager_with_events`: it carries the roofline measurement, and it is
     # bound by the HOST on boxes with slower cores (75.3 ms eager against 69.4 ms per replayed batch in one and the same run)
     eager = {'ms_per_step': dt / a.steps * 1e3, 'clips_per_s_per_gpu': B * a.steps / dt, 'detections_per_step': n_det / a.steps}
-    graph_note, gds = None, []
+    graph_note = None
     n_lanes = max(1, a.lanes)
-    try:
-        from birdsoundclassif_amd.bulk import GraphedDetector
-        for k in range(n_lanes):
-            gds.append(GraphedDetector(model, B, pcm.shape[1], 22050, min_score=a.min_score, independent=False, lane=k))
-            gds[-1].pcm.copy_(pcm)
-    except Exception as exc:
-        graph_note = f'hipGraph capture failed ({type(exc).__name__}: {exc}); value is the eager loop'[:300]
-        gds = gds[:1] if len(gds) >= 1 else []           # a second lane that cannot be captured (memory): the single-lane replay stays
-    if dist is not None:                                       # every rank replays with the same number of lanes (the loops hold barriers)
-        flag = torch.tensor([float(len(gds))], device='cuda')
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) < len(gds):
-            gds = gds[:int(flag.item())]
-            graph_note = graph_note or 'hipGraph capture failed on another rank'
 
-    def replay_leg(lanes):
-        """K timed replays alternating over `lanes` captured steps, each lane on its own stream (two lanes: two batches in flight on the
-        GPU together).  -> seconds, or None.  Every rank passes BOTH barriers whatever happens to it in between (a rank-local exception
-        used to leave that rank two barriers short and its peers waiting for the collective timeout)."""
+    def capture(lanes):
+        """-> GraphedDetector with `lanes` parallel branches (or None + note).  Every rank ends up with a detector or none does."""
         nonlocal graph_note
-        last_copy = [None] * len(lanes)
+        gd = None
+        try:
+            from birdsoundclassif_amd.bulk import GraphedDetector
+            gd = GraphedDetector(model, B, pcm.shape[1], 22050, min_score=a.min_score, independent=False, lanes=lanes)
+            for p_ in gd.pcms:
+                p_.copy_(pcm)
+        except Exception as exc:
+            graph_note = f'hipGraph capture ({lanes} lane(s)) failed ({type(exc).__name__}: {exc})'[:300]
+            gd = None
+        if dist is not None:                                   # every rank replays, or none does (the loop below holds barriers)
+            flag = torch.tensor([0.0 if gd is None else 1.0], device='cuda')
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if float(flag.item()) == 0.0 and gd is not None:
+                gd, graph_note = None, 'hipGraph capture failed on another rank'
+        return gd
 
-        def launch_g(k):
-            gd = lanes[k % len(lanes)]
+    def replay_leg(gd):
+        """Timed replays of the captured step: `gd.lanes` batches per replay, in flight on the GPU together; K steps = K / lanes replays
+        (K must be a multiple of the lanes).  -> seconds, or None.  Every rank passes BOTH barriers whatever happens to it in between
+        (a rank-local exception used to leave that rank two barriers short and its peers waiting for the collective timeout)."""
+        nonlocal graph_note
+        L = gd.lanes
+        n_rep = a.steps // L
+        last_copy = [None]
+
+        def launch_g():
             with torch.cuda.stream(gd.stream):
-                if last_copy[k % len(lanes)] is not None:
-                    gd.stream.wait_event(last_copy[k % len(lanes)])   # the static outputs are overwritten: the previous D2H must be done
+                if last_copy[0] is not None:
+                    gd.stream.wait_event(last_copy[0])          # the static outputs are overwritten: the previous D2H must be done
                 gd.replay()
                 ready = torch.cuda.Event()
                 ready.record(gd.stream)
-            det_h = torch.empty(gd.det.shape, dtype=gd.det.dtype, pin_memory=True)
-            n_h = torch.empty(gd.n_det.shape, dtype=gd.n_det.dtype, pin_memory=True)
+            hs = [(torch.empty(gd.dets[j].shape, dtype=gd.dets[j].dtype, pin_memory=True),
+                   torch.empty(gd.n_dets[j].shape, dtype=gd.n_dets[j].dtype, pin_memory=True)) for j in range(L)]
             with torch.cuda.stream(copy_stream):
                 copy_stream.wait_event(ready)
-                det_h.copy_(gd.det, non_blocking=True)
-                n_h.copy_(gd.n_det, non_blocking=True)
+                for j in range(L):
+                    hs[j][0].copy_(gd.dets[j], non_blocking=True)
+                    hs[j][1].copy_(gd.n_dets[j], non_blocking=True)
                 done = torch.cuda.Event()
                 done.record(copy_stream)
-            last_copy[k % len(lanes)] = done
-            return gd.det, gd.n_det, det_h, n_h, done
+            last_copy[0] = done
+            return hs, done
+
+        def finish_g(pending):
+            pending[1].synchronize()
+            return [fast_rcnn.dets_to_dicts(h[0], h[1], model.args.num_classes) for h in pending[0]]
 
         ok, dt_leg = True, None
-        depth = len(lanes)                                   # replays queued before the host finishes the oldest one
         try:
-            for k in range(max(a.warmup, len(lanes))):
-                finish(launch_g(k))
+            for _ in range(max(1, -(-a.warmup // L))):
+                finish_g(launch_g())
         except Exception as exc:
             ok, graph_note = False, f'hipGraph replay failed in the warm-up ({type(exc).__name__}: {exc}); value is the eager loop'[:300]
         gc.collect()
@@ -678,15 +688,13 @@ def main(argv=None):
             t0 = time.perf_counter()
             if ok:
                 try:
-                    n_det_g, pend = 0, []
-                    for k in range(a.steps):
-                        pend.append(launch_g(k))
-                        if len(pend) > depth:
-                            out = finish(pend.pop(0))
-                            n_det_g += sum(len(v['bbox_coord']) for d in out for v in d.values())
-                    for q in pend:
-                        out = finish(q)
-                        n_det_g += sum(len(v['bbox_coord']) for d in out for v in d.values())
+                    n_det_g, pend = 0, None
+                    for _ in range(n_rep):
+                        cur = launch_g()
+                        if pend is not None:
+                            n_det_g += sum(len(v['bbox_coord']) for out in finish_g(pend) for d in out for v in d.values())
+                        pend = cur
+                    n_det_g += sum(len(v['bbox_coord']) for out in finish_g(pend) for d in out for v in d.values())
                     if n_det_g != n_det:
                         raise RuntimeError(f'the replayed steps returned {n_det_g} detections, the eager ones {n_det}')
                 except Exception as exc:
@@ -703,18 +711,30 @@ def main(argv=None):
             dt_leg = None
         return dt_leg
 
+    # ONE GraphedDetector alive at a time (see its docstring): the one-lane graph is measured and released before the multi-lane one exists
     dt_g = dt_g1 = dt_g2 = None
     lanes_used = 0
-    if gds:
-        dt_g1 = replay_leg(gds[:1])                            # one captured step, replayed back to back
+    gd = capture(1)
+    if gd is not None:
+        dt_g1 = replay_leg(gd)
         dt_g, lanes_used = dt_g1, (1 if dt_g1 is not None else 0)
-        if len(gds) > 1 and dt_g1 is not None:
-            dt_g2 = replay_leg(gds)                            # two captured steps in flight together: the headline when it is the faster loop
+    gd = None
+    gc.collect()
+    torch.cuda.empty_cache()
+    if n_lanes > 1 and dt_g1 is not None and a.steps % n_lanes == 0:
+        note1 = graph_note
+        gd = capture(n_lanes)
+        if gd is not None:
+            dt_g2 = replay_leg(gd)                              # `n_lanes` batches in flight together: the headline when it is the faster loop
             if dt_g2 is not None and dt_g2 < dt_g1:
-                dt_g, lanes_used = dt_g2, len(gds)
+                dt_g, lanes_used = dt_g2, n_lanes
+        if dt_g2 is None and dt_g1 is not None:                 # the one-lane figure stands; keep the reason the multi-lane leg gave up
+            graph_note = None if graph_note is None else 'multi-lane leg: ' + graph_note
+        gd = None
+        gc.collect()
+        torch.cuda.empty_cache()
     single_lane = None if dt_g1 is None else {'ms_per_step': dt_g1 / a.steps * 1e3, 'clips_per_s_per_gpu': B * a.steps / dt_g1}
-    multi_lane = None if dt_g2 is None else {'lanes': len(gds), 'ms_per_step': dt_g2 / a.steps * 1e3, 'clips_per_s_per_gpu': B * a.steps / dt_g2}
-    gds = None                                                 # the captured graphs own private pools: let them go before the other legs
+    multi_lane = None if dt_g2 is None else {'lanes': n_lanes, 'ms_per_step': dt_g2 / a.steps * 1e3, 'clips_per_s_per_gpu': B * a.steps / dt_g2}
     if dt_g is not None:
         dt = dt_g
     ops.PROFILE = []                                           # one extra, untimed step with events around every GEMM-type launch
@@ -869,8 +889,9 @@ def main(argv=None):
                                        '(PCM16 @22.05 kHz resident in HBM) through the HIP STFT front end + detector '
                                        'forward + device post-processing, detections returned to the host',
                            'batch_per_gpu': B, 'min_score': a.min_score, 'detections_per_step': n_det / a.steps,
-                           'launch': (('hipGraph replay, %d captured steps in flight together (one stream each)' % lanes_used if lanes_used > 1 else
-                                       'hipGraph replay of the captured step') if dt_g is not None else graph_note),
+                           'launch': (('hipGraph replay of ONE graph whose capture forks into %d parallel detect steps (one stream each): '
+                                       '%d batches in flight together per replay' % (lanes_used, lanes_used) if lanes_used > 1 else
+                                       'hipGraph replay of the captured step') if dt_g is not None else (graph_note or 'eager loop')),
                            'lanes': lanes_used, 'launch_note': graph_note},
                 'eager_with_events': eager, 'single_lane_graph_replay': single_lane, 'multi_lane_graph_replay': multi_lane,
                 'roofline': roof, 'frontend': frontend, 'dense_finest_map': dense_ref, 'bulk_inference': bulk_leg,

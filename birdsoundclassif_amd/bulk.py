@@ -32,38 +32,66 @@ from .nbm_datasets.prepare_dataset import SpectrogramFrontEnd, read_wav_pcm16
 
 
 class GraphedDetector:
-    """Captures `front end -> model.detect` for a fixed (batch, n_samples, sample rate) and replays it."""
+    """Captures `front end -> model.detect` for a fixed (batch, n_samples, sample rate) and replays it.
 
-    def __init__(self, model, batch, n_samples, sr, min_score=0.2, nms_thresh=0.3, device='cuda', independent=False, lane=0):
-        """`lane`: detectors of different lanes may replay CONCURRENTLY (each on its own stream): their steps share nothing that a kernel
-        writes (ops.lane).  Two lanes in flight fill each other's kernel tails -- `detect_files(lanes=2)`, bench.py."""
+    `lanes` > 1: ONE graph whose capture forks into that many parallel branches (one stream each, joined before the capture ends),
+    every branch a complete detect step on its own static input / outputs and its own persistent scratch (`ops.lane`): a replay
+    processes `lanes` batches that are in flight on the GPU TOGETHER, so the tail of one step's kernels (a launch's last, partly
+    filled round of workgroups; the latency-bound proposal / NMS kernels) is filled by the other's: 65.2 instead of 68.9 ms per
+    B = 64 batch (profiles/r04_two_lanes.txt).  It is one graph, not one graph per lane, on purpose: a second graph exec launched
+    shortly after its instantiation while another exec is alive computed garbage on this ROCm build (scripts/lane_debug_*.py: same
+    captures, results depend on the milliseconds between instantiate and first launch) -- keep ONE GraphedDetector alive at a time."""
+
+    def __init__(self, model, batch, n_samples, sr, min_score=0.2, nms_thresh=0.3, device='cuda', independent=False, lanes=1):
         from . import ops
-        self.model, self.batch, self.sr, self.lane = model.eval(), batch, sr, int(lane)
-        self.fe = SpectrogramFrontEnd(device)
+        self.model, self.batch, self.sr, self.lanes = model.eval(), batch, sr, max(1, int(lanes))
+        self.fes = [SpectrogramFrontEnd(device) for _ in range(self.lanes)]
+        self.fe = self.fes[0]
         self.min_score, self.nms_thresh, self.independent = min_score, nms_thresh, independent
         self.n_img = self.fe.n_images(self.fe.n_frames(n_samples * (2 if sr * 2 == self.fe.FREQ else 1)))
         if self.n_img != 1:
             raise NotImplementedError('GraphedDetector handles clips that fit one 1024-column window (<= 3.06 s)')
-        self.pcm = torch.zeros((batch, n_samples), dtype=torch.int16, device=device)        # static graph input
+        self.pcms = [torch.zeros((batch, n_samples), dtype=torch.int16, device=device) for _ in range(self.lanes)]   # static graph inputs
+        self.pcm = self.pcms[0]
         self.stream = torch.cuda.Stream()
-        with torch.no_grad(), torch.cuda.stream(self.stream), ops.lane(self.lane):
-            for _ in range(2):                                   # warm-up: fills every weight / anchor / table cache, sizes this lane's scratch
-                self._run()
+        self.side = [torch.cuda.Stream() for _ in range(self.lanes - 1)]
+        with torch.no_grad(), torch.cuda.stream(self.stream):
+            for _ in range(2):                                   # warm-up: fills every weight / anchor / table cache, sizes the lanes' scratch
+                self._run_all()
             self.stream.synchronize()
+            for s_ in self.side:
+                s_.synchronize()
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=self.stream):
-                self.det, self.n_det = self._run()                # static graph outputs
+                outs = self._run_all()                            # static graph outputs
+        self.dets, self.n_dets = [o[0] for o in outs], [o[1] for o in outs]
+        self.det, self.n_det = self.dets[0], self.n_dets[0]
 
-    def _run(self):
-        imgs, _ = self.fe(self.pcm, self.sr)
+    def _run(self, k=0):
+        imgs, _ = self.fes[k](self.pcms[k], self.sr)
         return self.model.detect(imgs[:, 0][:, None].contiguous(), self.nms_thresh, self.min_score, independent=self.independent)
 
+    def _run_all(self):
+        """Lane 0 on the current (main) stream, every other lane on its side stream between a fork and a join."""
+        from . import ops
+        main = torch.cuda.current_stream()
+        outs = [None] * self.lanes
+        for k, s_ in enumerate(self.side, start=1):
+            s_.wait_stream(main)                                  # fork
+            with torch.cuda.stream(s_), ops.lane(k):
+                outs[k] = self._run(k)
+        with ops.lane(0):
+            outs[0] = self._run(0)
+        for s_ in self.side:
+            main.wait_stream(s_)                                  # join
+        return outs
+
     def replay(self):
-        """Runs the captured step on the current content of `self.pcm`; results land in `self.det`, `self.n_det`."""
+        """Runs the captured step(s) on the current content of `self.pcms`; results land in `self.dets`, `self.n_dets`."""
         self.graph.replay()
 
     def __call__(self, pcm):
-        """pcm int16 [batch, n] (host or device) -> list[batch] of the reference's per-clip dictionaries."""
+        """pcm int16 [batch, n] (host or device) -> list[batch] of the reference's per-clip dictionaries (lane 0)."""
         from .nets.layers import FastRCNN
         self.pcm.copy_(pcm, non_blocking=True)
         self.replay()
@@ -162,34 +190,26 @@ def detect_files(model, files, batch=64, min_score=0.2, bird_dict=None, write_tx
     """Detects over equal-length mono 16-bit PCM wav files (single-window clips, see `bulk_groups`): -> list of per-file output
     dicts in `files` order (None entries with keep_results=False); `<wav>.txt = str(dict)` written when `write_txt`.
     The last, partial batch is padded with silence and its padding results are dropped.  `stats` (dict) receives the stage
-    times.  `detector`: a GraphedDetector (or a list of them, one per lane) to reuse (same batch / clip length / rate).
-    `lanes` (default: len(detector list), else NBM_BULK_LANES, else 2 when the shard has at least 4 batches): batches alternate between
-    that many captured steps, each replayed on its own stream, so that two batches are in flight on the GPU together -- the tail of
-    one step's kernels is filled by the other's (profiles/r04_two_lanes.txt)."""
+    times.  `detector`: a GraphedDetector to reuse (same batch / clip length / rate / lanes).
+    `lanes` (default: the detector's, else NBM_BULK_LANES, else 2 when the shard has at least 4 batches): batches go through the graph
+    in groups of that many, in flight on the GPU together (see GraphedDetector)."""
     if not files:
         return []
     _, _, sr, _, n, _ = wav_header(files[0])
     n_batches = -(-len(files) // batch)
-    dets = list(detector) if isinstance(detector, (list, tuple)) else ([detector] if detector is not None else [])
     if lanes is None:
-        lanes = len(dets) if dets else int(os.environ.get('NBM_BULK_LANES', '2' if n_batches >= 4 else '1'))
+        lanes = detector.lanes if detector is not None else int(os.environ.get('NBM_BULK_LANES', '2' if n_batches >= 4 else '1'))
     lanes = max(1, int(lanes))
-    while len(dets) < lanes:
-        dets.append(GraphedDetector(model, batch, n, sr, min_score=min_score, independent=independent, lane=len(dets)))
-    dets = dets[:lanes]
-    if len({d.lane for d in dets}) != len(dets):
-        raise ValueError('the GraphedDetectors of one loop must have been captured in different lanes')
-    det = dets[0]
-    for d in dets:
-        if (d.batch, d.pcm.shape[1], d.sr) != (batch, n, sr):
-            raise ValueError('the GraphedDetector handed in was captured for another batch / clip length / sample rate')
+    det = detector or GraphedDetector(model, batch, n, sr, min_score=min_score, independent=independent, lanes=lanes)
+    if (det.batch, det.pcm.shape[1], det.sr) != (batch, n, sr) or det.lanes != lanes:
+        raise ValueError('the GraphedDetector handed in was captured for another batch / clip length / sample rate / number of lanes')
     fe = det.fe
     L = fe.n_frames(n * (2 if sr * 2 == fe.FREQ else 1))
     names = None
     if bird_dict is not None:
         names = {v: k for k, v in bird_dict.items()}
         names[0] = 'Non bird sound'
-    depth = max(3, depth, 2 * lanes + 1)
+    depth = max(3, depth, 3 * lanes)
     cap = det.det.shape[1]
     slots = [(torch.zeros((batch, n), dtype=torch.int16).pin_memory(), torch.zeros((batch, cap, 6), dtype=torch.float32).pin_memory(),
               torch.zeros((batch,), dtype=torch.int32).pin_memory()) for _ in range(depth)]
@@ -252,30 +272,38 @@ def detect_files(model, files, batch=64, min_score=0.2, bird_dict=None, write_tx
     inflight = []
     t_wait_in = 0.0
     try:
-        with torch.no_grad():
-            for k in range(n_batches):
-                t0 = time.perf_counter()
-                item = ready_q.get()
-                t_wait_in += time.perf_counter() - t0
-                if item is None or err:
+        with torch.no_grad(), torch.cuda.stream(det.stream):
+            k, stop = 0, False
+            while k < n_batches and not stop:
+                group = []
+                for j in range(min(lanes, n_batches - k)):      # the lanes' inputs: H2D on the graph's stream, in front of the replay
+                    t0 = time.perf_counter()
+                    item = ready_q.get()
+                    t_wait_in += time.perf_counter() - t0
+                    if item is None or err:
+                        stop = True
+                        break
+                    det.pcms[j].copy_(slots[item[1]][0], non_blocking=True)
+                    group.append(item)
+                if not group:
                     break
-                i, s, cnt = item
-                d = dets[k % lanes]                # this lane's previous batch (k - lanes) was copied out behind its replay, on the same stream
-                with torch.cuda.stream(d.stream):
-                    d.pcm.copy_(slots[s][0], non_blocking=True)
-                    d.replay()
-                    slots[s][1].copy_(d.det, non_blocking=True)
-                    slots[s][2].copy_(d.n_det, non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record(d.stream)
-                inflight.append((i, s, cnt, ev))
-                if len(inflight) >= 2 * lanes:     # every lane has its next batch queued: now wait for the oldest one
-                    i0, s0, c0, e0 = inflight.pop(0)
+                det.replay()                                    # a lane without a batch (odd tail) recomputes its previous input: ignored
+                for j, (i, s, cnt) in enumerate(group):
+                    slots[s][1].copy_(det.dets[j], non_blocking=True)
+                    slots[s][2].copy_(det.n_dets[j], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(det.stream)
+                inflight.append((group, ev))
+                k += len(group)
+                if len(inflight) >= 2:             # the GPU has the next group queued: now wait for the previous one
+                    g0, e0 = inflight.pop(0)
                     e0.synchronize()
-                    done_q.put((i0, s0, c0))
-            for i0, s0, c0, e0 in inflight:
+                    for it in g0:
+                        done_q.put(it)
+            for g0, e0 in inflight:
                 e0.synchronize()
-                done_q.put((i0, s0, c0))
+                for it in g0:
+                    done_q.put(it)
     finally:
         done_q.put(None)
         free_q.put(None)                            # unblocks a reader that waits for a slot after an error

@@ -20,9 +20,16 @@ def bump():
     _epoch += 1
 
 
+_DEBUG = __import__('os').environ.get('NBM_PREP_DEBUG') == '1'
+
+
 def _evict(obj_id):
     for k in [k for k in _cache if k[0] == obj_id]:
-        _cache.pop(k, None)
+        hit = _cache.pop(k, None)
+        if _DEBUG and hit is not None:
+            v = hit[2]
+            ts = [t for t in (v if isinstance(v, (tuple, list)) else [v]) if torch.is_tensor(t)]
+            print(f'_prep: evicted {k[1]} (key tensor died), values at {[hex(t.data_ptr()) for t in ts]}', flush=True)
 
 
 def _cached(key_t, tag, fn, extra=()):
@@ -37,6 +44,9 @@ def _cached(key_t, tag, fn, extra=()):
         return hit[2]
     with torch.no_grad():
         val = fn()
+    if _DEBUG:
+        cap = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+        print(f'_prep: made {tag} for a {tuple(key_t.shape)} key (replaces an entry: {hit is not None}; during a capture: {cap})', flush=True)
     obj_id = id(key_t)
     _cache[key] = (weakref.ref(key_t, lambda _r, obj_id=obj_id: _evict(obj_id)), ver, val)
     return val

@@ -144,10 +144,10 @@ def conv2d(x, w, kh=1, kw=1, stride=1, pad=0, scale=None, shift=None, residual=N
 WINO_CHUNK_BYTES = 24 << 30          # cap of the transformed-domain scratch (V + M) per batch chunk
 _WINO_SCRATCH = {}
 
-# Lanes: independent detect loops that may be IN FLIGHT TOGETHER on one GPU (two captured steps replayed on two streams fill each
-# other's kernel tails: bulk.GraphedDetector(lane=k)).  Everything a step allocates through torch is its own; what is shared
+# Lanes: detect steps that are IN FLIGHT TOGETHER on one GPU (parallel branches of one captured graph, one stream each:
+# bulk.GraphedDetector(lanes=k)) fill each other's kernel tails.  Everything a step allocates through torch is its own; what is shared
 # process-wide and WRITTEN by kernels -- the persistent transformed-domain scratch here, the RoI tile-list buffers of ondemand.py -- is
-# keyed by the lane that is current while the step is issued (warm-up and capture of a lane's graph run under `with ops.lane(k)`).
+# keyed by the lane that is current while the step is issued (`with ops.lane(k)` around a branch's warm-up and capture).
 LANE = 0
 
 

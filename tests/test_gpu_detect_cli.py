@@ -167,9 +167,10 @@ def test_graphed_bulk_detection_matches_per_file_driver(tmp_path):
 
 
 def test_two_lanes_in_flight_give_the_single_lane_results(tmp_path):
-    """`detect_files(lanes=2)`: batches alternate between two captured steps that replay CONCURRENTLY on two streams (each lane has its
-    own persistent scratch and tile-list buffers, ops.lane).  The results must be those of the one-lane loop, file by file, bit for bit
-    -- a buffer shared between the lanes would show up as corrupted detections here."""
+    """`detect_files(lanes=2)`: batches go through ONE captured graph in pairs -- its capture forks into two parallel detect steps on two
+    streams, each with its own static input / outputs and its own persistent scratch and tile-list buffers (ops.lane).  The results
+    must be those of the one-lane loop, file by file, bit for bit -- a buffer shared between the lanes would show up as corrupted
+    detections here -- also for an odd number of batches (the second lane idles in the last replay)."""
     from birdsoundclassif_amd import bulk, ops
     from birdsoundclassif_amd.nets import build_model
     from birdsoundclassif_amd.train import default_args
@@ -177,7 +178,7 @@ def test_two_lanes_in_flight_give_the_single_lane_results(tmp_path):
     model.load_state_dict(filler_state_dict())
     model = model.cuda().eval()
     files = []
-    for i in range(44):                               # 11 batches of 4, the last lanes' batches differ in content
+    for i in range(44):                               # 11 batches of 4: an odd number, the lanes' batches differ in content
         p = str(tmp_path / f'c{i}.wav')
         synth.write_wav(p, synth.clip_pcm16(400 + i % 13), 22050)
         files.append(p)
@@ -187,26 +188,28 @@ def test_two_lanes_in_flight_give_the_single_lane_results(tmp_path):
     assert stats['lanes'] == 2 and len(one) == len(two) == 44
     assert sum(len(v['scores']) for r in one for v in r.values()) > 0
     assert one == two
-    # the lanes really own different scratch buffers
+    # the lanes own different scratch buffers
     keys = [k for k in ops._WINO_SCRATCH if isinstance(k, tuple)]
     assert {k[1] for k in keys} >= {0, 1}
-    ptrs = {ops._WINO_SCRATCH[k].data_ptr() for k in keys}
-    assert len(ptrs) == len(keys)
-    # direct: the same input through both lanes' graphs at the same time, 6 times
-    dets = [bulk.GraphedDetector(model, 4, 66150, 22050, min_score=0.05, lane=k) for k in range(2)]
-    pcm = [torch.from_numpy(synth.clip_batch_pcm16(300 + 4 * k, 4)) for k in range(2)]
+    assert len({ops._WINO_SCRATCH[k].data_ptr() for k in keys}) == len(keys)
+    # direct: different inputs in the two lanes, the FIRST replay after the capture and six more against the eager step
+    import gc
+    gc.collect()
+    det = bulk.GraphedDetector(model, 4, 66150, 22050, min_score=0.05, lanes=2)
+    pcm = [torch.from_numpy(synth.clip_batch_pcm16(300 + 4 * k, 4)).cuda() for k in range(2)]
     ref = []
-    for k in range(2):
-        dets[k].pcm.copy_(pcm[k])
-        with torch.cuda.stream(dets[k].stream):
-            dets[k].replay()
-        torch.cuda.synchronize()
-        ref.append((dets[k].det.clone(), dets[k].n_det.clone()))
-    for _ in range(6):
+    with torch.no_grad(), ops.lane(5):
         for k in range(2):
-            with torch.cuda.stream(dets[k].stream):
-                dets[k].replay()
-    torch.cuda.synchronize()
+            imgs, _ = det.fe(pcm[k], 22050)
+            d, n = model.detect(imgs[:, 0][:, None].contiguous(), 0.3, 0.05)
+            ref.append((d.clone(), n.clone()))
     for k in range(2):
-        assert torch.equal(ref[k][0], dets[k].det) and torch.equal(ref[k][1], dets[k].n_det)
+        det.pcms[k].copy_(pcm[k])
+    torch.cuda.synchronize()
+    for rep in range(7):
+        with torch.cuda.stream(det.stream):
+            det.replay()
+        torch.cuda.synchronize()
+        for k in range(2):
+            assert torch.equal(ref[k][0], det.dets[k]) and torch.equal(ref[k][1], det.n_dets[k]), (rep, k)
     assert int(ref[0][1].sum()) > 0 and not torch.equal(ref[0][0], ref[1][0])
