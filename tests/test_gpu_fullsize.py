@@ -123,4 +123,4 @@ def test_config2_b128_train_steps_positive_and_negative():
     assert abs(out[128]['fresh_neg'] - out[8]['fresh_neg']) < 2e-4 and out[8]['fresh_neg'] > 0
     print(f"B=128 train: positive {out[128]['pos']}, negative {out[128]['neg']}, grad norms {out[128]['gn']}, "
           f"peak memory {out[128]['peak']:.1f} GiB")
-    assert out[128]['peak'] < 270
+    assert out[128]['peak'] < 230          # 169-200 GiB measured (positive + negative step); 288 GB on the card
