@@ -371,7 +371,7 @@ def parse_args(argv=None):
     ap.add_argument('--lanes', type=int, default=2,
                     help='detect steps in flight together on one GPU: parallel branches (one stream each) of ONE captured graph '
                          '(bulk.GraphedDetector(lanes=k)): the kernel tails of one step are filled by the other -- 65.2 against 68.9 ms '
-                         'per batch (profiles/r04_two_lanes.txt); needs --steps to be a multiple of it; 1 = one step at a time')
+                         'per batch (profiles/r04_two_lanes.txt); 1 = one step at a time')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--train-batch', type=int, default=128)
     ap.add_argument('--train-steps', type=int, default=8,
@@ -644,12 +644,13 @@ def main(argv=None):
         return gd
 
     def replay_leg(gd):
-        """Timed replays of the captured step: `gd.lanes` batches per replay, in flight on the GPU together; K steps = K / lanes replays
-        (K must be a multiple of the lanes).  -> seconds, or None.  Every rank passes BOTH barriers whatever happens to it in between
-        (a rank-local exception used to leave that rank two barriers short and its peers waiting for the collective timeout)."""
+        """Timed replays of the captured step: `gd.lanes` batches per replay, in flight on the GPU together; EXACTLY K steps = K // lanes
+        replays + (K mod lanes) eager steps behind them (in a lane of their own: the graph's branches own lanes 0 .. lanes-1).
+        -> seconds, or None.  Every rank passes BOTH barriers whatever happens to it in between (a rank-local exception used to leave
+        that rank two barriers short and its peers waiting for the collective timeout)."""
         nonlocal graph_note
         L = gd.lanes
-        n_rep = a.steps // L
+        n_rep, n_tail = a.steps // L, a.steps % L
         last_copy = [None]
 
         def launch_g():
@@ -694,7 +695,13 @@ def main(argv=None):
                         if pend is not None:
                             n_det_g += sum(len(v['bbox_coord']) for out in finish_g(pend) for d in out for v in d.values())
                         pend = cur
-                    n_det_g += sum(len(v['bbox_coord']) for out in finish_g(pend) for d in out for v in d.values())
+                    if pend is not None:
+                        n_det_g += sum(len(v['bbox_coord']) for out in finish_g(pend) for d in out for v in d.values())
+                    for _ in range(n_tail):                    # K is not a multiple of the lanes: the remaining steps, eagerly
+                        torch.cuda.current_stream().wait_stream(gd.stream)
+                        with ops.lane(L):
+                            out = step()
+                        n_det_g += sum(len(v['bbox_coord']) for d in out for v in d.values())
                     if n_det_g != n_det:
                         raise RuntimeError(f'the replayed steps returned {n_det_g} detections, the eager ones {n_det}')
                 except Exception as exc:
@@ -721,7 +728,7 @@ def main(argv=None):
     gd = None
     gc.collect()
     torch.cuda.empty_cache()
-    if n_lanes > 1 and dt_g1 is not None and a.steps % n_lanes == 0:
+    if n_lanes > 1 and dt_g1 is not None and a.steps >= n_lanes:
         note1 = graph_note
         gd = capture(n_lanes)
         if gd is not None:
@@ -873,6 +880,7 @@ def main(argv=None):
         del model
         import gc
         gc.collect()                              # the captured graphs of the detect / bulk legs own private pools: let them go
+        ops.release_lane_scratch(keep=(0,))       # ... and the second lane's persistent scratch (no graph is alive any more)
         torch.cuda.empty_cache()
         if os.environ.get('NBM_BENCH_MEMLOG') == '1':
             print(f'bench: before the train leg: allocated {torch.cuda.memory_allocated() / 2 ** 30:.1f} GiB, reserved '

@@ -184,6 +184,16 @@ def _wino_scratch(device, n_v, n_m):
     return buf[:n_v], buf[n_v:need]
 
 
+def release_lane_scratch(keep=(0,)):
+    """Frees the persistent scratch and tile-list buffers of every lane not in `keep` (tens of GB at B = 64).  Only when no captured
+    graph that was issued in those lanes is alive any more: a graph keeps the raw addresses."""
+    from . import ondemand
+    for key in [k for k in _WINO_SCRATCH if k[1] not in keep]:
+        del _WINO_SCRATCH[key]
+    for key in [k for k in ondemand._ROI_TILE_BUF if k[2] not in keep]:
+        del ondemand._ROI_TILE_BUF[key]
+
+
 WINO_FUSED_VARIANT = int(os.environ.get('NBM_WINO_FUSED_VARIANT', '0'))     # 0 auto, 128 / 64: channel-tile width
 
 
