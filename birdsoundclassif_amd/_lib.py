@@ -74,6 +74,9 @@ SIGNATURES = {
     'nbm_stem7x7': [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     'nbm_stem7x7_wgrad': [_P, _P, _I, _I, _I, _P, _P, _P],
     'nbm_maxpool3x3s2': [_P, _I, _I, _I, _I, _P, _I, _I, _P, _P],
+    'nbm_space_to_batch2': [_P, _I, _I, _I, _I, _P, _I, _P],
+    'nbm_avgpool2x2': [_P, _I, _I, _I, _I, _P, _P],
+    'nbm_avgpool2x2_bwd': [_P, _I, _I, _I, _I, _P, _P],
     'nbm_upsample_bilinear_add': [_P, _I, _I, _I, _I, _P, _P, _I, _I, _P],
     'nbm_softmax_rows': [_P, _L, _I, _L, _P],
     'nbm_dwconv3x3': [_P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _L, _P, _I, _I, _P],

@@ -532,6 +532,65 @@ extern "C" int nbm_maxpool3x3s2(const float* x, int B, int H, int W, int C, floa
   return nbm_launch_status();
 }
 
+// ---- `--dilation` (reference backbone.py:129-131: torchvision's replace_stride_with_dilation for layer4).  A 3x3 / dilation-2 / pad-2
+// convolution on an even-sized map IS four ordinary 3x3 / pad-1 convolutions on the four parity classes of its pixels, and everything
+// else in a bottleneck is point-wise: the dilated blocks run the ordinary kernels on the space-to-batch form of the map.
+//   forward (inverse = 0): y[(2a+b)*B + n][u][v][c] = x[n][2u+a][2v+b][c]   (x [B][H][W][C], y [4B][H/2][W/2][C])
+//   inverse = 1: the same index map read the other way (x is the [4B][H/2][W/2][C] side, y the [B][H][W][C] side)
+__global__ void space_to_batch2_kernel(const float* __restrict__ x, int B, int H, int W, int C4, float* __restrict__ y, int inverse) {
+  const int Hh = H >> 1, Wh = W >> 1;
+  const long long total = (long long)B * H * W * C4;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  f32x4* y4 = reinterpret_cast<f32x4*>(y);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    long long t = i / C4;                               // dense pixel index (n, yy, xx)
+    const int xx = (int)(t % W); t /= W;
+    const int yy = (int)(t % H);
+    const int n = (int)(t / H);
+    const long long packed = ((((long long)((yy & 1) * 2 + (xx & 1)) * B + n) * Hh + (yy >> 1)) * Wh + (xx >> 1)) * C4 + c;
+    if (inverse) y4[i] = x4[packed]; else y4[packed] = x4[i];
+  }
+}
+
+// AdaptiveAvgPool2d to exactly half the size (layers.py:84,94 with the RPN map of the dilated level: 48x128 -> 24x64): the mean of each
+// 2x2 block, summed in torch's CPU order (row by row), divided by 4
+__global__ void avgpool2x2_kernel(const float* __restrict__ x, int B, int Ho, int Wo, int C4, float* __restrict__ y) {
+  const long long total = (long long)B * Ho * Wo * C4;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  f32x4* y4 = reinterpret_cast<f32x4*>(y);
+  const int W = 2 * Wo;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    long long t = i / C4;
+    const int ox = (int)(t % Wo); t /= Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    const long long r0 = (((long long)b * 2 * Ho + 2 * oy) * W + 2 * ox) * C4 + c;
+    const f32x4 a = x4[r0], b1 = x4[r0 + C4], c1 = x4[r0 + (long long)W * C4], d = x4[r0 + (long long)W * C4 + C4];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (((a[e] + b1[e]) + c1[e]) + d[e]) * 0.25f;
+    y4[i] = o;
+  }
+}
+
+extern "C" int nbm_space_to_batch2(const float* x, int B, int H, int W, int C, float* y, int inverse, void* stream) {
+  if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || (H & 1) || (W & 1)) return NBM_EINVAL;
+  if (!nbm_aligned16(x) || !nbm_aligned16(y)) return NBM_EALIGN;
+  hipLaunchKernelGGL(space_to_batch2_kernel, dim3(grid_for((long long)B * H * W * (C / 4))), dim3(TPB), 0, (hipStream_t)stream, x, B, H, W,
+                     C / 4, y, inverse ? 1 : 0);
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_avgpool2x2(const float* x, int B, int Ho, int Wo, int C, float* y, void* stream) {
+  if (!x || !y || B <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || (C & 3)) return NBM_EINVAL;
+  if (!nbm_aligned16(x) || !nbm_aligned16(y)) return NBM_EALIGN;
+  hipLaunchKernelGGL(avgpool2x2_kernel, dim3(grid_for((long long)B * Ho * Wo * (C / 4))), dim3(TPB), 0, (hipStream_t)stream, x, B, Ho, Wo,
+                     C / 4, y);
+  return nbm_launch_status();
+}
+
 extern "C" int nbm_upsample_bilinear_add(const float* src, int B, int Hi, int Wi, int C, const float* add, float* y,
                                          int Ho, int Wo, void* stream) {
   if (!src || !y || B <= 0 || C <= 0 || (C & 3) || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return NBM_EINVAL;

@@ -1090,6 +1090,34 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 
 #define ST ((hipStream_t)stream)
 
+// gradient of nbm_avgpool2x2: every pixel of a 2x2 block receives a quarter of the block's gradient
+__global__ void avgpool2x2_bwd_kernel(const float* __restrict__ gy, int B, int Ho, int Wo, int C4, float* __restrict__ gx) {
+  const int H = 2 * Ho, W = 2 * Wo;
+  const long long total = (long long)B * H * W * C4;
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(gy);
+  f32x4* o4 = reinterpret_cast<f32x4*>(gx);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    long long t = i / C4;
+    const int xx = (int)(t % W); t /= W;
+    const int yy = (int)(t % H);
+    const int b = (int)(t / H);
+    const f32x4 g = g4[(((long long)b * Ho + (yy >> 1)) * Wo + (xx >> 1)) * C4 + c];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = g[e] * 0.25f;
+    o4[i] = o;
+  }
+}
+
+extern "C" int nbm_avgpool2x2_bwd(const float* gy, int B, int Ho, int Wo, int C, float* gx, void* stream) {
+  if (!gy || !gx || B <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || (C & 3)) return NBM_EINVAL;
+  if (!nbm_aligned16(gy) || !nbm_aligned16(gx)) return NBM_EALIGN;
+  hipLaunchKernelGGL(avgpool2x2_bwd_kernel, dim3(grid_for((long long)B * 4 * Ho * Wo * (C / 4))), dim3(TPB), 0, (hipStream_t)stream, gy, B,
+                     Ho, Wo, C / 4, gx);
+  return nbm_launch_status();
+}
+
 extern "C" int nbm_relu_bwd(const float* gy, const float* y, float* out, int64_t n, void* stream) {
   if (!gy || !y || !out || n <= 0) return NBM_EINVAL;
   hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n)), dim3(TPB), 0, ST, gy, y, out, (long long)n);

@@ -82,12 +82,16 @@ class _ResNetBody(nn.Module):
     """conv1/bn1/relu/maxpool/layer1..4 with torchvision's names; returns the 5 taps the reference takes
     with IntermediateLayerGetter (backbone.py:82-85): relu, layer1..layer4."""
 
-    def __init__(self, layers, norm_layer):
+    def __init__(self, layers, norm_layer, dilation=False):
+        """`dilation` (reference backbone.py:129-131: torchvision's `replace_stride_with_dilation=[False, False, True]`): layer4 keeps
+        layer3's resolution -- its first block runs with stride 1 (3x3 dilation 1, like torchvision: the first block uses the
+        PREVIOUS dilation), the following blocks with 3x3 / dilation 2 / padding 2.  Same parameters, same state_dict."""
         super().__init__()
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
         self.bn1 = norm_layer(64)
+        self.dilation = bool(dilation)
         inplanes = 64
-        for li, (planes, n, stride) in enumerate(zip((64, 128, 256, 512), layers, (1, 2, 2, 2)), start=1):
+        for li, (planes, n, stride) in enumerate(zip((64, 128, 256, 512), layers, (1, 2, 2, 1 if dilation else 2)), start=1):
             blocks = []
             for bi in range(n):
                 st = stride if bi == 0 else 1
@@ -95,6 +99,8 @@ class _ResNetBody(nn.Module):
                 if bi == 0 and (st != 1 or inplanes != planes * 4):
                     ds = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=st, bias=False), norm_layer(planes * 4))
                 blocks.append(_Bottleneck(inplanes, planes, st, ds, norm_layer))
+                if dilation and li == 4 and bi > 0:                   # state_dict / repr parity with torchvision's module
+                    blocks[-1].conv2.dilation, blocks[-1].conv2.padding = (2, 2), (2, 2)
                 blocks[-1].mask_input = not (li == 1 and bi == 0)      # layer1.0 reads the max-pool output
                 blocks[-1].mask_gy = bi == n - 1                       # the layer output is a tap (several consumers)
                 inplanes = planes * 4
@@ -110,8 +116,14 @@ class _ResNetBody(nn.Module):
         taps = [x]
         x = Fn.MaxPool.apply(x, True)              # the stem output is a ReLU output
         for li in range(1, 5):
-            for blk in getattr(self, f'layer{li}'):
+            for bi, blk in enumerate(getattr(self, f'layer{li}')):
+                if self.dilation and li == 4 and bi == 1:
+                    # the dilated blocks: a 3x3 / dilation-2 / pad-2 convolution is the ordinary 3x3 on the four parity classes of the
+                    # pixels, and the rest of a bottleneck is point-wise -> run the ordinary blocks on the space-to-batch form
+                    x = Fn.SpaceToBatch2.apply(x, False)
                 x = blk(x)
+            if self.dilation and li == 4 and len(self.layer4) > 1:
+                x = Fn.SpaceToBatch2.apply(x, True)
             taps.append(x)
         return taps
 
@@ -145,11 +157,9 @@ class Backbone(BackboneBase):
     def __init__(self, name, in_channels, train_backbone, dilation, norm_layer_name):
         if name not in _RESNET_LAYERS:
             raise ValueError(f'not supported {name}: the accelerated path implements {sorted(_RESNET_LAYERS)}')
-        if dilation:
-            raise NotImplementedError('--dilation (DC5) is outside the hot-path scope')
         if norm_layer_name != 'frozen_batchnorm':
             raise NotImplementedError('only --norm_layer_backbone frozen_batchnorm (reference default) is implemented')
-        super().__init__(_ResNetBody(_RESNET_LAYERS[name], FrozenBatchNorm2d), name, in_channels, train_backbone)
+        super().__init__(_ResNetBody(_RESNET_LAYERS[name], FrozenBatchNorm2d, dilation=dilation), name, in_channels, train_backbone)
 
 
 class Joiner(nn.Sequential):

@@ -642,6 +642,34 @@ class MaxPool(Function):
         return gx, None
 
 
+class SpaceToBatch2(Function):
+    """[B,H,W,C] -> [4B,H/2,W/2,C] (`inverse`: back): the pixel permutation around the dilated ResNet blocks (`--dilation`); its
+    gradient is the inverse permutation of the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, x, inverse):
+        ctx.inverse = bool(inverse)
+        return ops.space_to_batch2(x, inverse=ctx.inverse)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        return ops.space_to_batch2(gy.contiguous(), inverse=not ctx.inverse), None
+
+
+class AvgPool2x2(Function):
+    """nn.AdaptiveAvgPool2d to exactly half the size (reference layers.py:84,94 on the RPN map of the dilated level)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return ops.avgpool2x2(x)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        return ops.avgpool2x2_bwd(gy.contiguous())
+
+
 class UpsampleAdd(Function):
     @staticmethod
     def forward(ctx, src, add, Ho, Wo):

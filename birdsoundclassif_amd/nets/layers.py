@@ -102,9 +102,13 @@ class RegionProposalNetwork(nn.Module):
         feats = []
         for i, fm in enumerate(x):
             f = self.convs[str(i)](fm)
+            if tuple(f.shape[1:3]) == (2 * self.top_size[0], 2 * self.top_size[1]):
+                # `--dilation`: the coarsest level keeps layer3's resolution, the RPN up-samples it by 2 (stride 16 / 32 = 0.5) and
+                # nn.AdaptiveAvgPool2d(top_size) (layers.py:84,94) is then a real 2x2 average
+                f = Fn.AvgPool2x2.apply(f) if (torch.is_grad_enabled() and f.requires_grad) else ops.avgpool2x2(f)
             if tuple(f.shape[1:3]) != self.top_size:
                 raise NotImplementedError(f'RPN map {tuple(f.shape[1:3])} != top_size {self.top_size}: adaptive '
-                                          'average pooling to a different size is outside the hot-path scope')
+                                          'average pooling to a size other than the map itself or its half is outside the hot-path scope')
             feats.append(f)
         B, h, w, cn = feats[0].shape
         if torch.is_grad_enabled() and any(f.requires_grad for f in feats):

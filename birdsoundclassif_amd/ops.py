@@ -490,6 +490,42 @@ def maxpool3x3s2(x, with_index=False):
     return (y, idx) if with_index else y
 
 
+def space_to_batch2(x, inverse=False):
+    """x [B,H,W,C] (H, W even) -> [4B,H/2,W/2,C]: the four parity classes of the pixels as four images (class 2a+b major); `inverse`:
+    [4B,h,w,C] -> [B,2h,2w,C].  A 3x3 / dilation-2 / pad-2 convolution on x is the ordinary 3x3 / pad-1 convolution on this form."""
+    _chk(x, name='x')
+    if inverse:
+        B4, h, w, C_ = x.shape
+        assert B4 % 4 == 0
+        B, H, W = B4 // 4, 2 * h, 2 * w
+        y = torch.empty((B, H, W, C_), device=x.device, dtype=torch.float32)
+    else:
+        B, H, W, C_ = x.shape
+        if (H | W) & 1:
+            raise NotImplementedError('space_to_batch2 needs even map sizes (the dilated ResNet stage at 24 x 64)')
+        y = torch.empty((4 * B, H // 2, W // 2, C_), device=x.device, dtype=torch.float32)
+    check(lib().nbm_space_to_batch2(_ptr(x), B, H, W, C_, _ptr(y), int(bool(inverse)), _stream()), 'nbm_space_to_batch2')
+    return y
+
+
+def avgpool2x2(x):
+    """x [B,2h,2w,C] -> [B,h,w,C]: mean of each 2x2 block (nn.AdaptiveAvgPool2d to half the size)."""
+    _chk(x, name='x')
+    B, H, W, C_ = x.shape
+    assert H % 2 == 0 and W % 2 == 0
+    y = torch.empty((B, H // 2, W // 2, C_), device=x.device, dtype=torch.float32)
+    check(lib().nbm_avgpool2x2(_ptr(x), B, H // 2, W // 2, C_, _ptr(y), _stream()), 'nbm_avgpool2x2')
+    return y
+
+
+def avgpool2x2_bwd(gy):
+    _chk(gy, name='gy')
+    B, Ho, Wo, C_ = gy.shape
+    gx = torch.empty((B, 2 * Ho, 2 * Wo, C_), device=gy.device, dtype=torch.float32)
+    check(lib().nbm_avgpool2x2_bwd(_ptr(gy), B, Ho, Wo, C_, _ptr(gx), _stream()), 'nbm_avgpool2x2_bwd')
+    return gx
+
+
 def upsample_bilinear_add(src, Ho, Wo, add=None):
     _chk(src, name='src')
     B, Hi, Wi, C_ = src.shape

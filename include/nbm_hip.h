@@ -281,6 +281,15 @@ int nbm_stem7x7_wgrad(const float* img, const float* g, int B, int H, int W, flo
 /* 3x3 / stride 2 / pad 1 max pooling -- torchvision ResNet `maxpool` (backbone.py:131).  idx (may be NULL; training):
  * one byte per output element = r*3+s of the first maximum in scan order, consumed by nbm_maxpool3x3s2_bwd. */
 int nbm_maxpool3x3s2(const float* x, int B, int H, int W, int C, float* y, int Ho, int Wo, uint8_t* idx, void* stream);
+/* `--dilation` (backbone.py:129-131, torchvision replace_stride_with_dilation on layer4): a 3x3 / dilation-2 / pad-2 convolution on an
+ * even-sized map is four ordinary 3x3 / pad-1 convolutions on the parity classes of its pixels, so the dilated bottlenecks run the
+ * ordinary kernels on the space-to-batch form  y[(2a+b)*B + n][u][v][c] = x[n][2u+a][2v+b][c]  (x [B][H][W][C] -> y [4B][H/2][W/2][C];
+ * inverse != 0: the same map read the other way, x the packed side).  H, W even. */
+int nbm_space_to_batch2(const float* x, int B, int H, int W, int C, float* y, int inverse, void* stream);
+/* nn.AdaptiveAvgPool2d to exactly half the size (layers.py:84,94 on the 48x128 RPN map of the dilated level): x [B][2Ho][2Wo][C] ->
+ * y [B][Ho][Wo][C], mean of each 2x2 block; and its gradient (gx = gy / 4 on the block's four pixels). */
+int nbm_avgpool2x2(const float* x, int B, int Ho, int Wo, int C, float* y, void* stream);
+int nbm_avgpool2x2_bwd(const float* gy, int B, int Ho, int Wo, int C, float* gx, void* stream);
 
 /* y = bilinear_align_corners(src -> Ho x Wo) [+ add]  -- fpn.py:143-144, layers.py:35-37. */
 int nbm_upsample_bilinear_add(const float* src, int B, int Hi, int Wi, int C, const float* add,

@@ -108,6 +108,33 @@ def variants_golden():
     np.savez_compressed(os.path.join(OUT, 'variants_b2.npz'), **g)
 
 
+def dilation_golden():
+    """`--dilation` (backbone.py:129-131: layer4 at layer3's resolution, 3x3 dilation 2; the RPN's AdaptiveAvgPool2d becomes a real 2x2
+    average on that level, layers.py:84,94; the RoI pooling keeps stride 32 for it, layers.py:419-428) -- eval forward, B=2, a file of its
+    own (`variants_dilation_b2.npz`) so that the other variants' fixture is not rewritten."""
+    g = {}
+    tag = 'dilation'
+    args = ref_import.default_args(dilation=True)
+    model, _ = ref_import.build_reference_model(args, train=False)
+    sd = synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()})
+    model.load_state_dict(sd)
+    model.eval()
+    x = torch.from_numpy(synth.image_batch(0, 2))[:, None]
+    with torch.no_grad():
+        o = model.forward_first_stage(x)
+        for i, f in enumerate(o['fpn_out']):
+            pack(g, f'{tag}.fpn{i}', f, full_limit=10000)
+        pack(g, f'{tag}.rpn_cls_scores', o['rpn_cls_scores'], full_limit=10000)
+        pack(g, f'{tag}.rpn_bbox_reg', o['rpn_bbox_reg'], full_limit=10000)
+        pack(g, f'{tag}.rois', o['rois'])
+        rois2, roi_scores = model.head.prop_layer(o['rpn_cls_scores'], o['rpn_bbox_reg'])
+        assert torch.equal(rois2, o['rois'])
+        pack(g, f'{tag}.roi_scores', roi_scores)
+        pack_dets(g, f'{tag}.dets_min0.2', model(x, min_score=0.2))
+    print('variant', tag, [tuple(f.shape) for f in o['fpn_out']], tuple(o['rois'].shape), len(g[f'{tag}.dets_min0.2']))
+    np.savez_compressed(os.path.join(OUT, 'variants_dilation_b2.npz'), **g)
+
+
 def tf_rcnn_train_golden():
     """One positive optimisation step (reference train.py:205-257) with `--tf_rcnn`, both encoder flavours, B=2:
     losses, clip-norm, sampled gradients of head / FPN / backbone parameters."""
@@ -425,6 +452,8 @@ def main():
         return tf_rcnn_golden()
     if '--variants-only' in sys.argv:
         return variants_golden()
+    if '--dilation-only' in sys.argv:
+        return dilation_golden()
     if '--tf-train-only' in sys.argv:
         return tf_rcnn_train_golden()
     if '--labels-only' in sys.argv:
@@ -437,6 +466,7 @@ def main():
         return img_dataset_golden()
     tf_rcnn_golden()
     variants_golden()
+    dilation_golden()
     tf_rcnn_train_golden()
     img_dataset_golden()
     metrics_golden()

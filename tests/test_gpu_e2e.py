@@ -329,13 +329,15 @@ def test_chunked_stft_of_a_long_row(monkeypatch):
 
 @pytest.mark.parametrize('tag,kw', [('fpn_first', dict(fpn_first=True)), ('sandwich', dict(sandwich_attn=True)),
                                     ('posenc', dict(add_posenc=True)), ('bifpn', dict(fpn='bifpn', n_bifpn_layers=2)),
-                                    ('attn5', dict(pyramid_top_n_attn=5))])
+                                    ('attn5', dict(pyramid_top_n_attn=5)), ('dilation', dict(dilation=True))])
 def test_composition_flags_vs_reference_golden(tag, kw):
-    """--fpn_first / --sandwich_attn / --add_posenc (reference nbm_model.py:45-52) against the real reference's outputs,
-    forward and one optimisation step's worth of backward (finite gradients everywhere)."""
+    """--fpn_first / --sandwich_attn / --add_posenc (reference nbm_model.py:45-52) and --dilation (backbone.py:129-131: layer4 at
+    layer3's resolution with 3x3 / dilation 2 -- here: the ordinary kernels on the space-to-batch form -- the RPN's adaptive pooling a
+    real 2x2 average on that level, the RoI pooling's stride 32 kept) against the real reference's outputs, forward and one
+    optimisation step's worth of backward (finite gradients everywhere)."""
     from birdsoundclassif_amd.nets import build_model
     from birdsoundclassif_amd.train import default_args, build_optimizer, train_one_step
-    g = load_golden('variants_b2.npz')
+    g = load_golden('variants_dilation_b2.npz' if tag == 'dilation' else 'variants_b2.npz')
     args = default_args(device='cuda', **kw)
     m, crit = build_model(args)
     m.load_state_dict(filler_state_dict(**kw))

@@ -462,3 +462,42 @@ def test_anchor_targets_bit_exact_and_criterion_handover():
                                     args.rpn_neg_label, args.rpn_pos_label)
     f = flag.cpu().numpy()
     assert f[2] == 1 and f.sum() == 1
+
+
+def test_space_to_batch_makes_a_dilated_conv_an_ordinary_one_and_avgpool2x2():
+    """`--dilation` building blocks: nbm_space_to_batch2 and its inverse are permutations; the ordinary 3x3 / pad-1 convolution on the
+    space-to-batch form equals torch's 3x3 / dilation-2 / pad-2 convolution (forward and both gradients through the autograd
+    Functions); nbm_avgpool2x2 == F.adaptive_avg_pool2d to half the size, and its gradient."""
+    import torch.nn.functional as F
+    from birdsoundclassif_amd.nets import functional as Fn
+    B, H, W, Ci, Co = 2, 12, 16, 128, 128
+    x = torch.from_numpy(synth.normal('s2b.x', B * H * W * Ci).astype(np.float32)).view(B, H, W, Ci).cuda()
+    p = ops.space_to_batch2(x)
+    assert tuple(p.shape) == (4 * B, H // 2, W // 2, Ci)
+    for a in range(2):
+        for b in range(2):
+            assert torch.equal(p[(2 * a + b) * B:(2 * a + b + 1) * B], x[:, a::2, b::2])
+    assert torch.equal(ops.space_to_batch2(p, inverse=True), x)
+    w = (torch.from_numpy(synth.normal('s2b.w', Co * Ci * 9).astype(np.float32)).view(Co, Ci, 3, 3) * 0.05)
+    xr = x.detach().cpu().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, padding=2, dilation=2)
+    gy = torch.from_numpy(synth.normal('s2b.g', ref.numel()).astype(np.float32)).view_as(ref)
+    ref.backward(gy)
+    xd, wd = x.clone().requires_grad_(True), w.cuda().requires_grad_(True)
+    y = Fn.SpaceToBatch2.apply(Fn.conv(Fn.SpaceToBatch2.apply(xd, False), wd, kh=3, kw=3, pad=1), True)
+    got = y.permute(0, 3, 1, 2)
+    assert float((got.detach().cpu() - ref.detach()).abs().max()) < 2e-5 * float(ref.abs().max())
+    y.backward(gy.permute(0, 2, 3, 1).contiguous().cuda())
+    assert float((xd.grad.cpu().permute(0, 3, 1, 2) - xr.grad).abs().max()) < 1e-4 * float(xr.grad.abs().max())
+    assert float((wd.grad.cpu() - wr.grad).abs().max()) < 1e-4 * float(wr.grad.abs().max())
+    # 2x2 average pooling
+    t = x.detach().cpu().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    r = F.adaptive_avg_pool2d(t, (H // 2, W // 2))
+    g2 = torch.from_numpy(synth.normal('ap.g', r.numel()).astype(np.float32)).view_as(r)
+    r.backward(g2)
+    xa = x.clone().requires_grad_(True)
+    ya = Fn.AvgPool2x2.apply(xa)
+    assert float((ya.detach().cpu().permute(0, 3, 1, 2) - r.detach()).abs().max()) < 1e-6
+    ya.backward(g2.permute(0, 2, 3, 1).contiguous().cuda())
+    assert torch.equal(xa.grad.cpu().permute(0, 3, 1, 2), t.grad)

@@ -132,10 +132,10 @@ def test_merge_images_vs_golden():
 
 @pytest.mark.parametrize('tag,kw', [('fpn_first', dict(fpn_first=True)), ('sandwich', dict(sandwich_attn=True)),
                                     ('posenc', dict(add_posenc=True)), ('bifpn', dict(fpn='bifpn', n_bifpn_layers=2)),
-                                    ('attn5', dict(pyramid_top_n_attn=5))])
+                                    ('attn5', dict(pyramid_top_n_attn=5)), ('dilation', dict(dilation=True))])
 def test_composition_flags_vs_golden(tag, kw):
-    """--fpn_first / --sandwich_attn / --add_posenc (reference nbm_model.py:45-52)."""
-    g = load_golden('variants_b2.npz')
+    """--fpn_first / --sandwich_attn / --add_posenc (reference nbm_model.py:45-52); --dilation (backbone.py:129-131)."""
+    g = load_golden('variants_dilation_b2.npz' if tag == 'dilation' else 'variants_b2.npz')
     sd, cfg = filler_state_dict(**kw), O.make_cfg(**kw)
     x = torch.from_numpy(synth.image_batch(0, 2))[:, None]
     with torch.no_grad():
