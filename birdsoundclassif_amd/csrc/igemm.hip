@@ -19,6 +19,7 @@
 // of one M-tile, which share the gathered A rows, run on the same XCD.
 #include <stdlib.h>
 #include "nbm_common.h"
+#include "igemm_params.h"
 #include <type_traits>
 
 namespace {
@@ -29,28 +30,7 @@ constexpr int PITCH = 36;  // floats per LDS row (32 + 4 pad)
 enum { A_FAST = 0, A_GENERIC = 1 };
 enum { EPI_STD = 0 };
 
-struct IgemmParams {
-  const float* x; const float* w; float* y;
-  const float* scale; const float* shift; const float* residual;
-  long long x_gs, w_gs, y_gs, res_gs;
-  int M, N, K;           // K = kh*kw*Cin (valid)
-  int nk;                // number of 32-wide K steps
-  int H, W, Cin, kh, kw, stride, pad, Ho, Wo, HoWo;
-  int x_ld, w_ld, y_ld, res_ld;
-  int m_tiles, n_tiles;
-  float alpha; int act; int shift_per_row;
-  int vec_epi;           // epilogue may use 16-byte accesses (N % 4 == 0, pitches % 4 == 0, 16-byte aligned bases)
-  // fused top-down merge: y += bilinear_align_corners(up [B][up_H][up_W][N]) (vector epilogue only)
-  const float* up; int up_H, up_W; float up_sh, up_sw;
-  // ROWS instantiation only (1x1 / stride 1 / pad 0, one group, vector epilogue): GEMM row m is pixel row_pixel(m) of the dense
-  // NHWC maps x / y / residual (and of the `up` geometry) instead of pixel m -- the lateral convolution of a demand-driven FPN
-  // level is only evaluated where its consumer will read (nbm_gemm_conv, `rows`).
-  //   rows_mode 1: rows[m] = pixel index b*H*W + y*W + x, ascending, -1 = none (only at the end);
-  //   rows_mode 2: rows[m >> 4] = linear 2x2-tile id b*TH*TW + ty*TW + tx (or -1), row m = pixel (m & 15) of the tile's 4x4
-  //                input patch (rows 2ty-1.., columns 2tx-1..; outside the image = none).
-  //   rows_blocks (device, optional): number of leading 128-entry list blocks that are filled.
-  const int* rows; const int* rows_blocks; int rows_mode, rows_TH, rows_TW;
-};
+using nbm_igemm::IgemmParams;
 
 // STAGES = 2: the deep-K pipeline (double-buffered LDS, 2 workgroups per CU).  STAGES = 1: short-K layers (K <= 256: 1x1
 // convolutions whose time is output / residual traffic, not MFMA): single LDS buffer (36.8 KB) and an epilogue staged in
@@ -327,137 +307,9 @@ __global__ __launch_bounds__(256, BM > 128 ? 1 : STAGES == 1 ? 3 : 2) void igemm
   }
   __syncthreads();
 
-  // ---- epilogue.  C/D layout: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
-  if constexpr (EPI == EPI_STD) {
-    float* __restrict__ yg = p.y + (long long)g * p.y_gs;
-    const float* __restrict__ rg = p.residual ? p.residual + (long long)g * p.res_gs : nullptr;
-    if (p.vec_epi) {
-      // Stage the accumulator tile through LDS (the operand buffers are free after the last barrier) so that every
-      // lane finishes 4 consecutive channels: 16-byte residual / scale / shift loads and 16-byte stores instead of
-      // 64 dword stores per lane (store-issue bound on the short-K 1x1 layers).
-      constexpr int CP = BN + 4;
-      constexpr int HALVES = (STAGES == 1 || BM > 128) ? BM / WM : 1;   // single-stage LDS (or a 256-row tile) holds WM rows of the tile at a time
-      constexpr int HROWS = BM / HALVES;
-      static_assert(HROWS * CP <= STAGES * (BM + BN) * PITCH, "epilogue tile must fit the operand buffers");
-      float* Cs = lds;
-      constexpr int CH = BN / 4;                 // 16-byte chunks per tile row
-      constexpr int RPP = 256 / CH;              // rows per pass
-      const int cc = tid % CH, rr = tid / CH;
-      const int n = bn0 + cc * 4;
-      f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-      if (n < p.N) {
-        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
-        if (p.shift && !p.shift_per_row) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
-      }
-      constexpr int NR = (HROWS + RPP - 1) / RPP;      // tile rows a thread finishes
-#pragma unroll
-      for (int half = 0; half < HALVES; ++half) {
-      if (half) __syncthreads();
-      // the residual values of this thread's rows are requested before the accumulators go through LDS: loaded inside the row loop
-      // (behind its `m >= M` exit) they were NR dependent round trips at the end of every tile
-      f32x4 rq[NR];
-      const bool pre = !ROWS && rg && n < p.N;
-      if (pre) {
-#pragma unroll
-        for (int k = 0; k < NR; ++k) {
-          long long m = bm0 + half * HROWS + rr + k * RPP;
-          m = m < p.M ? m : p.M - 1;
-          rq[k] = *reinterpret_cast<const f32x4*>(rg + m * p.res_ld + n);
-        }
-      }
-      if (HALVES == 1 || wm0 == half * HROWS) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-          for (int e = 0; e < 16; ++e)
-            Cs[((HALVES == 1 ? wm0 : 0) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh) * CP + wn0 + j * 32 + lrow] = acc[i][j][e];
-      }
-      __syncthreads();
-      if (n < p.N) {
-#pragma unroll
-        for (int k = 0; k < NR; ++k) {
-          const int r = rr + k * RPP;
-          if (r >= HROWS) break;
-          long long m = bm0 + half * HROWS + r;
-          if (m >= p.M) break;
-          if constexpr (ROWS) {
-            m = row_pixel((int)m);
-            if (m < 0) continue;
-          }
-          f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CP + cc * 4);
-          const float rs = (p.shift_per_row && p.shift) ? p.shift[m] : 0.f;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = (v[e] * p.alpha) * sc[e] + sh[e] + rs;
-          if (rg) {
-            const f32x4 q = pre ? rq[k] : *reinterpret_cast<const f32x4*>(rg + (long long)m * p.res_ld + n);
-            v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3];
-          }
-          // (NEGATIVE: the rows in groups of 2 / 4 with the four gathered vectors of a whole group requested first -- 4: spills at the
-          // 256-register cap; 2: 242 registers, the merge laterals 3.039 / 1.376 / 0.621 ms against 3.042 / 1.364 / 0.621: what these
-          // launches wait for is not the gather's latency)
-          if (p.up) {       // same arithmetic as upsample_add_kernel (pointwise.hip): interp first, then + lateral
-#pragma clang fp contract(off)   // like torch's CPU upsample_bilinear2d: no fused multiply-adds in the coordinates or the
-                                 // blend (the compiler fused `scale * o - floor` in one instantiation of this kernel and not in
-                                 // another: 5e-6 apart)
-            const int b = (int)(m / p.HoWo), rem = (int)(m - (long long)b * p.HoWo);
-            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-            const float fy = p.up_sh * oy, fx = p.up_sw * ox;
-            const int y0 = (int)fy, x0 = (int)fx;
-            const int y1 = y0 + (y0 < p.up_H - 1 ? 1 : 0), x1 = x0 + (x0 < p.up_W - 1 ? 1 : 0);
-            const float ly = fminf(fmaxf(fy - y0, 0.f), 1.f), lx = fminf(fmaxf(fx - x0, 0.f), 1.f);
-            const float hy = 1.f - ly, hx = 1.f - lx;
-            const long long rb = (long long)b * p.up_H;
-            const float* ub = p.up + n;
-            const f32x4 v00 = *reinterpret_cast<const f32x4*>(ub + ((rb + y0) * p.up_W + x0) * p.N);
-            const f32x4 v01 = *reinterpret_cast<const f32x4*>(ub + ((rb + y0) * p.up_W + x1) * p.N);
-            const f32x4 v10 = *reinterpret_cast<const f32x4*>(ub + ((rb + y1) * p.up_W + x0) * p.N);
-            const f32x4 v11 = *reinterpret_cast<const f32x4*>(ub + ((rb + y1) * p.up_W + x1) * p.N);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              v[e] = (hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e])) + v[e];
-          }
-          if (p.act == NBM_ACT_RELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
-          } else if (p.act == NBM_ACT_SILU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + expf(-v[e]));
-          } else if (p.act == NBM_ACT_LEAKY) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
-          }
-          *reinterpret_cast<f32x4*>(yg + (long long)m * p.y_ld + n) = v;
-        }
-      }
-      }
-    } else {
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = bn0 + wn0 + j * 32 + lrow;
-      if (n >= p.N) continue;
-      const float sc = p.scale ? p.scale[n] : 1.0f;
-      const float sh = (p.shift && !p.shift_per_row) ? p.shift[n] : 0.0f;
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = bm0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-          if (m >= p.M) continue;
-          float v = acc[i][j][e] * p.alpha;
-          v = v * sc + sh;
-          if (p.shift_per_row && p.shift) v += p.shift[m];
-          if (rg) v += rg[(long long)m * p.res_ld + n];
-          if (p.act == NBM_ACT_RELU) v = fmaxf(v, 0.0f);
-          else if (p.act == NBM_ACT_SILU) v = v / (1.0f + expf(-v));
-          else if (p.act == NBM_ACT_LEAKY) v = v > 0.f ? v : 0.01f * v;
-          yg[(long long)m * p.y_ld + n] = v;
-        }
-      }
-    }
-    }
-  }
+#define NBM_EPI_LDS_FLOATS (STAGES * (BM + BN) * PITCH)
+#include "igemm_epilogue.inc"
+#undef NBM_EPI_LDS_FLOATS
 }
 
 // ---- streaming 1x1 (stride 1) for the layers whose whole weight matrix fits LDS (N * K <= 16 K: ResNet layer1's 64 -> 64 / 64 -> 256 /
@@ -721,6 +573,12 @@ extern "C" int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream) {
   }
   if (d->N > 64) {
     p.n_tiles = (d->N + 127) / 128;
+    // deep K on the bf16 matrix pipe through split fp32 operands (igemm_split.hip); NBM_SPLIT_BF16=0 keeps the fp32 instruction.
+    // Read per call: the parity tests flip it inside one process.  The choice depends on the LAYER (K, N), never on the number of rows:
+    // a clip's result must not depend on how many clips share its batch (the two kernels sum in different orders).
+    const char* split_env = getenv("NBM_SPLIT_BF16");
+    if (split_env && split_env[0] == '1' && fast && p.vec_epi && p.nk > 8)
+      return nbm_igemm::split_launch(p, d->groups, st);
     // short K and a 16-byte epilogue: the three-workgroups-per-CU variant (see the template comment)
     static const int shortk_max = getenv("NBM_SHORTK_MAX") ? atoi(getenv("NBM_SHORTK_MAX")) : 8;   // 0 disables
     if (fast && p.vec_epi && p.nk <= shortk_max)

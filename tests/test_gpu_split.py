@@ -1,0 +1,91 @@
+"""GPU: the deep-K implicit GEMM on the bf16 matrix pipe through split fp32 operands (csrc/igemm_split.hip, NBM_SPLIT_BF16=1) against
+float64 and against the fp32-matrix-instruction kernel of the same launch.  The split form must not be the less accurate of the two:
+its error against float64 is asserted to stay within 1.05 x the fp32 kernel's (measured 0.4-0.6 x)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from birdsoundclassif_amd import ops, synth          # noqa: E402
+
+
+def rnd(key, *shape, scale=1.0):
+    return torch.from_numpy((synth.normal(key, int(np.prod(shape))) * scale).astype(np.float32).reshape(shape))
+
+
+def krsc(w):
+    co, ci, kh, kw = w.shape
+    return w.permute(0, 2, 3, 1).reshape(co, -1).contiguous().cuda()
+
+
+def both(monkeypatch, fn):
+    monkeypatch.setenv('NBM_SPLIT_BF16', '0')
+    a = fn()
+    monkeypatch.setenv('NBM_SPLIT_BF16', '1')
+    b = fn()
+    torch.cuda.synchronize()
+    return a, b
+
+
+@pytest.mark.parametrize('cfg', [
+    # B, H, W, Cin, Cout, k, stride, pad                 K32 steps -> stages mod 6
+    (2, 24, 32, 512, 256, 1, 1, 0),        # 16 -> 2
+    (2, 24, 32, 384, 384, 1, 1, 0),        # 12 -> 0, N = 3 tiles
+    (3, 17, 23, 1024, 200, 1, 1, 0),       # 32 -> 4, ragged M (1173 rows) and N
+    (2, 21, 19, 128, 128, 3, 2, 1),        # 36 -> 0, taps at the image border, stride 2
+    (2, 12, 14, 512, 1024, 1, 2, 0),       # 1x1 stride 2
+    (1, 25, 33, 384, 256, 3, 1, 1),        # 108 -> 0, 3x3 stride 1
+    (1, 40, 64, 2048, 512, 1, 1, 0),       # 64 -> 2
+])
+def test_split_conv_against_float64_and_the_fp32_kernel(cfg, monkeypatch):
+    B, H, W, Ci, Co, k, st, pad = cfg
+    x = F.relu(rnd(('x', cfg), B, Ci, H, W))
+    w = rnd(('w', cfg), Co, Ci, k, k, scale=(2.0 / (Ci * k * k)) ** 0.5)
+    scale = 1 + 0.1 * rnd(('s', cfg), Co)
+    shift = 0.1 * rnd(('b', cfg), Co)
+    ref = F.conv2d(x.double(), w.double(), stride=st, padding=pad)
+    res = rnd(('r', cfg), *ref.shape)
+    ref = F.relu(ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1) + res.double())
+    xd, wd = x.permute(0, 2, 3, 1).contiguous().cuda(), krsc(w)
+    rd = res.permute(0, 2, 3, 1).contiguous().cuda()
+    f32, split = both(monkeypatch, lambda: ops.conv2d(xd, wd, k, k, st, pad, scale=scale.cuda(), shift=shift.cuda(), residual=rd,
+                                                      act=ops.ACT_RELU))
+    ref = ref.permute(0, 2, 3, 1)
+    e32 = (f32.cpu().double() - ref).abs()
+    esp = (split.cpu().double() - ref).abs()
+    assert float(esp.max()) <= 2e-5 * (1 + float(ref.abs().max())), (cfg, float(esp.max()))
+    rms32, rmssp = float((e32 ** 2).mean().sqrt()), float((esp ** 2).mean().sqrt())
+    assert rmssp <= 1.05 * rms32 + 1e-9, f'{cfg}: split rms error {rmssp:.3e} vs fp32 kernel {rms32:.3e}'
+    assert float((split - f32).abs().max()) <= 2e-5 * (1 + float(ref.abs().max()))
+
+
+def test_split_grouped_gemm_with_row_shift(monkeypatch):
+    """The attention form: groups of plain GEMMs (blockIdx.z), shift per row."""
+    G, M, K, N = 6, 1536, 512, 384
+    x = rnd('gx', G, M, K).cuda()
+    w = rnd('gw', G, N, K, scale=K ** -0.5).cuda()
+    sh = rnd('gs', G * M).cuda()
+
+    def run():
+        y = torch.empty(G, M, N, device='cuda')
+        ops.gemm_conv(x, w, y, B=1, H=M, W=1, Cin=K, N=N, groups=G, x_gs=M * K, w_gs=N * K, y_gs=M * N, alpha=0.5)
+        return y
+    f32, split = both(monkeypatch, run)
+    ref = 0.5 * torch.einsum('gmk,gnk->gmn', x.double().cpu(), w.double().cpu())
+    e32, esp = (f32.cpu().double() - ref).abs(), (split.cpu().double() - ref).abs()
+    assert float(esp.max()) <= 2e-5 * (1 + float(ref.abs().max()))
+    assert float((esp ** 2).mean().sqrt()) <= 1.05 * float((e32 ** 2).mean().sqrt()) + 1e-9
+    del sh
+
+
+def test_split_with_fused_topdown_merge(monkeypatch):
+    B, H, W, Ci, N = 2, 23, 37, 512, 384
+    x = rnd('upx', B, H, W, Ci).cuda()
+    w = rnd('upw', N, Ci, scale=0.05).cuda()
+    b = rnd('upb', N).cuda()
+    coarse = rnd('upc', B, 12, 19, N).cuda()
+    f32, split = both(monkeypatch, lambda: ops.conv2d(x, w, shift=b, alpha=2.0, up=coarse))
+    assert float((split - f32).abs().max()) <= 2e-5 * (1 + float(f32.abs().max()))
+    assert float((split - f32).abs().max()) > 0          # (the two kernels do differ in the last bits: the switch took effect)
