@@ -37,6 +37,7 @@ PMC_DOMINANT = 'r04_pmc_dominant.json'    # committed rocprofv3 --pmc passes of 
 PMC_WGRAD = 'r04_pmc_wgrad.json'          # ... of scripts/trainbench.py: the weight-gradient kernels (scripts/r04_profiles.sh)
 PMC_DGRAD = 'r04_pmc_dgrad.json'          # ... the data-gradient kernels
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+BF16_MFMA_PEAK_TFLOPS = 2500.0         # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16: 1024 FLOP/clk/SIMD), same guide
 FP64_MFMA_PEAK_TFLOPS = 78.6           # v_mfma_f64_16x16x4_f64: half the fp32 rate on this part (64 cycles / 2048 FLOP / SIMD)
 FPN0_GFLOP_PER_CLIP = 170.322          # fpn.out_convs.4, 3x3 384->256 @188x512
 FWD_GFLOP_PER_CLIP = 325.56            # SURVEY.md §6 (conv + addmm + bmm, forward)
@@ -380,6 +381,8 @@ def parse_args(argv=None):
                          'where 5-8 measure 427)')
     ap.add_argument('--no-train', action='store_true')
     ap.add_argument('--no-dense-reference', dest='no_dense_reference', action='store_true')
+    ap.add_argument('--no-split-leg', dest='no_split_leg', action='store_true',
+                    help='skip the extra detect leg with the deep-K GEMMs on the bf16 matrix pipe (split fp32 operands, opt-in mode)')
     ap.add_argument('--bulk-files', type=int, default=2048,
                     help='bulk_inference leg (configs[4] on this rank\'s shard): wav files on tmpfs -> txt files; 0 = skip')
     return ap.parse_args(argv)
@@ -546,6 +549,10 @@ def main(argv=None):
     from birdsoundclassif_amd.nets import build_model
     from birdsoundclassif_amd.train import default_args
 
+    # the headline legs run the library's DEFAULT deep-K kernel (fp32 matrix instruction) whatever the caller's environment says; the opt-in
+    # form (bf16 matrix pipe on split fp32 operands, csrc/igemm_split.hip) gets a leg of its own below (`split_bf16`)
+    split_env_was = os.environ.get('NBM_SPLIT_BF16')
+    os.environ['NBM_SPLIT_BF16'] = '0'
     B = a.batch
     model, _ = build_model(default_args(device='cuda'))
     model.load_state_dict(synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}))
@@ -643,7 +650,7 @@ def main(argv=None):
                 gd, graph_note = None, 'hipGraph capture failed on another rank'
         return gd
 
-    def replay_leg(gd):
+    def replay_leg(gd, check_det=True):
         """Timed replays of the captured step: `gd.lanes` batches per replay, in flight on the GPU together; EXACTLY K steps = K // lanes
         replays + (K mod lanes) eager steps behind them (in a lane of their own: the graph's branches own lanes 0 .. lanes-1).
         -> seconds, or None.  Every rank passes BOTH barriers whatever happens to it in between (a rank-local exception used to leave
@@ -702,7 +709,7 @@ def main(argv=None):
                         with ops.lane(L):
                             out = step()
                         n_det_g += sum(len(v['bbox_coord']) for d in out for v in d.values())
-                    if n_det_g != n_det:
+                    if check_det and n_det_g != n_det:
                         raise RuntimeError(f'the replayed steps returned {n_det_g} detections, the eager ones {n_det}')
                 except Exception as exc:
                     ok, graph_note = False, f'hipGraph replay failed ({type(exc).__name__}: {exc}); value is the eager loop'[:300]
@@ -744,6 +751,54 @@ def main(argv=None):
     multi_lane = None if dt_g2 is None else {'lanes': n_lanes, 'ms_per_step': dt_g2 / a.steps * 1e3, 'clips_per_s_per_gpu': B * a.steps / dt_g2}
     if dt_g is not None:
         dt = dt_g
+    # ---- opt-in mode, measured beside the headline (never IN it): the same step with every deep-K implicit GEMM on the bf16 matrix pipe
+    # through split fp32 operands (x = hi + mid + lo, six products, two fp32 accumulators: csrc/igemm_split.hip; error against float64
+    # <= the fp32 instruction's, asserted in tests/test_gpu_split.py).  Single-rank runs only, like the dense leg.
+    split_leg = None
+    if world == 1 and not a.no_split_leg and dt_g is not None:
+        os.environ['NBM_SPLIT_BF16'] = '1'
+        try:
+            step()
+            step()
+            torch.cuda.synchronize()
+            ops.PROFILE, ops.PROFILE_ONLY = [], 'deepk'
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            prof_s, ops.PROFILE, ops.PROFILE_ONLY = ops.PROFILE, None, None
+            note0 = graph_note
+            gd = capture(max(1, lanes_used))
+            dt_s = replay_leg(gd, check_det=False) if gd is not None else None
+            gd = None
+            gc.collect()
+            torch.cuda.empty_cache()
+            per_s = [(tag, s_.elapsed_time(e_)) for (tag, s_, e_) in prof_s if len(tag) == 9 and ops.is_deepk(tag[0], tag[1], tag[2], tag[2])]
+            gf = sum(2.0 * t[5] * ((t[3] - 1) // t[7] + 1) * ((t[4] - 1) // t[7] + 1) * t[1] * t[0] * t[2] * t[2] * t[6] / 1e9 for t, _ in per_s)
+            ms_s = sum(m for _, m in per_s)
+            split_leg = {'default': False, 'switch': 'NBM_SPLIT_BF16=1 (read per call by nbm_gemm_conv)',
+                         'value': None if dt_s is None else B * a.steps / dt_s, 'unit': 'clips/s',
+                         'ms_per_step': None if dt_s is None else dt_s / a.steps * 1e3, 'lanes': max(1, lanes_used),
+                         'launch_note': graph_note if dt_s is None else None,
+                         'kernel': 'igemm_split_kernel (csrc/igemm_split.hip): the launches the default mode gives to the dominant kernel, here with '
+                                   'fp32 operands split into three bf16 terms on their way into LDS and six v_mfma_f32_32x32x16_bf16 products per '
+                                   'K-slice (fp32 accumulate, hi*hi in an accumulator of its own)',
+                         'roofline': None if not per_s else {
+                             'bound': 'mfma', 'achieved': 6.0 * gf / ms_s, 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s (bf16 MFMA, executed: six products per fp32 product)',
+                             'frac': 6.0 * gf / ms_s / BF16_MFMA_PEAK_TFLOPS, 'fp32_equivalent_TFLOPs': gf / ms_s,
+                             'fp32_equivalent_over_fp32_mfma_peak': gf / ms_s / FP32_MFMA_PEAK_TFLOPS,
+                             'ms_per_step': ms_s / 3, 'launches_per_step': len(per_s) / 3, 'avg_launch_ms': ms_s / len(per_s),
+                             'note': 'fp32_equivalent_over_fp32_mfma_peak may exceed 1: these FLOPs do not run on the fp32 pipe -- it is NOT a roofline '
+                                     'fraction, `frac` (against the bf16 peak, six executed products per fp32 product) is'},
+                         'parity': 'tests/test_gpu_split.py (error against float64 <= the fp32 kernel\'s), tests/test_gpu_e2e.py [splitbf16]: golden RoIs / '
+                                   'detections of the reference bit for bit (one half-pixel tie of the bifpn variant, margin asserted)',
+                         'why_not_default': 'the contract metric is quoted on the reference\'s fp32 arithmetic; this form is fp32-accurate but sums in '
+                                            'another order on another pipe -- kept opt-in until a judge round has looked at it (DESIGN 4e)'}
+            graph_note = note0
+        except Exception as exc:                  # informational leg: never lose the headline line over it
+            split_leg = {'error': f'{type(exc).__name__}: {exc}'[:300]}
+        finally:
+            os.environ['NBM_SPLIT_BF16'] = '0'
+            ops.PROFILE, ops.PROFILE_ONLY = None, None
     ops.PROFILE = []                                           # one extra, untimed step with events around every GEMM-type launch
     ops.FLOPS = [0.0]                                          # ... and the executed-MFMA-FLOP counter of every GEMM launch
     step()
@@ -902,8 +957,9 @@ def main(argv=None):
                                        'hipGraph replay of the captured step') if dt_g is not None else (graph_note or 'eager loop')),
                            'lanes': lanes_used, 'launch_note': graph_note},
                 'eager_with_events': eager, 'single_lane_graph_replay': single_lane, 'multi_lane_graph_replay': multi_lane,
-                'roofline': roof, 'frontend': frontend, 'dense_finest_map': dense_ref, 'bulk_inference': bulk_leg,
-                'train_step': train, **dist_info}
+                'roofline': roof, 'split_bf16': split_leg, 'frontend': frontend, 'dense_finest_map': dense_ref, 'bulk_inference': bulk_leg,
+                'train_step': train, 'deep_k_gemm': 'fp32 matrix instruction (library default; NBM_SPLIT_BF16 pinned to 0 for every leg but `split_bf16`'
+                               + (f'; the caller had set it to {split_env_was!r}' if split_env_was not in (None, '0') else '') + ')', **dist_info}
         if world == 1 and not a.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -17,9 +17,10 @@
 //   * the six products of a stage run in ONE order (a0b0, a0b1, a1b0, a1b1, a0b2, a2b0), so only plane 0 needs a second fragment
 //     set: planes 1 and 2 of the next stage are read once their registers are dead (b1 / a1 after MFMA 32, b2 after 40, a2 at the
 //     start of the stage that uses it last);
-//   * the split is a stream of single vector instructions (11 per pair of floats) handed out three per MFMA gap, LDS and memory
-//     instructions at most two per gap: a 32x32x16 MFMA hides ~5 single-issue fillers of its own wave
-//     (/opt/skills/guides/MI355X_MICROARCH.md, cycle constants), and `sched_barrier` pins every gap.
+//   * the split is a stream of single vector instructions (11 per pair of floats); a stage's 48 MFMA gaps are three runs of 16, one per
+//     chunk of 8 floats: 11 gaps with four split instructions (and at most one fragment read), 3 with one plane write, 2 with one
+//     buffer load -- a 32x32x16 MFMA hides ~5 single-issue fillers of its own wave, a ds_write_b128 costs 13 cycles of issue
+//     (/opt/skills/guides/MI355X_MICROARCH.md, cycle constants) -- and `sched_barrier` pins every gap.
 // The gather (A from the NHWC activation, taps inner, channel chunks outer; W in KRSC) and the epilogue are those of igemm.hip.
 #include <stdlib.h>
 #include "nbm_common.h"
@@ -116,10 +117,12 @@ __global__ __launch_bounds__(256, 1) void igemm_split_kernel(const IgemmParams p
   int ld_t = 0, ld_r = 0, ld_s = 0, ld_c0 = 0;       // stage index, tap row / column, channel of the stage's first float
   unsigned ld_asoff = 0, ld_bsoff = 0; int ld_tap = 0;
   auto cursor_set = [&]() {
-    ld_tap = ld_r * p.kw + ld_s;
-    const bool live = ld_t < S;                       // past the end: every offset out of range (zeros, no memory access)
-    ld_asoff = live ? (unsigned)((((long long)ld_r * p.W + ld_s) * p.x_ld + ld_c0) * 4) : 0x80000000u;
-    ld_bsoff = live ? (unsigned)((ld_tap * p.Cin + ld_c0) * 4) : 0x80000000u;
+    // past the end (the last stages request data nobody splits): A offsets out of range through the tap test (bit 63 is never set; a
+    // buffer load's range check covers the per-lane offset only, NOT the scalar one), W reads its first K-slice again
+    const bool live = ld_t < S;
+    ld_tap = live ? ld_r * p.kw + ld_s : 63;
+    ld_asoff = live ? (unsigned)((((long long)ld_r * p.W + ld_s) * p.x_ld + ld_c0) * 4) : 0u;
+    ld_bsoff = live ? (unsigned)(((ld_r * p.kw + ld_s) * p.Cin + ld_c0) * 4) : 0u;
   };
   auto cursor_next = [&]() {
     ++ld_t;
@@ -208,22 +211,18 @@ __global__ __launch_bounds__(256, 1) void igemm_split_kernel(const IgemmParams p
       ([&] {
         constexpr int z = Z;
         mfma1(I<P>{}, I<z>{});
-        if constexpr (z < 2) { a2[2 * z] = rdA(bc, 2, 2 * z); a2[2 * z + 1] = rdA(bc, 2, 2 * z + 1); }
-        if constexpr (z >= 2 && z < 4) { a0[P ^ 1][2 * (z - 2)] = rdA(bn, 0, 2 * (z - 2)); a0[P ^ 1][2 * (z - 2) + 1] = rdA(bn, 0, 2 * (z - 2) + 1); }
-        if constexpr (z == 4) { b0[P ^ 1][0] = rdB(bn, 0, 0); b0[P ^ 1][1] = rdB(bn, 0, 1); }
+        // 16 gaps per chunk: 11 with four split micro-ops (+ at most one fragment read), 3 with one plane write, 2 with one buffer load
+        if constexpr (z < 4) a2[z] = rdA(bc, 2, z);
+        if constexpr (z >= 4 && z < 8) a0[P ^ 1][z - 4] = rdA(bn, 0, z - 4);
+        if constexpr (z >= 8 && z < 10) b0[P ^ 1][z - 8] = rdB(bn, 0, z - 8);
         if constexpr (z >= 32 && z < 34) b1[z - 32] = rdB(bn, 1, z - 32);
         if constexpr (z >= 34 && z < 38) a1[z - 34] = rdA(bn, 1, z - 34);
         if constexpr (z >= 40 && z < 42) b2[z - 40] = rdB(bn, 2, z - 40);
-        constexpr int u0 = 3 * z < UOPS ? 3 * z : UOPS, u1 = 3 * z + 3 < UOPS ? 3 * z + 3 : UOPS;
-        [&]<int... U>(std::integer_sequence<int, U...>) { (uop(I<R>{}, I<u0 + U>{}), ...); }(std::make_integer_sequence<int, u1 - u0>{});
-        // chunk c's last micro-op sits in gap (44 (c + 1) - 1) / 3: its plane writes in the three gaps behind, its two loads after those
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-          const int g0 = (44 * (c + 1) - 1) / 3 + 1;
-          if (z >= g0 && z < g0 + 3) pwrite(bw, c, z - g0);
-          if (c < CH - 1 && z >= g0 + 3 && z < g0 + 5) gload1(I<R>{}, c, z - g0 - 3);
-          if (c == CH - 1 && z >= g0 + 2 && z < g0 + 4) gload1(I<R>{}, c, z - g0 - 2);
-        }
+        constexpr int c = z / 16, q = z % 16;
+        if constexpr (q < 11)
+          [&]<int... U>(std::integer_sequence<int, U...>) { (uop(I<R>{}, I<44 * c + 4 * q + U>{}), ...); }(std::make_integer_sequence<int, 4>{});
+        if constexpr (q >= 11 && q < 14) pwrite(bw, c, q - 11);
+        if constexpr (q >= 14) gload1(I<R>{}, c, q - 14);
         __builtin_amdgcn_sched_barrier(0);
       }(), ...);
     }(std::make_integer_sequence<int, NM>{});

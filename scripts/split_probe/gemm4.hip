@@ -136,25 +136,21 @@ __global__ __launch_bounds__(256, 1) void gemm_split(const float* __restrict__ A
       ([&] {
         constexpr int z = Z;
         mfma1(I<P>{}, I<z>{});
+        // 16 gaps per chunk: 11 with four split micro-ops (+ at most one fragment read), 3 with one plane write, 2 with one global load
         if constexpr (!(ABL & 8) && NPROD == 6) {
-          if constexpr (z < 2) { a2[2 * z] = rdA(bc, 2, 2 * z); a2[2 * z + 1] = rdA(bc, 2, 2 * z + 1); }
-          if constexpr (z >= 2 && z < 4) { a0[P ^ 1][2 * (z - 2)] = rdA(bn, 0, 2 * (z - 2)); a0[P ^ 1][2 * (z - 2) + 1] = rdA(bn, 0, 2 * (z - 2) + 1); }
-          if constexpr (z == 4) { b0[P ^ 1][0] = rdB(bn, 0, 0); b0[P ^ 1][1] = rdB(bn, 0, 1); }
+          if constexpr (z < 4) a2[z] = rdA(bc, 2, z);
+          if constexpr (z >= 4 && z < 8) a0[P ^ 1][z - 4] = rdA(bn, 0, z - 4);
+          if constexpr (z >= 8 && z < 10) b0[P ^ 1][z - 8] = rdB(bn, 0, z - 8);
           if constexpr (z >= 32 && z < 34) b1[z - 32] = rdB(bn, 1, z - 32);
           if constexpr (z >= 34 && z < 38) a1[z - 34] = rdA(bn, 1, z - 34);
           if constexpr (z >= 40 && z < 42) b2[z - 40] = rdB(bn, 2, z - 40);
         }
         if constexpr (!(ABL & 4) && NPROD == 6) {
-          constexpr int u0 = 3 * z < UOPS ? 3 * z : UOPS, u1 = 3 * z + 3 < UOPS ? 3 * z + 3 : UOPS;
-          [&]<int... U>(std::integer_sequence<int, U...>) { (uop(I<R>{}, I<u0 + U>{}), ...); }(std::make_integer_sequence<int, u1 - u0>{});
-          // chunk c's last micro-op sits in gap (44 (c + 1) - 1) / 3: its plane writes in the three gaps behind, its two loads after those
-#pragma unroll
-          for (int c = 0; c < CH; ++c) {
-            const int g0 = (44 * (c + 1) - 1) / 3 + 1;
-            if (z >= g0 && z < g0 + 3) pwrite(bw, c, z - g0);
-            if (c < CH - 1 && z >= g0 + 3 && z < g0 + 5) gload1(s + 5, I<R>{}, c, z - g0 - 3);
-            if (c == CH - 1 && z >= g0 + 2 && z < g0 + 4) gload1(s + 5, I<R>{}, c, z - g0 - 2);
-          }
+          constexpr int c = z / 16, q = z % 16;
+          if constexpr (q < 11)
+            [&]<int... U>(std::integer_sequence<int, U...>) { (uop(I<R>{}, I<44 * c + 4 * q + U>{}), ...); }(std::make_integer_sequence<int, 4>{});
+          if constexpr (q >= 11 && q < 14) pwrite(bw, c, q - 11);
+          if constexpr (q >= 14) gload1(s + 5, I<R>{}, c, q - 14);
         }
         __builtin_amdgcn_sched_barrier(0);
       }(), ...);
