@@ -577,7 +577,8 @@ extern "C" int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream) {
     // Read per call: the parity tests flip it inside one process.  The choice depends on the LAYER (K, N), never on the number of rows:
     // a clip's result must not depend on how many clips share its batch (the two kernels sum in different orders).
     const char* split_env = getenv("NBM_SPLIT_BF16");
-    if (split_env && split_env[0] == '1' && fast && p.vec_epi && p.nk > 8 && d->kh * d->kw < 63)
+    static const int split_min_nk = getenv("NBM_SPLIT_MIN_NK") ? atoi(getenv("NBM_SPLIT_MIN_NK")) : 9;      // experiment switch (>= 3)
+    if (split_env && split_env[0] == '1' && fast && p.vec_epi && p.nk >= (split_min_nk < 3 ? 3 : split_min_nk) && d->kh * d->kw < 63)
       return nbm_igemm::split_launch(p, d->groups, st);
     // short K and a 16-byte epilogue: the three-workgroups-per-CU variant (see the template comment)
     static const int shortk_max = getenv("NBM_SHORTK_MAX") ? atoi(getenv("NBM_SHORTK_MAX")) : 8;   // 0 disables
