@@ -84,6 +84,10 @@ typedef struct nbm_gemm_desc {
   int rows_mode, rows_count, rows_TH, rows_TW;
 } nbm_gemm_desc;
 
+/* Environment switch, read on every call: NBM_SPLIT_BF16=1 runs the deep-K launches (K = kh*kw*Cin > 256, N > 64, Cin % 32 == 0,
+ * 16-byte epilogue; chosen by the LAYER, never by the number of rows) on the bf16 matrix pipe with each fp32 operand split into three
+ * bf16 terms and six products accumulated in fp32 (csrc/igemm_split.hip): same interface, fp32-accurate results in another
+ * summation order.  Default: the fp32 matrix instruction. */
 int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream);
 
 /* Winograd transforms for 3x3 / stride 1 / pad 1 convolutions (the FPN output convolutions, fpn.py:137,145, and their data /
