@@ -751,6 +751,19 @@ def main(argv=None):
     multi_lane = None if dt_g2 is None else {'lanes': n_lanes, 'ms_per_step': dt_g2 / a.steps * 1e3, 'clips_per_s_per_gpu': B * a.steps / dt_g2}
     if dt_g is not None:
         dt = dt_g
+    def gemm_gflop(tag):
+        Cin, N, k, H, W, Bn, groups, stride = tag[:8]
+        if len(tag) == 9 and isinstance(tag[8], tuple) and tag[8][0] == 'rpn-composite':      # k taps x 1, one output row: W cells
+            return 2.0 * W * N * Cin * k * groups / 1e9
+        return 2.0 * Bn * ((H - 1) // stride + 1) * ((W - 1) // stride + 1) * N * Cin * k * k * groups / 1e9
+
+    def what(tag):
+        Cin, N, k, H, W, Bn, groups, stride, label = tag
+        g = f' x{groups} groups' if groups > 1 else ''
+        lab = f' [{label[0]} {label[1]}x{label[2]}]' if isinstance(label, tuple) else ''
+        if isinstance(label, tuple) and label[0] == 'rpn-composite':
+            return f'{k} taps x {Cin}->{N} over {W} cells{lab}'
+        return f'{k}x{k} s{stride} {Cin}->{N} @{H}x{W} B={Bn}{g}{lab}'
     # ---- opt-in mode, measured beside the headline (never IN it): the same step with every deep-K implicit GEMM on the bf16 matrix pipe
     # through split fp32 operands (x = hi + mid + lo, six products, two fp32 accumulators: csrc/igemm_split.hip; error against float64
     # <= the fp32 instruction's, asserted in tests/test_gpu_split.py).  Single-rank runs only, like the dense leg.
@@ -773,7 +786,7 @@ def main(argv=None):
             gc.collect()
             torch.cuda.empty_cache()
             per_s = [(tag, s_.elapsed_time(e_)) for (tag, s_, e_) in prof_s if len(tag) == 9 and ops.is_deepk(tag[0], tag[1], tag[2], tag[2])]
-            gf = sum(2.0 * t[5] * ((t[3] - 1) // t[7] + 1) * ((t[4] - 1) // t[7] + 1) * t[1] * t[0] * t[2] * t[2] * t[6] / 1e9 for t, _ in per_s)
+            gf = sum(gemm_gflop(t) for t, _ in per_s)
             ms_s = sum(m for _, m in per_s)
             split_leg = {'default': False, 'switch': 'NBM_SPLIT_BF16=1 (read per call by nbm_gemm_conv)',
                          'value': None if dt_s is None else B * a.steps / dt_s, 'unit': 'clips/s',
@@ -841,15 +854,6 @@ def main(argv=None):
     # with K > 256, the attention GEMMs, the FPN laterals of levels 1-4 and the 25 grouped plane GEMMs of the cell transforms
     # (FPN levels 0 and 1 on demand).  `achieved` = MFMA FLOPs these launches EXECUTE (2 * M * N * K * groups) over their HIP-event
     # time on the launch stream inside the timed loop; avg_launch_ms is what rocprofv3 --stats reports as the kernel's average.
-    def gemm_gflop(tag):
-        Cin, N, k, H, W, Bn, groups, stride = tag[:8]
-        return 2.0 * Bn * ((H - 1) // stride + 1) * ((W - 1) // stride + 1) * N * Cin * k * k * groups / 1e9
-
-    def what(tag):
-        Cin, N, k, H, W, Bn, groups, stride, label = tag
-        g = f' x{groups} groups' if groups > 1 else ''
-        lab = f' [{label[0]} {label[1]}x{label[2]}]' if isinstance(label, tuple) else ''
-        return f'{k}x{k} s{stride} {Cin}->{N} @{H}x{W} B={Bn}{g}{lab}'
     deep = [(tag, s.elapsed_time(e)) for (tag, s, e) in prof if len(tag) == 9 and ops.is_deepk(tag[0], tag[1], tag[2], tag[2])]
     all_ms = sum(s.elapsed_time(e) for (tag, s, e) in prof_all if len(tag) == 9)
     fused_ms = sum(s.elapsed_time(e) for (tag, s, e) in prof_all

@@ -132,6 +132,8 @@ SIGNATURES = {
     'nbm_cell_weight_grad': [_P, _I, _I, _I, _P, _P],
     'nbm_cell_input': [_P, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     'nbm_cell_input_up': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P],
+    'nbm_cell_patches': [_P, _I, _I, _I, _I, _I, _P, _I, _I, _P],
+    'nbm_cell_patches_up': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P],
     'nbm_cell_dgrad_output': [_P, _I, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P],
     'nbm_cell_output': [_P, _P, _I, _I, _I, _I, _I, _P, _P],
     'nbm_weighted_sum': [_P, _P, _P, _P, _P, _L, _P],

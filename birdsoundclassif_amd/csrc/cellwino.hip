@@ -102,6 +102,9 @@ __global__ __launch_bounds__(256) void cell_outgrad_kernel(const float* __restri
 // x [B][H][W][C] -> Vx [25][T][C] = Vinv^T patch Vinv per cell (5x5 patch, rows S*oy-2 .. S*oy+2; outside the image = the
 // convolution's zero padding)
 // ld4 / coff4 (in 16-byte units): row pitch of Vx and the channel offset this call writes at -- two sources can fill one operand
+// RAW: the patch itself, plane a * 5 + l = patch pixel (row a, column l) -- the operand of a 5x5 / stride S convolution written as 25
+// taps of a [25][T][K] tensor (the RPN's strided reader composed with the output convolution in front of it: ondemand.rpn_composite)
+template <bool RAW>
 __global__ __launch_bounds__(256) void cell_input_kernel(const float* __restrict__ x, const CellGeom q, float* __restrict__ Vx, int ld4,
                                                          int coff4) {
   const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
@@ -126,11 +129,16 @@ __global__ __launch_bounds__(256) void cell_input_kernel(const float* __restrict
         const int xx = q.S * ox - 2 + l;
         const bool ok = (unsigned)y < (unsigned)q.H && (unsigned)xx < (unsigned)q.W;
         const f32x4 v = ok ? x4[(((long long)b * q.H + y) * q.W + xx) * q.C4 + c] : zero;
+        if constexpr (RAW) {
+          v4[((long long)(j * NP + l) * q.T + cell) * ld4 + coff4 + c] = v;
+        } else {
 #pragma unroll
-        for (int a = 0; a < NP; ++a)
-          if (CV[j][a] != 0.f) t[a][l] += CV[j][a] * v;
+          for (int a = 0; a < NP; ++a)
+            if (CV[j][a] != 0.f) t[a][l] += CV[j][a] * v;
+        }
       }
     }
+    if constexpr (RAW) continue;
 #pragma unroll
     for (int a = 0; a < NP; ++a)
 #pragma unroll
@@ -147,6 +155,7 @@ __global__ __launch_bounds__(256) void cell_input_kernel(const float* __restrict
 // The same transform of a patch that is not in memory: patch pixel = bilinear_align_corners(x1)[pixel] + bias (the top-down merge of
 // fpn.py:143-144 without the lateral term, which enters the plane GEMMs through its own 64-channel operand), 0 outside the image.
 // x1 [B][Hc][Wc][C]; same interpolation arithmetic as the merge epilogue of igemm.hip.
+template <bool RAW>
 __global__ __launch_bounds__(256) void cell_input_up_kernel(const float* __restrict__ x1, const float* __restrict__ bias, const CellGeom q,
                                                             int Hc, int Wc, float sh, float sw, float* __restrict__ Vx, int ld4, int coff4) {
 #pragma clang fp contract(off)
@@ -195,11 +204,16 @@ __global__ __launch_bounds__(256) void cell_input_up_kernel(const float* __restr
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           v[e] = ok ? (hy * (hx * v00[l][e] + lx * v01[l][e]) + ly * (hx * v10[l][e] + lx * v11[l][e])) + bv[e] : 0.f;
+        if constexpr (RAW) {
+          v4[((long long)(j * NP + l) * q.T + cell) * ld4 + coff4 + c] = v;
+        } else {
 #pragma unroll
-        for (int a = 0; a < NP; ++a)
-          if (CV[j][a] != 0.f) t[a][l] += CV[j][a] * v;
+          for (int a = 0; a < NP; ++a)
+            if (CV[j][a] != 0.f) t[a][l] += CV[j][a] * v;
+        }
       }
     }
+    if constexpr (RAW) continue;
 #pragma unroll
     for (int a = 0; a < NP; ++a)
 #pragma unroll
@@ -465,7 +479,7 @@ extern "C" int nbm_cell_input(const float* x, int B, int H, int W, int C, int st
   CellGeom q;
   if (!x || !Vx || !cell_geom(B, H, W, C, stride, q) || ld < c_off + C || c_off < 0) return NBM_EINVAL;
   if (!nbm_aligned16(x) || !nbm_aligned16(Vx) || (ld & 3) || (c_off & 3)) return NBM_EALIGN;
-  hipLaunchKernelGGL(cell_input_kernel, dim3(stream_grid(q.T * q.C4, q.C4)), dim3(256), 0, (hipStream_t)stream, x, q, Vx, ld / 4,
+  hipLaunchKernelGGL(cell_input_kernel<false>, dim3(stream_grid(q.T * q.C4, q.C4)), dim3(256), 0, (hipStream_t)stream, x, q, Vx, ld / 4,
                      c_off / 4);
   return nbm_launch_status();
 }
@@ -476,8 +490,28 @@ extern "C" int nbm_cell_input_up(const float* x1, const float* bias, int B, int 
   if (!x1 || !Vx || !cell_geom(B, H, W, C, stride, q) || Hc <= 0 || Wc <= 0 || ld < c_off + C || c_off < 0) return NBM_EINVAL;
   if (!nbm_aligned16(x1) || !nbm_aligned16(Vx) || (bias && !nbm_aligned16(bias)) || (ld & 3) || (c_off & 3)) return NBM_EALIGN;
   const float sh = H > 1 ? (float)(Hc - 1) / (float)(H - 1) : 0.f, sw = W > 1 ? (float)(Wc - 1) / (float)(W - 1) : 0.f;
-  hipLaunchKernelGGL(cell_input_up_kernel, dim3(stream_grid(q.T * q.C4, q.C4)), dim3(256), 0, (hipStream_t)stream, x1, bias, q, Hc, Wc, sh,
+  hipLaunchKernelGGL(cell_input_up_kernel<false>, dim3(stream_grid(q.T * q.C4, q.C4)), dim3(256), 0, (hipStream_t)stream, x1, bias, q, Hc, Wc, sh,
                      sw, Vx, ld / 4, c_off / 4);
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_cell_patches(const float* x, int B, int H, int W, int C, int stride, float* Vx, int ld, int c_off, void* stream) {
+  CellGeom q;
+  if (!x || !Vx || !cell_geom(B, H, W, C, stride, q) || ld < c_off + C || c_off < 0) return NBM_EINVAL;
+  if (!nbm_aligned16(x) || !nbm_aligned16(Vx) || (ld & 3) || (c_off & 3)) return NBM_EALIGN;
+  hipLaunchKernelGGL(cell_input_kernel<true>, dim3(stream_grid(q.T * q.C4, q.C4)), dim3(256), 0, (hipStream_t)stream, x, q, Vx, ld / 4,
+                     c_off / 4);
+  return nbm_launch_status();
+}
+
+extern "C" int nbm_cell_patches_up(const float* x1, const float* bias, int B, int H, int W, int C, int Hc, int Wc, int stride, float* Vx,
+                                   int ld, int c_off, void* stream) {
+  CellGeom q;
+  if (!x1 || !Vx || !cell_geom(B, H, W, C, stride, q) || Hc <= 0 || Wc <= 0 || ld < c_off + C || c_off < 0) return NBM_EINVAL;
+  if (!nbm_aligned16(x1) || !nbm_aligned16(Vx) || (bias && !nbm_aligned16(bias)) || (ld & 3) || (c_off & 3)) return NBM_EALIGN;
+  const float sh = H > 1 ? (float)(Hc - 1) / (float)(H - 1) : 0.f, sw = W > 1 ? (float)(Wc - 1) / (float)(W - 1) : 0.f;
+  hipLaunchKernelGGL(cell_input_up_kernel<true>, dim3(stream_grid(q.T * q.C4, q.C4)), dim3(256), 0, (hipStream_t)stream, x1, bias, q, Hc, Wc,
+                     sh, sw, Vx, ld / 4, c_off / 4);
   return nbm_launch_status();
 }
 

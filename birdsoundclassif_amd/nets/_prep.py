@@ -143,6 +143,67 @@ def bn_affine(weight, bias, mean, var, eps, conv_bias=None):
     return _cached(weight, ('bn', conv_bias is not None), make, extra=extra)
 
 
+def _rpn_composite64(out_w, out_b, dw_w, dw_b, pt_w, rmask, smask, lat_wk, alpha):
+    """float64: (W_eff [N][5][5][K], const [N]) of `rpn_composite` for one class of cells."""
+    n1, c = out_w.shape[0], out_w.shape[1]
+    m_ = dw_w.shape[0]
+    mult = m_ // n1
+    wo = out_w.detach().double().repeat_interleave(mult, 0)              # [M, C, 3, 3]: depthwise channel m reads out_conv channel m // mult
+    wd = dw_w.detach().double().reshape(m_, 3, 3)
+    bo = (out_b.detach().double() if out_b is not None else torch.zeros(n1, dtype=torch.float64, device=out_w.device)).repeat_interleave(mult)
+    d = torch.zeros((m_, c, 5, 5), dtype=torch.float64, device=out_w.device)
+    cb = torch.zeros((m_,), dtype=torch.float64, device=out_w.device)
+    for r in range(3):
+        for s_ in range(3):
+            if (rmask >> r) & 1 and (smask >> s_) & 1:
+                d[:, :, r:r + 3, s_:s_ + 3] += wd[:, r, s_, None, None, None] * wo
+                cb += wd[:, r, s_] * bo
+    if dw_b is not None:
+        cb += dw_b.detach().double()
+    wp = pt_w.detach().double().reshape(pt_w.shape[0], m_)
+    we = torch.einsum('nm,mcae->naec', wp, d)                            # [N, 5, 5, C]
+    const = wp @ cb
+    if lat_wk is not None:
+        wl = lat_wk.detach().double()                                    # [C, Cin]
+        we = torch.cat([we, float(alpha) * torch.einsum('naec,ci->naei', we, wl)], -1)
+    return we, const
+
+
+def _rpn_extra(out_b, dw_w, dw_b, pt_w, scale, shift, lat_wk, alpha):
+    others = [t for t in (out_b, dw_w, dw_b, pt_w, scale, shift, lat_wk) if t is not None]
+    return tuple(v for t in others for v in (t.data_ptr(), t._version)) + (float(alpha),)
+
+
+def rpn_composite(out_w, out_b, dw_w, dw_b, pt_w, scale, shift, lat_wk=None, alpha=1.0):
+    """The RPN's strided reader composed with the output convolution in front of it (evaluation mode): fpn.py:137,145 `out_conv`
+    (3x3 / pad 1, linear) -> layers.py:22-29 depthwise 3x3 / stride S / pad 1 (channel multiplier m) -> 1x1 -> BatchNorm (running
+    statistics) -> SiLU is ONE 5x5 / stride S / pad 2 convolution of the merged map followed by scale / shift / SiLU:
+        W_eff[n][a, e][c] = sum_m pt[n][m] sum_{r + u = a, s + v = e} dw[m][r, s] out_w[m // mult][c][u, v]
+        const[n]          = sum_m pt[n][m] (sum_{r, s} dw[m][r, s] out_b[m // mult] + dw_b[m])
+    `lat_wk` [C][Cin] (+ alpha): the lateral 1x1 in front of out_conv was deferred, the patches are [up(x1) + b | t] and the weights
+    [W_eff | alpha W_eff W_lat].  `scale`, `shift`: `bn_affine` of the block (1x1 bias folded in).
+    -> (w [N][25 * K] tap-major, scale [N], shift' [N] = scale * const + shift) for the cells whose nine depthwise taps all lie inside
+    the map; float64 arithmetic, once per weight version.  Border cells: `rpn_composite_delta`."""
+    def make():
+        we, const = _rpn_composite64(out_w, out_b, dw_w, dw_b, pt_w, 7, 7, lat_wk, alpha)
+        return we.reshape(we.shape[0], -1).float().contiguous(), scale, (scale.double() * const + shift.double()).float().contiguous()
+    return _cached(out_w, ('rpnc', lat_wk is not None), make, extra=_rpn_extra(out_b, dw_w, dw_b, pt_w, scale, shift, lat_wk, alpha))
+
+
+def rpn_composite_delta(out_w, out_b, dw_w, dw_b, pt_w, scale, shift, rmask, smask, taps, lat_wk=None, alpha=1.0):
+    """Border cells of `rpn_composite`: the depthwise convolution pads the OUTPUT of out_conv with zeros, which a padded 5x5 convolution
+    of the input does not reproduce -- a cell whose depthwise tap rows / columns are not all inside the map (`rmask` / `smask`: bit set =
+    inside) has weights of its own.  -> (dw [N][len(taps) * K], dshift [N]): W_class - W_interior on the listed patch taps (a * 5 + e;
+    the caller lists those where the difference is not zero and the patch can hold data) and scale * (const_class - const_interior)."""
+    def make():
+        we, const = _rpn_composite64(out_w, out_b, dw_w, dw_b, pt_w, rmask, smask, lat_wk, alpha)
+        wi, ci = _rpn_composite64(out_w, out_b, dw_w, dw_b, pt_w, 7, 7, lat_wk, alpha)
+        d = (we - wi).reshape(we.shape[0], 25, -1)[:, list(taps)]
+        return d.reshape(d.shape[0], -1).float().contiguous(), (scale.double() * (const - ci)).float().contiguous()
+    return _cached(out_w, ('rpnd', int(rmask), int(smask), tuple(taps), lat_wk is not None), make,
+                   extra=_rpn_extra(out_b, dw_w, dw_b, pt_w, scale, shift, lat_wk, alpha))
+
+
 def cat_rows(tag, *tensors):
     """Concatenate several [Ni, K] weight matrices (or [Ni] biases) along dim 0, cached on the first."""
     def make():

@@ -238,7 +238,7 @@ class Conv(Function):
             y, ctx.lazy = ondemand.conv3x3_winograd_lazy(x, _prep.wino23(weight), sh, lazy_stride[0],
                                                          _prep.cell_weight(weight, forward=True) if ondemand.CELL_FWD else None,
                                                          fold=lambda wk, alpha, transposed=False: _prep.cell_weight_folded(weight, wk, alpha, transposed),
-                                                         keep=lazy_stride[1])
+                                                         keep=lazy_stride[1], raw=(weight, bias))
         elif lazy_stride and kh == 1:
             # the lateral 1x1 (+ top-down merge) in front of a demand-driven 3x3: only the pixels that convolution reads
             # deferred: write nothing, the consumer takes t / up / the weights into its cell-domain GEMMs -- provided its backward

@@ -53,6 +53,7 @@ class DepthwiseSepConv2d(nn.Module):
         train: batch statistics (nn.BatchNorm2d semantics) through the differentiable ops."""
         st = int(max(1, self.stride))
         if self.training:
+            ondemand.pattern_materialize(x)          # (a no-grad pass in training mode left the map's pattern pixels pending)
             if self.stride < 1:
                 size = ((1 / self.stride) * np.array(x.shape[1:3])).astype(np.int64).tolist()
                 x = Fn.UpsampleAdd.apply(x, None, size[0], size[1])
@@ -65,6 +66,13 @@ class DepthwiseSepConv2d(nn.Module):
             out = Fn.BatchNormTrain.apply(out, self.norm.weight, self.norm.bias, self.norm.running_mean,
                                           self.norm.running_var, self.norm.eps, self.norm.momentum)
             return Fn.Silu.apply(out)
+        if pe_act is None and self.stride >= 1:
+            # a demand-driven FPN map read for the first time (evaluation mode): this block composed with the map's own convolution is
+            # one 5x5 / stride convolution of that convolution's input -- the map's pattern pixels are never formed
+            f = ondemand.rpn_composite(x, self, _prep)
+            if f is not None:
+                return f
+        ondemand.pattern_materialize(x)              # (no-op unless x is such a map and this block could not take it)
         if self.stride < 1:
             size = ((1 / self.stride) * np.array(x.shape[1:3])).astype(np.int64).tolist()
             x = ops.upsample_bilinear_add(x, size[0], size[1])

@@ -186,7 +186,7 @@ class LazyMap:
     12 GB alive until the garbage collector runs); its consumers keep it alive and hand it back to `lazy_complete`.
     The operands stay here for as long as the map lives, so EVERY RoI pooling on the map -- not only the first -- finds the
     tiles under its windows computed (`done` counts them); the state goes when the map does (`_forget`)."""
-    __slots__ = ('x', 'U', 'bias', 'skip', 'stride', 'chunks', 'roi', 'keep', 'sparse', 'overlap', 'lateral', 'rois', 'done', 'vg', 'cell_gb', 'cell_gb_done', 'vx', '__weakref__')
+    __slots__ = ('x', 'U', 'bias', 'skip', 'stride', 'chunks', 'roi', 'keep', 'sparse', 'overlap', 'lateral', 'rois', 'done', 'vg', 'cell_gb', 'cell_gb_done', 'vx', 'raw', 'pending', '__weakref__')
 
     def __init__(self, x, U, bias, stride):
         self.x, self.U, self.bias, self.stride = x, U, bias, stride
@@ -199,10 +199,12 @@ class LazyMap:
         self.cell_gb = None     # ... and the bias gradient of the pattern pixels, summed by the same kernel
         self.cell_gb_done = None    # chunks whose pattern pixels are in cell_gb already (a chunk's Vg may be computed twice)
         self.vx = None          # deferred lateral + a backward pass to come: {chunk: [transform(up + b) | transform(t)]} of the forward pass
+        self.raw = None         # (weight, bias) of the convolution as the module holds them (rpn_composite)
+        self.pending = None     # evaluation mode: the pattern pass was NOT run (Ucell, Ufold) -- rpn_composite or pattern_materialize
 
     def release(self):
         """Called by the backward pass of the convolution: no RoI pooling can follow on a map whose gradient has been consumed."""
-        self.x = self.U = self.bias = self.lateral = self.vg = self.cell_gb = self.cell_gb_done = self.vx = None
+        self.x = self.U = self.bias = self.lateral = self.vg = self.cell_gb = self.cell_gb_done = self.vx = self.raw = self.pending = None
 
     def __del__(self):          # the pinned counters go back to the pool
         try:
@@ -343,7 +345,10 @@ def _cell_operand(st, b0, nb, H, W, C_, x, n_out=0, ci=None):
     return V, M, C_, T
 
 
-def conv3x3_winograd_lazy(x, U, bias, stride, Ucell=None, fold=None, keep=False):
+COMPOSITE = os.environ.get('NBM_RPN_COMPOSITE', '1') != '0'     # evaluation mode: the RPN's reader composed with this convolution (rpn_composite)
+
+
+def conv3x3_winograd_lazy(x, U, bias, stride, Ucell=None, fold=None, keep=False, raw=None):
     """Finest-level output convolution, pattern tiles only (see above) -> (y [B,H,W,N] with the other pixels unwritten,
     LazyMap).  `Ucell` (_prep.cell_weight(w, forward=True)): the pattern pixels through the cell transforms (F(3x3,3x3) per
     stride x stride cell: 25 plane products per cell instead of the ~49 of the listed F(2x2,3x3) tiles) -- exactly the 9 / 64
@@ -369,6 +374,12 @@ def conv3x3_winograd_lazy(x, U, bias, stride, Ucell=None, fold=None, keep=False)
         st.lateral.ufold_t = fold(st.lateral.wk, st.lateral.alpha, transposed=True)      # same cache entry, [25][C + Cin][N]
     img_bytes = H * W * N * 4
     chunk = lazy_chunk(x)
+    st.raw = raw
+    # evaluation mode: the one reader of the pattern pixels, the RPN's depthwise-separable block, takes this convolution INTO its own
+    # (rpn_composite): the pattern pass waits until somebody asks (the block, or pattern_materialize for any other reader)
+    defer_pattern = bool(COMPOSITE and cell_ok and raw is not None and not st.keep and not torch.is_grad_enabled())
+    if defer_pattern:
+        st.pending = (Ucell, Ufold)
     for ci, b0 in enumerate(range(0, B, chunk)):
         nb = min(chunk, B - b0)
         pat = wino23_pattern(nb, H, W, stride, x.device)
@@ -378,6 +389,9 @@ def conv3x3_winograd_lazy(x, U, bias, stride, Ucell=None, fold=None, keep=False)
         # stride 3 / 4: no tile is free of pattern pixels, but the gradient still lives on 9 / S^2 of the pixels (+ the RoI windows):
         # the cell transforms take that share (overlapping 5x5 patches, added class by class), the listed kernel the RoI share
         st.overlap = bool(not st.sparse and cell_ok and CELL_BWD and 3 <= stride < 5 and N % 32 == 0)
+        if cell_ok and defer_pattern:
+            st.skip = None
+            continue
         if cell_ok:                                  # (3x3 blocks of different cells never overlap)
             stream = _stream()
             Vx, M, K, T = _cell_operand(st, b0, nb, H, W, C_, x, n_out=N, ci=ci)
@@ -400,6 +414,130 @@ def conv3x3_winograd_lazy(x, U, bias, stride, Ucell=None, fold=None, keep=False)
     _LAZY[y.data_ptr()] = (st, weakref.ref(y))      # valid while the map object itself (or a view of it) is alive
     weakref.finalize(y, _forget, _LAZY, y.data_ptr(), id(st))     # ... and gone with it (operands included)
     return y, st
+
+
+def pattern_materialize(fm):
+    """Run the pattern pass of a demand-driven map whose pass was left pending (evaluation mode, see conv3x3_winograd_lazy): the 9
+    pattern pixels of every cell through the cell transforms, into `fm`.  No-op for every other tensor."""
+    st = lazy_state(fm)
+    if st is None or st.pending is None:
+        return
+    Ucell, Ufold = st.pending
+    st.pending = None
+    B, H, W, N = fm.shape
+    C_ = st.x.shape[-1]
+    img_bytes = H * W * N * 4
+    stream = _stream()
+    for ci, (b0, nb, pat) in enumerate(st.chunks):
+        Vx, M, K, T = _cell_operand(st, b0, nb, H, W, C_, st.x, n_out=N, ci=ci)
+        gemm_conv(Vx, Ufold if Ufold is not None else Ucell, M, B=1, H=T, W=1, Cin=K, N=N, groups=25, x_gs=T * K, w_gs=N * K, y_gs=T * N)
+        check(lib().nbm_cell_output(_ptr(M), _ptr(st.bias), nb, H, W, N, st.stride, C.c_void_p(fm.data_ptr() + b0 * img_bytes), stream),
+              'nbm_cell_output')
+
+
+_BORDER_IDX = {}
+
+
+def _border_classes(nb, H, W, S, device):
+    """Cells whose depthwise taps do not all lie inside the map, grouped by (row mask, column mask)
+    -> [(rmask, smask, taps: patch taps a * 5 + e where the class's weights differ from the interior's AND the patch can hold data,
+         tap index tensor [nt, 1], cell index tensor [Tb])]."""
+    key = (nb, H, W, S, str(device))
+    hit = _BORDER_IDX.get(key)
+    if hit is None:
+        OH, OW = (H - 1) // S + 1, (W - 1) // S + 1
+        rm = [sum(1 << r for r in range(3) if 0 <= S * oy - 1 + r < H) for oy in range(OH)]
+        sm = [sum(1 << s_ for s_ in range(3) if 0 <= S * ox - 1 + s_ < W) for ox in range(OW)]
+        cls = {}
+        for oy in range(OH):
+            for ox in range(OW):
+                if (rm[oy], sm[ox]) != (7, 7):
+                    cls.setdefault((rm[oy], sm[ox]), []).append((oy, ox))
+        hit = []
+        for (r_, s_), cells in sorted(cls.items()):
+            live_a = {a for oy, _ in cells for a in range(5) if 0 <= S * oy - 2 + a < H}
+            live_e = {e for _, ox in cells for e in range(5) if 0 <= S * ox - 2 + e < W}
+            dropped = [(r, c) for r in range(3) for c in range(3) if not ((r_ >> r) & 1 and (s_ >> c) & 1)]
+            taps = [a * 5 + e for a in sorted(live_a) for e in sorted(live_e) if any(0 <= a - r <= 2 and 0 <= e - c <= 2 for r, c in dropped)]
+            lin = np.array(sorted(oy * OW + ox for oy, ox in cells), dtype=np.int64)
+            idx = (np.arange(nb, dtype=np.int64)[:, None] * (OH * OW) + lin[None, :]).reshape(-1)
+            hit.append((r_, s_, tuple(taps), torch.tensor(taps, dtype=torch.int64, device=device)[:, None], torch.from_numpy(idx).to(device)))
+        _BORDER_IDX[key] = hit
+    return hit
+
+
+def rpn_composite(fm, block, prep):
+    """Evaluation mode: the output of `block` (layers.DepthwiseSepConv2d, the RPN's reader of the map: depthwise 3x3 / stride S ->
+    1x1 -> BatchNorm -> SiLU) on the demand-driven map `fm` WITHOUT the map's pattern pixels: the block composed with the map's own
+    3x3 convolution is one 5x5 / stride S convolution of the convolution's INPUT (`_prep.rpn_composite`), evaluated as an implicit
+    GEMM over the raw 5x5 patches (nbm_cell_patches: [25][cells][K], 25 taps of K channels; deferred lateral: [up(x1) + b | t]) --
+    the same 25 K N products per cell as the cell transforms' plane GEMMs, but no input transform arithmetic, no 25-plane intermediate,
+    no output transform, no depthwise pass and no 1x1 behind it.  Border cells (a depthwise tap in the zero padding of the map) differ
+    from the interior in a handful of taps: their difference goes in front, through the residual input of the first launch.
+    -> [B, OH, OW, N], or None when `fm` is not a map with a pending pattern pass."""
+    st = lazy_state(fm)
+    if st is None or st.pending is None or st.raw is None:
+        return None
+    S = st.stride
+    if int(max(1, block.stride)) != S or block.stride < 1 or getattr(block, 'pe_proj', None) is not None:
+        return None
+    B, H, W, _ = fm.shape
+    C_ = st.x.shape[-1]
+    lt = st.lateral if st.lateral is not None and st.lateral.deferred else None
+    K = C_ + (lt.t.shape[-1] if lt is not None else 0)
+    OH, OW = (H - 1) // S + 1, (W - 1) // S + 1
+    out_w, out_b = st.raw
+    scale, shift = prep.bn_affine(block.norm.weight, block.norm.bias, block.norm.running_mean, block.norm.running_var, block.norm.eps,
+                                  conv_bias=block.pt_wise.bias)
+    N2 = block.pt_wise.weight.shape[0]
+    wargs = (out_w, out_b, block.depth_wise.weight, block.depth_wise.bias, block.pt_wise.weight, scale, shift)
+    wkw = dict(lat_wk=lt.wk[:, :lt.t.shape[-1]] if lt is not None else None, alpha=lt.alpha if lt is not None else 1.0)
+    w, sc, sh = prep.rpn_composite(*wargs, **wkw)
+    f = torch.empty((B, OH, OW, N2), device=fm.device, dtype=torch.float32)
+    stream = _stream()
+    keep_label, ops._PROFILE_LABEL = ops._PROFILE_LABEL, ('rpn-composite', H, W)
+    try:
+        for (b0, nb, pat) in st.chunks:
+            T = nb * OH * OW
+            V = ops._wino_scratch(fm.device, 25 * T * K, 0)[0]
+            if lt is not None:
+                Cin = lt.t.shape[-1]
+                check(lib().nbm_cell_patches_up(_ptr(lt.up[b0:b0 + nb]), _ptr(lt.bias), nb, H, W, C_, lt.up.shape[1], lt.up.shape[2], S, _ptr(V),
+                                                K, 0, stream), 'nbm_cell_patches_up')
+                check(lib().nbm_cell_patches(_ptr(lt.t[b0:b0 + nb]), nb, H, W, Cin, S, _ptr(V), K, C_, stream), 'nbm_cell_patches')
+            else:
+                check(lib().nbm_cell_patches(_ptr(st.x[b0:b0 + nb]), nb, H, W, C_, S, _ptr(V), K, 0, stream), 'nbm_cell_patches')
+            fc = f[b0:b0 + nb]
+            # border classes first: scale * (W_class - W_interior) . patch + scale * (const_class - const_interior) of their cells, a few
+            # taps each, scattered into an otherwise zero [T, N] tensor that the first launch below adds
+            border = _border_classes(nb, H, W, S, fm.device)
+            R = None
+            if border:
+                R = torch.zeros((T, N2), device=fm.device, dtype=torch.float32)
+                Vv = V[:25 * T * K].view(25, T, K)
+                for rmask, smask, taps, tap_idx, idx in border:
+                    if not taps:
+                        continue
+                    dwt, dsh = prep.rpn_composite_delta(*wargs, rmask, smask, taps, **wkw)
+                    Vb = Vv[tap_idx, idx[None, :]]                      # [taps, cells of the class, K], gathered
+                    Tb, nt = idx.numel(), len(taps)
+                    fb = torch.empty((Tb, N2), device=fm.device, dtype=torch.float32)
+                    gemm_conv(Vb, dwt, fb, B=1, H=nt, W=Tb, Cin=K, N=N2, kh=nt, kw=1, Ho=1, Wo=Tb, x_ld=K, w_ld=nt * K, scale=sc, shift=dsh)
+                    R.index_copy_(0, idx, fb)
+            # One launch per patch ROW (5 taps x K), chained through the residual input (y = scale * acc + [shift + R | y]; SiLU on the
+            # last): a single fmaf chain over all 25 K products rounds 25 K times against a running sum that has grown to the whole result
+            # -- measured 1.5 x the rms error of the route through the pattern pixels (25 sums of K); five chains of 5 K are below it.  It
+            # also keeps a tap's plane offset ((tap index) x T x K floats) inside the 2 GB window of a buffer resource.
+            ppl = max(1, min(5, ((1 << 31) - (1 << 24)) // (T * K * 4)))
+            for p0 in range(0, 25, ppl):
+                npl = min(ppl, 25 - p0)
+                res = fc if p0 else R
+                gemm_conv(V[p0 * T * K:], w[:, p0 * K:], fc, B=1, H=npl, W=T, Cin=K, N=N2, kh=npl, kw=1, Ho=1, Wo=T, x_ld=K, w_ld=25 * K,
+                          scale=sc, shift=sh if p0 == 0 else None, residual=res, res_ld=N2 if res is not None else None,
+                          act=ops.ACT_SILU if p0 + npl == 25 else ops.ACT_NONE)
+    finally:
+        ops._PROFILE_LABEL = keep_label
+    return f
 
 
 def lazy_state(fm):

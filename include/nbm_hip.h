@@ -202,6 +202,13 @@ int nbm_cell_input(const float* x, int B, int H, int W, int C, int stride, float
  * top-down merge of fpn.py:143-144 without its lateral term), 0 outside the image */
 int nbm_cell_input_up(const float* x1, const float* bias, int B, int H, int W, int C, int Hc, int Wc, int stride, float* Vx, int ld,
                       int c_off, void* stream);
+/* The untransformed forms: Vx [25][cells][ld], plane 5 a + l = pixel (row a, column l) of every cell's 5x5 patch (0 outside the image)
+ * -- the operand of a 5x5 / stride S convolution written as 25 taps.  The RPN's strided reader (layers.py:62-65: depthwise 3x3 / stride S
+ * -> 1x1 -> BatchNorm -> SiLU) composed with the linear output convolution in front of it (fpn.py:137,145) is ONE such convolution: in
+ * evaluation mode the pattern pixels of the on-demand FPN levels are never formed (ondemand.rpn_composite). */
+int nbm_cell_patches(const float* x, int B, int H, int W, int C, int stride, float* Vx, int ld, int c_off, void* stream);
+int nbm_cell_patches_up(const float* x1, const float* bias, int B, int H, int W, int C, int Hc, int Wc, int stride, float* Vx, int ld,
+                        int c_off, void* stream);
 int nbm_cell_dgrad_output(const float* M, int B, int H, int W, int C, int stride, float* gx, int parity_class,
                           int ld /* row pitch of M, >= c_off + C */, int c_off /* first channel of M read */,
                           float* bias_grad /* optional [C]: += sum of the patch pixels written (inside the image) */, void* stream);

@@ -57,6 +57,14 @@ for tag, ms in rows:
         print(f'{ms:8.3f}      -         -      fused Winograd kernel of 3x3 {Cin}->{N} @{label[1]}x{label[2]}, tiles under the RoIs (device-side list)')
         tot += ms
         continue
+    if label is not None and label[0] == 'rpn-composite':
+        what = (f'{k} of the 25 taps of the RPN reader composed with the 3x3 in front of it, 5x5 {Cin}->{N} @{label[1]}x{label[2]} over {W} cells '
+                '(evaluation mode: no pattern pixels; nbm_cell_patches is a separate HBM-bound kernel, not in this table)')
+        fl = 2.0 * W * N * Cin * k / 1e9
+        by = 4.0 * (k * W * Cin + 2 * W * N + N * Cin * k) / 1e9
+        tot += ms
+        print(f'{ms:8.3f}  {fl / ms:8.1f}  {by / ms * 1e3:9.0f}   {what}')
+        continue
     if label is not None and label[0] == 'cell-fwd':
         what = (f'25 plane GEMMs of the cell transforms, 3x3 {Cin}->{N} @{label[1]}x{label[2]} on demand (pattern pixels: {H} cells; '
                 'nbm_cell_input / nbm_cell_output are separate HBM-bound kernels, not in this table)')

@@ -746,3 +746,72 @@ def test_cell_weight_kernels_equal_the_float64_einsum():
     assert got_w.shape == ref_w.shape and float((got_w - ref_w).abs().max()) <= 2e-7 * float(ref_w.abs().max())
     got_w2 = ops.cell_weight_grad(dU[:, :, :C_].contiguous())
     assert torch.equal(got_w, got_w2)
+
+
+@pytest.mark.parametrize('shape', [(2, 47, 66, 64, 384, 128, 8, True), (1, 188, 512, 64, 384, 256, 8, True), (2, 94, 128, 0, 384, 256, 4, False),
+                                   (3, 45, 61, 32, 96, 64, 6, True), (2, 33, 41, 0, 64, 64, 4, False), (2, 24, 32, 0, 128, 128, 3, False)])
+def test_rpn_block_composed_with_the_output_convolution(shape):
+    """Evaluation mode (ondemand.rpn_composite): the RPN's reader of a demand-driven map -- depthwise 3x3 / stride S (multiplier 2) -> 1x1
+    -> BatchNorm -> SiLU, reference layers.py:13-46 -- composed with the map's own 3x3 convolution (and the deferred lateral + merge in
+    front of it) is one 5x5 / stride S convolution of the inputs.  Against float64 of the reference's chain of layers on EVERY cell (the
+    top / left border classes, where a depthwise tap falls into the zero padding, included), and against the route through the map's
+    pattern pixels (pattern_materialize + the block's own kernels): the composite must not be the less accurate one.  The map itself
+    stays unwritten (NaN poison)."""
+    import torch.nn.functional as F
+    from birdsoundclassif_amd.nets.layers import DepthwiseSepConv2d
+    B, H, W, Cin, C, N, S, deferred = shape
+    wo = rnd(('cwo', shape), N, C, 3, 3, scale=0.05).cuda()
+    bo = rnd(('cbo', shape), N).cuda()
+    blk = DepthwiseSepConv2d(N, N, stride=S, expansion_fact=2).cuda().eval()
+    with torch.no_grad():
+        for k_, p_ in blk.named_parameters():
+            p_.copy_(rnd(('cblk', k_, shape), *p_.shape, scale=0.3 if p_.dim() > 1 else 0.5).cuda())
+        blk.norm.weight.add_(1.0)
+        blk.norm.running_mean.copy_(rnd(('cbm', shape), N, scale=0.2).cuda())
+        blk.norm.running_var.copy_(rnd(('cbv', shape), N).abs().cuda() + 0.5)
+    if deferred:
+        t = rnd(('ct', shape), B, H, W, Cin).cuda()
+        wl = rnd(('cwl', shape), C, Cin, 1, 1, scale=0.1).cuda()
+        bl = rnd(('cbl', shape), C).cuda()
+        up = rnd(('cup', shape), B, (H + 1) // 2, (W + 1) // 2, C).cuda()
+        alpha = 2.0
+        merged = ops.conv2d(t, _prep.krsc(wl), shift=bl, alpha=alpha, up=up)
+    else:
+        merged = rnd(('cx', shape), B, H, W, C).cuda()
+
+    def lazy_map(raw):
+        ondemand.LAZY_POISON = True
+        try:
+            x = ondemand.conv1x1_lazy(t, _prep.krsc(wl), bl, alpha, up, S, defer=True) if deferred else merged
+            with torch.no_grad():
+                return ondemand.conv3x3_winograd_lazy(x, _prep.wino23(wo), bo, S, _prep.cell_weight(wo, forward=True),
+                                                      fold=lambda wk, a, transposed=False: _prep.cell_weight_folded(wo, wk, a, transposed),
+                                                      raw=raw)
+        finally:
+            ondemand.LAZY_POISON = False
+    # float64 reference of the chain of layers
+    md = merged.double().permute(0, 3, 1, 2)
+    o = F.conv2d(md, wo.double(), bo.double(), padding=1)
+    d = F.conv2d(o, blk.depth_wise.weight.double(), blk.depth_wise.bias.double(), stride=S, padding=1, groups=N)
+    p = F.conv2d(d, blk.pt_wise.weight.double(), blk.pt_wise.bias.double())
+    p = (p - blk.norm.running_mean.double()[None, :, None, None]) / torch.sqrt(blk.norm.running_var.double() + blk.norm.eps)[None, :, None, None] \
+        * blk.norm.weight.double()[None, :, None, None] + blk.norm.bias.double()[None, :, None, None]
+    ref = (p * torch.sigmoid(p)).permute(0, 2, 3, 1)
+    with torch.no_grad():
+        y, st = lazy_map((wo, bo))
+        assert st.pending is not None and bool(torch.isnan(y).all())             # nothing computed yet
+        f = blk(y)
+        assert st.pending is not None and bool(torch.isnan(y).all()), 'the composite route wrote pattern pixels'
+        y2, st2 = lazy_map(None)                                                # the route through the pattern pixels
+        assert st2.pending is None
+        f2 = blk(y2)
+        y3, st3 = lazy_map((wo, bo))                                            # pending, then asked for by another reader
+        ondemand.pattern_materialize(y3)
+        assert st3.pending is None and torch.equal(torch.nan_to_num(y3), torch.nan_to_num(y2))
+    assert tuple(f.shape) == tuple(ref.shape) == tuple(f2.shape)
+    e1, e2 = (f.double() - ref).abs(), (f2.double() - ref).abs()
+    scale_ = max(1.0, float(ref.abs().max()))
+    assert float(e1.max()) <= 2e-5 * scale_, (float(e1.max()), scale_)
+    assert float(e1[:, 0].max()) <= 2e-5 * scale_ and float(e1[:, :, 0].max()) <= 2e-5 * scale_          # border classes
+    assert float((e1 ** 2).mean().sqrt()) <= 1.05 * float((e2 ** 2).mean().sqrt()) + 1e-9, \
+        f'composite rms error {float((e1 ** 2).mean().sqrt()):.3e} vs pattern route {float((e2 ** 2).mean().sqrt()):.3e}'
