@@ -174,31 +174,36 @@ def _rpn_extra(out_b, dw_w, dw_b, pt_w, scale, shift, lat_wk, alpha):
     return tuple(v for t in others for v in (t.data_ptr(), t._version)) + (float(alpha),)
 
 
-def rpn_composite(out_w, out_b, dw_w, dw_b, pt_w, scale, shift, lat_wk=None, alpha=1.0):
+def rpn_composite(out_w, out_b, dw_w, dw_b, pt_w, scale, shift, lat_wk=None, alpha=1.0, parts=None):
     """The RPN's strided reader composed with the output convolution in front of it (evaluation mode): fpn.py:137,145 `out_conv`
     (3x3 / pad 1, linear) -> layers.py:22-29 depthwise 3x3 / stride S / pad 1 (channel multiplier m) -> 1x1 -> BatchNorm (running
     statistics) -> SiLU is ONE 5x5 / stride S / pad 2 convolution of the merged map followed by scale / shift / SiLU:
         W_eff[n][a, e][c] = sum_m pt[n][m] sum_{r + u = a, s + v = e} dw[m][r, s] out_w[m // mult][c][u, v]
         const[n]          = sum_m pt[n][m] (sum_{r, s} dw[m][r, s] out_b[m // mult] + dw_b[m])
-    `lat_wk` [C][Cin] (+ alpha): the lateral 1x1 in front of out_conv was deferred, the patches are [up(x1) + b | t] and the weights
-    [W_eff | alpha W_eff W_lat].  `scale`, `shift`: `bn_affine` of the block (1x1 bias folded in).
-    -> (w [N][25 * K] tap-major, scale [N], shift' [N] = scale * const + shift) for the cells whose nine depthwise taps all lie inside
+    `lat_wk` [C][Cin] (+ alpha): the lateral 1x1 in front of out_conv was deferred, the operands are [up(x1) + b | t] and the weights
+    [W_eff | alpha W_eff W_lat].  `scale`, `shift`: `bn_affine` of the block (1x1 bias folded in).  `parts`: channel ranges
+    ((c0, c1), ...) of K -- one weight tensor [N][25 * (c1 - c0)] (tap-major) per range, for launches that each take a slice of the
+    channels; default: all of K in one.
+    -> (tuple of weight tensors, scale [N], shift' [N] = scale * const + shift) for the cells whose nine depthwise taps all lie inside
     the map; float64 arithmetic, once per weight version.  Border cells: `rpn_composite_delta`."""
     def make():
         we, const = _rpn_composite64(out_w, out_b, dw_w, dw_b, pt_w, 7, 7, lat_wk, alpha)
-        return we.reshape(we.shape[0], -1).float().contiguous(), scale, (scale.double() * const + shift.double()).float().contiguous()
-    return _cached(out_w, ('rpnc', lat_wk is not None), make, extra=_rpn_extra(out_b, dw_w, dw_b, pt_w, scale, shift, lat_wk, alpha))
+        rng = parts if parts is not None else ((0, we.shape[-1]),)
+        ws = tuple(we[..., c0:c1].reshape(we.shape[0], -1).float().contiguous() for c0, c1 in rng)
+        return ws, scale, (scale.double() * const + shift.double()).float().contiguous()
+    return _cached(out_w, ('rpnc', lat_wk is not None, parts), make, extra=_rpn_extra(out_b, dw_w, dw_b, pt_w, scale, shift, lat_wk, alpha))
 
 
 def rpn_composite_delta(out_w, out_b, dw_w, dw_b, pt_w, scale, shift, rmask, smask, taps, lat_wk=None, alpha=1.0):
     """Border cells of `rpn_composite`: the depthwise convolution pads the OUTPUT of out_conv with zeros, which a padded 5x5 convolution
     of the input does not reproduce -- a cell whose depthwise tap rows / columns are not all inside the map (`rmask` / `smask`: bit set =
-    inside) has weights of its own.  -> (dw [N][len(taps) * K], dshift [N]): W_class - W_interior on the listed patch taps (a * 5 + e;
-    the caller lists those where the difference is not zero and the patch can hold data) and scale * (const_class - const_interior)."""
+    inside) has weights of its own.  -> (dw [N][len(taps) * K], dshift [N]): scale * (W_class - W_interior) on the listed patch taps
+    (a * 5 + e; the caller lists those where the difference is not zero and the patch can hold data) and scale * (const_class -
+    const_interior) -- the BatchNorm scale is folded in, so the launch that applies them needs no per-channel epilogue operand."""
     def make():
         we, const = _rpn_composite64(out_w, out_b, dw_w, dw_b, pt_w, rmask, smask, lat_wk, alpha)
         wi, ci = _rpn_composite64(out_w, out_b, dw_w, dw_b, pt_w, 7, 7, lat_wk, alpha)
-        d = (we - wi).reshape(we.shape[0], 25, -1)[:, list(taps)]
+        d = (we - wi).reshape(we.shape[0], 25, -1)[:, list(taps)] * scale.double()[:, None, None]
         return d.reshape(d.shape[0], -1).float().contiguous(), (scale.double() * (const - ci)).float().contiguous()
     return _cached(out_w, ('rpnd', int(rmask), int(smask), tuple(taps), lat_wk is not None), make,
                    extra=_rpn_extra(out_b, dw_w, dw_b, pt_w, scale, shift, lat_wk, alpha))

@@ -441,7 +441,8 @@ _BORDER_IDX = {}
 def _border_classes(nb, H, W, S, device):
     """Cells whose depthwise taps do not all lie inside the map, grouped by (row mask, column mask)
     -> [(rmask, smask, taps: patch taps a * 5 + e where the class's weights differ from the interior's AND the patch can hold data,
-         tap index tensor [nt, 1], cell index tensor [Tb])]."""
+         tap index tensor [nt, 1], cell index tensor [Tb], (pixel index [nt, Tb] of those taps in a [nb * H * W, C] map (clamped), mask
+         [nt, Tb] of the patch pixels that lie in the padding, or None))]."""
     key = (nb, H, W, S, str(device))
     hit = _BORDER_IDX.get(key)
     if hit is None:
@@ -455,25 +456,44 @@ def _border_classes(nb, H, W, S, device):
                     cls.setdefault((rm[oy], sm[ox]), []).append((oy, ox))
         hit = []
         for (r_, s_), cells in sorted(cls.items()):
+            cells = sorted(cells)
             live_a = {a for oy, _ in cells for a in range(5) if 0 <= S * oy - 2 + a < H}
             live_e = {e for _, ox in cells for e in range(5) if 0 <= S * ox - 2 + e < W}
             dropped = [(r, c) for r in range(3) for c in range(3) if not ((r_ >> r) & 1 and (s_ >> c) & 1)]
             taps = [a * 5 + e for a in sorted(live_a) for e in sorted(live_e) if any(0 <= a - r <= 2 and 0 <= e - c <= 2 for r, c in dropped)]
-            lin = np.array(sorted(oy * OW + ox for oy, ox in cells), dtype=np.int64)
+            lin = np.array([oy * OW + ox for oy, ox in cells], dtype=np.int64)
             idx = (np.arange(nb, dtype=np.int64)[:, None] * (OH * OW) + lin[None, :]).reshape(-1)
-            hit.append((r_, s_, tuple(taps), torch.tensor(taps, dtype=torch.int64, device=device)[:, None], torch.from_numpy(idx).to(device)))
+            py = np.array([[S * oy - 2 + t // 5 for oy, _ in cells] for t in taps], dtype=np.int64)          # [nt, cells]
+            px = np.array([[S * ox - 2 + t % 5 for _, ox in cells] for t in taps], dtype=np.int64)
+            pix = None
+            if taps:
+                inside = (py >= 0) & (py < H) & (px >= 0) & (px < W)                                         # a patch pixel in the padding reads 0
+                one = np.clip(py, 0, H - 1) * W + np.clip(px, 0, W - 1)                                      # [nt, cells]
+                lin_px = (np.arange(nb, dtype=np.int64)[None, :, None] * (H * W) + one[:, None, :]).reshape(len(taps), -1)
+                bad = None if bool(inside.all()) else torch.from_numpy(np.broadcast_to(~inside[:, None, :], (len(taps), nb, len(cells)))
+                                                                       .reshape(len(taps), -1).copy()).to(device)
+                pix = (torch.from_numpy(lin_px).to(device), bad)
+            hit.append((r_, s_, tuple(taps), torch.tensor(taps, dtype=torch.int64, device=device)[:, None], torch.from_numpy(idx).to(device), pix))
         _BORDER_IDX[key] = hit
     return hit
+
+
+DIRECT_GATHER = os.environ.get('NBM_RPN_DIRECT', '1') != '0'    # rpn_composite: operands that exist as dense maps are gathered by the GEMM itself
 
 
 def rpn_composite(fm, block, prep):
     """Evaluation mode: the output of `block` (layers.DepthwiseSepConv2d, the RPN's reader of the map: depthwise 3x3 / stride S ->
     1x1 -> BatchNorm -> SiLU) on the demand-driven map `fm` WITHOUT the map's pattern pixels: the block composed with the map's own
-    3x3 convolution is one 5x5 / stride S convolution of the convolution's INPUT (`_prep.rpn_composite`), evaluated as an implicit
-    GEMM over the raw 5x5 patches (nbm_cell_patches: [25][cells][K], 25 taps of K channels; deferred lateral: [up(x1) + b | t]) --
-    the same 25 K N products per cell as the cell transforms' plane GEMMs, but no input transform arithmetic, no 25-plane intermediate,
-    no output transform, no depthwise pass and no 1x1 behind it.  Border cells (a depthwise tap in the zero padding of the map) differ
-    from the interior in a handful of taps: their difference goes in front, through the residual input of the first launch.
+    3x3 convolution is one 5x5 / stride S / pad 2 convolution of the convolution's INPUT (`_prep.rpn_composite`) -- the same 25 K N
+    products per cell as the cell transforms' plane GEMMs, but no transform arithmetic, no 25-plane intermediate, no output transform,
+    no depthwise pass and no 1x1 behind it.  An operand that exists as a dense map (the merged map of a level whose pattern covers every
+    pixel; the lateral's input t of a deferred lateral) is gathered by the implicit GEMM itself, in channel slices; the interpolated
+    operand of a deferred lateral (up(x1) + b, position-dependent weights: not a convolution of x1) goes through raw 5x5 patches
+    (nbm_cell_patches_up: [25][cells][C], 25 taps) and one launch per patch row.  The launches are chained through the residual input
+    (y = scale * acc + [shift + R | y]; SiLU on the last): a single fmaf chain over all 25 K products rounds 25 K times against a running
+    sum that has grown to the whole result -- measured 1.5 x the rms error of the route through the pattern pixels; 3-6 shorter chains
+    are below it.  Border cells (a depthwise tap in the zero padding of the map) differ from the interior in a handful of taps: their
+    difference goes in front (R), through the residual input of the first launch.
     -> [B, OH, OW, N], or None when `fm` is not a map with a pending pattern pass."""
     st = lazy_state(fm)
     if st is None or st.pending is None or st.raw is None:
@@ -484,29 +504,46 @@ def rpn_composite(fm, block, prep):
     B, H, W, _ = fm.shape
     C_ = st.x.shape[-1]
     lt = st.lateral if st.lateral is not None and st.lateral.deferred else None
-    K = C_ + (lt.t.shape[-1] if lt is not None else 0)
+    Cin = lt.t.shape[-1] if lt is not None else 0
+    K = C_ + Cin
     OH, OW = (H - 1) // S + 1, (W - 1) // S + 1
     out_w, out_b = st.raw
     scale, shift = prep.bn_affine(block.norm.weight, block.norm.bias, block.norm.running_mean, block.norm.running_var, block.norm.eps,
                                   conv_bias=block.pt_wise.bias)
     N2 = block.pt_wise.weight.shape[0]
     wargs = (out_w, out_b, block.depth_wise.weight, block.depth_wise.bias, block.pt_wise.weight, scale, shift)
-    wkw = dict(lat_wk=lt.wk[:, :lt.t.shape[-1]] if lt is not None else None, alpha=lt.alpha if lt is not None else 1.0)
-    w, sc, sh = prep.rpn_composite(*wargs, **wkw)
+    wkw = dict(lat_wk=lt.wk[:, :Cin] if lt is not None else None, alpha=lt.alpha if lt is not None else 1.0)
+    # operands: ('patch', c0, c1) = channels [c0, c1) of K from the patch tensor V; ('map', tensor, c0, c1, k0) = channels [c0, c1) of a
+    # dense map that are channels [k0, ...) of K
+    if lt is not None:
+        direct_t = DIRECT_GATHER and Cin % 32 == 0
+        operands = [('patch', 0, C_)] + ([('map', lt.t, 0, Cin, C_)] if direct_t else [])
+        KV = C_ if direct_t else K                  # channels held by the patch tensor
+    elif DIRECT_GATHER and C_ % 32 == 0:
+        q32 = C_ // 32                               # channel slices (multiples of 32): 3 or 4 links where the channel count allows
+        cc = C_ // (3 if q32 % 3 == 0 else 4 if q32 % 4 == 0 else 2 if q32 % 2 == 0 else 1)
+        operands = [('map', st.x, c0, c0 + cc, c0) for c0 in range(0, C_, cc)]
+        KV = 0
+    else:
+        operands, KV = [('patch', 0, C_)], C_
+    parts = tuple((0, KV) if op[0] == 'patch' else (op[4], op[4] + op[3] - op[2]) for op in operands)
+    ws, sc, sh = prep.rpn_composite(*wargs, **wkw, parts=parts)
     f = torch.empty((B, OH, OW, N2), device=fm.device, dtype=torch.float32)
     stream = _stream()
     keep_label, ops._PROFILE_LABEL = ops._PROFILE_LABEL, ('rpn-composite', H, W)
     try:
         for (b0, nb, pat) in st.chunks:
             T = nb * OH * OW
-            V = ops._wino_scratch(fm.device, 25 * T * K, 0)[0]
-            if lt is not None:
-                Cin = lt.t.shape[-1]
-                check(lib().nbm_cell_patches_up(_ptr(lt.up[b0:b0 + nb]), _ptr(lt.bias), nb, H, W, C_, lt.up.shape[1], lt.up.shape[2], S, _ptr(V),
-                                                K, 0, stream), 'nbm_cell_patches_up')
-                check(lib().nbm_cell_patches(_ptr(lt.t[b0:b0 + nb]), nb, H, W, Cin, S, _ptr(V), K, C_, stream), 'nbm_cell_patches')
-            else:
-                check(lib().nbm_cell_patches(_ptr(st.x[b0:b0 + nb]), nb, H, W, C_, S, _ptr(V), K, 0, stream), 'nbm_cell_patches')
+            V = None
+            if KV:
+                V = ops._wino_scratch(fm.device, 25 * T * KV, 0)[0]
+                if lt is not None:
+                    check(lib().nbm_cell_patches_up(_ptr(lt.up[b0:b0 + nb]), _ptr(lt.bias), nb, H, W, C_, lt.up.shape[1], lt.up.shape[2], S,
+                                                    _ptr(V), KV, 0, stream), 'nbm_cell_patches_up')
+                    if KV > C_:
+                        check(lib().nbm_cell_patches(_ptr(lt.t[b0:b0 + nb]), nb, H, W, Cin, S, _ptr(V), KV, C_, stream), 'nbm_cell_patches')
+                else:
+                    check(lib().nbm_cell_patches(_ptr(st.x[b0:b0 + nb]), nb, H, W, C_, S, _ptr(V), KV, 0, stream), 'nbm_cell_patches')
             fc = f[b0:b0 + nb]
             # border classes first: scale * (W_class - W_interior) . patch + scale * (const_class - const_interior) of their cells, a few
             # taps each, scattered into an otherwise zero [T, N] tensor that the first launch below adds
@@ -514,27 +551,54 @@ def rpn_composite(fm, block, prep):
             R = None
             if border:
                 R = torch.zeros((T, N2), device=fm.device, dtype=torch.float32)
-                Vv = V[:25 * T * K].view(25, T, K)
-                for rmask, smask, taps, tap_idx, idx in border:
+                Vv = V[:25 * T * KV].view(25, T, KV) if KV else None
+                for rmask, smask, taps, tap_idx, idx, pix in border:
                     if not taps:
                         continue
                     dwt, dsh = prep.rpn_composite_delta(*wargs, rmask, smask, taps, **wkw)
-                    Vb = Vv[tap_idx, idx[None, :]]                      # [taps, cells of the class, K], gathered
                     Tb, nt = idx.numel(), len(taps)
+                    cols = []                                   # the class's operand rows [taps, cells, K], gathered piece by piece
+                    for op in operands:
+                        if op[0] == 'patch':
+                            cols.append(Vv[tap_idx, idx[None, :]])
+                        else:
+                            m_ = op[1][b0:b0 + nb]
+                            g_ = m_.reshape(-1, m_.shape[-1]).index_select(0, pix[0].reshape(-1))[:, op[2]:op[3]].reshape(nt, Tb, -1)
+                            if pix[1] is not None:
+                                g_ = g_.masked_fill(pix[1][..., None], 0.0)
+                            cols.append(g_)
+                    Vb = cols[0] if len(cols) == 1 else torch.cat(cols, -1)
                     fb = torch.empty((Tb, N2), device=fm.device, dtype=torch.float32)
-                    gemm_conv(Vb, dwt, fb, B=1, H=nt, W=Tb, Cin=K, N=N2, kh=nt, kw=1, Ho=1, Wo=Tb, x_ld=K, w_ld=nt * K, scale=sc, shift=dsh)
+                    # few rows, a long K: 32-column slices as groups (128 x 32 tiles: a quarter of the serial MFMA work per K-step of
+                    # the 128 x 128 tile; 150 -> ~35 us per class); the shift comes in through the residual input, which has a group stride
+                    if N2 % 32 == 0:
+                        gemm_conv(Vb, dwt, fb, B=1, H=nt, W=Tb, Cin=K, N=32, kh=nt, kw=1, Ho=1, Wo=Tb, x_ld=K, w_ld=nt * K, y_ld=N2,
+                                  groups=N2 // 32, x_gs=0, w_gs=32 * nt * K, y_gs=32, residual=dsh.expand(Tb, N2).contiguous(), res_ld=N2,
+                                  res_gs=32)
+                    else:
+                        gemm_conv(Vb, dwt, fb, B=1, H=nt, W=Tb, Cin=K, N=N2, kh=nt, kw=1, Ho=1, Wo=Tb, x_ld=K, w_ld=nt * K, shift=dsh)
                     R.index_copy_(0, idx, fb)
-            # One launch per patch ROW (5 taps x K), chained through the residual input (y = scale * acc + [shift + R | y]; SiLU on the
-            # last): a single fmaf chain over all 25 K products rounds 25 K times against a running sum that has grown to the whole result
-            # -- measured 1.5 x the rms error of the route through the pattern pixels (25 sums of K); five chains of 5 K are below it.  It
-            # also keeps a tap's plane offset ((tap index) x T x K floats) inside the 2 GB window of a buffer resource.
-            ppl = max(1, min(5, ((1 << 31) - (1 << 24)) // (T * K * 4)))
-            for p0 in range(0, 25, ppl):
-                npl = min(ppl, 25 - p0)
-                res = fc if p0 else R
-                gemm_conv(V[p0 * T * K:], w[:, p0 * K:], fc, B=1, H=npl, W=T, Cin=K, N=N2, kh=npl, kw=1, Ho=1, Wo=T, x_ld=K, w_ld=25 * K,
-                          scale=sc, shift=sh if p0 == 0 else None, residual=res, res_ld=N2 if res is not None else None,
-                          act=ops.ACT_SILU if p0 + npl == 25 else ops.ACT_NONE)
+            # the chain of launches
+            links = []
+            for op, w in zip(operands, ws):
+                if op[0] == 'patch':
+                    # one launch per patch ROW (5 taps x KV); a tap's plane lies (tap index) x T x KV floats behind the first -- groups of
+                    # planes whose offsets stay inside the 2 GB window of a buffer resource
+                    ppl = max(1, min(5, ((1 << 31) - (1 << 24)) // (T * KV * 4)))
+                    for p0 in range(0, 25, ppl):
+                        npl = min(ppl, 25 - p0)
+                        links.append(dict(x=V[p0 * T * KV:], w=w[:, p0 * KV:], B=1, H=npl, W=T, Cin=KV, kh=npl, kw=1, Ho=1, Wo=T, x_ld=KV,
+                                          w_ld=25 * KV))
+                else:
+                    m_ = op[1][b0:b0 + nb]
+                    cw = op[3] - op[2]
+                    links.append(dict(x=m_[..., op[2]:], w=w, B=nb, H=H, W=W, Cin=cw, kh=5, kw=5, stride=S, pad=2, Ho=OH, Wo=OW,
+                                      x_ld=m_.shape[-1], w_ld=25 * cw))
+            for i, ln in enumerate(links):
+                res = R if i == 0 else fc
+                ops._PROFILE_LABEL = ('rpn-composite' if ln['kw'] == 1 else 'rpn-composite-map', H, W)
+                gemm_conv(ln.pop('x'), ln.pop('w'), fc, N=N2, scale=sc, shift=sh if i == 0 else None, residual=res,
+                          res_ld=N2 if res is not None else None, act=ops.ACT_SILU if i == len(links) - 1 else ops.ACT_NONE, **ln)
     finally:
         ops._PROFILE_LABEL = keep_label
     return f

@@ -65,6 +65,12 @@ for tag, ms in rows:
         tot += ms
         print(f'{ms:8.3f}  {fl / ms:8.1f}  {by / ms * 1e3:9.0f}   {what}')
         continue
+    if label is not None and label[0] == 'rpn-composite-map':
+        what = (f'{Cin} of the channels of the RPN reader composed with the 3x3 in front of it, 5x5 s{st} {Cin}->{N} @{H}x{W} B={Bb}, gathered from '
+                'the dense map (evaluation mode: no pattern pixels)')
+        tot += ms
+        print(f'{ms:8.3f}  {fl / ms:8.1f}  {by / ms * 1e3:9.0f}   {what}')
+        continue
     if label is not None and label[0] == 'cell-fwd':
         what = (f'25 plane GEMMs of the cell transforms, 3x3 {Cin}->{N} @{label[1]}x{label[2]} on demand (pattern pixels: {H} cells; '
                 'nbm_cell_input / nbm_cell_output are separate HBM-bound kernels, not in this table)')
