@@ -851,8 +851,8 @@ def main(argv=None):
 
     # roofline of the dominant kernel = igemm_kernel<128,128,64,64,A_FAST,EPI_STD,2> (csrc/igemm.hip), the deep-K instantiation of
     # the implicit-GEMM kernel: every launch of a step that nbm_gemm_conv dispatches to it -- the ResNet 1x1 / strided 3x3 layers
-    # with K > 256, the attention GEMMs, the FPN laterals of levels 1-4 and the 25 grouped plane GEMMs of the cell transforms
-    # (FPN levels 0 and 1 on demand).  `achieved` = MFMA FLOPs these launches EXECUTE (2 * M * N * K * groups) over their HIP-event
+    # with K > 256, the attention GEMMs, the FPN laterals of levels 1-4 and the launches of the composed RPN reader (FPN levels 0 and
+    # 1 on demand).  `achieved` = MFMA FLOPs these launches EXECUTE (2 * M * N * K * groups) over their HIP-event
     # time on the launch stream inside the timed loop; avg_launch_ms is what rocprofv3 --stats reports as the kernel's average.
     deep = [(tag, s.elapsed_time(e)) for (tag, s, e) in prof if len(tag) == 9 and ops.is_deepk(tag[0], tag[1], tag[2], tag[2])]
     all_ms = sum(s.elapsed_time(e) for (tag, s, e) in prof_all if len(tag) == 9)
@@ -882,8 +882,8 @@ def main(argv=None):
         top = sorted(big.items(), key=lambda kv: -kv[1][0])[:4]
         roof = {'bound': 'mfma', 'kernel': 'igemm_kernel<128,128,64,64,A_FAST,EPI_STD,STAGES=2>: fp32-MFMA implicit GEMM, deep-K '
                                            'instantiation (128x128x32 tiles, double-buffered LDS, fused epilogue); all its launches of a '
-                                           'step: ResNet 1x1 / strided 3x3 layers with K > 256, attention, FPN laterals, the 25 grouped '
-                                           'plane GEMMs of the cell transforms of the on-demand FPN levels',
+                                           'step: ResNet 1x1 / strided 3x3 layers with K > 256, attention, FPN laterals, the 5x5 / stride-S '
+                                           'launches of the RPN reader composed with the output convolution of the on-demand FPN levels (DESIGN 4f)',
                 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS,
                 'traffic': traffic, 'traffic_unit': 'bytes/launch (2*FETCH_SIZE + WRITE_SIZE, mean over the launches)',
                 'traffic_source': f'profiles/{PMC_DOMINANT}: separate rocprofv3 --pmc passes of this command, NOT measured in this run '
