@@ -209,6 +209,19 @@ def rpn_composite_delta(out_w, out_b, dw_w, dw_b, pt_w, scale, shift, rmask, sma
                    extra=_rpn_extra(out_b, dw_w, dw_b, pt_w, scale, shift, lat_wk, alpha))
 
 
+def lateral_of_projection(lat_w, lat_b, proj_w, proj_b):
+    """FPN lateral 1x1 (fpn.py:143) applied to `fm + final_projection(ctx)` (self_attention.py:55,76) without forming that sum:
+    lateral(fm + W_o ctx + b_o) = W_l fm + (W_l W_o) ctx + (W_l b_o + b_l).  -> (W_l W_o as KRSC rows [N][d], shift [N]); float64
+    arithmetic, once per weight version (evaluation mode: fpn.FPN.forward on a `Projected` level)."""
+    def make():
+        wl = lat_w.detach().double().reshape(lat_w.shape[0], -1)
+        wc = wl @ proj_w.detach().double()
+        sh = wl @ proj_b.detach().double() + (lat_b.detach().double() if lat_b is not None else 0.0)
+        return wc.float().contiguous(), sh.float().contiguous()
+    others = [t for t in (lat_b, proj_w, proj_b) if t is not None]
+    return _cached(lat_w, 'latproj', make, extra=tuple(v for t in others for v in (t.data_ptr(), t._version)))
+
+
 def cat_rows(tag, *tensors):
     """Concatenate several [Ni, K] weight matrices (or [Ni] biases) along dim 0, cached on the first."""
     def make():

@@ -7,9 +7,10 @@ of the detector's forward FLOPs; they run on the fp32-MFMA implicit-GEMM kernel.
 import torch
 import torch.nn as nn
 
-from . import functional as Fn
+from .. import ops
+from . import _prep, functional as Fn
 from .layers import DepthwiseSepConv2d
-from .self_attention import Scaled, materialize
+from .self_attention import Projected, Scaled, materialize
 
 
 class FusionModule(nn.Module):
@@ -108,8 +109,17 @@ class FPN(nn.Module):
         outs, merged = [], None
         for i in range(len(x) - 1, -1, -1):                       # coarsest level first
             fm = x[i]
-            t, alpha = (fm.tensor, fm.factor) if isinstance(fm, Scaled) else (fm, 1.0)
             c = self.pt_wise[str(i)]
+            if isinstance(fm, Projected):
+                # evaluation mode: the level is fm + ctx W_o^T + b_o with the projection still to do -- the lateral takes it into its own
+                # weights: W_l fm + shift, then (W_l W_o) ctx + that + the top-down merge
+                wc, sh = _prep.lateral_of_projection(c.weight, c.bias, fm.wo, fm.bo)
+                y1 = ops.conv2d(fm.tensor, _prep.krsc(c.weight), shift=sh)
+                merged = ops.conv2d(fm.ctx, wc, residual=y1, up=merged)
+                outs.insert(0, Fn.conv(merged, self.out_convs[str(len(x) - 1 - i)].weight, bias=self.out_convs[str(len(x) - 1 - i)].bias,
+                                       kh=3, kw=3, pad=1, lazy_stride=(lazy_strides or {}).get(i), accept_stash=i > 0))
+                continue
+            t, alpha = (fm.tensor, fm.factor) if isinstance(fm, Scaled) else (fm, 1.0)
             # the lateral of a demand-driven level is itself only evaluated where that level's output convolution reads it;
             # the finest level has no finer level that would read `merged`
             oc = self.out_convs[str(len(x) - 1 - i)]

@@ -856,6 +856,25 @@ class RoiPool(Function):
         return (None, None, None, None, None, None, *gf)
 
 
+def attention_context(x, wq, bq, wk, bk, wv, bv, inv):
+    """x [B, L, C] -> (qkv [B*L, 3d], p [B, L, L] softmaxed, ctx [B*L, d], wqkv): self_attention.py:40-50 up to (not including) the
+    final projection."""
+    B, L, Cc = x.shape
+    d = wq.shape[0]
+    x2d = x.view(B * L, Cc)
+    wqkv = torch.cat([wq.detach(), wk.detach(), wv.detach()], 0)
+    bqkv = torch.cat([bq.detach(), bk.detach(), bv.detach()], 0)
+    qkv = ops.linear(x2d, wqkv, bqkv)                                             # [B*L, 3d]
+    p = torch.empty((B, L, L), device=x.device, dtype=torch.float32)
+    ops.gemm_conv(qkv, qkv[:, d:], p, B=1, H=L, W=1, Cin=d, N=L, x_ld=3 * d, w_ld=3 * d, groups=B,
+                  x_gs=L * 3 * d, w_gs=L * 3 * d, y_gs=L * L, alpha=inv)
+    ops.softmax_rows_(p.view(B * L, L))
+    cx = torch.empty((B * L, d), device=x.device, dtype=torch.float32)
+    ops.conv_dgrad(p, qkv[:, 2 * d:], cx, B=1, H=L, W=1, Cin=d, N=L, g_ld=L, w_ld=3 * d, out_ld=d, groups=B,
+                   g_gs=L * L, w_gs=L * 3 * d, out_gs=L * d)                       # ctx = P @ V
+    return qkv, p, cx, wqkv
+
+
 class Attention(Function):
     """fm + SelfAttention(fm) (reference self_attention.py:24-56,76) with a hand-written backward: 5 forward and
     9 backward fp32-MFMA GEMM launches (NT / NN / TN forms), row softmax and its gradient."""
@@ -863,18 +882,8 @@ class Attention(Function):
     @staticmethod
     def forward(ctx, x, wq, bq, wk, bk, wv, bv, wo, bo, inv):
         B, L, Cc = x.shape
-        d = wq.shape[0]
         x2d = x.view(B * L, Cc)
-        wqkv = torch.cat([wq.detach(), wk.detach(), wv.detach()], 0)
-        bqkv = torch.cat([bq.detach(), bk.detach(), bv.detach()], 0)
-        qkv = ops.linear(x2d, wqkv, bqkv)                                             # [B*L, 3d]
-        p = torch.empty((B, L, L), device=x.device, dtype=torch.float32)
-        ops.gemm_conv(qkv, qkv[:, d:], p, B=1, H=L, W=1, Cin=d, N=L, x_ld=3 * d, w_ld=3 * d, groups=B,
-                      x_gs=L * 3 * d, w_gs=L * 3 * d, y_gs=L * L, alpha=inv)
-        ops.softmax_rows_(p.view(B * L, L))
-        cx = torch.empty((B * L, d), device=x.device, dtype=torch.float32)
-        ops.conv_dgrad(p, qkv[:, 2 * d:], cx, B=1, H=L, W=1, Cin=d, N=L, g_ld=L, w_ld=3 * d, out_ld=d, groups=B,
-                       g_gs=L * L, w_gs=L * 3 * d, out_gs=L * d)                       # ctx = P @ V
+        qkv, p, cx, wqkv = attention_context(x, wq, bq, wk, bk, wv, bv, inv)
         out = ops.linear(cx, wo.detach(), bo.detach(), residual=x2d)
         ctx.save_for_backward(x, qkv, p, cx, wqkv, wo)
         ctx.inv = inv

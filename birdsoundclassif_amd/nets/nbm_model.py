@@ -15,6 +15,8 @@ from . import functional as Fn
 from .self_attention import build_sa_layers, materialize
 from .head import build_head
 
+DEFER_PROJECTION = os.environ.get('NBM_DEFER_PROJECTION', '1') != '0'      # evaluation mode: attention's final projection folded into the FPN laterals
+
 
 class NbmModel(nn.Module):
     """reference nbm_model.py:22-80."""
@@ -65,10 +67,13 @@ class NbmModel(nn.Module):
             return materialize(self.attn(self.fpn(features)))
         if getattr(self.args, 'sandwich_attn', False):
             return materialize(self.attn[1](self.fpn(self.attn[0](features))))
+        # evaluation mode, plain FPN: the attention levels' final projection is folded into the FPN's laterals (self_attention.Projected)
+        defer = (not torch.is_grad_enabled()) and type(self.fpn).__name__ == 'FPN' and DEFER_PROJECTION
+        levels = self.attn(features, defer_projection=True) if defer else self.attn(features)
         if lazy and self._lazy_strides():
-            out = self.fpn(self.attn(features), lazy_strides=self._lazy_strides())
+            out = self.fpn(levels, lazy_strides=self._lazy_strides())
         else:
-            out = self.fpn(self.attn(features))
+            out = self.fpn(levels)
         Fn.fpn_out_register(out, token or None)  # the early backward pass of the RPN branch parks its gradients by these maps (train.step)
         return out
 

@@ -19,6 +19,10 @@ from . import _prep, functional as Fn
 # SURVEY Appendix C-1).  Instead of materialising 2*fm the pyramid hands (fm, 2.0) to the FPN, whose
 # lateral 1x1 convolution applies the factor exactly in its epilogue (power of two).
 Scaled = namedtuple('Scaled', ['tensor', 'factor'])
+# Evaluation mode, pyramid straight in front of the FPN: an attention level is handed over as (fm, ctx, W_o, b_o) -- its value is
+# fm + ctx W_o^T + b_o, but the one consumer, the FPN's lateral 1x1, is linear too and takes the projection into its own weights
+# (fpn.FPN.forward, _prep.lateral_of_projection): 2 C d multiply-adds per token become 2 p d (p = 384 lateral channels, C = 1024 / 2048).
+Projected = namedtuple('Projected', ['tensor', 'ctx', 'wo', 'bo'])
 
 
 class SelfAttention(nn.Module):
@@ -47,8 +51,8 @@ class SelfAttention(nn.Module):
             self._pe[key] = t[:, None, :].expand(h, w, c).contiguous().to(device)
         return self._pe[key]
 
-    def forward(self, inpt, residual=True):
-        """inpt NHWC [B,h,w,C] -> NHWC [B,h,w,C] = (inpt +) module(inpt)."""
+    def forward(self, inpt, residual=True, defer_projection=False):
+        """inpt NHWC [B,h,w,C] -> NHWC [B,h,w,C] = (inpt +) module(inpt); `defer_projection` (no gradient, plain level): `Projected`."""
         B, h, w, Cc = inpt.shape
         if not residual:
             raise NotImplementedError('SelfAttention without the SAPyramid residual is not on the hot path')
@@ -63,6 +67,10 @@ class SelfAttention(nn.Module):
         if L % 32:
             raise NotImplementedError(f'attention over {h}x{w} tokens: the P.V GEMM needs H*W % 32 == 0')
         inv = float(np.float32(1.0) / np.float32(np.round(np.sqrt(d), 2)))            # self_attention.py:47
+        if defer_projection and not self.position_encoding and not torch.is_grad_enabled() and d % 32 == 0:
+            _, _, cx, _ = Fn.attention_context(x.view(B, L, Cc), self.query.weight, self.query.bias, self.key.weight, self.key.bias,
+                                               self.value.weight, self.value.bias, inv)
+            return Projected(inpt, cx.view(B, h, w, d), self.final_projection.weight, self.final_projection.bias)
         out = Fn.Attention.apply(x.view(B, L, Cc), self.query.weight, self.query.bias, self.key.weight, self.key.bias,
                                  self.value.weight, self.value.bias, self.final_projection.weight,
                                  self.final_projection.bias, inv).view(B, h, w, Cc)        # = x + attention(x)
@@ -83,19 +91,27 @@ class SAPyramid(nn.Module):
                 str(i): SelfAttention(cn, cn // 2) if (i >= (len(channels) - top_n)) else nn.Identity()
                 for (i, cn) in enumerate(channels)})
 
-    def forward(self, x):
-        """x: bottom-up list of NHWC maps -> list of `fm + module(fm)`; identity levels as Scaled(fm, 2.0)."""
+    def forward(self, x, defer_projection=False):
+        """x: bottom-up list of NHWC maps -> list of `fm + module(fm)`; identity levels as Scaled(fm, 2.0); with `defer_projection`
+        (the caller is the plain FPN, evaluation mode) attention levels as Projected(fm, ctx, W_o, b_o)."""
         out = []
         for i, fm in enumerate(x):
             m = self.attention_modules[str(i)]
-            out.append(Scaled(fm, 2.0) if isinstance(m, nn.Identity) else m(fm, residual=True))
+            out.append(Scaled(fm, 2.0) if isinstance(m, nn.Identity) else m(fm, residual=True, defer_projection=defer_projection))
         return out
 
 
 def materialize(levels):
     """Scaled(fm, f) -> f * fm: for consumers that cannot fold the factor into a GEMM epilogue (the heads, when the
     pyramid runs AFTER the FPN: --fpn_first / --sandwich_attn)."""
-    return [Fn.Scale.apply(l.tensor, l.factor) if isinstance(l, Scaled) else l for l in levels]
+    def one(l):
+        if isinstance(l, Scaled):
+            return Fn.Scale.apply(l.tensor, l.factor)
+        if isinstance(l, Projected):
+            B, h, w, Cc = l.tensor.shape
+            return ops.linear(l.ctx.reshape(B * h * w, -1), l.wo.detach(), l.bo.detach(), residual=l.tensor.reshape(B * h * w, Cc)).view(B, h, w, Cc)
+        return l
+    return [one(l) for l in levels]
 
 
 def build_sa_layers(args, channels):
