@@ -222,6 +222,18 @@ def lateral_of_projection(lat_w, lat_b, proj_w, proj_b):
     return _cached(lat_w, 'latproj', make, extra=tuple(v for t in others for v in (t.data_ptr(), t._version)))
 
 
+def value_of_lateral(lat_w, proj_w, val_w, val_b):
+    """The attention's value projection composed with its final projection AND the FPN lateral that reads the level (evaluation mode):
+    ctx W_o^T W_l^T = P (x W_v^T + b_v) W_o^T W_l^T = P (x W_v'^T + b_v') with W_v' = W_l W_o W_v [p][C], b_v' = W_l W_o b_v -- the value
+    rows are p = 384 wide instead of d = C / 2, and P V' IS the lateral's image of the attention branch (rows of P sum to one).
+    -> (W_v' [p][C], b_v' [p]); float64 arithmetic, once per weight version."""
+    def make():
+        wlo = lat_w.detach().double().reshape(lat_w.shape[0], -1) @ proj_w.detach().double()      # [p][d]
+        return (wlo @ val_w.detach().double()).float().contiguous(), (wlo @ val_b.detach().double()).float().contiguous()
+    others = [proj_w, val_w, val_b]
+    return _cached(lat_w, 'vallat', make, extra=tuple(v for t in others for v in (t.data_ptr(), t._version)))
+
+
 def cat_rows(tag, *tensors):
     """Concatenate several [Ni, K] weight matrices (or [Ni] biases) along dim 0, cached on the first."""
     def make():

@@ -114,8 +114,11 @@ class FPN(nn.Module):
                 # evaluation mode: the level is fm + ctx W_o^T + b_o with the projection still to do -- the lateral takes it into its own
                 # weights: W_l fm + shift, then (W_l W_o) ctx + that + the top-down merge
                 wc, sh = _prep.lateral_of_projection(c.weight, c.bias, fm.wo, fm.bo)
-                y1 = ops.conv2d(fm.tensor, _prep.krsc(c.weight), shift=sh)
-                merged = ops.conv2d(fm.ctx, wc, residual=y1, up=merged)
+                if fm.lateral:                         # ctx is already W_l W_o ctx: the lateral itself, + ctx through the residual input
+                    merged = ops.conv2d(fm.tensor, _prep.krsc(c.weight), shift=sh, residual=fm.ctx, up=merged)
+                else:
+                    y1 = ops.conv2d(fm.tensor, _prep.krsc(c.weight), shift=sh)
+                    merged = ops.conv2d(fm.ctx, wc, residual=y1, up=merged)
                 outs.insert(0, Fn.conv(merged, self.out_convs[str(len(x) - 1 - i)].weight, bias=self.out_convs[str(len(x) - 1 - i)].bias,
                                        kh=3, kw=3, pad=1, lazy_stride=(lazy_strides or {}).get(i), accept_stash=i > 0))
                 continue

@@ -857,21 +857,22 @@ class RoiPool(Function):
 
 
 def attention_context(x, wq, bq, wk, bk, wv, bv, inv):
-    """x [B, L, C] -> (qkv [B*L, 3d], p [B, L, L] softmaxed, ctx [B*L, d], wqkv): self_attention.py:40-50 up to (not including) the
-    final projection."""
+    """x [B, L, C] -> (qkv [B*L, 2d + dv], p [B, L, L] softmaxed, ctx [B*L, dv], wqkv): self_attention.py:40-50 up to (not including)
+    the final projection.  dv = rows of wv (= d in the module; the evaluation path passes value weights composed with what follows)."""
     B, L, Cc = x.shape
-    d = wq.shape[0]
+    d, dv = wq.shape[0], wv.shape[0]
+    ld = 2 * d + dv
     x2d = x.view(B * L, Cc)
     wqkv = torch.cat([wq.detach(), wk.detach(), wv.detach()], 0)
     bqkv = torch.cat([bq.detach(), bk.detach(), bv.detach()], 0)
-    qkv = ops.linear(x2d, wqkv, bqkv)                                             # [B*L, 3d]
+    qkv = ops.linear(x2d, wqkv, bqkv)                                             # [B*L, 2d + dv]
     p = torch.empty((B, L, L), device=x.device, dtype=torch.float32)
-    ops.gemm_conv(qkv, qkv[:, d:], p, B=1, H=L, W=1, Cin=d, N=L, x_ld=3 * d, w_ld=3 * d, groups=B,
-                  x_gs=L * 3 * d, w_gs=L * 3 * d, y_gs=L * L, alpha=inv)
+    ops.gemm_conv(qkv, qkv[:, d:], p, B=1, H=L, W=1, Cin=d, N=L, x_ld=ld, w_ld=ld, groups=B,
+                  x_gs=L * ld, w_gs=L * ld, y_gs=L * L, alpha=inv)
     ops.softmax_rows_(p.view(B * L, L))
-    cx = torch.empty((B * L, d), device=x.device, dtype=torch.float32)
-    ops.conv_dgrad(p, qkv[:, 2 * d:], cx, B=1, H=L, W=1, Cin=d, N=L, g_ld=L, w_ld=3 * d, out_ld=d, groups=B,
-                   g_gs=L * L, w_gs=L * 3 * d, out_gs=L * d)                       # ctx = P @ V
+    cx = torch.empty((B * L, dv), device=x.device, dtype=torch.float32)
+    ops.conv_dgrad(p, qkv[:, 2 * d:], cx, B=1, H=L, W=1, Cin=dv, N=L, g_ld=L, w_ld=ld, out_ld=dv, groups=B,
+                   g_gs=L * L, w_gs=L * ld, out_gs=L * dv)                         # ctx = P @ V
     return qkv, p, cx, wqkv
 
 

@@ -69,7 +69,7 @@ class NbmModel(nn.Module):
             return materialize(self.attn[1](self.fpn(self.attn[0](features))))
         # evaluation mode, plain FPN: the attention levels' final projection is folded into the FPN's laterals (self_attention.Projected)
         defer = (not torch.is_grad_enabled()) and type(self.fpn).__name__ == 'FPN' and DEFER_PROJECTION
-        levels = self.attn(features, defer_projection=True) if defer else self.attn(features)
+        levels = self.attn(features, defer_projection=self.fpn.pt_wise) if defer else self.attn(features)
         if lazy and self._lazy_strides():
             out = self.fpn(levels, lazy_strides=self._lazy_strides())
         else:

@@ -19,10 +19,14 @@ from . import _prep, functional as Fn
 # SURVEY Appendix C-1).  Instead of materialising 2*fm the pyramid hands (fm, 2.0) to the FPN, whose
 # lateral 1x1 convolution applies the factor exactly in its epilogue (power of two).
 Scaled = namedtuple('Scaled', ['tensor', 'factor'])
-# Evaluation mode, pyramid straight in front of the FPN: an attention level is handed over as (fm, ctx, W_o, b_o) -- its value is
-# fm + ctx W_o^T + b_o, but the one consumer, the FPN's lateral 1x1, is linear too and takes the projection into its own weights
-# (fpn.FPN.forward, _prep.lateral_of_projection): 2 C d multiply-adds per token become 2 p d (p = 384 lateral channels, C = 1024 / 2048).
-Projected = namedtuple('Projected', ['tensor', 'ctx', 'wo', 'bo'])
+# Evaluation mode, pyramid straight in front of the plain FPN: an attention level is handed over unfinished.  Its value is
+# fm + ctx W_o^T + b_o, but the one consumer, the FPN's lateral 1x1 (W_l, b_l), is linear too:
+#   * `lateral=False`: (fm, ctx, W_o, b_o) -- the lateral takes the projection into its own weights (fpn.FPN.forward,
+#     _prep.lateral_of_projection): 2 C d multiply-adds per token become 2 p d (p = 384 lateral channels, C = 1024 / 2048, d = C / 2);
+#   * `lateral=True` (the pyramid was given the laterals): `ctx` is already W_l W_o times the module's context, [.., p] -- the VALUE
+#     projection was composed with W_o and W_l (_prep.value_of_lateral), so values, P V and the hand-over are p wide instead of d and no
+#     projection GEMM is left at all: the lateral adds `ctx` through its residual input.
+Projected = namedtuple('Projected', ['tensor', 'ctx', 'wo', 'bo', 'lateral'])
 
 
 class SelfAttention(nn.Module):
@@ -68,9 +72,13 @@ class SelfAttention(nn.Module):
             raise NotImplementedError(f'attention over {h}x{w} tokens: the P.V GEMM needs H*W % 32 == 0')
         inv = float(np.float32(1.0) / np.float32(np.round(np.sqrt(d), 2)))            # self_attention.py:47
         if defer_projection and not self.position_encoding and not torch.is_grad_enabled() and d % 32 == 0:
-            _, _, cx, _ = Fn.attention_context(x.view(B, L, Cc), self.query.weight, self.query.bias, self.key.weight, self.key.bias,
-                                               self.value.weight, self.value.bias, inv)
-            return Projected(inpt, cx.view(B, h, w, d), self.final_projection.weight, self.final_projection.bias)
+            wv, bv, lat = self.value.weight, self.value.bias, isinstance(defer_projection, nn.Conv2d)
+            if lat:                                    # the FPN lateral that will read this level
+                if defer_projection.weight.shape[0] % 32 or defer_projection.weight.shape[1] != Cc:
+                    raise ValueError('the lateral handed to SelfAttention does not read this level')
+                wv, bv = _prep.value_of_lateral(defer_projection.weight, self.final_projection.weight, wv, bv)
+            _, _, cx, _ = Fn.attention_context(x.view(B, L, Cc), self.query.weight, self.query.bias, self.key.weight, self.key.bias, wv, bv, inv)
+            return Projected(inpt, cx.view(B, h, w, -1), self.final_projection.weight, self.final_projection.bias, lat)
         out = Fn.Attention.apply(x.view(B, L, Cc), self.query.weight, self.query.bias, self.key.weight, self.key.bias,
                                  self.value.weight, self.value.bias, self.final_projection.weight,
                                  self.final_projection.bias, inv).view(B, h, w, Cc)        # = x + attention(x)
@@ -93,11 +101,12 @@ class SAPyramid(nn.Module):
 
     def forward(self, x, defer_projection=False):
         """x: bottom-up list of NHWC maps -> list of `fm + module(fm)`; identity levels as Scaled(fm, 2.0); with `defer_projection`
-        (the caller is the plain FPN, evaluation mode) attention levels as Projected(fm, ctx, W_o, b_o)."""
+        (True, or the FPN's laterals {str(level): nn.Conv2d}: the caller is the plain FPN, evaluation mode) attention levels as `Projected`."""
         out = []
         for i, fm in enumerate(x):
             m = self.attention_modules[str(i)]
-            out.append(Scaled(fm, 2.0) if isinstance(m, nn.Identity) else m(fm, residual=True, defer_projection=defer_projection))
+            dp = defer_projection[str(i)] if isinstance(defer_projection, (dict, nn.ModuleDict)) else defer_projection
+            out.append(Scaled(fm, 2.0) if isinstance(m, nn.Identity) else m(fm, residual=True, defer_projection=dp))
         return out
 
 
@@ -108,6 +117,8 @@ def materialize(levels):
         if isinstance(l, Scaled):
             return Fn.Scale.apply(l.tensor, l.factor)
         if isinstance(l, Projected):
+            if l.lateral:
+                raise ValueError('a level handed over in its lateral form has no value of its own (only the FPN lateral it was made for reads it)')
             B, h, w, Cc = l.tensor.shape
             return ops.linear(l.ctx.reshape(B * h * w, -1), l.wo.detach(), l.bo.detach(), residual=l.tensor.reshape(B * h * w, Cc)).view(B, h, w, Cc)
         return l

@@ -425,6 +425,10 @@ def test_attention_projection_folded_into_the_fpn_laterals(model):
         assert [type(l).__name__ for l in handed] == ['Scaled', 'Scaled', 'Scaled', 'Projected', 'Projected']
         for a, b in zip(materialize(handed), materialize(plain)):
             assert torch.equal(a, b)
+        lat = model.attn(feats, defer_projection=model.fpn.pt_wise)         # what the model passes: the laterals themselves
+        assert all(l.lateral and l.ctx.shape[-1] == model.fpn.pt_wise['3'].weight.shape[0] for l in lat[3:])
+        with pytest.raises(ValueError):
+            materialize(lat)
         keep = nbm_model.DEFER_PROJECTION
         try:
             nbm_model.DEFER_PROJECTION = True
