@@ -69,7 +69,7 @@ class DepthwiseSepConv2d(nn.Module):
         if pe_act is None and self.stride >= 1:
             # a demand-driven FPN map read for the first time (evaluation mode): this block composed with the map's own convolution is
             # one 5x5 / stride convolution of that convolution's input -- the map's pattern pixels are never formed
-            f = ondemand.rpn_composite(x, self, _prep)
+            f = ondemand.rpn_composite(x, self)
             if f is not None:
                 return f
         ondemand.pattern_materialize(x)              # (no-op unless x is such a map and this block could not take it)

@@ -481,7 +481,7 @@ def _border_classes(nb, H, W, S, device):
 DIRECT_GATHER = os.environ.get('NBM_RPN_DIRECT', '1') != '0'    # rpn_composite: operands that exist as dense maps are gathered by the GEMM itself
 
 
-def rpn_composite(fm, block, prep):
+def rpn_composite(fm, block):
     """Evaluation mode: the output of `block` (layers.DepthwiseSepConv2d, the RPN's reader of the map: depthwise 3x3 / stride S ->
     1x1 -> BatchNorm -> SiLU) on the demand-driven map `fm` WITHOUT the map's pattern pixels: the block composed with the map's own
     3x3 convolution is one 5x5 / stride S / pad 2 convolution of the convolution's INPUT (`_prep.rpn_composite`) -- the same 25 K N
@@ -498,6 +498,7 @@ def rpn_composite(fm, block, prep):
     st = lazy_state(fm)
     if st is None or st.pending is None or st.raw is None:
         return None
+    from .nets import _prep as prep                  # (nets imports this module)
     S = st.stride
     if int(max(1, block.stride)) != S or block.stride < 1 or getattr(block, 'pe_proj', None) is not None:
         return None
