@@ -82,9 +82,11 @@ class NbmModel(nn.Module):
         Tensors are NCHW-shaped views of NHWC storage.  `host_work(rpn_cls_scores, rpn_bbox_reg)` (optional callable) runs after
         every kernel of the first stage has been queued and before the host waits for the RoI count, i.e. hidden behind the GPU work.
         `lazy=False` (default): every map of 'fpn_out' is dense, like the reference's.  `lazy=True` (what this package's own
-        `train.step` and `detect` pass): 'fpn_out'[0] holds only the pixels its consumers read -- the RPN pattern now, the tiles
-        under the RoI windows once a RoI pooling (`forward_second_stage`, any number of times, any RoIs) runs on THIS tensor or a
-        full view of it; every other pixel is unwritten memory, so a clone / slice / arithmetic on the map is meaningless."""
+        `train.step` and `detect` pass): 'fpn_out'[0] (and [1]) hold only the pixels their consumers read -- the RPN pattern now, the
+        tiles under the RoI windows once a RoI pooling (`forward_second_stage`, any number of times, any RoIs) runs on THIS tensor or a
+        full view of it; every other pixel is unwritten memory, so a clone / slice / arithmetic on the map is meaningless.  Without a
+        gradient to come (evaluation) not even the RPN pattern is formed: the RPN's first block is composed with the map's own
+        convolution; `ondemand.pattern_materialize(map)` forms the pattern pixels for a caller that wants to read them."""
         fpn_out = self._fpn_nhwc(samples, lazy=lazy)
         rois, cls, reg = self.head.forward_first_stage([f.permute(0, 3, 1, 2) for f in fpn_out], host_work)
         return {'rois': rois, 'rpn_cls_scores': cls, 'rpn_bbox_reg': reg,
