@@ -32,13 +32,15 @@ def _evict(obj_id):
             print(f'_prep: evicted {k[1]} (key tensor died), values at {[hex(t.data_ptr()) for t in ts]}', flush=True)
 
 
-def _cached(key_t, tag, fn, extra=()):
+def _cached(key_t, tag, fn, extra=(), epoch=True):
     """Prepared copy of `key_t`.  An entry belongs to ONE tensor object: it keeps a weak reference to it and is only
     valid while that referent is alive and is `key_t` itself -- CPython reuses ids and the caching allocator reuses
     device addresses, so (id, data_ptr, version) alone can match a different model's parameter after the first model was
     freed.  Entries are dropped when their tensor dies (the prepared copies would otherwise leak on the device)."""
     key = (id(key_t), tag)
-    ver = (key_t.data_ptr(), key_t._version, key_t.device, _epoch) + tuple(extra)
+    # `epoch=False`: the inputs are buffers that no kernel ever writes through a raw pointer (FrozenBatchNorm): torch's own version
+    # counters see every change they can undergo (load_state_dict, .to()), so the entry outlives the optimiser steps
+    ver = (key_t.data_ptr(), key_t._version, key_t.device, _epoch if epoch else -1) + tuple(extra)
     hit = _cache.get(key)
     if hit is not None and hit[0]() is key_t and hit[1] == ver:
         return hit[2]
@@ -127,7 +129,7 @@ def stem_fold(w1, w_init, b_init):
     return _cached(w1, 'stem', make, extra=(w_init.data_ptr(), w_init._version, b_init.data_ptr(), b_init._version))
 
 
-def bn_affine(weight, bias, mean, var, eps, conv_bias=None):
+def bn_affine(weight, bias, mean, var, eps, conv_bias=None, frozen=False):
     """Fold (conv bias +) BatchNorm running statistics into per-channel (scale, shift):
     y = (z + conv_bias - mean) * weight / sqrt(var + eps) + bias  =  z * scale + shift."""
     def make():
@@ -140,7 +142,10 @@ def bn_affine(weight, bias, mean, var, eps, conv_bias=None):
     # key that changes with every update would leave one stale entry per update behind
     extra = (weight._version, bias._version, mean._version, var._version, None if conv_bias is None else conv_bias._version,
              mean.data_ptr(), var.data_ptr(), bias.data_ptr())
-    return _cached(weight, ('bn', conv_bias is not None), make, extra=extra)
+    # `frozen` (backbone.FrozenBatchNorm2d): the 53 affines of the ResNet body used to be recomputed after EVERY optimiser step (five
+    # pointwise launches each: 265 of the ~650 small torch launches of a training step, scripts/small_launches.py) because the step
+    # invalidates every prepared copy; their four tensors are buffers nothing writes behind torch's back
+    return _cached(weight, ('bn', conv_bias is not None), make, extra=extra, epoch=not frozen)
 
 
 def _rpn_composite64(out_w, out_b, dw_w, dw_b, pt_w, rmask, smask, lat_wk, alpha):

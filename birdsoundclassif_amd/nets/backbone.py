@@ -35,7 +35,7 @@ class FrozenBatchNorm2d(nn.Module):
                                       error_msgs)
 
     def affine(self):
-        return _prep.bn_affine(self.weight, self.bias, self.running_mean, self.running_var, 1e-5)
+        return _prep.bn_affine(self.weight, self.bias, self.running_mean, self.running_var, 1e-5, frozen=True)
 
 
 class _Bottleneck(nn.Module):
