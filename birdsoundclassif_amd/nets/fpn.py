@@ -10,7 +10,7 @@ import torch.nn as nn
 from .. import ops
 from . import _prep, functional as Fn
 from .layers import DepthwiseSepConv2d
-from .self_attention import Projected, Scaled, materialize
+from .self_attention import Deferred, Projected, Scaled, materialize
 
 
 class FusionModule(nn.Module):
@@ -110,6 +110,15 @@ class FPN(nn.Module):
         for i in range(len(x) - 1, -1, -1):                       # coarsest level first
             fm = x[i]
             c = self.pt_wise[str(i)]
+            if isinstance(fm, Deferred):
+                # training: attention module + lateral (+ merge) as one tape node, composed (functional.AttnLateral)
+                m = fm.module
+                merged = Fn.AttnLateral.apply(fm.tensor, m.query.weight, m.query.bias, m.key.weight, m.key.bias, m.value.weight, m.value.bias,
+                                              m.final_projection.weight, m.final_projection.bias, c.weight, c.bias, merged, fm.inv)
+                oc_ = self.out_convs[str(len(x) - 1 - i)]
+                outs.insert(0, Fn.conv(merged, oc_.weight, bias=oc_.bias, kh=3, kw=3, pad=1, lazy_stride=(lazy_strides or {}).get(i),
+                                       accept_stash=i > 0))
+                continue
             if isinstance(fm, Projected):
                 # evaluation mode: the level is fm + ctx W_o^T + b_o with the projection still to do -- the lateral takes it into its own
                 # weights: W_l fm + shift, then (W_l W_o) ctx + that + the top-down merge

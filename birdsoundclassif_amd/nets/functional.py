@@ -876,6 +876,103 @@ def attention_context(x, wq, bq, wk, bk, wv, bv, inv):
     return qkv, p, cx, wqkv
 
 
+def _mat(a, b_t):
+    """a [m, k] @ b_t[n, k]^T -> [m, n] through the library's own GEMM (small weight-sized products of the composed attention branch)."""
+    return ops.linear(a.contiguous(), b_t.contiguous())
+
+
+class AttnLateral(Function):
+    """lateral(fm + SelfAttention(fm)) [+ bilinear(up)] as ONE tape node, composed: the module's final projection W_o and the
+    FPN lateral W_l that reads the level are both linear, so the value projection is taken to W_v' = W_l W_o W_v (p = 384 rows instead
+    of d = C / 2), P V' is already the lateral's image of the attention branch, and the level fm + ctx W_o^T + b_o (C wide) is never
+    formed: y = W_l fm + (W_l b_o + b_l) + P V' + up.  Reference: self_attention.py:24-56,76 + fpn.py:143-144; the gradients of all
+    eleven tensors follow by the chain rule through the two small weight products (hand-written: 3 + 6 small GEMMs)."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, wo, bo, wl, bl, up, inv):
+        B, h, w, Cc = x.shape
+        L, M = h * w, B * h * w
+        d, p_ = wq.shape[0], wl.shape[0]
+        wl2 = wl.detach().reshape(p_, Cc)
+        wlo = _mat(wl2, wo.detach().t())                              # [p, d] = W_l W_o
+        wvp = _mat(wlo, wv.detach().t())                              # [p, C] = W_l W_o W_v
+        bvp = _mat(wlo, bv.detach()[None, :]).view(p_)                # W_l W_o b_v
+        sh = torch.empty((p_, 1), device=x.device, dtype=torch.float32)
+        ops.gemm_conv(wl2, bo.detach()[None, :].contiguous(), sh, B=1, H=p_, W=1, Cin=Cc, N=1, shift=bl.detach(), shift_per_row=True)
+        sh = sh.view(p_)                                              # W_l b_o + b_l
+        qkv, p, cx, wqkv = attention_context(x.view(B, L, Cc), wq, bq, wk, bk, wvp, bvp, inv)
+        y = ops.conv2d(x, _prep.krsc(wl), shift=sh, residual=cx.view(B, h, w, p_), up=up)
+        ctx.save_for_backward(x, qkv, p, wqkv, wlo, wl, wo, wv, bv, bo)
+        ctx.inv, ctx.d = inv, d
+        ctx.up_hw = tuple(up.shape[1:3]) if up is not None else None
+        # gradient hand-over (see _STASH): d/dx to the backbone stage that reads the tap too, d/d(up) to the coarse map's output convolution
+        ctx.stash_x = _stash_wanted(x)
+        ctx.stash_up, ctx.up_ptr = _stash_wanted(up), (up.data_ptr() if up is not None else 0)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, qkv, p, wqkv, wlo, wl, wo, wv, bv, bo = ctx.saved_tensors
+        inv, d = ctx.inv, ctx.d
+        B, h, w, Cc = x.shape
+        L, M = h * w, B * h * w
+        p_ = wl.shape[0]
+        ld = 2 * d + p_
+        dev = x.device
+        need = ctx.needs_input_grad
+        g = gy.contiguous()
+        g2 = g.view(M, p_)
+        x2d = x.view(M, Cc)
+        wl2 = wl.detach().reshape(p_, Cc)
+        gup = None
+        if ctx.up_hw is not None and need[11]:
+            gup = ops.upsample_bilinear_bwd(g, *ctx.up_hw)
+            if ctx.stash_up:
+                _STASH[ctx.up_ptr] = gup
+                arm_end_of_backward_check()
+                gup = None
+        # ---- the lateral's own term W_l fm + shift
+        gsh = ops.colsum(g2)                                          # d/d(W_l b_o + b_l)
+        gwl = torch.zeros((p_, Cc), device=dev, dtype=torch.float32)
+        ops.conv_wgrad(g2, x2d, gwl, B=1, H=M, W=1, Cin=Cc, N=p_)      # g^T fm
+        # ---- the attention branch: ctx' = P V' enters y through the residual input, so d/d(ctx') = g
+        gp = torch.empty((B, L, L), device=dev, dtype=torch.float32)
+        ops.gemm_conv(g2, qkv[:, 2 * d:], gp, B=1, H=L, W=1, Cin=p_, N=L, x_ld=p_, w_ld=ld, groups=B,
+                      x_gs=L * p_, w_gs=L * ld, y_gs=L * L)            # dP = g V'^T
+        gqkv = torch.zeros((M, ld), device=dev, dtype=torch.float32)
+        ops.conv_wgrad(p, g2, gqkv[:, 2 * d:], B=1, H=L, W=1, Cin=p_, N=L, g_ld=L, x_ld=p_, out_ld=ld, groups=B,
+                       g_gs=L * L, x_gs=L * p_, out_gs=L * ld)          # dV' = P^T g
+        gs = ops.softmax_rows_bwd(p.view(M, L), gp.view(M, L), alpha=inv)
+        ops.conv_dgrad(gs, qkv[:, d:], gqkv, B=1, H=L, W=1, Cin=d, N=L, g_ld=L, w_ld=ld, out_ld=ld, groups=B,
+                       g_gs=L * L, w_gs=L * ld, out_gs=L * ld)          # dQ = dS K
+        ops.conv_wgrad(gs, qkv, gqkv[:, d:], B=1, H=L, W=1, Cin=d, N=L, g_ld=L, x_ld=ld, out_ld=ld, groups=B,
+                       g_gs=L * L, x_gs=L * ld, out_gs=L * ld)          # dK = dS^T Q
+        gbqkv = ops.colsum(gqkv)
+        gwqkv = torch.zeros((ld, Cc), device=dev, dtype=torch.float32)
+        ops.conv_wgrad(gqkv, x2d, gwqkv, B=1, H=M, W=1, Cin=Cc, N=ld)
+        gx = None
+        if need[0]:
+            gx_lat = torch.empty((M, Cc), device=dev, dtype=torch.float32)
+            ops.conv_dgrad(g2, wl2, gx_lat, B=1, H=M, W=1, Cin=Cc, N=p_)                 # g W_l
+            gx = torch.empty((M, Cc), device=dev, dtype=torch.float32)
+            ops.conv_dgrad(gqkv, wqkv, gx, B=1, H=M, W=1, Cin=Cc, N=ld, residual=gx_lat)  # + d[Q | K | V'] W
+            gx = gx.view(B, h, w, Cc)
+            if ctx.stash_x:                           # the backbone stage that reads the tap adds this in its own kernel
+                _STASH[x.data_ptr()] = gx
+                arm_end_of_backward_check()
+                gx = None
+        # ---- chain rule through W_v' = W_lo W_v, b_v' = W_lo b_v, W_lo = W_l W_o, shift = W_l b_o + b_l
+        gwvp, gbvp = gwqkv[2 * d:], gbqkv[2 * d:]
+        gwlo = _mat(gwvp, wv.detach()) + gbvp[:, None] * bv.detach()[None, :]            # [p, d]
+        gwv = _mat(wlo.t(), gwvp.t())                                                    # W_lo^T dW_v'  [d, C]
+        gbv = _mat(wlo.t(), gbvp[None, :]).view(d)
+        gbo = _mat(wl2.t(), gsh[None, :]).view(Cc)
+        gwl = gwl + gsh[:, None] * bo.detach()[None, :] + _mat(gwlo, wo.detach())        # direct + through the shift + through W_lo
+        gwo = _mat(wl2.t(), gwlo.t())                                                    # W_l^T dW_lo  [C, d]
+        return (gx, gwqkv[:d], gbqkv[:d], gwqkv[d:2 * d], gbqkv[d:2 * d], gwv, gbv, gwo, gbo, gwl.view_as(wl), gsh, gup, None)
+
+
 class Attention(Function):
     """fm + SelfAttention(fm) (reference self_attention.py:24-56,76) with a hand-written backward: 5 forward and
     9 backward fp32-MFMA GEMM launches (NT / NN / TN forms), row softmax and its gradient."""

@@ -15,6 +15,7 @@ from . import functional as Fn
 from .self_attention import build_sa_layers, materialize
 from .head import build_head
 
+DEFER_PROJECTION_TRAIN = os.environ.get('NBM_DEFER_PROJECTION_TRAIN', '1') != '0'
 DEFER_PROJECTION = os.environ.get('NBM_DEFER_PROJECTION', '1') != '0'      # evaluation mode: attention's final projection folded into the FPN laterals
 
 
@@ -68,7 +69,8 @@ class NbmModel(nn.Module):
         if getattr(self.args, 'sandwich_attn', False):
             return materialize(self.attn[1](self.fpn(self.attn[0](features))))
         # evaluation mode, plain FPN: the attention levels' final projection is folded into the FPN's laterals (self_attention.Projected)
-        defer = (not torch.is_grad_enabled()) and type(self.fpn).__name__ == 'FPN' and DEFER_PROJECTION
+        # (with a gradient to come: module + lateral as one composed tape node, functional.AttnLateral -- NBM_DEFER_PROJECTION_TRAIN=0: off)
+        defer = type(self.fpn).__name__ == 'FPN' and DEFER_PROJECTION and (not torch.is_grad_enabled() or DEFER_PROJECTION_TRAIN)
         levels = self.attn(features, defer_projection=self.fpn.pt_wise) if defer else self.attn(features)
         if lazy and self._lazy_strides():
             out = self.fpn(levels, lazy_strides=self._lazy_strides())

@@ -27,6 +27,9 @@ Scaled = namedtuple('Scaled', ['tensor', 'factor'])
 #     projection was composed with W_o and W_l (_prep.value_of_lateral), so values, P V and the hand-over are p wide instead of d and no
 #     projection GEMM is left at all: the lateral adds `ctx` through its residual input.
 Projected = namedtuple('Projected', ['tensor', 'ctx', 'wo', 'bo', 'lateral'])
+# The same composition with a gradient to come: the level is not computed at all here -- the FPN runs module + lateral as ONE tape node
+# (functional.AttnLateral) on (fm, this module, 1 / denominator).
+Deferred = namedtuple('Deferred', ['tensor', 'module', 'inv'])
 
 
 class SelfAttention(nn.Module):
@@ -71,6 +74,9 @@ class SelfAttention(nn.Module):
         if L % 32:
             raise NotImplementedError(f'attention over {h}x{w} tokens: the P.V GEMM needs H*W % 32 == 0')
         inv = float(np.float32(1.0) / np.float32(np.round(np.sqrt(d), 2)))            # self_attention.py:47
+        if isinstance(defer_projection, nn.Conv2d) and not self.position_encoding and torch.is_grad_enabled() and d % 32 == 0 \
+                and defer_projection.weight.shape[0] % 32 == 0 and defer_projection.weight.shape[1] == Cc and Cc % 32 == 0:
+            return Deferred(inpt, self, inv)
         if defer_projection and not self.position_encoding and not torch.is_grad_enabled() and d % 32 == 0:
             wv, bv, lat = self.value.weight, self.value.bias, isinstance(defer_projection, nn.Conv2d)
             if lat:                                    # the FPN lateral that will read this level
@@ -116,6 +122,8 @@ def materialize(levels):
     def one(l):
         if isinstance(l, Scaled):
             return Fn.Scale.apply(l.tensor, l.factor)
+        if isinstance(l, Deferred):
+            raise ValueError('a level deferred to the FPN has no value of its own (only functional.AttnLateral computes it, lateral included)')
         if isinstance(l, Projected):
             if l.lateral:
                 raise ValueError('a level handed over in its lateral form has no value of its own (only the FPN lateral it was made for reads it)')

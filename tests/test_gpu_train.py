@@ -784,3 +784,46 @@ def test_a_backward_pass_that_leaves_a_stashed_gradient_raises_by_itself():
     with pytest.raises(RuntimeError, match='never picked up'):
         y.sum().backward()                       # ... but only the first consumer's branch is back-propagated
     assert not Fn._STASH
+
+
+@pytest.mark.parametrize('shape', [(2, 8, 16, 128, 96, True), (1, 12, 32, 256, 64, False)])
+def test_attention_and_lateral_as_one_composed_node(shape):
+    """functional.AttnLateral (training form): lateral(fm + SelfAttention(fm)) + bilinear(up) with the value projection taken to
+    W_l W_o W_v -- output and the gradients of all twelve tensors against the uncomposed chain of tape nodes (Attention, then the lateral
+    convolution with its fused merge), which the golden training fixtures pin against the reference."""
+    B, h, w, Cc, p_, with_up = shape
+    d = Cc // 2
+    torch.manual_seed(3)
+
+    def mk(*s, scale=1.0):
+        return (torch.randn(*s, device='cuda') * scale).requires_grad_(True)
+    x = mk(B, h, w, Cc)
+    wq, wk, wv = mk(d, Cc, scale=Cc ** -0.5), mk(d, Cc, scale=Cc ** -0.5), mk(d, Cc, scale=Cc ** -0.5)
+    bq, bk, bv = mk(d, scale=0.1), mk(d, scale=0.1), mk(d, scale=0.1)
+    wo, bo = mk(Cc, d, scale=d ** -0.5), mk(Cc, scale=0.1)
+    wl, bl = mk(p_, Cc, 1, 1, scale=Cc ** -0.5), mk(p_, scale=0.1)
+    up = mk(B, (h + 1) // 2, (w + 1) // 2, p_) if with_up else None
+    inv = float(np.float32(1.0) / np.float32(np.round(np.sqrt(d), 2)))
+    gy = torch.randn(B, h, w, p_, device='cuda')
+    leaves = [x, wq, bq, wk, bk, wv, bv, wo, bo, wl, bl] + ([up] if with_up else [])
+    names = ['x', 'wq', 'bq', 'wk', 'bk', 'wv', 'bv', 'wo', 'bo', 'wl', 'bl', 'up']
+
+    def run(composed):
+        for t in leaves:
+            t.grad = None
+        Fn.stash_reset(None)
+        if composed:
+            y = Fn.AttnLateral.apply(x, wq, bq, wk, bk, wv, bv, wo, bo, wl, bl, up, inv)
+        else:
+            out = Fn.Attention.apply(x.view(B, h * w, Cc), wq, bq, wk, bk, wv, bv, wo, bo, inv).view(B, h, w, Cc)
+            y = Fn.conv(out, wl, bias=bl, up=up)
+        y.backward(gy)
+        return y.detach().clone(), [t.grad.detach().clone() for t in leaves]
+    y0, g0 = run(False)
+    y1, g1 = run(True)
+    assert float((y1 - y0).abs().max()) <= 2e-5 * max(1.0, float(y0.abs().max()))
+    gmax = max(float(b.abs().max()) for b in g0)
+    for n, a, b in zip(names, g1, g0):
+        # (the key bias shifts every score of a row alike: its gradient is zero up to rounding noise, ~1e-6 here -- hence the absolute term)
+        scale_ = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2e-4 * scale_ + 1e-6 * gmax, (n, float((a - b).abs().max()), scale_, gmax)
