@@ -5,6 +5,8 @@ reference's NCHW-shaped return values (as permuted views of the NHWC buffers the
 `*_device` methods are the sync-free internal path (fixed-capacity buffers + device-side counters) used by
 `NbmModel.forward`.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -87,6 +89,9 @@ class DepthwiseSepConv2d(nn.Module):
         return ops.conv2d(out, _prep.krsc(self.pt_wise.weight), scale=s, shift=b, act=ops.ACT_SILU)
 
 
+MERGE_RPN_HEADS = os.environ.get('NBM_MERGE_RPN_HEADS', '1') != '0'     # training: class and box heads of an RPN level as one GEMM
+
+
 class RegionProposalNetwork(nn.Module):
     """reference layers.py:49-99."""
 
@@ -123,6 +128,13 @@ class RegionProposalNetwork(nn.Module):
             cls_l, reg_l = [], []
             for i, f in enumerate(feats):
                 c, r = self.cls_score[str(i)], self.bbox_reg[str(i)]
+                if MERGE_RPN_HEADS:
+                    # both heads of a level read the same map: ONE GEMM with the 6 + 12 output channels side by side -- forward, data
+                    # gradient and weight gradient each run once instead of twice (N = 6 / 12 GEMMs sit at 8-14 TF/s: 7 ms of a step)
+                    y = Fn.conv(f, torch.cat([c.weight, r.weight], 0), bias=torch.cat([c.bias, r.bias], 0))
+                    cls_l.append(y[..., :A * 2])
+                    reg_l.append(y[..., A * 2:])
+                    continue
                 cls_l.append(Fn.conv(f, c.weight, bias=c.bias))
                 reg_l.append(Fn.conv(f, r.weight, bias=r.bias))
             cls_raw = torch.cat(cls_l, -1)
