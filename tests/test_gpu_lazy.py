@@ -815,3 +815,24 @@ def test_rpn_block_composed_with_the_output_convolution(shape):
     assert float(e1[:, 0].max()) <= 2e-5 * scale_ and float(e1[:, :, 0].max()) <= 2e-5 * scale_          # border classes
     assert float((e1 ** 2).mean().sqrt()) <= 1.05 * float((e2 ** 2).mean().sqrt()) + 1e-9, \
         f'composite rms error {float((e1 ** 2).mean().sqrt()):.3e} vs pattern route {float((e2 ** 2).mean().sqrt()):.3e}'
+
+
+def test_composed_reader_under_batch_chunking(model):
+    """ondemand.rpn_composite walks the batch chunks of the map (ops.WINO_CHUNK_BYTES): several chunks give the one-chunk result bit for
+    bit, and the route through the pattern pixels (NBM_RPN_COMPOSITE=0) the same RoIs."""
+    B = 16
+    x = torch.from_numpy(np.tile(synth.image_batch(0, 8), (B // 8, 1, 1))).cuda()[:, None]
+    keep = (ops.WINO_CHUNK_BYTES, ondemand.COMPOSITE)
+    res = {}
+    try:
+        for chunk_gb, comp in ((24, True), (2, True), (2, False)):
+            ops.WINO_CHUNK_BYTES, ondemand.COMPOSITE = chunk_gb << 30, comp
+            with torch.no_grad():
+                o = model.forward_first_stage(x, lazy=True)
+            res[(chunk_gb, comp)] = (o['rpn_cls_scores'].float().clone(), o['rois'].clone())
+        assert ondemand.lazy_chunk(torch.empty(B, 188, 512, 384, device='meta')) < B          # the 2 GB setting did chunk level 0
+    finally:
+        ops.WINO_CHUNK_BYTES, ondemand.COMPOSITE = keep
+    one, many, pattern = res[(24, True)], res[(2, True)], res[(2, False)]
+    assert torch.equal(one[0], many[0]) and torch.equal(one[1], many[1])
+    assert float((many[0] - pattern[0]).abs().max()) < 2e-5 and torch.equal(many[1], pattern[1])
