@@ -282,3 +282,90 @@ def test_fused_adamw_load_state_dict_restores_the_flat_moments(monkeypatch, tmp_
     # a later checkpoint of the resumed run stores the LIVE moments
     sd = ob.state_dict()['state']
     assert torch.equal(sd[0]['exp_avg'], ob._flat[0]['m'][:48].view(6, 8))
+
+
+# --------------------------------------------------------------------------- a rank whose step raises
+def _peer_fail_main(rank, port, flavour):
+    """Child process: three `train_one_step` calls of a 2-rank job; rank 1's step raises in the third.  Exit code 0 only if all three
+    steps returned (i.e. never with the behaviour under test)."""
+    import time
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=2)
+    patch_cpu_optimizer()
+    from birdsoundclassif_amd import train
+    train.DP_OVERLAP = True
+    if flavour == 'flat':
+        train._device_backend = lambda d: 'nccl'               # the GPU job's control flow: bitmap + error bit over their own gloo group
+        train.init_control_group(dist)
+    m = TwoStage()
+    opt = train.FusedAdamW(_groups(m), lr=1e-2, weight_decay=1e-2) if flavour == 'flat' else torch.optim.AdamW(_groups(m), lr=1e-2)
+
+    class Crit:
+        weight_dict = {'l': 1.0}
+
+    def fake_step(model, criterion, batch, device, negative_sample, early_backward=False):
+        it, x = batch
+        if it == 2 and rank == 1:
+            raise ValueError('rank 1: broken batch in step 2')
+        return {'l': model.loss(x, True)}
+
+    train.step = fake_step
+    for it in range(3):
+        x = torch.full((4, 8), 0.1 * (rank + 1) + 0.05 * it) + torch.arange(8.0) * 0.01
+        t0 = time.perf_counter()
+        try:
+            train.train_one_step(m, Crit(), opt, (it, x), 0.05, 'cpu', False)
+        except Exception as exc:
+            print(f'rank {rank} step {it}: {type(exc).__name__}: {exc} [{time.perf_counter() - t0:.2f} s]', flush=True)
+            raise SystemExit(3)
+        print(f'rank {rank} step {it}: ok', flush=True)
+    raise SystemExit(0)
+
+
+def test_a_rank_whose_step_raises_takes_every_rank_out_of_the_same_step():
+    """The error bit behind the touched bitmap (`allreduce_grads(failed=)`): rank 1 raises inside step 2 -> it still joins the step's
+    collectives, rank 0 raises PeerStepError in the SAME step; both fresh child processes exit non-zero within seconds instead of
+    rank 0 blocking in the all-reduce.  Flat (FusedAdamW, separate control group) and plain-module branch."""
+    import subprocess, sys, time
+    for flavour in ('flat', 'plain'):
+        port = _free_port()
+        t0 = time.time()
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--peer-fail', str(r), str(port), flavour],
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                                  cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))) for r in range(2)]
+        outs = []
+        for p in procs:
+            try:
+                outs.append(p.communicate(timeout=90)[0])
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                raise AssertionError(f'[{flavour}] a rank was still blocked after 90 s')
+        assert [p.returncode for p in procs] == [3, 3], outs
+        assert 'rank 0 step 0: ok' in outs[0] and 'rank 0 step 1: ok' in outs[0] and 'rank 0 step 2: PeerStepError' in outs[0], outs[0]
+        assert 'rank 1 step 1: ok' in outs[1] and 'rank 1 step 2: ValueError: rank 1: broken batch' in outs[1], outs[1]
+        assert time.time() - t0 < 60
+
+
+
+def test_boundary_hook_leaves_buffer_0_alone_while_an_rpn_share_is_parked(monkeypatch):
+    """`parked_flush` back-propagates a parked RPN share into FPN / attention gradients AFTER the backbone-boundary hook has
+    fired; the hook must not start buffer 0's all-reduce then (allreduce_grads starts it behind the flush)."""
+    from birdsoundclassif_amd import train
+    from birdsoundclassif_amd.nets import functional as Fn
+
+    class Opt:
+        def flat_grads(self):
+            raise AssertionError('the exchange must not start')
+
+    st = {'handles': [], 'started': 0, 't0': None, 'opt': Opt()}
+    monkeypatch.setitem(train._PENDING, 1, st)
+    monkeypatch.setitem(Fn._PARKED, 123, (None, None, None))
+    assert train.backbone_boundary_hook(torch.zeros(1)) is None and st['started'] == 0
+
+
+if __name__ == '__main__':
+    import sys
+    if len(sys.argv) == 5 and sys.argv[1] == '--peer-fail':
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        _peer_fail_main(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
