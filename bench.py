@@ -73,15 +73,11 @@ def train_bench(rank, world, dist, batch, steps, warmup, mix_steps=10):
     model = model.cuda().train()
     crit.train()
     opt, _ = build_optimizer(model, args)
-    base = synth.image_batch(rank * 8, 8)
-    img = torch.from_numpy(np.tile(base, (-(-batch // 8), 1, 1))[:batch].copy()).cuda()
-    neg = torch.from_numpy(np.tile(synth.image_batch(100 + rank * 8, 8), (-(-batch // 8), 1, 1))[:batch].copy()).cuda()
-    bbs, idss, lens = [], [], []
-    for i in range(batch):
-        bb, ids, ln = synth.label_batch(rank * 8 + i % 8, 1)
-        bbs.append(bb), idss.append(ids)
-        lens += ln
-    data = [img, neg, torch.cat(bbs), torch.cat(idss), lens]      # labels stay on the host, as a DataLoader delivers them
+    # `batch` DISTINCT images / label sets per rank (8 tiled clips never show the batch-coupled paths a mixed batch)
+    img = torch.from_numpy(synth.image_batch(rank * batch, batch)).cuda()
+    neg = torch.from_numpy(synth.image_batch(100000 + rank * batch, batch)).cuda()
+    bb, ids, lens = synth.label_batch(rank * batch, batch)
+    data = [img, neg, bb, ids, list(lens)]                        # labels stay on the host, as a DataLoader delivers them
     np.random.seed(1000 + rank)
 
     def sync_all():
@@ -239,7 +235,7 @@ def train_bench(rank, world, dist, batch, steps, warmup, mix_steps=10):
     torch.cuda.empty_cache()
     v = pos['clips_per_s']
     exec_tflops = v / world * exec_gflop_per_clip / 1e3
-    return {'value': v, 'unit': 'clips/s', 'batch_per_gpu': batch, 'global_batch': world * batch, 'steps': steps,
+    return {'value': v, 'unit': 'clips/s', 'batch_per_gpu': batch, 'distinct_images': batch, 'global_batch': world * batch, 'steps': steps,
             'ms_per_step': pos['ms_per_step'], 'ms_per_step_with_the_instruments_on': pos['ms_per_step_instrumented'],
             'parallelism': f'dp{world}', 'per_rank': per_rank,
             'exchange': None if world == 1 else ('one all-reduce (AVG) per flat gradient buffer; the non-backbone buffer starts inside the backward '
@@ -558,9 +554,11 @@ def main(argv=None):
     model.load_state_dict(synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}))
     model = model.cuda().eval()
     fe = SpectrogramFrontEnd('cuda')
-    # a few distinct clips tiled to the batch: the input content does not change the work
-    base = synth.clip_batch_pcm16(rank * 8, 8)
-    pcm = torch.from_numpy(np.tile(base, (-(-B // 8), 1))[:B].copy()).cuda()
+    # B DISTINCT clips per rank: the batch-coupled minima of the proposal stage, the device RoI tile lists and the NMS launches see a
+    # mixed batch (tests/test_gpu_fullsize.py checks the same 64 clips against the oracle)
+    pcm_host = synth.clip_batch_pcm16(rank * B, B)
+    distinct_clips = len({bytes(r) for r in pcm_host})
+    pcm = torch.from_numpy(pcm_host).cuda()
 
     fast_rcnn = model.head.fast_rcnn
 
@@ -650,7 +648,7 @@ def main(argv=None):
                 gd, graph_note = None, 'hipGraph capture failed on another rank'
         return gd
 
-    def replay_leg(gd, check_det=True):
+    def replay_leg(gd, expect=None):
         """Timed replays of the captured step: `gd.lanes` batches per replay, in flight on the GPU together; EXACTLY K steps = K // lanes
         replays + (K mod lanes) eager steps behind them (in a lane of their own: the graph's branches own lanes 0 .. lanes-1).
         -> seconds, or None.  Every rank passes BOTH barriers whatever happens to it in between (a rank-local exception used to leave
@@ -706,11 +704,12 @@ def main(argv=None):
                         n_det_g += sum(len(v['bbox_coord']) for out in finish_g(pend) for d in out for v in d.values())
                     for _ in range(n_tail):                    # K is not a multiple of the lanes: the remaining steps, eagerly
                         torch.cuda.current_stream().wait_stream(gd.stream)
-                        with ops.lane(L):
+                        with ops.lane(max(gd.lane_ids) + 1):
                             out = step()
                         n_det_g += sum(len(v['bbox_coord']) for d in out for v in d.values())
-                    if check_det and n_det_g != n_det:
-                        raise RuntimeError(f'the replayed steps returned {n_det_g} detections, the eager ones {n_det}')
+                    want = n_det if expect is None else expect
+                    if n_det_g != want:
+                        raise RuntimeError(f'the replayed steps returned {n_det_g} detections, the eager ones {want}')
                 except Exception as exc:
                     ok, graph_note = False, f'hipGraph replay failed ({type(exc).__name__}: {exc}); value is the eager loop'[:300]
             sync_all()
@@ -725,7 +724,7 @@ def main(argv=None):
             dt_leg = None
         return dt_leg
 
-    # ONE GraphedDetector alive at a time (see its docstring): the one-lane graph is measured and released before the multi-lane one exists
+    # the one-lane graph is measured and released before the multi-lane one exists (memory: every live detector owns its lanes' scratch)
     dt_g = dt_g1 = dt_g2 = None
     lanes_used = 0
     gd = capture(1)
@@ -772,7 +771,8 @@ def main(argv=None):
         os.environ['NBM_SPLIT_BF16'] = '1'
         try:
             step()
-            step()
+            out_s = step()                                       # the eager step in THIS mode: what the replays of the leg must reproduce
+            n_det_split = sum(len(v['bbox_coord']) for d in out_s for v in d.values()) * a.steps
             torch.cuda.synchronize()
             ops.PROFILE, ops.PROFILE_ONLY = [], 'deepk'
             for _ in range(3):
@@ -781,7 +781,7 @@ def main(argv=None):
             prof_s, ops.PROFILE, ops.PROFILE_ONLY = ops.PROFILE, None, None
             note0 = graph_note
             gd = capture(max(1, lanes_used))
-            dt_s = replay_leg(gd, check_det=False) if gd is not None else None
+            dt_s = replay_leg(gd, expect=n_det_split) if gd is not None else None
             gd = None
             gc.collect()
             torch.cuda.empty_cache()
@@ -955,7 +955,7 @@ def main(argv=None):
                 'config': {'workload': 'BASELINE.json configs[1]: 1xMI355X inference, batch=64 synthetic 3 s clips '
                                        '(PCM16 @22.05 kHz resident in HBM) through the HIP STFT front end + detector '
                                        'forward + device post-processing, detections returned to the host',
-                           'batch_per_gpu': B, 'min_score': a.min_score, 'detections_per_step': n_det / a.steps,
+                           'batch_per_gpu': B, 'distinct_clips': distinct_clips, 'min_score': a.min_score, 'detections_per_step': n_det / a.steps,
                            'launch': (('hipGraph replay of ONE graph whose capture forks into %d parallel detect steps (one stream each): '
                                        '%d batches in flight together per replay' % (lanes_used, lanes_used) if lanes_used > 1 else
                                        'hipGraph replay of the captured step') if dt_g is not None else (graph_note or 'eager loop')),

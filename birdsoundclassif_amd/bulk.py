@@ -38,9 +38,14 @@ class GraphedDetector:
     every branch a complete detect step on its own static input / outputs and its own persistent scratch (`ops.lane`): a replay
     processes `lanes` batches that are in flight on the GPU TOGETHER, so the tail of one step's kernels (a launch's last, partly
     filled round of workgroups; the latency-bound proposal / NMS kernels) is filled by the other's: 65.2 instead of 68.9 ms per
-    B = 64 batch (profiles/r04_two_lanes.txt).  It is one graph, not one graph per lane, on purpose: a second graph exec launched
-    shortly after its instantiation while another exec is alive computed garbage on this ROCm build (scripts/lane_debug_*.py: same
-    captures, results depend on the milliseconds between instantiate and first launch) -- keep ONE GraphedDetector alive at a time."""
+    B = 64 batch (profiles/r04_two_lanes.txt).
+
+    Fence (profiles/r05_graph_pair.txt): the HIP runtime that torch 2.10+rocm7.0 bundles (7.0.51831) loses MEMSET nodes of a
+    replayed graph exec -- round 4's "second graph exec computes garbage / faults" was the proposal stage's counters, zeroed by
+    hipMemsetAsync = memset nodes, keeping the previous replay's values.  The library zeroes with kernels now, and the capture is
+    refused unless its graph consists of kernel (and empty fork / join) nodes only (`ops.graph_census`), whoever issued the others.
+    The persistent scratch / tile-list buffers of the lanes are held as captured (`self._held`), so no later growth or release can
+    recycle memory this graph writes to.  Several detectors may be alive at a time (`tests/test_gpu_detect_cli.py`)."""
 
     def __init__(self, model, batch, n_samples, sr, min_score=0.2, nms_thresh=0.3, device='cuda', independent=False, lanes=1):
         from . import ops
@@ -55,17 +60,64 @@ class GraphedDetector:
         self.pcm = self.pcms[0]
         self.stream = torch.cuda.Stream()
         self.side = [torch.cuda.Stream() for _ in range(self.lanes - 1)]
+        self.lane_ids = self._claim_lanes(self, self.lanes)
+        try:
+            self._capture(ops)
+        except BaseException:
+            self.close()                                          # a refused / failed capture leaves no lane claimed and no graph behind
+            raise
+
+    def _capture(self, ops):
         with torch.no_grad(), torch.cuda.stream(self.stream):
             for _ in range(2):                                   # warm-up: fills every weight / anchor / table cache, sizes the lanes' scratch
                 self._run_all()
             self.stream.synchronize()
             for s_ in self.side:
                 s_.synchronize()
-            self.graph = torch.cuda.CUDAGraph()
+            self.graph = torch.cuda.CUDAGraph(keep_graph=True)
             with torch.cuda.graph(self.graph, stream=self.stream):
                 outs = self._run_all()                            # static graph outputs
+        self.census = ops.graph_census(self.graph.raw_cuda_graph())
+        bad = {k: v for k, v in self.census.items() if v and k not in ('kernel', 'empty')}
+        if bad or not self.census['kernel']:
+            raise RuntimeError(f'the captured detect step holds graph nodes other than kernels: {bad} (census {self.census}).  Memset '
+                               'nodes are not replayed reliably by the HIP runtime torch bundles (DESIGN 4d): refusing to replay this graph')
+        self.graph.instantiate()
+        self._held = ops.lane_buffers(set(self.lane_ids))
         self.dets, self.n_dets = [o[0] for o in outs], [o[1] for o in outs]
         self.det, self.n_det = self.dets[0], self.n_dets[0]
+
+    # lanes in use by live detectors: a second detector alive beside the first gets scratch of its own instead of sharing buffers
+    # whose addresses both graphs would write through (two replays on two streams would race on them)
+    _LANES_IN_USE = {}
+
+    @classmethod
+    def _claim_lanes(cls, owner, n):
+        import weakref
+        for k in [k for k, ref in cls._LANES_IN_USE.items() if ref() is None]:
+            del cls._LANES_IN_USE[k]
+        ids, k = [], 0
+        while len(ids) < n:
+            if k not in cls._LANES_IN_USE:
+                ids.append(k)
+                cls._LANES_IN_USE[k] = weakref.ref(owner)
+            k += 1
+        return ids
+
+    def close(self):
+        """Drops the graph, its static buffers and its hold on the lanes' scratch; lanes other than 0 are released to the allocator."""
+        from . import ops
+        self.graph = None
+        self._held = []
+        self.pcms = self.dets = self.n_dets = []
+        self.pcm = self.det = self.n_det = None
+        for k in getattr(self, 'lane_ids', []):
+            ref = self._LANES_IN_USE.get(k)
+            if ref is not None and ref() in (self, None):
+                del self._LANES_IN_USE[k]
+        self.lane_ids = []
+        others = set(self._LANES_IN_USE)
+        ops.release_lane_scratch(keep=tuple(others | {0}))
 
     def _run(self, k=0):
         imgs, _ = self.fes[k](self.pcms[k], self.sr)
@@ -78,9 +130,9 @@ class GraphedDetector:
         outs = [None] * self.lanes
         for k, s_ in enumerate(self.side, start=1):
             s_.wait_stream(main)                                  # fork
-            with torch.cuda.stream(s_), ops.lane(k):
+            with torch.cuda.stream(s_), ops.lane(self.lane_ids[k]):
                 outs[k] = self._run(k)
-        with ops.lane(0):
+        with ops.lane(self.lane_ids[0]):
             outs[0] = self._run(0)
         for s_ in self.side:
             main.wait_stream(s_)                                  # join
@@ -201,6 +253,7 @@ def detect_files(model, files, batch=64, min_score=0.2, bird_dict=None, write_tx
         lanes = detector.lanes if detector is not None else int(os.environ.get('NBM_BULK_LANES', '2' if n_batches >= 4 else '1'))
     lanes = max(1, int(lanes))
     det = detector or GraphedDetector(model, batch, n, sr, min_score=min_score, independent=independent, lanes=lanes)
+    own_det = detector is None
     if (det.batch, det.pcm.shape[1], det.sr) != (batch, n, sr) or det.lanes != lanes:
         raise ValueError('the GraphedDetector handed in was captured for another batch / clip length / sample rate / number of lanes')
     fe = det.fe
@@ -309,6 +362,9 @@ def detect_files(model, files, batch=64, min_score=0.2, bird_dict=None, write_tx
         free_q.put(None)                            # unblocks a reader that waits for a slot after an error
         th_w.join()
         th_r.join(timeout=5)
+        if own_det:                                 # graph, static buffers and the extra lanes' scratch (tens of GB at B = 64) go now,
+            torch.cuda.synchronize()                # not whenever the caller's frame dies: the per-file driver may run right behind this
+            det.close()
     if err:
         raise err[0]
     if stats is not None:

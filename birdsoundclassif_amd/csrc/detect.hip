@@ -584,7 +584,7 @@ extern "C" int nbm_rpn_decode(const float* cls, const float* reg, const float* a
       KA % n_anchor)
     return NBM_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(keep_count, 0, sizeof(int) * B, st);
+  hipError_t e = nbm_zero_async(keep_count, sizeof(int) * B, st);
   if (e != hipSuccess) return (int)e;
   dim3 grid((KA + 255) / 256, B);
   hipLaunchKernelGGL(rpn_decode_kernel, grid, dim3(256), 0, st, cls, reg, anchors, KA, n_anchor, img_w, img_h,
@@ -657,7 +657,7 @@ extern "C" int nbm_roi_tiles(const float* rois, const int* n_roi, int B, int roi
   const size_t lds = (size_t)(((thw + 31) >> 5) + 1) * 4;
   if (lds > 60000) return NBM_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(n_blocks, 0, sizeof(int), st) != hipSuccess) return (int)hipGetLastError();
+  if (nbm_zero_async(n_blocks, sizeof(int), st) != hipSuccess) return (int)hipGetLastError();
   hipLaunchKernelGGL(roi_tiles_kernel, dim3(B), dim3(256), lds, st, p);
   return nbm_launch_status();
 }

@@ -16,6 +16,24 @@ static inline int nbm_launch_status() {
 
 static inline bool nbm_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
+// Zero fill as a KERNEL launch.  The library never calls hipMemsetAsync: inside a stream capture that call becomes a MEMSET NODE, and
+// the HIP runtime torch 2.10+rocm7.0 bundles (7.0.51831) loses memset nodes of a graph exec from its second launch on (AQL packet
+// capture; scripts/graph_pair_repro.hip, profiles/r05_graph_pair.txt) -- the counters of the proposal stage then kept the
+// previous replay's values.  A kernel node is replayed reliably.  p: 4-byte aligned, bytes % 4 == 0.
+namespace {
+__global__ void nbm_zero_words_kernel(uint32_t* __restrict__ p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+}  // namespace
+static inline hipError_t nbm_zero_async(void* p, size_t bytes, hipStream_t st) {
+  if ((((uintptr_t)p) & 3u) || (bytes & 3u)) return hipErrorInvalidValue;
+  const size_t n = bytes >> 2;
+  if (!n) return hipSuccess;
+  const size_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(nbm_zero_words_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, (uint32_t*)p, n);
+  return hipGetLastError();
+}
+
 // Order-preserving map float -> uint32 (larger float => larger key); NaN sorts above +inf.
 __device__ __forceinline__ uint32_t nbm_f2key(float f) {
   uint32_t u = __float_as_uint(f);

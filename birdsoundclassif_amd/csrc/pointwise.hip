@@ -1,6 +1,7 @@
 // HBM-bound stages of the NBM hot path: waveform preparation, spectrogram normalise/window, and the
 // point-wise / small-window detector layers.  All NHWC fp32; every kernel is a coalesced grid-stride
 // sweep with the channel (or time) index fastest across lanes.
+#include <stdlib.h>
 #include "nbm_common.h"
 
 namespace {
@@ -458,7 +459,29 @@ __global__ void pair_softmax_kernel(const float* __restrict__ x, long long n_pix
 
 }  // namespace
 
-extern "C" const char* nbm_version(void) { return "nbm_hip 0.2 (gfx950)"; }
+extern "C" const char* nbm_version(void) { return "nbm_hip 0.3 (gfx950)"; }
+
+extern "C" int nbm_graph_census(void* graph, long long counts[6]) {
+  if (!graph || !counts) return NBM_EINVAL;
+  for (int i = 0; i < 6; ++i) counts[i] = 0;
+  size_t n = 0;
+  hipError_t e = hipGraphGetNodes((hipGraph_t)graph, nullptr, &n);
+  if (e != hipSuccess) return (int)e;
+  if (!n) return NBM_OK;
+  hipGraphNode_t* nodes = (hipGraphNode_t*)malloc(n * sizeof(hipGraphNode_t));
+  if (!nodes) return NBM_EINVAL;
+  e = hipGraphGetNodes((hipGraph_t)graph, nodes, &n);
+  for (size_t i = 0; e == hipSuccess && i < n; ++i) {
+    hipGraphNodeType t;
+    e = hipGraphNodeGetType(nodes[i], &t);
+    if (e != hipSuccess) break;
+    const int k = t == hipGraphNodeTypeKernel ? 0 : t == hipGraphNodeTypeMemcpy ? 1 : t == hipGraphNodeTypeMemset ? 2
+                : t == hipGraphNodeTypeHost ? 3 : t == hipGraphNodeTypeEmpty ? 4 : 5;
+    counts[k] += 1;
+  }
+  free(nodes);
+  return e == hipSuccess ? NBM_OK : (int)e;
+}
 
 extern "C" int nbm_pcm16_to_wave(const int16_t* pcm, int64_t pcm_ld, int batch, int n, int upsample,
                                  const int32_t* hq, int64_t first, int64_t count, float* out, int64_t out_ld, int lead,

@@ -1177,7 +1177,7 @@ extern "C" int nbm_weighted_sum_bwd(const float* x0, const float* x1, const floa
 }
 extern "C" int nbm_colsum(const float* g, int64_t M, int N, int ld, float* out, void* stream) {
   if (!g || !out || M <= 0 || N <= 0 || ld < N) return NBM_EINVAL;
-  hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * N, ST);
+  hipError_t e = nbm_zero_async(out, sizeof(float) * N, ST);
   if (e != hipSuccess) return (int)e;
   dim3 grid(grid_for(M, 4, 1024), (N + 63) / 64);
   hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, ST, g, (long long)M, N, ld, out);
@@ -1249,8 +1249,8 @@ extern "C" int nbm_dwconv3x3_bwd(const float* x, const float* g, const float* w,
     else hipLaunchKernelGGL(dwconv_bwd_data_kernel<0>, grid, dim3(TPB), 0, ST, g, B, H, W, Cin, mult, stride, w, gx, Ho, Wo, 0);
   }
   if (gw) {
-    hipError_t e = hipMemsetAsync(gw, 0, sizeof(float) * Cout * 9, ST);
-    if (e == hipSuccess && gb) e = hipMemsetAsync(gb, 0, sizeof(float) * Cout, ST);
+    hipError_t e = nbm_zero_async(gw, sizeof(float) * Cout * 9, ST);
+    if (e == hipSuccess && gb) e = nbm_zero_async(gb, sizeof(float) * Cout, ST);
     if (e != hipSuccess) return (int)e;
     // 192 workgroup columns: every workgroup ends with 2560 atomics on the same 5120 addresses, and that tail grows with the grid
     // (B = 128, 24 x 64 outputs, 512 channels: 64 -> 0.75, 128 -> 0.48, 192 -> 0.44, 256 -> 0.47, 512 -> 0.63, 1024 -> 0.86 ms)
@@ -1303,7 +1303,7 @@ extern "C" int nbm_bn_train_fwd(const float* x, int64_t M, int C, const float* w
                                 float momentum, float* run_mean, float* run_var, double* stats_ws, float* mean,
                                 float* invstd, float* y, void* stream) {
   if (!x || !w || !b || !stats_ws || !mean || !invstd || !y || M <= 0 || C <= 0) return NBM_EINVAL;
-  hipError_t e = hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * C, ST);
+  hipError_t e = nbm_zero_async(stats_ws, sizeof(double) * 2 * C, ST);
   if (e != hipSuccess) return (int)e;
   dim3 grid(grid_for(M, 4, 1024), (C + 63) / 64);
   hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), 0, ST, x, (long long)M, C, stats_ws);
@@ -1315,7 +1315,7 @@ extern "C" int nbm_bn_train_fwd(const float* x, int64_t M, int C, const float* w
 extern "C" int nbm_bn_train_bwd(const float* g, const float* x, int64_t M, int C, const float* mean, const float* invstd,
                                 const float* w, double* red_ws, float* gx, float* gw, float* gb, void* stream) {
   if (!g || !x || !mean || !invstd || !w || !red_ws || !gx || !gw || !gb || M <= 0 || C <= 0 || M * (int64_t)C < C) return NBM_EINVAL;
-  hipError_t e = hipMemsetAsync(red_ws, 0, sizeof(double) * 2 * C, ST);
+  hipError_t e = nbm_zero_async(red_ws, sizeof(double) * 2 * C, ST);
   if (e != hipSuccess) return (int)e;
   dim3 grid(grid_for(M, 4, 1024), (C + 63) / 64);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, ST, g, x, (long long)M, C, mean, invstd, red_ws);

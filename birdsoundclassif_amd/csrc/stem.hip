@@ -274,7 +274,7 @@ extern "C" int nbm_stem7x7_wgrad(const float* img, const float* g, int B, int H,
   if (strips > 0x7fffffffll) return NBM_EUNSUPPORTED;
   p.n_strips = (int)strips;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(D, 0, sizeof(float) * 64 * 64, st) != hipSuccess || hipMemsetAsync(Cb, 0, sizeof(float) * 64 * 49, st) != hipSuccess)
+  if (nbm_zero_async(D, sizeof(float) * 64 * 64, st) != hipSuccess || nbm_zero_async(Cb, sizeof(float) * 64 * 49, st) != hipSuccess)
     return (int)hipGetLastError();
   const int grid = (int)(strips < 1024 ? strips : 1024);
   hipLaunchKernelGGL(stem_wgrad_kernel, dim3(grid), dim3(256), 0, st, p);

@@ -44,8 +44,15 @@ def main(argv=None):
             continue
         batch = min(args.bulk_batch, -(-len(group) // 8) * 8)
         try:
-            bulk.detect_files(model, group, batch=batch, min_score=args.min_score, bird_dict=bird_dict, write_txt=True,
-                              keep_results=False)
+            try:
+                bulk.detect_files(model, group, batch=batch, min_score=args.min_score, bird_dict=bird_dict, write_txt=True,
+                                  keep_results=False)
+            except torch.cuda.OutOfMemoryError:
+                # two lanes = a second set of persistent scratch and graph-pool activations: degrade to one batch in flight
+                torch.cuda.empty_cache()
+                print(f'bulk route: out of device memory with two batches in flight; retrying the group of {len(group)} clips with one lane')
+                bulk.detect_files(model, group, batch=batch, min_score=args.min_score, bird_dict=bird_dict, write_txt=True,
+                                  keep_results=False, lanes=1)
         except (ValueError, NotImplementedError, OSError) as exc:
             # a file whose header disagrees with its data, a truncated or changing file, a decode the bulk reader does not do: the
             # per-file driver (= the reference's behaviour) takes the whole group (it rewrites the txt files the bulk route finished)

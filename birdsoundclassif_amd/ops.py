@@ -184,6 +184,28 @@ def _wino_scratch(device, n_v, n_m):
     return buf[:n_v], buf[n_v:need]
 
 
+GRAPH_NODE_KINDS = ('kernel', 'memcpy', 'memset', 'host', 'empty', 'other')
+
+
+def graph_census(raw_graph):
+    """{node kind: count} of a captured hipGraph_t (`torch.cuda.CUDAGraph(keep_graph=True).raw_cuda_graph()`), nbm_graph_census."""
+    counts = (C.c_longlong * 6)()
+    check(_lib.load().nbm_graph_census(C.c_void_p(int(raw_graph)), C.byref(counts)), 'nbm_graph_census')
+    return dict(zip(GRAPH_NODE_KINDS, (int(v) for v in counts)))
+
+
+def lane_buffers(lanes):
+    """The persistent scratch / tile-list tensors of the given lanes AS THEY ARE NOW: a captured graph bakes their raw addresses in, so
+    its owner keeps these references -- a later growth (`_wino_scratch` drops the dict entry before it allocates the larger buffer) or
+    `release_lane_scratch` then cannot hand the memory a live graph writes to to another tensor."""
+    from . import ondemand
+    held = [buf for key, buf in _WINO_SCRATCH.items() if key[1] in lanes and buf is not None]
+    for key, bufs in ondemand._ROI_TILE_BUF.items():
+        if key[2] in lanes:
+            held.extend(bufs)
+    return held
+
+
 def release_lane_scratch(keep=(0,)):
     """Frees the persistent scratch and tile-list buffers of every lane not in `keep` (tens of GB at B = 64).  Only when no captured
     graph that was issued in those lanes is alive any more: a graph keeps the raw addresses."""

@@ -35,6 +35,13 @@ extern "C" {
 
 const char* nbm_version(void);
 
+/* Census of a captured graph (a `hipGraph_t`, e.g. torch.cuda.CUDAGraph(keep_graph=True).raw_cuda_graph()): counts[0..5] = kernel,
+ * memcpy, memset, host, empty (fork / join), other nodes.  No counterpart in the reference (nbm_detect.py:23-28 runs one eager model
+ * call per file); it is the fence of the captured bulk loop (bulk.GraphedDetector): the HIP runtime torch 2.10+rocm7.0 bundles
+ * (7.0.51831) loses MEMSET nodes of a graph exec from its second launch on (scripts/graph_pair_repro.hip), so a step is
+ * only replayed when its graph holds kernel (and empty) nodes alone.  This library itself never creates memset nodes. */
+int nbm_graph_census(void* graph, long long counts[6]);
+
 /* ------------------------------------------------------------------------------------------------
  * Implicit-GEMM convolution / batched GEMM on the fp32 MFMA (v_mfma_f32_32x32x2_f32).
  *

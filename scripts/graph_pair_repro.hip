@@ -1,9 +1,12 @@
-// Torch-free, library-free control experiment for DESIGN 4d: two captured graph execs alive in one process, each a chain of NODES
-// kernel nodes (large by-value argument structs, a data dependency from node to node through device memory, memset nodes in
-// between), the second exec launched immediately after the first one's launch has completed.  Every kernel checks the checksum of
-// its own argument struct (stale / foreign kernel arguments show up as `bad_args`) and the chain's result shows up in `wrong`.
-// No kernel takes a pointer argument: a corrupted argument cannot turn into a wild access.
-//   hipcc --offload-arch=gfx950 -O2 scripts/graph_pair_repro.hip -o scripts/graph_pair_repro && scripts/graph_pair_repro [nodes] [delay_ms]
+// Torch-free, library-free control experiment for DESIGN 4d: captured graph execs alive together in one process, each a chain of
+// kernel nodes (large by-value argument structs, a data dependency from node to node through device memory) with MEMSET nodes in
+// between, like the product's detect step (csrc/detect.hip: the counters of rpn_select / roi_tiles are zeroed by hipMemsetAsync).
+// Every kernel checks the checksum of its own argument struct and logs which (graph, node) block it saw; every memset node is
+// followed by a kernel that checks that the memset HAS happened and dirties the region again.  No kernel takes a pointer argument:
+// a corrupted argument cannot turn into a wild access.
+//   hipcc --offload-arch=gfx950 -O2 scripts/graph_pair_repro.hip -o scripts/graph_pair_repro
+//   scripts/graph_pair_repro [nodes=300] [delay_ms=0] [execs=2] [big_memset=1] [small_memset_bytes=256] [host_memsets=1]
+//   host_memsets = 0: the host issues NO hipMemset between the launches (the execution-log counter is reset by a kernel instead)
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
@@ -12,66 +15,97 @@
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
-constexpr int N = 1 << 22;
-__device__ float g_buf[2][2][N];            // [graph][ping-pong][N]
-__device__ unsigned g_bad_args[2];
-__device__ unsigned g_scratch[2][1024];         // target of the memset nodes between the kernel nodes
-struct Args { unsigned long long magic[30]; unsigned long long sum; int graph, node, n, pad; };
+constexpr int N = 1 << 22, MAXG = 3, SCR = 4096;
+__device__ float g_buf[MAXG][2][N];                // [graph][ping-pong][N]
+__device__ unsigned g_bad_args[MAXG], g_bad_memset[MAXG], g_bad_nodes[64], g_n_bad_nodes;   // which checking kernels found their memset missing
+__device__ unsigned g_log[4096], g_count;          // execution log: which (graph, node) argument block every launched kernel saw
+__device__ unsigned g_scratch[MAXG][SCR];          // target of the small memset nodes (the product's counters)
+struct Args { unsigned long long magic[30]; unsigned long long sum; int graph, node, n, flags, scr_words, pad; };
+enum { F_INIT = 1, F_CHECK_MEMSET = 2 };
 
 __global__ void step_kernel(Args a) {
   unsigned long long s = 0;
   for (int i = 0; i < 30; ++i) s += a.magic[i] * (i + 1);
-  if (s != a.sum || a.graph < 0 || a.graph > 1 || a.n != N) { if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&g_bad_args[a.graph & 1], 1u); return; }
+  if (s != a.sum || a.graph < 0 || a.graph >= MAXG || a.n != N) { if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&g_bad_args[0], 1u); return; }
+  if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned slot = atomicAdd(&g_count, 1u); if (slot < 4096) g_log[slot] = ((unsigned)a.graph << 16) | (unsigned)a.node; }
+  if ((a.flags & F_CHECK_MEMSET) && blockIdx.x == 0) {        // the memset node in front of this kernel must have zeroed the region
+    unsigned dirty = 0;
+    for (int i = threadIdx.x; i < a.scr_words; i += blockDim.x) { dirty |= g_scratch[a.graph][i]; g_scratch[a.graph][i] = 0xD1A7u; }
+    if (__syncthreads_or(dirty != 0) && threadIdx.x == 0) { atomicAdd(&g_bad_memset[a.graph], 1u); const unsigned z = atomicAdd(&g_n_bad_nodes, 1u); if (z < 64) g_bad_nodes[z] = ((unsigned)a.graph << 16) | (unsigned)a.node; }
+  }
   const float* src = g_buf[a.graph][a.node & 1];
   float* dst = g_buf[a.graph][(a.node + 1) & 1];
   // reads a neighbour that another workgroup (most likely on another XCD) wrote in the previous node
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) dst[i] = src[(i + 4099) & (N - 1)] + 1.0f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x)
+    dst[i] = (a.flags & F_INIT) ? 1.0f : src[(i + 4099) & (N - 1)] + 1.0f;
 }
 
+__global__ void reset_kernel() { g_count = 0; }
+
 int main(int argc, char** argv) {
-  int nodes = argc > 1 ? atoi(argv[1]) : 300, delay_ms = argc > 2 ? atoi(argv[2]) : 0;
+  const int nodes = argc > 1 ? atoi(argv[1]) : 300, delay_ms = argc > 2 ? atoi(argv[2]) : 0, execs = argc > 3 ? atoi(argv[3]) : 2;
+  const int big = argc > 4 ? atoi(argv[4]) : 1, small_bytes = argc > 5 ? atoi(argv[5]) : 256, host_memsets = argc > 6 ? atoi(argv[6]) : 1;
+  if (execs < 1 || execs > MAXG || small_bytes > SCR * 4) return 2;
   int rt = 0; CK(hipRuntimeGetVersion(&rt));
-  float* base; unsigned *bad, *scr;
+  float* base; unsigned *bad, *badm, *scr, *lg, *cnt;
   CK(hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_buf))); CK(hipGetSymbolAddress((void**)&bad, HIP_SYMBOL(g_bad_args)));
-  CK(hipGetSymbolAddress((void**)&scr, HIP_SYMBOL(g_scratch)));
-  hipStream_t st[2]; hipGraph_t gr[2]; hipGraphExec_t ex[2];
-  for (int g = 0; g < 2; ++g) {
+  CK(hipGetSymbolAddress((void**)&badm, HIP_SYMBOL(g_bad_memset))); CK(hipGetSymbolAddress((void**)&scr, HIP_SYMBOL(g_scratch)));
+  CK(hipGetSymbolAddress((void**)&lg, HIP_SYMBOL(g_log))); CK(hipGetSymbolAddress((void**)&cnt, HIP_SYMBOL(g_count)));
+  printf("[hip runtime %d] %d exec(s) alive, %d kernel nodes each, %s, memset nodes of %d bytes every 16 nodes, %d ms between launches, host-side hipMemset between launches: %s\n", rt, execs, nodes,
+         big ? "first node = 16 MB memset of the chain's input" : "chain initialised by its first KERNEL", small_bytes, delay_ms, host_memsets ? "yes" : "no");
+  hipStream_t st[MAXG]; hipGraph_t gr[MAXG]; hipGraphExec_t ex[MAXG];
+  for (int g = 0; g < execs; ++g) {
     CK(hipStreamCreate(&st[g]));
     CK(hipStreamBeginCapture(st[g], hipStreamCaptureModeGlobal));
-    CK(hipMemsetAsync(base + (size_t)g * 2 * N, 0, sizeof(float) * N, st[g]));
+    if (big) CK(hipMemsetAsync(base + (size_t)g * 2 * N, 0, sizeof(float) * N, st[g]));
     for (int k = 0; k < nodes; ++k) {
-      Args a; a.sum = 0; a.graph = g; a.node = k; a.n = N; a.pad = 0;
+      Args a; a.sum = 0; a.graph = g; a.node = k; a.n = N; a.flags = (!big && k == 0) ? F_INIT : 0; a.scr_words = small_bytes / 4; a.pad = 0;
+      if (k % 16 == 7) { CK(hipMemsetAsync(scr + g * SCR, 0, small_bytes, st[g])); a.flags |= F_CHECK_MEMSET; }
       for (int i = 0; i < 30; ++i) { a.magic[i] = 0x9E3779B97F4A7C15ull * (unsigned long long)(g * 100003 + k * 31 + i + 1); a.sum += a.magic[i] * (i + 1); }
       hipLaunchKernelGGL(step_kernel, dim3(2048), dim3(256), 0, st[g], a);
-      if (k % 16 == 7) CK(hipMemsetAsync(scr + g * 1024, 0, 1024 * sizeof(unsigned), st[g]));   // memset nodes like the product's counters
     }
     CK(hipStreamEndCapture(st[g], &gr[g]));
     CK(hipGraphInstantiate(&ex[g], gr[g], nullptr, nullptr, 0));
   }
-  CK(hipMemset(bad, 0, 2 * sizeof(unsigned)));
+  CK(hipMemset(bad, 0, MAXG * sizeof(unsigned))); CK(hipMemset(badm, 0, MAXG * sizeof(unsigned)));
+  CK(hipMemset(scr, 0x5A, sizeof(unsigned) * MAXG * SCR));      // dirty before the FIRST launch too: a memset node that never runs shows at once
+  if (big) CK(hipMemset(base, 0x7F, sizeof(float) * MAXG * 2 * N));
   std::vector<float> h(N);
+  const float want_v = (float)nodes;          // node 0 writes 1 in both modes (0 + 1 or the init value), the last node `nodes`
   int fails = 0;
+  auto check_values = [&](int g, const char* what) {
+    CK(hipMemcpy(h.data(), base + ((size_t)g * 2 + (nodes & 1)) * N, sizeof(float) * N, hipMemcpyDeviceToHost));
+    long wrong = 0, first = -1, last = -1; float v0 = 0;
+    for (int i = 0; i < N; ++i) if (h[i] != want_v) { if (first < 0) { first = i; v0 = h[i]; } last = i; ++wrong; }
+    unsigned b[MAXG], bm[MAXG]; CK(hipMemcpy(b, bad, sizeof(b), hipMemcpyDeviceToHost)); CK(hipMemcpy(bm, badm, sizeof(bm), hipMemcpyDeviceToHost));
+    printf("  %s exec %d: %ld of %d chain values wrong", what, g, wrong, N);
+    if (wrong) printf(" (first at %ld = %g instead of %g, last at %ld)", first, v0, want_v, last);
+    printf("; kernels that found their memset NOT done so far: %u; kernels with a bad argument block so far: %u\n", bm[g], b[0]);
+    fails += wrong != 0 || bm[g] != 0 || b[0] != 0;
+  };
   for (int round = 0; round < 3; ++round) {
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < execs; ++g) {
+      if (host_memsets) CK(hipMemset(cnt, 0, sizeof(unsigned))); else { hipLaunchKernelGGL(reset_kernel, dim3(1), dim3(1), 0, 0); CK(hipDeviceSynchronize()); }
       CK(hipGraphLaunch(ex[g], st[g])); CK(hipStreamSynchronize(st[g]));
+      std::vector<unsigned> log(4096); unsigned n_run = 0;      // the log must read (g, 0), (g, 1), ... (g, nodes - 1)
+      CK(hipMemcpy(&n_run, cnt, sizeof(unsigned), hipMemcpyDeviceToHost)); CK(hipMemcpy(log.data(), lg, sizeof(unsigned) * 4096, hipMemcpyDeviceToHost));
+      int off = 0;
+      for (int k = 0; k < nodes && k < 4096; ++k) off += (unsigned)k >= n_run || log[k] != (((unsigned)g << 16) | (unsigned)k);
+      char what[64]; snprintf(what, sizeof(what), "launch %d,", round);
+      if (off || n_run != (unsigned)nodes) { printf("  %s exec %d: %u kernels ran (%d captured), %d out of order / with another node's arguments\n", what, g, n_run, nodes, off); ++fails; }
+      check_values(g, what);
       if (delay_ms) std::this_thread::sleep_for(std::chrono::milliseconds(delay_ms));
     }
-    for (int g = 0; g < 2; ++g) {
-      CK(hipMemcpy(h.data(), base + ((size_t)g * 2 + (nodes & 1)) * N, sizeof(float) * N, hipMemcpyDeviceToHost));
-      long wrong = 0; for (int i = 0; i < N; ++i) wrong += h[i] != (float)nodes;
-      unsigned b[2]; CK(hipMemcpy(b, bad, sizeof(b), hipMemcpyDeviceToHost));
-      printf("[hip runtime %d, %d nodes, delay %d ms] round %d graph %d: wrong values %ld, kernels with bad arguments %u\n", rt, nodes, delay_ms, round, g, wrong, b[g]);
-      fails += wrong != 0 || b[g] != 0;
-    }
   }
-  // both execs in flight together on their two streams
-  for (int r = 0; r < 4; ++r) for (int g = 0; g < 2; ++g) CK(hipGraphLaunch(ex[g], st[g]));
-  CK(hipDeviceSynchronize());
-  for (int g = 0; g < 2; ++g) {
-    CK(hipMemcpy(h.data(), base + ((size_t)g * 2 + (nodes & 1)) * N, sizeof(float) * N, hipMemcpyDeviceToHost));
-    long wrong = 0; for (int i = 0; i < N; ++i) wrong += h[i] != (float)nodes;
-    printf("[hip runtime %d] concurrent graph %d: wrong values %ld\n", rt, g, wrong); fails += wrong != 0;
+  if (execs > 1) {                                               // all execs in flight together on their streams
+    for (int r = 0; r < 4; ++r) for (int g = 0; g < execs; ++g) CK(hipGraphLaunch(ex[g], st[g]));
+    CK(hipDeviceSynchronize());
+    for (int g = 0; g < execs; ++g) check_values(g, "4 concurrent launches,");
   }
+  unsigned nb = 0, bn[64]; unsigned *pb, *pn;
+  CK(hipGetSymbolAddress((void**)&pb, HIP_SYMBOL(g_bad_nodes))); CK(hipGetSymbolAddress((void**)&pn, HIP_SYMBOL(g_n_bad_nodes)));
+  CK(hipMemcpy(&nb, pn, sizeof(unsigned), hipMemcpyDeviceToHost)); CK(hipMemcpy(bn, pb, sizeof(bn), hipMemcpyDeviceToHost));
+  if (nb) { printf("  memset nodes found missing, in order of detection (exec:node behind the memset):"); for (unsigned i = 0; i < nb && i < 24; ++i) printf(" %u:%u", bn[i] >> 16, bn[i] & 0xffff); printf("\n"); }
   printf(fails ? "FAIL\n" : "PASS\n");
   return fails ? 1 : 0;
 }

@@ -188,24 +188,24 @@ def test_two_lanes_in_flight_give_the_single_lane_results(tmp_path):
     assert stats['lanes'] == 2 and len(one) == len(two) == 44
     assert sum(len(v['scores']) for r in one for v in r.values()) > 0
     assert one == two
-    # the lanes own different scratch buffers
+    # detect_files closed the detector it had built: the second lane's scratch went back to the allocator
+    assert {k[1] for k in ops._WINO_SCRATCH if isinstance(k, tuple)} == {0}
+    # direct: different inputs in the two lanes, the FIRST replay after the capture and six more against the eager step.  The eager
+    # references are computed BEFORE the detector exists, and between the capture and the first replay there is nothing but the
+    # device-to-device copy of the inputs (an eager step in between used to hide the failure this test is cited for)
+    import gc
+    gc.collect()
+    pcm = [torch.from_numpy(synth.clip_batch_pcm16(300 + 4 * k, 4)).cuda() for k in range(2)]
+    ref = _eager_refs(model, pcm)
+    det = bulk.GraphedDetector(model, 4, 66150, 22050, min_score=0.05, lanes=2)
+    assert det.census['memset'] == det.census['memcpy'] == 0 and det.census['kernel'] > 300
+    # the lanes own different scratch buffers, and the detector holds them as captured
     keys = [k for k in ops._WINO_SCRATCH if isinstance(k, tuple)]
     assert {k[1] for k in keys} >= {0, 1}
     assert len({ops._WINO_SCRATCH[k].data_ptr() for k in keys}) == len(keys)
-    # direct: different inputs in the two lanes, the FIRST replay after the capture and six more against the eager step
-    import gc
-    gc.collect()
-    det = bulk.GraphedDetector(model, 4, 66150, 22050, min_score=0.05, lanes=2)
-    pcm = [torch.from_numpy(synth.clip_batch_pcm16(300 + 4 * k, 4)).cuda() for k in range(2)]
-    ref = []
-    with torch.no_grad(), ops.lane(5):
-        for k in range(2):
-            imgs, _ = det.fe(pcm[k], 22050)
-            d, n = model.detect(imgs[:, 0][:, None].contiguous(), 0.3, 0.05)
-            ref.append((d.clone(), n.clone()))
+    assert {ops._WINO_SCRATCH[k].data_ptr() for k in keys if k[1] in det.lane_ids} <= {t.data_ptr() for t in det._held}
     for k in range(2):
         det.pcms[k].copy_(pcm[k])
-    torch.cuda.synchronize()
     for rep in range(7):
         with torch.cuda.stream(det.stream):
             det.replay()
@@ -213,3 +213,100 @@ def test_two_lanes_in_flight_give_the_single_lane_results(tmp_path):
         for k in range(2):
             assert torch.equal(ref[k][0], det.dets[k]) and torch.equal(ref[k][1], det.n_dets[k]), (rep, k)
     assert int(ref[0][1].sum()) > 0 and not torch.equal(ref[0][0], ref[1][0])
+
+
+def _eager_refs(model, pcms, independent=False):
+    from birdsoundclassif_amd import ops
+    from birdsoundclassif_amd.nbm_datasets.prepare_dataset import SpectrogramFrontEnd
+    fe, ref = SpectrogramFrontEnd('cuda'), []
+    with torch.no_grad(), ops.lane(9):
+        for p_ in pcms:
+            imgs, _ = fe(p_, 22050)
+            d, n = model.detect(imgs[:, 0][:, None].contiguous(), 0.3, 0.05, independent=independent)
+            ref.append((d.clone(), n.clone()))
+    torch.cuda.synchronize()
+    return ref
+
+
+def _model():
+    from birdsoundclassif_amd.nets import build_model
+    from birdsoundclassif_amd.train import default_args
+    model, _ = build_model(default_args(device='cuda'))
+    model.load_state_dict(filler_state_dict())
+    return model.cuda().eval()
+
+
+def test_several_graph_execs_alive_at_once_replay_correctly():
+    """DESIGN 4d, round 5.  Round 4: with two captured detect steps alive in one process one of them returned garbage (B = 64: 0
+    detections) or faulted (B = 4).  Cause (scripts/graph_pair_repro.hip, profiles/r05_graph_pair.txt): the HIP runtime torch bundles
+    loses MEMSET nodes of replayed graph execs; the proposal stage's counters were zeroed by hipMemsetAsync.  The library zeroes with
+    kernels now: three detectors alive together -- every exec's FIRST replay right behind the previous exec's, with nothing in between,
+    then interleaved and concurrent replays on their own streams -- all return the eager results bit for bit, and no graph holds a
+    memset / memcpy node."""
+    from birdsoundclassif_amd import bulk
+    model = _model()
+    B = 4
+    pcm = [torch.from_numpy(synth.clip_batch_pcm16(300 + B * k, B)).cuda() for k in range(4)]
+    ref = _eager_refs(model, pcm)
+    dets = [bulk.GraphedDetector(model, B, 66150, 22050, min_score=0.05), bulk.GraphedDetector(model, B, 66150, 22050, min_score=0.05),
+            bulk.GraphedDetector(model, B, 66150, 22050, min_score=0.05, lanes=2)]
+    assert len({k for d in dets for k in d.lane_ids}) == 4          # live detectors never share a lane's scratch
+    for d in dets:
+        assert d.census['memset'] == d.census['memcpy'] == d.census['host'] == d.census['other'] == 0 and d.census['kernel'] > 100, d.census
+    feeds = [(dets[0].pcms[0], 0), (dets[1].pcms[0], 1), (dets[2].pcms[0], 2), (dets[2].pcms[1], 3)]
+    for buf, k in feeds:
+        buf.copy_(pcm[k])
+    torch.cuda.synchronize()
+
+    def check(tag):
+        got = [(dets[0].dets[0], dets[0].n_dets[0]), (dets[1].dets[0], dets[1].n_dets[0]), (dets[2].dets[0], dets[2].n_dets[0]),
+               (dets[2].dets[1], dets[2].n_dets[1])]
+        for k in range(4):
+            assert torch.equal(got[k][0], ref[k][0]) and torch.equal(got[k][1], ref[k][1]), (tag, k, int(got[k][1].sum()), int(ref[k][1].sum()))
+
+    for rep in range(3):                                            # back to back, each exec's first replay included
+        for d in dets:
+            with torch.cuda.stream(d.stream):
+                d.replay()
+            torch.cuda.synchronize()
+        check(('sequential', rep))
+    for rep in range(3):                                            # all three in flight together
+        for _ in range(2):
+            for d in dets:
+                with torch.cuda.stream(d.stream):
+                    d.replay()
+        torch.cuda.synchronize()
+        check(('concurrent', rep))
+    assert int(ref[0][1].sum()) > 0
+    # a detector that is closed gives its lanes back
+    dets[1].close()
+    d4 = bulk.GraphedDetector(model, B, 66150, 22050, min_score=0.05)
+    assert d4.lane_ids == [1]
+    d4.pcm.copy_(pcm[1])
+    with torch.cuda.stream(d4.stream):
+        d4.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(d4.det, ref[1][0]) and torch.equal(d4.n_det, ref[1][1])
+
+
+def test_a_captured_step_with_a_memset_node_is_refused():
+    """The fence behind the fix: whoever puts a memset node into the captured step (here: a hipMemsetAsync issued through ctypes on the
+    runtime torch has loaded), `GraphedDetector` refuses to replay that graph."""
+    import ctypes
+    from birdsoundclassif_amd import bulk
+    path = [l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l][0]
+    hip = ctypes.CDLL(path)
+    hip.hipMemsetAsync.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+    hip.hipMemsetAsync.restype = ctypes.c_int
+    junk = torch.ones(64, dtype=torch.int32, device='cuda')
+
+    class WithMemset(bulk.GraphedDetector):
+        def _run(self, k=0):
+            out = super()._run(k)
+            assert hip.hipMemsetAsync(junk.data_ptr(), 0, 64, torch.cuda.current_stream().cuda_stream) == 0
+            return out
+
+    with pytest.raises(RuntimeError, match='memset'):
+        WithMemset(_model(), 2, 66150, 22050, min_score=0.05)
+    ok = bulk.GraphedDetector(_model(), 2, 66150, 22050, min_score=0.05)      # the failed capture left nothing behind
+    assert ok.census['memset'] == 0 and ok.lane_ids == [0]

@@ -69,6 +69,51 @@ def test_config1_b64_inference_equals_b8_equals_oracle():
     assert peak < 200
 
 
+def oracle_detect_chunked(sd, cfg, x, min_score, chunk=8):
+    """The oracle on a batch it cannot hold at once: everything per image (backbone, attention, FPN, RPN heads; eval mode, so no batch
+    statistics) in chunks, then the ProposalLayer ONCE over the whole batch -- its two batch-coupled counts (reference layers.py:287
+    `min` of the surviving anchors over the batch, nets_utils.py:236 `min` of the NMS keep counts) see all images, like in one reference
+    call -- then the second stage chunk by chunk on the kept FPN maps (per RoI, no batch coupling).  -> (first-stage dict, detections)."""
+    cls, reg, fpn = [], [], []
+    with torch.no_grad():
+        for b0 in range(0, x.shape[0], chunk):
+            feats = O.backbone_forward(sd, x[b0:b0 + chunk])
+            fo = O.fpn_forward(sd, O.sa_pyramid(sd, feats, cfg.pyramid_top_n_attn))
+            c, r = O.rpn_forward(sd, cfg, fo, False, None)
+            cls.append(c), reg.append(r), fpn.append(fo)
+        rois, roi_scores = O.proposal_layer(cfg, torch.cat(cls), torch.cat(reg), False)
+        dets = []
+        for i, b0 in enumerate(range(0, x.shape[0], chunk)):
+            dets += O.forward_second_stage(sd, cfg, fpn[i], rois[b0:b0 + chunk], 0.3, min_score, False)
+    return {'rois': rois, 'roi_scores': roi_scores}, dets
+
+
+def test_config1_b64_distinct_clips_equal_the_oracle():
+    """configs[1] on 64 DIFFERENT clips in ONE call: the batch-coupled minima, the device RoI tile lists and the
+    64-image NMS launches see 64 different images; RoIs and class / box assignments against the oracle over the same 64 images."""
+    from birdsoundclassif_amd.nbm_datasets.prepare_dataset import SpectrogramFrontEnd
+    model, _ = build()
+    fe = SpectrogramFrontEnd('cuda')
+    pcm = torch.from_numpy(synth.clip_batch_pcm16(0, 64)).cuda()
+    assert len({bytes(r) for r in pcm.cpu().numpy()}) == 64
+    with torch.no_grad():
+        img, _ = fe(pcm, 22050)
+        det, n = model.detect(img, min_score=0.05)
+        rois = model.forward_first_stage(img, lazy=True)['rois']          # the timed path
+    sd, cfg = filler_state_dict(), O.make_cfg()
+    ref1, ref = oracle_detect_chunked(sd, cfg, img.cpu(), 0.05)
+    assert ref1['rois'].shape == rois.shape and rois.shape[0] == 64
+    exact = sum(bool(torch.equal(rois[b].cpu(), ref1['rois'][b])) for b in range(64))
+    assert_rois_equal_up_to_near_ties(rois, ref1['rois'], ref1['roi_scores'], what='RoIs of 64 distinct clips')
+    got = dets_to_rows(model.head.fast_rcnn.dets_to_dicts(det.cpu(), n.cpu(), model.args.num_classes))
+    want = dets_to_rows(ref)
+    assert got.shape == want.shape and len(got) > 64
+    assert np.array_equal(got[:, :6], want[:, :6]), 'class / box assignments differ from the oracle'
+    assert np.abs(got[:, 6] - want[:, 6]).max() < 1e-4
+    print(f'B=64 distinct clips: {len(got)} detections == oracle; RoI lists identical row for row in {exact} of 64 images '
+          f'(the others: permuted runs of score ties only), {rois.shape[1]} RoIs per image')
+
+
 def test_config2_b128_train_steps_positive_and_negative():
     from birdsoundclassif_amd import train as T
     args = T.default_args(device='cuda')
