@@ -46,7 +46,18 @@ struct BwdParams {
   int phased;                // NN, stride 2: M tiles are grouped by the parity class of (iy + pad, ix + pad)
   int ph_tiles[4];           //   M tiles of each class; tile_m = 4 * (tile within class) + class, so the four classes of
                              //   one image region run side by side and fill the same DRAM pages together
+  int ablate;                // NN, timing-only build (-DNBM_ABLATE_NN, `make ablate_nn`; never shipped): NBM_NN_ABLATE bits, see ABL_*
 };
+
+// Attribution of igemm_nn_kernel's time (scripts/dgrad_ablate.py -> profiles/r05_dgrad_attribution.txt).  Each bit
+// removes ONE component from the kernel; results are wrong by design.  The shipped build compiles none of this (`abl()` is constant 0).
+enum { ABL_NO_MASK = 1, ABL_NO_RESIDUAL = 2, ABL_NO_ASCALE = 4, ABL_NO_TAP_SELECT = 8, ABL_NO_STORE = 16, ABL_NO_EPILOGUE = 32,
+       ABL_NO_LOADS = 64, ABL_NO_LDS_WRITES = 128 };
+#ifdef NBM_ABLATE_NN
+#define NBM_ABL(p, bit) (((p).ablate & (bit)) != 0)
+#else
+#define NBM_ABL(p, bit) false
+#endif
 
 __device__ __forceinline__ int xcd_tile(int nwg, int bid) {
   const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
@@ -159,23 +170,29 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
   f32x4 ra[4], rb[BPASS], rsc = {1.f, 1.f, 1.f, 1.f};
   int cur_r = r_begin, cur_s = s_begin, cur_n0 = 0;
 
+  int abl_loads_done = 0;
   auto load_tiles = [&]() {
+    if (NBM_ABL(p, ABL_NO_LOADS) && abl_loads_done >= 2) return;           // operands stay what the first two loads fetched
+    ++abl_loads_done;
     const int tap = cur_r * p.kw + cur_s;
     const unsigned a_soff = (unsigned)((maxoff - ((long long)(cur_r / st) * p.Wo + cur_s / st) * p.g_ld + cur_n0) * 4);
     const unsigned b_soff = (unsigned)(((long long)cur_n0 * p.w_row + (long long)tap * p.Cin) * 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = buf_load4(rsrc_a, ((a_taps[i] >> tap) & 1ull) ? a_rel[i] : OOB, a_soff);
+    for (int i = 0; i < 4; ++i) ra[i] = buf_load4(rsrc_a, (NBM_ABL(p, ABL_NO_TAP_SELECT) || ((a_taps[i] >> tap) & 1ull)) ? a_rel[i] : OOB, a_soff);
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) rb[i] = buf_load4(rsrc_b, b_rel[i], b_soff);
-    if (p.a_scale) rsc = *reinterpret_cast<const f32x4*>(p.a_scale + cur_n0 + c4 * 4);
+    if (p.a_scale && !NBM_ABL(p, ABL_NO_ASCALE)) rsc = *reinterpret_cast<const f32x4*>(p.a_scale + cur_n0 + c4 * 4);
     cur_s += t_step;
     if (cur_s >= p.kw) { cur_s = s_begin; cur_r += t_step; if (cur_r >= p.kh) { cur_r = r_begin; cur_n0 += BK; } }
   };
+  int abl_writes_done = 0;
   auto store_lds = [&](int buf) {
+    if (NBM_ABL(p, ABL_NO_LDS_WRITES) && abl_writes_done >= 2) return;
+    ++abl_writes_done;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       f32x4 v = ra[i];
-      v[0] *= rsc[0]; v[1] *= rsc[1]; v[2] *= rsc[2]; v[3] *= rsc[3];
+      if (!NBM_ABL(p, ABL_NO_ASCALE)) { v[0] *= rsc[0]; v[1] *= rsc[1]; v[2] *= rsc[2]; v[3] *= rsc[3]; }
       *reinterpret_cast<f32x4*>(As + (buf * BM + r0 + 32 * i) * PITCH + c4 * 4) = v;
     }
 #pragma unroll
@@ -278,7 +295,20 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
   __syncthreads();
 
   float* __restrict__ og = p.out + (long long)grp * p.out_gs;
-  const float* __restrict__ rg = p.residual ? p.residual + (long long)grp * p.res_gs : nullptr;
+  const float* __restrict__ rg = (p.residual && !NBM_ABL(p, ABL_NO_RESIDUAL)) ? p.residual + (long long)grp * p.res_gs : nullptr;
+  const float* __restrict__ mk_ = NBM_ABL(p, ABL_NO_MASK) ? nullptr : p.mask;
+  const float* __restrict__ r2_ = NBM_ABL(p, ABL_NO_RESIDUAL) ? nullptr : p.residual2;
+  if (NBM_ABL(p, ABL_NO_EPILOGUE)) {                                       // keep the accumulators alive: a store that never happens
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) t += acc[i][j][e];
+    if (t == 1.2345e-30f) og[0] = t;
+    return;
+  }
   auto out_pixel = [&](int q) -> long long {                  // output row of tile row q (q < rows_here)
     if (!p.phased) return q;
     int b, iy, ix;
@@ -302,14 +332,14 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
       // residual / mask values of this thread's rows: requested before the accumulators go through LDS (inside the row loop, behind
       // its exit test, they were 2 NR dependent round trips at the end of every tile -- igemm.hip)
       f32x4 rq[NR], mq[NR];
-      const bool pre = c < p.Cin && (rg || p.mask);
+      const bool pre = c < p.Cin && (rg || mk_);
       if (pre) {
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
           const int qq = min(q0 + half * HROWS + rr + k * RPP, rows_here - 1);
           const long long m = out_pixel(qq);
           if (rg) rq[k] = *reinterpret_cast<const f32x4*>(rg + m * p.res_ld + c);
-          if (p.mask) mq[k] = *reinterpret_cast<const f32x4*>(p.mask + m * p.mask_ld + c);
+          if (mk_) mq[k] = *reinterpret_cast<const f32x4*>(mk_ + m * p.mask_ld + c);
         }
       }
       if (HALVES == 1 || wm0 == half * HROWS) {
@@ -337,21 +367,21 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
           const f32x4 q = rq[k];
           v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3];
         }
-        if (p.residual2) {          // the data gradient of a 1x1 / stride-2 shortcut, kept at its own (half) resolution
+        if (r2_) {          // the data gradient of a 1x1 / stride-2 shortcut, kept at its own (half) resolution
           const int hw = p.H * p.W, b_ = (int)(m / hw), rem_ = (int)(m - (long long)b_ * hw);
           const int iy_ = rem_ / p.W, ix_ = rem_ - iy_ * p.W;
           if (!((iy_ | ix_) & 1)) {
             const long long m2 = ((long long)b_ * ((p.H + 1) >> 1) + (iy_ >> 1)) * ((p.W + 1) >> 1) + (ix_ >> 1);
-            const f32x4 q = *reinterpret_cast<const f32x4*>(p.residual2 + m2 * p.res2_ld + c);
+            const f32x4 q = *reinterpret_cast<const f32x4*>(r2_ + m2 * p.res2_ld + c);
             v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3];
           }
         }
-        if (p.mask) {
+        if (mk_) {
           const f32x4 q = mq[k];
 #pragma unroll
           for (int e = 0; e < 4; ++e) if (!(q[e] > 0.f)) v[e] = 0.f;
         }
-        *reinterpret_cast<f32x4*>(og + (long long)m * p.out_ld + c) = v;
+        if (!NBM_ABL(p, ABL_NO_STORE) || v[0] == 1.2345e-30f) *reinterpret_cast<f32x4*>(og + (long long)m * p.out_ld + c) = v;
       }
     }
     return;
@@ -369,13 +399,13 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
         const long long m = out_pixel(q);
         float v = acc[i][j][e] * p.alpha;
         if (rg) v += rg[(long long)m * p.res_ld + c];
-        if (p.residual2) {
+        if (r2_) {
           const int hw = p.H * p.W, b_ = (int)(m / hw), rem_ = (int)(m - (long long)b_ * hw);
           const int iy_ = rem_ / p.W, ix_ = rem_ - iy_ * p.W;
           if (!((iy_ | ix_) & 1))
-            v += p.residual2[(((long long)b_ * ((p.H + 1) >> 1) + (iy_ >> 1)) * ((p.W + 1) >> 1) + (ix_ >> 1)) * p.res2_ld + c];
+            v += r2_[(((long long)b_ * ((p.H + 1) >> 1) + (iy_ >> 1)) * ((p.W + 1) >> 1) + (ix_ >> 1)) * p.res2_ld + c];
         }
-        if (p.mask && !(p.mask[(long long)m * p.mask_ld + c] > 0.f)) v = 0.f;
+        if (mk_ && !(mk_[(long long)m * p.mask_ld + c] > 0.f)) v = 0.f;
         og[(long long)m * p.out_ld + c] = v;
       }
   }
@@ -698,6 +728,9 @@ extern "C" int nbm_conv_dgrad(const nbm_bwd_desc* d, void* stream) {
     }
     p.m_tiles = 4 * tmax;
   }
+#ifdef NBM_ABLATE_NN
+  p.ablate = getenv("NBM_NN_ABLATE") ? atoi(getenv("NBM_NN_ABLATE")) : 0;       // read per call: the probe switches it between launches
+#endif
   hipStream_t st = (hipStream_t)stream;
   // short K (<= 8 steps of 32) and a 16-byte epilogue: the three-workgroups-per-CU variant (see the template comment)
   static const int shortk_max = getenv("NBM_NN_SHORTK_MAX") ? atoi(getenv("NBM_NN_SHORTK_MAX")) : 8;   // 0 disables
