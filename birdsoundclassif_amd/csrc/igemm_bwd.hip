@@ -51,7 +51,7 @@ struct BwdParams {
 
 // Attribution of igemm_nn_kernel's time (scripts/dgrad_ablate.py -> profiles/r05_dgrad_attribution.txt).  Each bit
 // removes ONE component from the kernel; results are wrong by design.  The shipped build compiles none of this (`abl()` is constant 0).
-enum { ABL_NO_MASK = 1, ABL_NO_RESIDUAL = 2, ABL_NO_ASCALE = 4, ABL_NO_TAP_SELECT = 8, ABL_NO_STORE = 16, ABL_NO_EPILOGUE = 32,
+enum { ABL_NO_MASK = 1, ABL_NO_RESIDUAL = 2, ABL_NO_ASCALE = 4, /* 8: was the tap select -- unmasked taps read outside the tensor */ ABL_NO_STORE = 16, ABL_NO_EPILOGUE = 32,
        ABL_NO_LOADS = 64, ABL_NO_LDS_WRITES = 128 };
 #ifdef NBM_ABLATE_NN
 #define NBM_ABL(p, bit) (((p).ablate & (bit)) != 0)
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
     const unsigned a_soff = (unsigned)((maxoff - ((long long)(cur_r / st) * p.Wo + cur_s / st) * p.g_ld + cur_n0) * 4);
     const unsigned b_soff = (unsigned)(((long long)cur_n0 * p.w_row + (long long)tap * p.Cin) * 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = buf_load4(rsrc_a, (NBM_ABL(p, ABL_NO_TAP_SELECT) || ((a_taps[i] >> tap) & 1ull)) ? a_rel[i] : OOB, a_soff);
+    for (int i = 0; i < 4; ++i) ra[i] = buf_load4(rsrc_a, ((a_taps[i] >> tap) & 1ull) ? a_rel[i] : OOB, a_soff);
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) rb[i] = buf_load4(rsrc_b, b_rel[i], b_soff);
     if (p.a_scale && !NBM_ABL(p, ABL_NO_ASCALE)) rsc = *reinterpret_cast<const f32x4*>(p.a_scale + cur_n0 + c4 * 4);

@@ -23,7 +23,7 @@ LAUNCHES = [
     ('FPN lateral 1x1 256->384 @94x256 (G 384 -> dX 256) + residual', 94, 256, 256, 384, 1, 1, False, True, False, None),
     ('attention [q|k|v] 1024->1408 (G 1408 -> dX 1024), plain GEMM', 1536 * B, 1, 1024, 1408, 1, 1, False, False, False, 1),
 ]
-BITS = [(0, 'nothing removed'), (1, '- mask'), (2, '- residual(s)'), (4, '- a_scale multiply'), (8, '- tap select'), (16, '- global stores'),
+BITS = [(0, 'nothing removed'), (1, '- mask'), (2, '- residual(s)'), (4, '- a_scale multiply'), (16, '- global stores'),
         (32, '- whole epilogue'), (64, '- global loads (main loop)'), (128, '- LDS writes (main loop)'), (192, '- loads - LDS writes'),
         (224, 'MFMA + LDS reads + barriers only')]
 ablate_build = 'ablate' in os.environ.get('NBM_LIB', '')
