@@ -278,6 +278,11 @@ class Conv(Function):
             raise RuntimeError('demand-driven FPN map: a RoI pooling ran on it without recording its tile lists (the map was '
                                'produced under no_grad?) -- its gradient would be dropped')
         listed = ctx.lazy is not None and ondemand.listed_backward(ctx.lazy) and (ctx.lazy.sparse or (LAZY_DGRAD and LAZY_WGRAD))
+        if ctx.lazy is not None and ctx.lazy.comp is not None and not (listed and LAZY_DGRAD and LAZY_WGRAD and N % 32 == 0 and N >= 64 and
+                                                                      ctx.needs_input_grad[0] and ctx.needs_input_grad[1]):
+            raise RuntimeError('this demand-driven FPN map was read by the composed RPN block (Fn.RpnComposite): only the listed '
+                               'cell-domain backward pass carries that share -- one RoI pooling per map, NBM_LAZY_DGRAD / NBM_LAZY_WGRAD on '
+                               '(or NBM_RPN_COMPOSITE_TRAIN=0)')
         # a deferred lateral whose consumer's backward pass (which ran before this node's) already produced this node's gradients
         pre = ctx.lat_state.grads if ctx.lat_state is not None else None
         raw = pre
@@ -741,6 +746,46 @@ class DwConv(Function):
         gx, gw, gb = ops.dwconv3x3_bwd(x, gy, weight.detach(), mult, stride,
                                        need_gx=ctx.needs_input_grad[0], need_gw=True, has_bias=has_bias)
         return gx, gw, gb, None, None
+
+
+class RpnComposite(Function):
+    """Training mode: the RPN's first block on a demand-driven FPN level -- depthwise 3x3 / stride S -> 1x1, in front of its BatchNorm
+    (reference layers.py:22-29, 62-65) -- composed with the level's output convolution (fpn.py:137,145) in the cell domain
+    (ondemand.train_composite_*): ONE GEMM over the transformed patches the forward pass keeps anyway; the map's pattern
+    pixels, the 25-plane intermediate, `cell_output` / `cell_outgrad`, the depthwise and 1x1 passes do not exist.  `fm` is an input for
+    the graph's sake only: its share of d/d(map) never exists in the pixel domain -- the data- and weight-gradient shares are left on
+    the LazyMap for the convolution's own backward node, which runs after this one."""
+
+    @staticmethod
+    def forward(ctx, fm, dw_w, dw_b, pt_w, pt_b):
+        st = ondemand.lazy_state(fm)
+        f = ondemand.train_composite_forward(st, fm, dw_w, dw_b, pt_w, pt_b)
+        ctx.st, ctx.fm_ptr, ctx.fm_shape = st, fm.data_ptr(), tuple(fm.shape)
+        ctx.save_for_backward(dw_w, dw_b, pt_w, pt_b)
+        return f
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gf):
+        dw_w, dw_b, pt_w, pt_b = ctx.saved_tensors
+        st = ctx.st
+        g_dw, g_dwb, g_pt, g_ptb = ondemand.train_composite_backward(st, gf.contiguous(), dw_w, dw_b, pt_w, pt_b)
+        gfm = None
+        if ctx.needs_input_grad[0]:
+            # the convolution's backward node must run even if no RoI pooling sends it a gradient: hand it an all-zero share
+            ptr = ctx.fm_ptr
+            if EARLY and ptr in _FPN_OUT and GRAD_SHARE:
+                acc = e = None
+                if (ondemand.ZERO_POOL and LAZY_DGRAD and LAZY_WGRAD and ondemand.CELL_BWD and st.sparse and st.keep and st.stride >= 5):
+                    acc, e = ondemand.zero_acquire(ctx.fm_shape, gf.device, ('map-grad', st.stride))      # persistent zeros: no fill
+                if acc is None:
+                    acc = torch.zeros(ctx.fm_shape, device=gf.device, dtype=torch.float32)
+                _PARKED[ptr] = (acc, _FPN_OUT[ptr], e)       # the RoI pooling's backward pass scatters into it; parked_flush otherwise
+            else:
+                ref = _GRAD_ACC.pop(ptr, None)
+                if ref is None or ref() is None:             # no RoI pooling left a map for this level
+                    gfm = torch.zeros(ctx.fm_shape, device=gf.device, dtype=torch.float32)
+        return gfm, g_dw, g_dwb, g_pt, g_ptb
 
 
 class Film(Function):

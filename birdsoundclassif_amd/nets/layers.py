@@ -55,7 +55,15 @@ class DepthwiseSepConv2d(nn.Module):
         train: batch statistics (nn.BatchNorm2d semantics) through the differentiable ops."""
         st = int(max(1, self.stride))
         if self.training:
-            ondemand.pattern_materialize(x)          # (a no-grad pass in training mode left the map's pattern pixels pending)
+            if pe_act is None and ondemand.train_composite_ready(x, self) is not None:
+                # a demand-driven FPN map with a backward pass to come: this block (up to its BatchNorm) composed with the map's own
+                # convolution in the cell domain -- the map's pattern pixels are never formed (DESIGN 4h)
+                out = Fn.RpnComposite.apply(x, self.depth_wise.weight, self.depth_wise.bias, self.pt_wise.weight, self.pt_wise.bias)
+                self.norm.num_batches_tracked += 1
+                out = Fn.BatchNormTrain.apply(out, self.norm.weight, self.norm.bias, self.norm.running_mean,
+                                              self.norm.running_var, self.norm.eps, self.norm.momentum)
+                return Fn.Silu.apply(out)
+            ondemand.pattern_materialize(x)          # (the map's pattern pixels were left pending and this block cannot take them)
             if self.stride < 1:
                 size = ((1 / self.stride) * np.array(x.shape[1:3])).astype(np.int64).tolist()
                 x = Fn.UpsampleAdd.apply(x, None, size[0], size[1])

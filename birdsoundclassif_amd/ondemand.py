@@ -186,7 +186,7 @@ class LazyMap:
     12 GB alive until the garbage collector runs); its consumers keep it alive and hand it back to `lazy_complete`.
     The operands stay here for as long as the map lives, so EVERY RoI pooling on the map -- not only the first -- finds the
     tiles under its windows computed (`done` counts them); the state goes when the map does (`_forget`)."""
-    __slots__ = ('x', 'U', 'bias', 'skip', 'stride', 'chunks', 'roi', 'keep', 'sparse', 'overlap', 'lateral', 'rois', 'done', 'vg', 'cell_gb', 'cell_gb_done', 'vx', 'raw', 'pending', '__weakref__')
+    __slots__ = ('x', 'U', 'bias', 'skip', 'stride', 'chunks', 'roi', 'keep', 'sparse', 'overlap', 'lateral', 'rois', 'done', 'vg', 'cell_gb', 'cell_gb_done', 'vx', 'raw', 'pending', 'comp', '__weakref__')
 
     def __init__(self, x, U, bias, stride):
         self.x, self.U, self.bias, self.stride = x, U, bias, stride
@@ -200,11 +200,12 @@ class LazyMap:
         self.cell_gb_done = None    # chunks whose pattern pixels are in cell_gb already (a chunk's Vg may be computed twice)
         self.vx = None          # deferred lateral + a backward pass to come: {chunk: [transform(up + b) | transform(t)]} of the forward pass
         self.raw = None         # (weight, bias) of the convolution as the module holds them (rpn_composite)
-        self.pending = None     # evaluation mode: the pattern pass was NOT run (Ucell, Ufold) -- rpn_composite or pattern_materialize
+        self.pending = None     # the pattern pass was NOT run (Ucell, Ufold) -- rpn_composite (eval) / train_composite_forward, or pattern_materialize
+        self.comp = None        # training: state of the RPN reader composed with this convolution in the cell domain (train_composite_*)
 
     def release(self):
         """Called by the backward pass of the convolution: no RoI pooling can follow on a map whose gradient has been consumed."""
-        self.x = self.U = self.bias = self.lateral = self.vg = self.cell_gb = self.cell_gb_done = self.vx = self.raw = self.pending = None
+        self.x = self.U = self.bias = self.lateral = self.vg = self.cell_gb = self.cell_gb_done = self.vx = self.raw = self.pending = self.comp = None
 
     def __del__(self):          # the pinned counters go back to the pool
         try:
@@ -346,6 +347,7 @@ def _cell_operand(st, b0, nb, H, W, C_, x, n_out=0, ci=None):
 
 
 COMPOSITE = os.environ.get('NBM_RPN_COMPOSITE', '1') != '0'     # evaluation mode: the RPN's reader composed with this convolution (rpn_composite)
+TRAIN_COMPOSITE = os.environ.get('NBM_RPN_COMPOSITE_TRAIN', '1') != '0'   # training: the same composition in the cell domain (train_composite_*)
 
 
 def conv3x3_winograd_lazy(x, U, bias, stride, Ucell=None, fold=None, keep=False, raw=None):
@@ -378,7 +380,11 @@ def conv3x3_winograd_lazy(x, U, bias, stride, Ucell=None, fold=None, keep=False,
     # evaluation mode: the one reader of the pattern pixels, the RPN's depthwise-separable block, takes this convolution INTO its own
     # (rpn_composite): the pattern pass waits until somebody asks (the block, or pattern_materialize for any other reader)
     defer_pattern = bool(COMPOSITE and cell_ok and raw is not None and not st.keep and not torch.is_grad_enabled())
-    if defer_pattern:
+    # training: the same reader composed with this convolution in the CELL domain (train_composite_forward): the pattern pass waits too
+    # (`keep` was decided with grad mode as the caller sees it; inside Function.forward it is off)
+    defer_train = bool(TRAIN_COMPOSITE and CELL_BWD and cell_ok and raw is not None and st.keep and N % 32 == 0)
+    if defer_pattern or defer_train:
+        defer_pattern = True
         st.pending = (Ucell, Ufold)
     for ci, b0 in enumerate(range(0, B, chunk)):
         nb = min(chunk, B - b0)
@@ -603,6 +609,227 @@ def rpn_composite(fm, block):
     finally:
         ops._PROFILE_LABEL = keep_label
     return f
+
+
+# ---- training mode: the RPN's reader composed with the demand-driven convolution in the CELL domain
+# Reference chain (fpn.py:137,145 out_conv 3x3 + bias -> layers.py:22-29 depthwise 3x3 / stride S / pad 1, channel multiplier `mult`, + bias ->
+# 1x1 + bias -> BatchNorm): linear in front of the BatchNorm also with batch statistics.  The cell transforms (4c) give the 3x3 block of
+# the map that the depthwise taps read as  Y_n' = E^T M_n' E + out_b[n'],  M_xi,n' = Vx_xi . U_xi[n']  (xi = the 25 planes), so
+#     f[n2] = sum_m pt[n2][m] (<dw_m, Y_{m // mult}> + dw_b[m]) + pt_b[n2]
+#           = sum_xi Vx_xi . (A_xi U_xi)[n2] + const[n2],      A_xi[n2][n'] = sum_{m // mult = n'} pt[n2][m] (E dw_m E^T)[xi]
+# -- ONE GEMM over the transformed patches Vx the forward pass computes and keeps anyway ([25][cells][K] read as 25 taps), instead of 25
+# plane GEMMs into a [25][cells][N] intermediate, the block transform (`cell_output`), the depthwise pass and the 1x1; the pattern
+# pixels of the map are never formed.  Backward: dW'_xi = g_f^T Vx_xi (one grouped weight-gradient GEMM; no `cell_outgrad`, no depthwise /
+# 1x1 backward kernels), dA_xi = dW'_xi U_xi^T -> d(pt), d(dw) (autograd over the tiny weight-side function `_compose_rpn_cell`),
+# dU_xi = A_xi^T dW'_xi goes where the cell path's `dUc` goes (weight gradient of out_conv, lateral fold-back), M'_xi = g_f W'_xi goes
+# where the plane data-gradient GEMMs' output goes (`cell_dgrad_output`, deferred-lateral variants included).  The RoI share of the
+# map's gradient then includes the pattern pixels (skip_pattern = 0) and is ADDED to the cell share.
+# Border cells (a depthwise tap in the zero padding of the map: top row / left column / corner at this geometry): the padding zeroes
+# those taps, i.e. their class has its own dw (masked) and therefore its own A and W' -- the same GEMMs on the class's gathered rows.
+_CE = ((1.0, 0.0, 0.0), (1.0, 1.0, 1.0), (1.0, -1.0, 1.0), (1.0, 2.0, 4.0), (1.0, -2.0, 4.0))      # csrc/cellwino.hip CE
+
+
+_DEV_CONST = {}
+
+
+def _dev_const(device, key, values):
+    """Small constant on the device, uploaded ONCE per device: a per-call torch.tensor(..., device=...) is a pageable H2D copy, i.e. a
+    stream synchronisation -- 36 of them per training step cost 36 ms (the host lost its run-ahead every time)."""
+    k = (str(device), key)
+    t = _DEV_CONST.get(k)
+    if t is None:
+        t = _DEV_CONST[k] = torch.tensor(values, dtype=torch.float32).to(device)
+    return t
+
+
+def _compose_rpn_cell(dw_w, dw_b, pt_w, pt_b, out_b, masks, mult):
+    """Weight side of the composition, differentiable (plain torch elementwise / reduce ops on weight-sized tensors, no GEMM):
+    -> (A [classes][25][N2][N1], const [classes][N2]) for the cell classes `masks` = ((row mask, column mask), ...)."""
+    m_ = dw_w.shape[0]
+    n1, n2 = m_ // mult, pt_w.shape[0]
+    E = _dev_const(dw_w.device, 'E', _CE)                                            # [5][3]
+    dw = dw_w.reshape(m_, 3, 3)
+    pt = pt_w.reshape(n2, n1, mult)
+    ob = out_b if out_b is not None else torch.zeros((n1,), device=dw_w.device, dtype=torch.float32)
+    As, consts = [], []
+    for rm, sm in masks:
+        mr = _dev_const(dw_w.device, ('mask', rm), [float((rm >> r) & 1) for r in range(3)])
+        ms = _dev_const(dw_w.device, ('mask', sm), [float((sm >> c) & 1) for c in range(3)])
+        dwm = dw * mr[None, :, None] * ms[None, None, :]
+        t = (E[None, :, :, None] * dwm[:, None, :, :]).sum(2)                         # [M][5 (a)][3 (s)]
+        cw = (t[:, :, None, :] * E[None, None, :, :]).sum(3).reshape(n1, mult, 25)    # (E dw E^T)[a][b], plane xi = 5 a + b
+        As.append((pt[None] * cw.permute(2, 0, 1)[:, None]).sum(3))                   # [25][N2][N1]
+        cb = dwm.sum((1, 2)) * ob.repeat_interleave(mult)
+        if dw_b is not None:
+            cb = cb + dw_b
+        c_ = (pt.reshape(n2, m_) * cb[None, :]).sum(1)
+        consts.append(c_ + pt_b if pt_b is not None else c_)
+    return torch.stack(As), torch.stack(consts)
+
+
+def _cell_classes(nb, H, W, S, device):
+    """[(row mask, column mask, cell indices or None)]: the interior class first (None = every cell not listed below), then the border
+    classes of `_border_classes`."""
+    return [(7, 7, None)] + [(r_, s_, idx) for r_, s_, _, _, idx, _ in _border_classes(nb, H, W, S, device)]
+
+
+def _chain_planes(V, Wf, out, T, K, N2, shift):
+    """out [T][N2] = sum over the 25 planes of V ([25][T][K] flat) x Wf [N2][25 K] (tap-major) + shift: launches of up to five planes
+    each, chained through the residual input (see rpn_composite: shorter fmaf chains, and a plane group stays inside the 2 GB window of
+    a buffer resource)."""
+    ppl = max(1, min(5, ((1 << 31) - (1 << 24)) // (T * K * 4)))
+    for p0 in range(0, 25, ppl):
+        npl = min(ppl, 25 - p0)
+        gemm_conv(V[p0 * T * K:], Wf[:, p0 * K:], out, B=1, H=npl, W=T, Cin=K, N=N2, kh=npl, kw=1, Ho=1, Wo=T, x_ld=K, w_ld=25 * K,
+                  shift=shift if p0 == 0 else None, residual=out if p0 else None, res_ld=N2 if p0 else None)
+
+
+def train_composite_ready(fm, block):
+    """The LazyMap of `fm` if `block` (layers.DepthwiseSepConv2d in training mode) can take the map's pending pattern pass into itself."""
+    st = lazy_state(fm)
+    if (st is None or st.pending is None or st.raw is None or not st.keep or not TRAIN_COMPOSITE or not torch.is_grad_enabled() or
+            not (st.sparse or st.overlap) or getattr(block, 'pe_proj', None) is not None or block.stride < 1 or
+            int(max(1, block.stride)) != st.stride or block.depth_wise.weight.shape[0] % st.U.shape[1]):
+        return None
+    return st
+
+
+TRAIN_COMPOSITE_CALLS = [0]      # tests: how many blocks went through the composed form
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = str(device)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
+def train_composite_forward(st, fm, dw_w, dw_b, pt_w, pt_b):
+    """-> f [B, OH, OW, N2]: the block's output in front of its BatchNorm.  Leaves in st.comp what the backward pass needs."""
+    from .nets import _prep as prep
+    TRAIN_COMPOSITE_CALLS[0] += 1
+    B, H, W, _ = fm.shape
+    S = st.stride
+    C_ = st.x.shape[-1]
+    N1 = st.U.shape[1]
+    N2 = pt_w.shape[0]
+    mult = dw_w.shape[0] // N1
+    OH, OW = (H - 1) // S + 1, (W - 1) // S + 1
+    Ucell, Ufold = st.pending
+    st.pending = None
+    out_w, out_b = st.raw
+    lt = st.lateral if st.lateral is not None and st.lateral.deferred else None
+    Ufwd = Ufold if Ufold is not None else Ucell                                      # [25][N1][K]
+    Ut = lt.ufold_t if lt is not None else prep.cell_weight(out_w)                     # [25][K][N1]
+    K = Ufwd.shape[2]
+    assert tuple(Ut.shape) == (25, K, N1) and tuple(Ufwd.shape) == (25, N1, K)
+    classes = {}
+    for (b0, nb, _) in st.chunks:
+        classes[nb] = _cell_classes(nb, H, W, S, fm.device)
+    masks = tuple((r_, s_) for r_, s_, _ in next(iter(classes.values())))
+    with torch.no_grad():
+        A, const = _compose_rpn_cell(dw_w.detach(), None if dw_b is None else dw_b.detach(), pt_w.detach(),
+                                     None if pt_b is None else pt_b.detach(), None if out_b is None else out_b.detach(), masks, mult)
+    A = A.contiguous()
+    Wf, Wb = [], []
+    for c in range(len(masks)):
+        wf = torch.empty((N2, 25 * K), device=fm.device, dtype=torch.float32)         # W'[n2][xi K + k] = (A_xi U_xi)[n2][k]
+        gemm_conv(A[c], Ut, wf, B=1, H=N2, W=1, Cin=N1, N=K, groups=25, x_gs=N2 * N1, w_gs=K * N1, y_gs=K, y_ld=25 * K)
+        wb = torch.empty((25, K, N2), device=fm.device, dtype=torch.float32)          # the same values as [xi][k][n2]
+        gemm_conv(Ut, A[c], wb, B=1, H=K, W=1, Cin=N1, N=N2, groups=25, x_gs=K * N1, w_gs=N2 * N1, y_gs=K * N2)
+        Wf.append(wf), Wb.append(wb)
+    f = torch.empty((B, OH, OW, N2), device=fm.device, dtype=torch.float32)
+    keep_label, ops._PROFILE_LABEL = ops._PROFILE_LABEL, ('rpn-composite-train', H, W)
+    try:
+        for ci, (b0, nb, pat) in enumerate(st.chunks):
+            V, _, Kc, T = _cell_operand(st, b0, nb, H, W, C_, st.x, n_out=N1, ci=ci)   # transformed patches; kept in st.vx for the backward pass
+            assert Kc == K and T == nb * OH * OW
+            fc = f[b0:b0 + nb].view(T, N2)
+            # border classes on a side stream, beside the interior launches: few rows against K = 25 x 448 -- a serial K loop that fills a
+            # fraction of the chip (one launch per class, 32-column slices as groups: 8 x the workgroups at a quarter of the MFMA work
+            # per K-step each); their rows then replace what the interior weights wrote there
+            main = torch.cuda.current_stream()
+            side = _side_stream(fm.device)
+            side.wait_stream(main)
+            border = []
+            with torch.cuda.stream(side):
+                for c, (_, _, idx) in enumerate(classes[nb]):
+                    if idx is None:
+                        continue
+                    Tb = idx.numel()
+                    Vb = V[:25 * T * K].view(25, T, K).index_select(1, idx)
+                    fb = torch.empty((Tb, N2), device=fm.device, dtype=torch.float32)
+                    if N2 % 32 == 0 and 25 * Tb * K * 4 < (1 << 31) - (1 << 24):
+                        gemm_conv(Vb, Wf[c], fb, B=1, H=25, W=Tb, Cin=K, N=32, kh=25, kw=1, Ho=1, Wo=Tb, x_ld=K, w_ld=25 * K, y_ld=N2,
+                                  groups=N2 // 32, x_gs=0, w_gs=32 * 25 * K, y_gs=32, residual=const[c].expand(Tb, N2).contiguous(),
+                                  res_ld=N2, res_gs=32)
+                    else:
+                        _chain_planes(Vb.view(-1), Wf[c], fb, Tb, K, N2, const[c].contiguous())
+                    fb.record_stream(main)
+                    border.append((idx, fb))
+            _chain_planes(V, Wf[0], fc, T, K, N2, const[0].contiguous())
+            main.wait_stream(side)
+            for idx, fb in border:
+                fc.index_copy_(0, idx, fb)
+    finally:
+        ops._PROFILE_LABEL = keep_label
+    st.comp = dict(A=A, Wf=Wf, Wb=Wb, Ufwd=Ufwd, Ut=Ut, K=K, N2=N2, mult=mult, masks=masks, classes=classes, g=None, dUc=None, gb=None)
+    return f
+
+
+def train_composite_backward(st, gf, dw_w, dw_b, pt_w, pt_b):
+    """gf [B, OH, OW, N2] = d/df.  -> (d dw_w, d dw_b, d pt_w, d pt_b); leaves in st.comp: `g` (per chunk: d/df with the border rows
+    zeroed + the border classes' rows) for the data gradient, `dUc` [25][N1][K] (gradient wrt the transformed kernel) and `gb` (the
+    share of out_conv's bias gradient) for the convolution's own backward pass."""
+    cp = st.comp
+    if cp is None or st.vx is None:
+        raise RuntimeError('the composed RPN reader has no forward state left (backward called twice, or the demand-driven map was released)')
+    B, OH, OW, N2 = gf.shape
+    K, A = cp['K'], cp['A']
+    N1 = A.shape[3]
+    ncls = A.shape[0]
+    dev = gf.device
+    dWf = [torch.zeros((N2, 25 * K), device=dev, dtype=torch.float32) for _ in range(ncls)]
+    G = torch.zeros((ncls, N2), device=dev, dtype=torch.float32)
+    per_chunk = []
+    for ci, (b0, nb, pat) in enumerate(st.chunks):
+        T = nb * OH * OW
+        V = st.vx[ci]
+        g = gf[b0:b0 + nb].reshape(T, N2)
+        g_int = g.clone()
+        parts = []
+        for c, (_, _, idx) in enumerate(cp['classes'][nb]):
+            if idx is None:
+                continue
+            g_c = g.index_select(0, idx).contiguous()
+            g_int.index_fill_(0, idx, 0.0)
+            Tb = idx.numel()
+            Vb = V[:25 * T * K].view(25, T, K).index_select(1, idx).view(-1)
+            conv_wgrad(g_c, Vb, dWf[c], B=1, H=Tb, W=1, Cin=K, N=N2, groups=25, g_gs=0, x_gs=Tb * K, out_gs=K, out_ld=25 * K)
+            G[c] += ops.colsum(g_c, N2)
+            parts.append((c, idx, g_c))
+        conv_wgrad(g_int, V, dWf[0], B=1, H=T, W=1, Cin=K, N=N2, groups=25, g_gs=0, x_gs=T * K, out_gs=K, out_ld=25 * K)
+        G[0] += ops.colsum(g_int, N2)
+        per_chunk.append((g_int, parts))
+    # d/dA_xi = dW'_xi U_xi^T; d/dU_xi = sum over the classes of A_xi^T dW'_xi
+    dA = torch.empty((ncls, 25, N2, N1), device=dev, dtype=torch.float32)
+    dUc = torch.zeros((25, N1, K), device=dev, dtype=torch.float32)
+    for c in range(ncls):
+        gemm_conv(dWf[c], cp['Ufwd'], dA[c], B=1, H=N2, W=1, Cin=K, N=N1, groups=25, x_ld=25 * K, x_gs=K, w_gs=N1 * K, y_gs=N2 * N1)
+        conv_wgrad(A[c], dWf[c], dUc, B=1, H=N2, W=1, Cin=K, N=N1, groups=25, g_gs=N2 * N1, x_ld=25 * K, x_gs=K, out_gs=N1 * K)
+    # the weight side by autograd over the small differentiable function (elementwise / reduce kernels on weight-sized tensors)
+    out_b = st.raw[1]
+    leaves = [t.detach().requires_grad_(True) if t is not None else None for t in (dw_w, dw_b, pt_w, pt_b, out_b)]
+    with torch.enable_grad():
+        A2, c2 = _compose_rpn_cell(*leaves, cp['masks'], cp['mult'])
+        wanted = [t for t in leaves if t is not None]
+        grads = torch.autograd.grad([A2, c2], wanted, [dA, G])
+    it = iter(grads)
+    g_dw, g_dwb, g_pt, g_ptb, g_ob = [next(it) if t is not None else None for t in leaves]
+    cp['g'], cp['dUc'], cp['gb'] = per_chunk, dUc, g_ob
+    st.vx = None                                      # the transformed patches have served (forward GEMM, dW')
+    return g_dw, g_dwb, g_pt, g_ptb
 
 
 def lazy_state(fm):
@@ -855,20 +1082,40 @@ def conv3x3_winograd_dgrad_tiles(st, g, Ut, Ucell=None, base=None, lateral_grads
         dt_img_bytes = H * W * Cin * 4
         split = bool(UPBWD_SPLIT and st.stride >= 5)
         shares = []                  # split: (compact RoI share of d/d(merged map), its tile list, first image, images) per chunk
+    comp = st.comp if cell else None
+    if st.comp is not None and (not cell or st.comp['g'] is None):
+        raise RuntimeError('the RPN reader of this demand-driven map was composed with its convolution (train_composite_forward) but '
+                           'its backward pass has not run / the cell-domain data gradient is switched off: the pattern share of the '
+                           'gradient would be dropped (NBM_RPN_COMPOSITE_TRAIN=0 restores the uncomposed chain)')
     for ci, (b0, nb, _) in enumerate(st.chunks):
         if cell:
-            vg = _cell_outgrad(st, g, ci, b0, nb)
-            T = vg.shape[1]
-            M, _ = ops._wino_scratch(g.device, 25 * T * C_, 0)
+            mp = C_                                    # row pitch of the plane products M [25][T][mp]
             global_label = ops._PROFILE_LABEL
             ops._PROFILE_LABEL = ('cell-dgrad', H, W)
-            if do_lat:
-                M, _ = ops._wino_scratch(g.device, 25 * T * K, 0)
             try:
-                if do_lat:
-                    gemm_conv(vg, Ud, M, B=1, H=T, W=1, Cin=N, N=K, groups=25, x_gs=T * N, w_gs=K * N, y_gs=T * K)
+                if comp is not None:
+                    # composed reader: M'_xi = g_f W'_xi straight from d/df [T][N2] (shared by the 25 groups); the border classes' rows
+                    # with their own weights, written over the (zero) rows the interior launch left for them
+                    g_int, parts = comp['g'][ci]
+                    T, N2, mp = g_int.shape[0], comp['N2'], comp['K']
+                    assert mp == (K if do_lat else mp) and mp >= C_
+                    M, _ = ops._wino_scratch(g.device, 25 * T * mp, 0)
+                    gemm_conv(g_int, comp['Wb'][0], M, B=1, H=T, W=1, Cin=N2, N=mp, groups=25, x_gs=0, w_gs=mp * N2, y_gs=T * mp)
+                    for c, idx, g_c in parts:
+                        Tb = idx.numel()
+                        Mc = torch.empty((25, Tb, mp), device=g.device, dtype=torch.float32)
+                        gemm_conv(g_c, comp['Wb'][c], Mc, B=1, H=Tb, W=1, Cin=N2, N=mp, groups=25, x_gs=0, w_gs=mp * N2, y_gs=Tb * mp)
+                        M[:25 * T * mp].view(25, T, mp).index_copy_(1, idx, Mc)
                 else:
-                    gemm_conv(vg, Ucell, M, B=1, H=T, W=1, Cin=N, N=C_, groups=25, x_gs=T * N, w_gs=C_ * N, y_gs=T * C_)
+                    vg = _cell_outgrad(st, g, ci, b0, nb)
+                    T = vg.shape[1]
+                    if do_lat:
+                        mp = K
+                        M, _ = ops._wino_scratch(g.device, 25 * T * K, 0)
+                        gemm_conv(vg, Ud, M, B=1, H=T, W=1, Cin=N, N=K, groups=25, x_gs=T * N, w_gs=K * N, y_gs=T * K)
+                    else:
+                        M, _ = ops._wino_scratch(g.device, 25 * T * C_, 0)
+                        gemm_conv(vg, Ucell, M, B=1, H=T, W=1, Cin=N, N=C_, groups=25, x_gs=T * N, w_gs=C_ * N, y_gs=T * C_)
             finally:
                 ops._PROFILE_LABEL = global_label
             if do_lat:            # d/d(merged map) patches (+ their sum = pattern share of the lateral's bias gradient), d/dt patches
@@ -878,7 +1125,7 @@ def conv3x3_winograd_dgrad_tiles(st, g, Ut, Ucell=None, base=None, lateral_grads
                                                   None, _stream()), 'nbm_cell_dgrad_output')
             else:
                 for cls in (range(4) if overlap else (-1,)):
-                    check(lib().nbm_cell_dgrad_output(_ptr(M), nb, H, W, C_, st.stride, C.c_void_p(gx.data_ptr() + b0 * img_bytes), cls, C_, 0,
+                    check(lib().nbm_cell_dgrad_output(_ptr(M), nb, H, W, C_, st.stride, C.c_void_p(gx.data_ptr() + b0 * img_bytes), cls, mp, 0,
                                                       None, _stream()), 'nbm_cell_dgrad_output')
         else:
             pat = wino23_pattern(nb, H, W, st.stride, g.device, dilate=1)
@@ -896,8 +1143,9 @@ def conv3x3_winograd_dgrad_tiles(st, g, Ut, Ucell=None, base=None, lateral_grads
                     tl = tl[:n]
                     gx_p, dt_p = C.c_void_p(gx.data_ptr() + b0 * img_bytes), C.c_void_p(dt.data_ptr() + b0 * dt_img_bytes)
                     Gc = torch.zeros((n * 4, C_), device=g.device, dtype=torch.float32)
-                    _wino23_tiles_run(g[b0:b0 + nb], Ut, None, Gc.data_ptr(), tl, None, n, 'wino23-dgrad-rois', skip_pattern=st.stride,
-                                      compact=True)
+                    # (composed reader: the pattern pixels of g hold the RoI pooling's share only -- nothing is masked)
+                    _wino23_tiles_run(g[b0:b0 + nb], Ut, None, Gc.data_ptr(), tl, None, n, 'wino23-dgrad-rois',
+                                      skip_pattern=0 if comp is not None else st.stride, compact=True)
                     if split:
                         shares.append((Gc, tl, b0, nb))
                     else:
@@ -924,8 +1172,9 @@ def conv3x3_winograd_dgrad_tiles(st, g, Ut, Ucell=None, base=None, lateral_grads
             tiles, n_blocks = buf
             check(lib().nbm_roi_tiles(_ptr(rois[b0:b0 + nb]), _ptr(n_roi[b0:b0 + nb] if per else n_roi), nb, rois.shape[1], nl, level,
                                       fh, fw, None if cell else _ptr(pat.full), 1, _ptr(tiles), _ptr(n_blocks), per, _stream()), 'nbm_roi_tiles')
+            # composed reader: g holds the RoI pooling's share only (pattern pixels included), ADDED to the cell patches
             _wino23_tiles_run(g[b0:b0 + nb], Ut, None, gx.data_ptr() + b0 * img_bytes, tiles, n_blocks, None, 'wino23-dgrad-rois',
-                              skip_pattern=st.stride if overlap else 0, accumulate=overlap)
+                              skip_pattern=st.stride if (overlap and comp is None) else 0, accumulate=overlap or comp is not None)
             if pool is not None:
                 tl, nbk = tiles.clone(), n_blocks.clone()          # the list buffer is shared by all chunks / levels
                 zero_note(pool, lambda p_=gx.data_ptr() + b0 * img_bytes, nb_=nb, tl_=tl, nbk_=nbk: check(
@@ -983,9 +1232,15 @@ def conv3x3_winograd_wgrad_tiles(st, x, g, want_bias=False, cell=None):
     lmax = max(128, (ops.WINO_CHUNK_BYTES // (16 * (C_ + N) * 4)) // 128 * 128)
     stream = _stream()
     thw = ((H + 1) // 2) * ((W + 1) // 2)
+    comp = st.comp if cell else None
+    if st.comp is not None and (not cell or st.comp['dUc'] is None):
+        raise RuntimeError('the RPN reader of this demand-driven map was composed with its convolution but its backward pass has not run '
+                           '/ the cell-domain weight gradient is switched off (NBM_RPN_COMPOSITE_TRAIN=0 restores the uncomposed chain)')
     for ci, (b0, nb, pat) in enumerate(st.chunks):
         lists, infos = ([], []) if cell else ([pat.tiles], [pat.entry_pm])
-        if cell:
+        if cell and comp is not None:
+            dUc = comp['dUc']                                  # composed reader: A^T dW', summed over chunks and classes by its backward pass
+        elif cell:
             vg = _cell_outgrad(st, g, ci, b0, nb)              # from the data gradient's pass when that ran first
             Vx, _, K, T = _cell_operand(st, b0, nb, H, W, C_, x, ci=ci)   # deferred lateral: K = C + Cin, dUc is the gradient of [U | alpha U W]
             if dUc.shape[2] != K:
@@ -1027,10 +1282,12 @@ def conv3x3_winograd_wgrad_tiles(st, x, g, want_bias=False, cell=None):
             check(lib().nbm_wino23_input_tiles(_ptr(xs), nb, H, W, C_, _ptr(lst), L, _ptr(info[l0:]), _ptr(V), stream),
                   'nbm_wino23_input_tiles')
             check(lib().nbm_wino23_outgrad_tiles(_ptr(gs), nb, H, W, N, _ptr(lst), L, _ptr(info[l0:]), _ptr(dM), _ptr(gb),
-                                                 st.stride if cell else 0, stream), 'nbm_wino23_outgrad_tiles')
+                                                 st.stride if (cell and comp is None) else 0, stream), 'nbm_wino23_outgrad_tiles')
             conv_wgrad(dM, V, dU, B=1, H=L, W=1, Cin=C_, N=N, groups=16, g_gs=L * N, x_gs=L * C_, out_gs=N * C_)
     if cell and gb is not None:
-        gb += st.cell_gb
+        share = comp['gb'] if comp is not None else st.cell_gb
+        if share is not None:
+            gb += share
     if cell:
         st.vg = st.cell_gb = st.cell_gb_done = None
         if dUc.shape[2] != C_:          # deferred lateral: d/dU = d/d(first block) + alpha * d/d(second block) W^T  (second block = alpha U W)

@@ -720,6 +720,72 @@ def test_lateral_gradients_from_the_cell_domain_equal_the_dense_passes():
     assert any('fpn' in k for k in res['split'])
 
 
+@pytest.mark.parametrize('mode', ['early-backward', 'one-backward', 'chunked', 'negative-step', 'rpn-failed'])
+def test_rpn_block_composed_with_the_output_convolution_in_training(mode, monkeypatch):
+    """DESIGN 4h (round 5): in TRAINING mode the RPN's first block on the demand-driven levels 0 / 1 -- depthwise 3x3 / stride S -> 1x1,
+    reference layers.py:22-29,62-65 -- composed with the level's output convolution (fpn.py:137,145) in the cell domain
+    (Fn.RpnComposite): losses, BatchNorm buffers and EVERY parameter gradient of a step equal those of the uncomposed chain of tape
+    nodes (cell transforms -> pattern pixels -> DwConv -> 1x1), border cells (top row / left column / corner: depthwise taps in the
+    map's zero padding) included.  Variants: the RPN branch back-propagated early (train.step's split backward: the composed node
+    parks an empty share for the RoI pooling) or with everything else; the batch cut into chunks of one image; a negative step
+    (1000 RoIs per image, no early pass); a step that ends after the first stage (the parked share is flushed)."""
+    from birdsoundclassif_amd import train as T
+    from birdsoundclassif_amd.nets import build_model
+    args = T.default_args(device='cuda', **(dict(min_threshold=5000) if mode == 'rpn-failed' else {}))    # no box survives: "RPN failed"
+    B = 3
+    img = torch.from_numpy(synth.image_batch(0, B))
+    neg = torch.from_numpy(synth.image_batch(50, B))
+    bb, ids, lens = synth.label_batch(0, B)
+    batch = [img, neg, bb, ids, lens]
+    if mode == 'chunked':
+        monkeypatch.setattr(ops, 'WINO_CHUNK_BYTES', 700 << 20)         # level 0: one image per chunk
+    if mode == 'one-backward':
+        monkeypatch.setattr(T, 'SPLIT_BACKWARD', False)
+    res = {}
+    for composed in (False, True):
+        model, crit = build_model(args)
+        model.load_state_dict(filler_state_dict())
+        model = model.cuda().train()
+        crit.train()
+        np.random.seed(5)
+        ondemand.TRAIN_COMPOSITE = composed
+        ondemand.ZERO_POOL_CHECK = True
+        ondemand.TRAIN_COMPOSITE_CALLS[0] = 0
+        try:
+            model.zero_grad()
+            loss = T.step(model, crit, batch, 'cuda', mode == 'negative-step', early_backward=True)
+            tot = sum(loss[k] * crit.weight_dict[k] for k in loss if k in crit.weight_dict)
+            if tot.requires_grad:
+                tot.backward()
+            Fn.parked_flush()
+            Fn.stash_check_empty()
+        finally:
+            ondemand.TRAIN_COMPOSITE = True
+            ondemand.ZERO_POOL_CHECK = False
+            ondemand.zero_pool_clear()
+        torch.cuda.synchronize()
+        assert ondemand.TRAIN_COMPOSITE_CALLS[0] == (2 if composed else 0)
+        res[composed] = dict(loss={k: float(v) for k, v in loss.items()},
+                             grads={k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None},
+                             bufs={k: v.detach().clone() for k, v in model.named_buffers() if 'rpn.convs' in k and 'running' in k})
+    a, b = res[False], res[True]
+    if mode == 'rpn-failed':
+        assert not any(k.startswith('sec') for k in a['loss'])
+    assert set(a['loss']) == set(b['loss'])
+    for k in a['loss']:
+        assert abs(a['loss'][k] - b['loss'][k]) <= 2e-5 * max(1.0, abs(a['loss'][k])), (k, a['loss'][k], b['loss'][k])
+    assert set(a['grads']) == set(b['grads']) and any('rpn.convs.0.depth_wise' in k for k in a['grads'])
+    for k, g in a['grads'].items():
+        g2 = b['grads'][k]
+        assert torch.isfinite(g2).all(), k
+        # (the biases in front of the BatchNorm have a zero gradient: rounding noise of ~1e-7 on both sides)
+        tol = 2e-4 * float(g.abs().max()) + 1e-6
+        err = float((g - g2).abs().max())
+        assert err <= tol, (mode, k, err, tol)
+    for k, v in a['bufs'].items():
+        assert float((v - b['bufs'][k]).abs().max()) <= 1e-5 * max(1.0, float(v.abs().max())), k
+
+
 def test_cell_weight_kernels_equal_the_float64_einsum():
     """`nbm_cell_weight` / `nbm_cell_weight_fold` / `nbm_cell_weight_grad` (csrc/cellwino.hip: the kernel side of the cell transforms,
     float64 arithmetic, one rounding) against the float64 `torch.einsum` restatement they replaced on the training path: U = E w E^T in
