@@ -65,6 +65,7 @@ _P, _I, _L, _F, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 # name -> argtypes (restype is int unless noted); must list every symbol of include/nbm_hip.h
 SIGNATURES = {
     'nbm_graph_census': [_P, C.POINTER(C.c_longlong * 6)],
+    'nbm_copy_rect': [_P, _P, _L, _L, _I, _L, _L, _I, _I, _P],
     'nbm_gemm_conv': [C.POINTER(GemmDesc), _P],
     'nbm_pcm16_to_wave': [_P, _L, _I, _I, _I, _P, _L, _L, _P, _L, _I, _I, _P],
     'nbm_resample_to_wave': [_P, _L, _I, _L, _I, _I, _P, _I, _L, _L, _P, _L, _I, _I, _I, _P],

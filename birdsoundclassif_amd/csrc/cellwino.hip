@@ -556,3 +556,35 @@ extern "C" int nbm_cell_weight_grad(const float* dU, int N, int C, int ld, float
   hipLaunchKernelGGL(cell_weight_grad_kernel, dim3((unsigned)((N * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dU, N, C, ld, dW);
   return nbm_launch_status();
 }
+
+// ---- rectangle of a [n_outer][.][.] row-major array <-> packed rows (the border-cell classes of the composed RPN reader, DESIGN 4h:
+// a rectangle [r0, r1) x [c0, c1) of the OH x OW cell grid of every (plane, image), rows of (c1 - c0) * K floats).  16-byte accesses.
+namespace {
+__global__ __launch_bounds__(256) void copy_rect_kernel(float4* __restrict__ strided, float4* __restrict__ packed, long long n_outer,
+                                                         long long outer_pitch4, int n_rows, long long row_pitch4, long long width4,
+                                                         int to_strided, int zero_strided) {
+  const long long total = n_outer * n_rows * width4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long w = i % width4, rr = i / width4;
+    const long long r = rr % n_rows, o = rr / n_rows;
+    float4* sp = strided + o * outer_pitch4 + r * row_pitch4 + w;
+    if (to_strided) *sp = packed[i];
+    else {
+      packed[i] = *sp;
+      if (zero_strided) *sp = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int nbm_copy_rect(float* strided, float* packed, int64_t n_outer, int64_t outer_pitch, int n_rows, int64_t row_pitch, int64_t width,
+                             int to_strided, int zero_strided, void* stream) {
+  if (!strided || !packed || n_outer <= 0 || n_rows <= 0 || width <= 0 || row_pitch < width || outer_pitch < 0) return NBM_EINVAL;
+  if (!nbm_aligned16(strided) || !nbm_aligned16(packed) || (outer_pitch & 3) || (row_pitch & 3) || (width & 3)) return NBM_EALIGN;
+  const long long total = (long long)n_outer * n_rows * (width / 4);
+  const long long blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(copy_rect_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, (float4*)strided,
+                     (float4*)packed, (long long)n_outer, (long long)(outer_pitch / 4), n_rows, (long long)(row_pitch / 4),
+                     (long long)(width / 4), to_strided, zero_strided);
+  return nbm_launch_status();
+}

@@ -667,10 +667,36 @@ def _compose_rpn_cell(dw_w, dw_b, pt_w, pt_b, out_b, masks, mult):
     return torch.stack(As), torch.stack(consts)
 
 
-def _cell_classes(nb, H, W, S, device):
-    """[(row mask, column mask, cell indices or None)]: the interior class first (None = every cell not listed below), then the border
-    classes of `_border_classes`."""
-    return [(7, 7, None)] + [(r_, s_, idx) for r_, s_, _, _, idx, _ in _border_classes(nb, H, W, S, device)]
+_CELL_CLASSES = {}
+
+
+def _cell_classes(H, W, S):
+    """Classes of cells by which of their depthwise taps lie inside the map: [(row mask, column mask, (oy0, oy1), (ox0, ox1))], every
+    class a rectangle of the OH x OW cell grid (interior: all nine taps inside; at the reference geometries the top row, the left column
+    and the corner have taps in the padding).  The interior class comes first.  None when a class is not a rectangle."""
+    key = (H, W, S)
+    if key not in _CELL_CLASSES:
+        OH, OW = (H - 1) // S + 1, (W - 1) // S + 1
+        rm = [sum(1 << r for r in range(3) if 0 <= S * oy - 1 + r < H) for oy in range(OH)]
+        sm = [sum(1 << c for c in range(3) if 0 <= S * ox - 1 + c < W) for ox in range(OW)]
+
+        def ranges(masks):
+            out = {}
+            for i, m in enumerate(masks):
+                if m in out:
+                    lo, hi = out[m]
+                    if i != hi:
+                        return None                  # the same mask in two separate runs: not a rectangle
+                    out[m] = (lo, i + 1)
+                else:
+                    out[m] = (i, i + 1)
+            return out
+        rr, cc = ranges(rm), ranges(sm)
+        cls = None
+        if rr is not None and cc is not None and 7 in rr and 7 in cc:
+            cls = [(7, 7, rr[7], cc[7])] + [(r_, c_, rr[r_], cc[c_]) for r_ in sorted(rr) for c_ in sorted(cc) if (r_, c_) != (7, 7)]
+        _CELL_CLASSES[key] = cls
+    return _CELL_CLASSES[key]
 
 
 def _chain_planes(V, Wf, out, T, K, N2, shift):
@@ -689,7 +715,8 @@ def train_composite_ready(fm, block):
     st = lazy_state(fm)
     if (st is None or st.pending is None or st.raw is None or not st.keep or not TRAIN_COMPOSITE or not torch.is_grad_enabled() or
             not (st.sparse or st.overlap) or getattr(block, 'pe_proj', None) is not None or block.stride < 1 or
-            int(max(1, block.stride)) != st.stride or block.depth_wise.weight.shape[0] % st.U.shape[1]):
+            int(max(1, block.stride)) != st.stride or block.depth_wise.weight.shape[0] % st.U.shape[1] or
+            _cell_classes(fm.shape[1], fm.shape[2], st.stride) is None):
         return None
     return st
 
@@ -724,10 +751,8 @@ def train_composite_forward(st, fm, dw_w, dw_b, pt_w, pt_b):
     Ut = lt.ufold_t if lt is not None else prep.cell_weight(out_w)                     # [25][K][N1]
     K = Ufwd.shape[2]
     assert tuple(Ut.shape) == (25, K, N1) and tuple(Ufwd.shape) == (25, N1, K)
-    classes = {}
-    for (b0, nb, _) in st.chunks:
-        classes[nb] = _cell_classes(nb, H, W, S, fm.device)
-    masks = tuple((r_, s_) for r_, s_, _ in next(iter(classes.values())))
+    classes = _cell_classes(H, W, S)
+    masks = tuple((r_, s_) for r_, s_, _, _ in classes)
     with torch.no_grad():
         A, const = _compose_rpn_cell(dw_w.detach(), None if dw_b is None else dw_b.detach(), pt_w.detach(),
                                      None if pt_b is None else pt_b.detach(), None if out_b is None else out_b.detach(), masks, mult)
@@ -746,32 +771,40 @@ def train_composite_forward(st, fm, dw_w, dw_b, pt_w, pt_b):
             V, _, Kc, T = _cell_operand(st, b0, nb, H, W, C_, st.x, n_out=N1, ci=ci)   # transformed patches; kept in st.vx for the backward pass
             assert Kc == K and T == nb * OH * OW
             fc = f[b0:b0 + nb].view(T, N2)
-            # border classes on a side stream, beside the interior launches: few rows against K = 25 x 448 -- a serial K loop that fills a
-            # fraction of the chip (one launch per class, 32-column slices as groups: 8 x the workgroups at a quarter of the MFMA work
-            # per K-step each); their rows then replace what the interior weights wrote there
+            # border classes on a side stream, beside the interior launches (few rows: they would leave most of the chip idle): the
+            # class's rows -- a rectangle of the cell grid -- copied out, ONE grouped GEMM over the 25 planes with the class's weights
+            # (a single launch over K = 25 x 448 is a serial loop of 350 K-steps on a quarter of the CUs: 0.74 ms per class and chunk),
+            # the 25 partial sums added; the rows then replace what the interior weights wrote there
             main = torch.cuda.current_stream()
             side = _side_stream(fm.device)
             side.wait_stream(main)
             border = []
+            fflat = f[b0:b0 + nb].view(-1)
             with torch.cuda.stream(side):
-                for c, (_, _, idx) in enumerate(classes[nb]):
-                    if idx is None:
+                for c, (_, _, (r0, r1), (c0, c1)) in enumerate(classes):
+                    if c == 0:
                         continue
-                    Tb = idx.numel()
-                    Vb = V[:25 * T * K].view(25, T, K).index_select(1, idx)
-                    fb = torch.empty((Tb, N2), device=fm.device, dtype=torch.float32)
-                    if N2 % 32 == 0 and 25 * Tb * K * 4 < (1 << 31) - (1 << 24):
-                        gemm_conv(Vb, Wf[c], fb, B=1, H=25, W=Tb, Cin=K, N=32, kh=25, kw=1, Ho=1, Wo=Tb, x_ld=K, w_ld=25 * K, y_ld=N2,
-                                  groups=N2 // 32, x_gs=0, w_gs=32 * 25 * K, y_gs=32, residual=const[c].expand(Tb, N2).contiguous(),
-                                  res_ld=N2, res_gs=32)
-                    else:
-                        _chain_planes(Vb.view(-1), Wf[c], fb, Tb, K, N2, const[c].contiguous())
+                    nr, nc = r1 - r0, c1 - c0
+                    Tb = nb * nr * nc
+                    Vb = torch.empty((25 * Tb * K,), device=fm.device, dtype=torch.float32)
+                    ops.copy_rect(V, (r0 * OW + c0) * K, Vb, 25 * nb, OH * OW * K, nr, OW * K, nc * K)
+                    part = torch.empty((25, Tb, N2), device=fm.device, dtype=torch.float32)
+                    gemm_conv(Vb, Wf[c], part, B=1, H=Tb, W=1, Cin=K, N=N2, groups=25, x_gs=Tb * K, w_ld=25 * K, w_gs=K, y_gs=Tb * N2)
+                    fb = part.sum(0)
+                    fb += const[c]
                     fb.record_stream(main)
-                    border.append((idx, fb))
-            _chain_planes(V, Wf[0], fc, T, K, N2, const[0].contiguous())
+                    border.append(((r0, r1), (c0, c1), fb))
+            # interior weights on every cell: five groups of five planes (K = 5 x 448 each) into partial sums, added afterwards -- one
+            # launch of 5 x (cells / 128) x 2 workgroups fills whole rounds of the chip where a chain of five 2-tile-wide launches
+            # ended each in a partly filled third round (+4.8 ms per step, measured), and five short fmaf chains round less
+            part5 = torch.empty((5, T, N2), device=fm.device, dtype=torch.float32)
+            gemm_conv(V, Wf[0], part5, B=1, H=5, W=T, Cin=K, N=N2, kh=5, kw=1, Ho=1, Wo=T, x_ld=K, w_ld=25 * K, groups=5, x_gs=5 * T * K,
+                      w_gs=5 * K, y_gs=T * N2)
+            torch.sum(part5, 0, out=fc)
+            fc += const[0]
             main.wait_stream(side)
-            for idx, fb in border:
-                fc.index_copy_(0, idx, fb)
+            for (r0, r1), (c0, c1), fb in border:
+                ops.copy_rect(fflat, (r0 * OW + c0) * N2, fb, nb, OH * OW * N2, r1 - r0, OW * N2, (c1 - c0) * N2, to_strided=True)
     finally:
         ops._PROFILE_LABEL = keep_label
     st.comp = dict(A=A, Wf=Wf, Wb=Wb, Ufwd=Ufwd, Ut=Ut, K=K, N2=N2, mult=mult, masks=masks, classes=classes, g=None, dUc=None, gb=None)
@@ -796,22 +829,24 @@ def train_composite_backward(st, gf, dw_w, dw_b, pt_w, pt_b):
     for ci, (b0, nb, pat) in enumerate(st.chunks):
         T = nb * OH * OW
         V = st.vx[ci]
-        g = gf[b0:b0 + nb].reshape(T, N2)
-        g_int = g.clone()
+        g_int = gf[b0:b0 + nb].reshape(T, N2).clone()
+        gflat = g_int.view(-1)
         parts = []
-        for c, (_, _, idx) in enumerate(cp['classes'][nb]):
-            if idx is None:
+        for c, (_, _, (r0, r1), (c0, c1)) in enumerate(cp['classes']):
+            if c == 0:
                 continue
-            g_c = g.index_select(0, idx).contiguous()
-            g_int.index_fill_(0, idx, 0.0)
-            Tb = idx.numel()
-            Vb = V[:25 * T * K].view(25, T, K).index_select(1, idx).view(-1)
+            nr, nc = r1 - r0, c1 - c0
+            Tb = nb * nr * nc
+            g_c = torch.empty((Tb, N2), device=dev, dtype=torch.float32)
+            ops.copy_rect(gflat, (r0 * OW + c0) * N2, g_c, nb, OH * OW * N2, nr, OW * N2, nc * N2, zero=True)     # ... and zeroed in g_int
+            Vb = torch.empty((25 * Tb * K,), device=dev, dtype=torch.float32)
+            ops.copy_rect(V, (r0 * OW + c0) * K, Vb, 25 * nb, OH * OW * K, nr, OW * K, nc * K)
             conv_wgrad(g_c, Vb, dWf[c], B=1, H=Tb, W=1, Cin=K, N=N2, groups=25, g_gs=0, x_gs=Tb * K, out_gs=K, out_ld=25 * K)
             G[c] += ops.colsum(g_c, N2)
-            parts.append((c, idx, g_c))
+            parts.append((c, (r0, r1), (c0, c1), g_c))
         conv_wgrad(g_int, V, dWf[0], B=1, H=T, W=1, Cin=K, N=N2, groups=25, g_gs=0, x_gs=T * K, out_gs=K, out_ld=25 * K)
         G[0] += ops.colsum(g_int, N2)
-        per_chunk.append((g_int, parts))
+        per_chunk.append((g_int, parts, (nb, OH, OW)))
     # d/dA_xi = dW'_xi U_xi^T; d/dU_xi = sum over the classes of A_xi^T dW'_xi
     dA = torch.empty((ncls, 25, N2, N1), device=dev, dtype=torch.float32)
     dUc = torch.zeros((25, N1, K), device=dev, dtype=torch.float32)
@@ -1096,16 +1131,16 @@ def conv3x3_winograd_dgrad_tiles(st, g, Ut, Ucell=None, base=None, lateral_grads
                 if comp is not None:
                     # composed reader: M'_xi = g_f W'_xi straight from d/df [T][N2] (shared by the 25 groups); the border classes' rows
                     # with their own weights, written over the (zero) rows the interior launch left for them
-                    g_int, parts = comp['g'][ci]
+                    g_int, parts, (nb_, OHc, OWc) = comp['g'][ci]
                     T, N2, mp = g_int.shape[0], comp['N2'], comp['K']
                     assert mp == (K if do_lat else mp) and mp >= C_
                     M, _ = ops._wino_scratch(g.device, 25 * T * mp, 0)
                     gemm_conv(g_int, comp['Wb'][0], M, B=1, H=T, W=1, Cin=N2, N=mp, groups=25, x_gs=0, w_gs=mp * N2, y_gs=T * mp)
-                    for c, idx, g_c in parts:
-                        Tb = idx.numel()
-                        Mc = torch.empty((25, Tb, mp), device=g.device, dtype=torch.float32)
+                    for c, (r0, r1), (c0, c1), g_c in parts:
+                        Tb = g_c.shape[0]
+                        Mc = torch.empty((25 * Tb * mp,), device=g.device, dtype=torch.float32)
                         gemm_conv(g_c, comp['Wb'][c], Mc, B=1, H=Tb, W=1, Cin=N2, N=mp, groups=25, x_gs=0, w_gs=mp * N2, y_gs=Tb * mp)
-                        M[:25 * T * mp].view(25, T, mp).index_copy_(1, idx, Mc)
+                        ops.copy_rect(M, (r0 * OWc + c0) * mp, Mc, 25 * nb_, OHc * OWc * mp, r1 - r0, OWc * mp, (c1 - c0) * mp, to_strided=True)
                 else:
                     vg = _cell_outgrad(st, g, ci, b0, nb)
                     T = vg.shape[1]

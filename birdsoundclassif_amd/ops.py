@@ -326,6 +326,17 @@ def cell_weight(weight, forward=True, lateral=None, alpha=1.0, both=False):
     return (Unc, Ucn) if both else (Unc if forward else Ucn)
 
 
+def copy_rect(strided, base_off, packed, n_outer, outer_pitch, n_rows, row_pitch, width, to_strided=False, zero=False):
+    """nbm_copy_rect on a flat fp32 tensor `strided` (element offset `base_off` of the rectangle's first float) and a contiguous
+    `packed` [n_outer * n_rows * width]; counts in floats."""
+    assert strided.dtype == torch.float32 and packed.dtype == torch.float32 and packed.is_contiguous()
+    assert packed.numel() >= n_outer * n_rows * width
+    assert base_off + (n_outer - 1) * outer_pitch + (n_rows - 1) * row_pitch + width <= strided.numel()
+    check(lib().nbm_copy_rect(C.c_void_p(strided.data_ptr() + 4 * base_off), _ptr(packed), n_outer, outer_pitch, n_rows, row_pitch, width,
+                              int(bool(to_strided)), int(bool(zero)), _stream()), 'nbm_copy_rect')
+    return packed
+
+
 def cell_weight_grad(dU):
     """dU [25, N, K >= C] (columns beyond C ignored when `dU` is a [..., :C] view) -> dW [N, C, 3, 3] = E^T dU E."""
     assert dU.dim() == 3 and dU.shape[0] == 25 and dU.stride(2) == 1 and dU.stride(0) == dU.shape[1] * dU.stride(1)

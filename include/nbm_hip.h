@@ -216,6 +216,14 @@ int nbm_cell_input_up(const float* x1, const float* bias, int B, int H, int W, i
 int nbm_cell_patches(const float* x, int B, int H, int W, int C, int stride, float* Vx, int ld, int c_off, void* stream);
 int nbm_cell_patches_up(const float* x1, const float* bias, int B, int H, int W, int C, int Hc, int Wc, int stride, float* Vx, int ld,
                         int c_off, void* stream);
+
+/* Rectangle copy between a strided array and packed rows (no counterpart in the reference: plumbing of the composed RPN reader in
+ * training mode, DESIGN 4h -- the border-cell classes of reference layers.py:22-29's depthwise padding are rectangles [r0, r1) x [c0, c1)
+ * of the OH x OW cell grid of every (plane, image)): for o < n_outer, r < n_rows:  packed[(o * n_rows + r) * width ...] <->
+ * strided[o * outer_pitch + r * row_pitch ...], `width` floats each.  to_strided = 0: packed <- strided (zero_strided = 1 also clears
+ * the source rectangle); to_strided = 1: strided <- packed.  All counts in floats, multiples of 4; 16-byte aligned pointers. */
+int nbm_copy_rect(float* strided, float* packed, int64_t n_outer, int64_t outer_pitch, int n_rows, int64_t row_pitch, int64_t width,
+                  int to_strided, int zero_strided, void* stream);
 int nbm_cell_dgrad_output(const float* M, int B, int H, int W, int C, int stride, float* gx, int parity_class,
                           int ld /* row pitch of M, >= c_off + C */, int c_off /* first channel of M read */,
                           float* bias_grad /* optional [C]: += sum of the patch pixels written (inside the image) */, void* stream);
