@@ -647,24 +647,28 @@ def _compose_rpn_cell(dw_w, dw_b, pt_w, pt_b, out_b, masks, mult):
     -> (A [classes][25][N2][N1], const [classes][N2]) for the cell classes `masks` = ((row mask, column mask), ...)."""
     m_ = dw_w.shape[0]
     n1, n2 = m_ // mult, pt_w.shape[0]
-    E = _dev_const(dw_w.device, 'E', _CE)                                            # [5][3]
-    dw = dw_w.reshape(m_, 3, 3)
+    dev = dw_w.device
+    E = _dev_const(dev, 'E', _CE)                                                    # [5][3]
+    mr = _dev_const(dev, ('rmask', masks), [[float((rm >> r) & 1) for r in range(3)] for rm, _ in masks])      # [classes][3]
+    ms = _dev_const(dev, ('smask', masks), [[float((sm >> c) & 1) for c in range(3)] for _, sm in masks])
+    dw = dw_w.reshape(1, m_, 3, 3)
     pt = pt_w.reshape(n2, n1, mult)
-    ob = out_b if out_b is not None else torch.zeros((n1,), device=dw_w.device, dtype=torch.float32)
-    As, consts = [], []
-    for rm, sm in masks:
-        mr = _dev_const(dw_w.device, ('mask', rm), [float((rm >> r) & 1) for r in range(3)])
-        ms = _dev_const(dw_w.device, ('mask', sm), [float((sm >> c) & 1) for c in range(3)])
-        dwm = dw * mr[None, :, None] * ms[None, None, :]
-        t = (E[None, :, :, None] * dwm[:, None, :, :]).sum(2)                         # [M][5 (a)][3 (s)]
-        cw = (t[:, :, None, :] * E[None, None, :, :]).sum(3).reshape(n1, mult, 25)    # (E dw E^T)[a][b], plane xi = 5 a + b
-        As.append((pt[None] * cw.permute(2, 0, 1)[:, None]).sum(3))                   # [25][N2][N1]
-        cb = dwm.sum((1, 2)) * ob.repeat_interleave(mult)
-        if dw_b is not None:
-            cb = cb + dw_b
-        c_ = (pt.reshape(n2, m_) * cb[None, :]).sum(1)
-        consts.append(c_ + pt_b if pt_b is not None else c_)
-    return torch.stack(As), torch.stack(consts)
+    dwm = dw * mr[:, None, :, None] * ms[:, None, None, :]                           # [classes][M][3][3]: taps in the padding zeroed
+    t = (E[None, None, :, :, None] * dwm[:, :, None, :, :]).sum(3)                   # [classes][M][5 (a)][3 (s)]
+    cw = (t[:, :, :, None, :] * E[None, None, None, :, :]).sum(4)                    # (E dw E^T)[a][b], plane xi = 5 a + b
+    cw = cw.reshape(len(masks), n1, mult, 25)
+    A = (pt[None, None] * cw.permute(0, 3, 1, 2)[:, :, None]).sum(4)                 # [classes][25][N2][N1]
+    cb = dwm.sum((2, 3))                                                              # [classes][M]
+    if out_b is not None:
+        cb = cb * out_b.repeat_interleave(mult)[None, :]
+    else:
+        cb = cb * 0.0
+    if dw_b is not None:
+        cb = cb + dw_b[None, :]
+    const = (pt.reshape(1, n2, m_) * cb[:, None, :]).sum(2)                           # [classes][N2]
+    if pt_b is not None:
+        const = const + pt_b[None, :]
+    return A, const
 
 
 _CELL_CLASSES = {}
@@ -765,6 +769,7 @@ def train_composite_forward(st, fm, dw_w, dw_b, pt_w, pt_b):
         gemm_conv(Ut, A[c], wb, B=1, H=K, W=1, Cin=N1, N=N2, groups=25, x_gs=K * N1, w_gs=N2 * N1, y_gs=K * N2)
         Wf.append(wf), Wb.append(wb)
     f = torch.empty((B, OH, OW, N2), device=fm.device, dtype=torch.float32)
+    kept_vb = {}
     keep_label, ops._PROFILE_LABEL = ops._PROFILE_LABEL, ('rpn-composite-train', H, W)
     try:
         for ci, (b0, nb, pat) in enumerate(st.chunks):
@@ -793,6 +798,8 @@ def train_composite_forward(st, fm, dw_w, dw_b, pt_w, pt_b):
                     fb = part.sum(0)
                     fb += const[c]
                     fb.record_stream(main)
+                    Vb.record_stream(main)
+                    kept_vb[(ci, c)] = Vb             # the weight gradient of the class reads the same rows again
                     border.append(((r0, r1), (c0, c1), fb))
             # interior weights on every cell: five groups of five planes (K = 5 x 448 each) into partial sums, added afterwards -- one
             # launch of 5 x (cells / 128) x 2 workgroups fills whole rounds of the chip where a chain of five 2-tile-wide launches
@@ -807,7 +814,7 @@ def train_composite_forward(st, fm, dw_w, dw_b, pt_w, pt_b):
                 ops.copy_rect(fflat, (r0 * OW + c0) * N2, fb, nb, OH * OW * N2, r1 - r0, OW * N2, (c1 - c0) * N2, to_strided=True)
     finally:
         ops._PROFILE_LABEL = keep_label
-    st.comp = dict(A=A, Wf=Wf, Wb=Wb, Ufwd=Ufwd, Ut=Ut, K=K, N2=N2, mult=mult, masks=masks, classes=classes, g=None, dUc=None, gb=None)
+    st.comp = dict(A=A, Wf=Wf, Wb=Wb, Ufwd=Ufwd, Ut=Ut, K=K, N2=N2, mult=mult, masks=masks, classes=classes, vb=kept_vb, g=None, dUc=None, gb=None)
     return f
 
 
@@ -839,8 +846,7 @@ def train_composite_backward(st, gf, dw_w, dw_b, pt_w, pt_b):
             Tb = nb * nr * nc
             g_c = torch.empty((Tb, N2), device=dev, dtype=torch.float32)
             ops.copy_rect(gflat, (r0 * OW + c0) * N2, g_c, nb, OH * OW * N2, nr, OW * N2, nc * N2, zero=True)     # ... and zeroed in g_int
-            Vb = torch.empty((25 * Tb * K,), device=dev, dtype=torch.float32)
-            ops.copy_rect(V, (r0 * OW + c0) * K, Vb, 25 * nb, OH * OW * K, nr, OW * K, nc * K)
+            Vb = cp['vb'].pop((ci, c))
             conv_wgrad(g_c, Vb, dWf[c], B=1, H=Tb, W=1, Cin=K, N=N2, groups=25, g_gs=0, x_gs=Tb * K, out_gs=K, out_ld=25 * K)
             G[c] += ops.colsum(g_c, N2)
             parts.append((c, (r0, r1), (c0, c1), g_c))
