@@ -44,6 +44,15 @@ FWD_GFLOP_PER_CLIP = 325.56            # SURVEY.md §6 (conv + addmm + bmm, forw
 TRAIN_GFLOP_PER_CLIP = 993.45          # SURVEY.md §6 (fwd + bwd, positive step)
 
 
+def conv_algorithmic_bytes(B, H, W, Cin, N, k, stride, groups, kind):
+    """ALGORITHMIC HBM bytes of one implicit-GEMM launch (every operand once): forward / data gradient = activation in +
+    weights + activation out; weight gradient = both activations + the weight-sized result.  Epilogue operands that depend on the call
+    site (residual, ReLU mask, merged coarse map) are NOT included: the wasted-traffic ratio traffic / algorithmic is an upper bound."""
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    a_in, a_out, w = B * H * W * Cin, B * Ho * Wo * N, N * k * k * Cin
+    return 4.0 * groups * (a_in + a_out + w)
+
+
 def pmc_traffic(name, same_workload):
     """`traffic` (HBM bytes per launch, 2 x FETCH_SIZE + WRITE_SIZE) of a kernel family from THIS round's committed rocprofv3 --pmc
     passes (counters cannot be read live), or null with the reason."""
@@ -161,6 +170,7 @@ def train_bench(rank, world, dist, batch, steps, warmup, mix_steps=10):
                     'all_wgrad_ms_per_step': all_ms / steps,
                     'largest_launches': [{'B,H,W,Cin,N,k,stride,groups': list(t[1:]), 'ms': sum(wg[t]) / len(wg[t]),
                                           'launches': len(wg[t]), 'executed_TFLOPs': gflop(t) * len(wg[t]) / sum(wg[t])} for t in top],
+                    'algorithmic_bytes_per_launch': sum(conv_algorithmic_bytes(*t[1:6], t[6], t[7], t[8], 'wgrad') * len(v) for t, v in wg.items()) / n_launch,
                     **pmc_traffic(PMC_WGRAD, batch == 128)}
     dg = {}
     for tag, e0, e1 in prof:
@@ -180,6 +190,9 @@ def train_bench(rank, world, dist, batch, steps, warmup, mix_steps=10):
                       'avg_launch_ms': d_ms / d_n, 'launches': d_n, 'all_dgrad_ms_per_step': d_ms / steps,
                       'largest_launches': [{'B,H,W,Cin,N,k,stride,groups': list(t[1:]), 'ms': sum(dg[t]) / len(dg[t]), 'launches': len(dg[t]),
                                             'executed_TFLOPs': dgflop(t) * len(dg[t]) / sum(dg[t])} for t in dtop],
+                      'algorithmic_bytes_per_launch': sum(conv_algorithmic_bytes(*t[1:6], t[6], t[7], t[8], 'dgrad') * len(v) for t, v in dg.items()) / d_n,
+                      'algorithmic_bytes_note': 'G + weights + dX; the shortcut-gradient and ReLU-mask operands of the bottleneck epilogues (as '
+                                                'large as dX each) are not included: profiles/r05_dgrad_attribution.txt has them per launch',
                       **pmc_traffic(PMC_DGRAD, batch == 128)}
     pos = {'ms_per_step': dt / steps * 1e3, 'clips_per_s': world * batch * steps / dt, 'ms_per_step_instrumented': dt_instr / steps * 1e3}
     # SURVEY 8d (ii), second figure: the same step with the front end fused in -- PCM16 clips resident in HBM -> 2x up-sample -> STFT-dB
@@ -266,11 +279,11 @@ def bulk_bench(model, rank, world, dist, n_files, batch, min_score, headline_cli
     from birdsoundclassif_amd import bulk, synth
     root = tempfile.mkdtemp(prefix=f'nbm_bulk_r{rank}_', dir='/dev/shm' if os.path.isdir('/dev/shm') else None)
     try:
-        base = [synth.clip_pcm16(rank * 8 + i) for i in range(8)]
+        base = [synth.clip_pcm16(rank * 64 + i) for i in range(64)]      # 64 distinct clips, cycled: a batch of 64 holds 64 different files
         files = []
         for i in range(n_files):
             path = os.path.join(root, f'clip{i:06d}.wav')
-            synth.write_wav(path, base[i % 8], 22050)
+            synth.write_wav(path, base[i % 64], 22050)
             files.append(path)
         names = {f'Species {i}': i for i in range(1, 151)}
         det = bulk.GraphedDetector(model, batch, 66150, 22050, min_score=min_score, independent=True, lanes=max(1, lanes))
@@ -287,6 +300,7 @@ def bulk_bench(model, rank, world, dist, n_files, batch, min_score, headline_cli
         n_txt = sum(1 for f in files if os.path.isfile(bulk.txt_path(f)))
         import ast
         n_det = sum(len(v['scores']) for f in files[:batch] for v in ast.literal_eval(open(bulk.txt_path(f)).read()).values())
+        det.close()
         del det
         torch.cuda.empty_cache()
         # a rank that fails in this optional leg must not leave the others in a barrier)
@@ -379,7 +393,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-dense-reference', dest='no_dense_reference', action='store_true')
     ap.add_argument('--no-split-leg', dest='no_split_leg', action='store_true',
                     help='skip the extra detect leg with the deep-K GEMMs on the bf16 matrix pipe (split fp32 operands, opt-in mode)')
-    ap.add_argument('--bulk-files', type=int, default=2048,
+    ap.add_argument('--bulk-files', type=int, default=16384,
                     help='bulk_inference leg (configs[4] on this rank\'s shard): wav files on tmpfs -> txt files; 0 = skip')
     return ap.parse_args(argv)
 
@@ -756,6 +770,13 @@ def main(argv=None):
             return 2.0 * W * N * Cin * k * groups / 1e9
         return 2.0 * Bn * ((H - 1) // stride + 1) * ((W - 1) // stride + 1) * N * Cin * k * k * groups / 1e9
 
+    def gemm_bytes(tag):
+        """Algorithmic HBM bytes of one launch of the forward implicit GEMM (input + weights + output, each once)."""
+        Cin, N, k, H, W, Bn, groups, stride = tag[:8]
+        if len(tag) == 9 and isinstance(tag[8], tuple) and tag[8][0] == 'rpn-composite':      # k taps x 1 over W cells: [k][W][Cin] in, [W][N] out
+            return 4.0 * groups * (k * W * Cin + W * N + N * k * Cin)
+        return conv_algorithmic_bytes(Bn, H, W, Cin, N, k, stride, groups, 'fwd')
+
     def what(tag):
         Cin, N, k, H, W, Bn, groups, stride, label = tag
         g = f' x{groups} groups' if groups > 1 else ''
@@ -886,6 +907,8 @@ def main(argv=None):
                                            'launches of the RPN reader composed with the output convolution of the on-demand FPN levels (DESIGN 4f)',
                 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS,
                 'traffic': traffic, 'traffic_unit': 'bytes/launch (2*FETCH_SIZE + WRITE_SIZE, mean over the launches)',
+                'algorithmic_bytes_per_launch': sum(gemm_bytes(tag) for tag, _, _ in per) / len(per),
+                'wasted_traffic_ratio': None if traffic is None else traffic / (sum(gemm_bytes(tag) for tag, _, _ in per) / len(per)),
                 'traffic_source': f'profiles/{PMC_DOMINANT}: separate rocprofv3 --pmc passes of this command, NOT measured in this run '
                                   '(counters cannot be read live); null when batch / on-demand mode differ from that profile'
                                   + (f' -- null here: {traffic_why}' if traffic_why else ''),

@@ -5,6 +5,7 @@ forward AND backward computation below is a HIP kernel of libnbm_hip.so.  Replac
 reference's `losses.backward()` (reference train.py:212).  Activations NHWC fp32; weights arrive in the checkpoint
 layout and their gradients are returned in the same layout.
 """
+import os
 import weakref
 
 import torch
@@ -25,6 +26,31 @@ def _pad32_rows(g2d, n):
     out = torch.zeros((g2d.shape[0], n32), device=g2d.device, dtype=torch.float32)
     out[:, :n] = g2d
     return out
+
+
+# Weight / bias gradients straight into the optimiser's flat gradient buffer: `train.FusedAdamW` gives every
+# parameter a pre-assigned gradient view that ONE memset zeroes per step; a weight-gradient kernel whose output layout IS the
+# parameter's layout (1x1 convolutions, nn.Linear: KRSC rows == [Cout][Cin]) accumulates into that view and the node returns None --
+# instead of a zero fill of a temporary, the kernel, and autograd's AccumulateGrad add into the same view (~100 fills + ~100 adds of a
+# B = 128 step).  The optimiser's post-accumulate hook is called by hand (`mark`), since autograd never sees the gradient.
+GRAD_SINK = {}          # data_ptr of a parameter -> (weakref to it, mark)
+DIRECT_WGRAD = os.environ.get('NBM_DIRECT_WGRAD', '1') != '0'
+
+
+def grad_sink(param, rows, cols):
+    """-> ([rows][cols] view of the parameter's own zero-initialised gradient, mark) or None."""
+    if not DIRECT_WGRAD or param is None or not torch.is_tensor(param):
+        return None
+    e = GRAD_SINK.get(param.data_ptr())
+    if e is None:
+        return None
+    q = e[0]()
+    if q is None or q.data_ptr() != param.data_ptr() or q.shape != param.shape:
+        return None
+    g = q.grad
+    if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.numel() != rows * cols or (g.data_ptr() & 15):
+        return None
+    return g.view(rows, cols), (lambda q=q, mark=e[1]: mark(q))
 
 
 def _w_to_ref_layout(gw, weight):
@@ -254,6 +280,7 @@ class Conv(Function):
             y = ops.conv2d(x, wk, kh, kw, stride, pad, scale=scale, shift=sh, residual=residual, act=act, alpha=alpha, up=up)
         ctx.geom = (kh, kw, stride, pad, act, alpha)
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
+        ctx.bias_param = bias                 # (for grad_sink: the bias gradient may go straight into the parameter's own gradient view)
         ctx.up_hw = tuple(up.shape[1:3]) if up is not None else None
         # gradient hand-over (see _STASH): leave d/dx / d/d(up) for the tensor's other consumer, or pick up what it left
         ctx.stash_x = kh == 1 and _stash_wanted(x)
@@ -278,11 +305,15 @@ class Conv(Function):
             raise RuntimeError('demand-driven FPN map: a RoI pooling ran on it without recording its tile lists (the map was '
                                'produced under no_grad?) -- its gradient would be dropped')
         listed = ctx.lazy is not None and ondemand.listed_backward(ctx.lazy) and (ctx.lazy.sparse or (LAZY_DGRAD and LAZY_WGRAD))
+        if ctx.lazy is not None and ctx.lazy.comp is not None and ctx.lazy.comp['g'] is None:
+            ctx.lazy.comp = None          # the composed RPN block received no gradient (its output did not reach the loss): no share to add
         if ctx.lazy is not None and ctx.lazy.comp is not None and not (listed and LAZY_DGRAD and LAZY_WGRAD and N % 32 == 0 and N >= 64 and
-                                                                      ctx.needs_input_grad[0] and ctx.needs_input_grad[1]):
-            raise RuntimeError('this demand-driven FPN map was read by the composed RPN block (Fn.RpnComposite): only the listed '
-                               'cell-domain backward pass carries that share -- one RoI pooling per map, NBM_LAZY_DGRAD / NBM_LAZY_WGRAD on '
-                               '(or NBM_RPN_COMPOSITE_TRAIN=0)')
+                                                                      len(ctx.lazy.rois) <= 1):
+            # the map was read by the composed RPN block (Fn.RpnComposite) but the listed cell-domain passes will not run (a second RoI
+            # pooling on the map: the RoI shares of two tile lists are ADDED to the cell share in the composed form, a tile in both lists
+            # would count twice): its share goes into gy in the pixel domain, and the pass proceeds as without the composition
+            g = gy = ondemand.train_composite_fallback(ctx.lazy, g.view(B, H, W, N))
+            gp = _pad32_rows(g.view(-1, N), N)
         # a deferred lateral whose consumer's backward pass (which ran before this node's) already produced this node's gradients
         pre = ctx.lat_state.grads if ctx.lat_state is not None else None
         raw = pre
@@ -342,12 +373,22 @@ class Conv(Function):
             gw = _w_to_ref_layout(gwk, weight)
             gb = pre['gb'] if want_gb else None
         elif ctx.needs_input_grad[1]:
-            gwk = torch.zeros_like(wk)
+            same_layout = (weight.dim() == 2 or (kh == 1 and kw == 1)) and wk.shape[1] == weight.shape[1]
+            sink = grad_sink(weight, N, wk.shape[1]) if same_layout else None
+            gwk = sink[0] if sink is not None else torch.zeros_like(wk)
+            bsink = grad_sink(ctx.bias_param, 1, N) if want_gb else None
             if want_gb:                                   # the bias gradient rides along in the weight-gradient kernel
-                gb = torch.zeros((N,), device=x.device, dtype=torch.float32)
+                gb = bsink[0].view(N) if bsink is not None else torch.zeros((N,), device=x.device, dtype=torch.float32)
             ops.conv_wgrad(gp, x, gwk, B=B, H=H, W=W, Cin=Cin, N=N, kh=kh, kw=kw, stride=stride, pad=pad,
                            g_ld=gp.shape[1], out_ld=wk.shape[1], row_scale=scale, alpha=alpha, bias_grad=gb)
-            gw = _w_to_ref_layout(gwk, weight)
+            if sink is not None:                          # accumulated in place: autograd gets no gradient to add
+                sink[1]()
+                gw = None
+            else:
+                gw = _w_to_ref_layout(gwk, weight)
+            if bsink is not None:
+                bsink[1]()
+                gb = None
         elif want_gb:
             gb = pre['gb'] if pre is not None else ops.colsum(gp, N)
         if ctx.lazy is not None:
@@ -410,8 +451,13 @@ class Bottleneck(Function):
         k1, k2, k3 = _prep.krsc(w1), _prep.krsc(w2), _prep.krsc(w3)
 
         def wgrad(g2d, inp, wk, weight, scale, **geom):
-            out = torch.zeros_like(wk)
+            sink = grad_sink(weight, wk.shape[0], wk.shape[1]) if (weight.shape[2] == 1 and weight.shape[3] == 1 and
+                                                                    wk.shape[1] == weight.shape[1]) else None
+            out = sink[0] if sink is not None else torch.zeros_like(wk)
             ops.conv_wgrad(g2d, inp, out, row_scale=scale, g_ld=g2d.shape[1], out_ld=wk.shape[1], **geom)
+            if sink is not None:
+                sink[1]()
+                return None
             return _w_to_ref_layout(out, weight)
 
         gw3 = wgrad(g3r, a2, k3, w3, s3, B=B, H=Ho, W=Wo, Cin=P, N=N3) if need[3] else None

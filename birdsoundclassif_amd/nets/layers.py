@@ -55,7 +55,7 @@ class DepthwiseSepConv2d(nn.Module):
         train: batch statistics (nn.BatchNorm2d semantics) through the differentiable ops."""
         st = int(max(1, self.stride))
         if self.training:
-            if pe_act is None and ondemand.train_composite_ready(x, self) is not None:
+            if pe_act is None and Fn.LAZY_DGRAD and Fn.LAZY_WGRAD and ondemand.train_composite_ready(x, self) is not None:
                 # a demand-driven FPN map with a backward pass to come: this block (up to its BatchNorm) composed with the map's own
                 # convolution in the cell domain -- the map's pattern pixels are never formed (DESIGN 4h)
                 out = Fn.RpnComposite.apply(x, self.depth_wise.weight, self.depth_wise.bias, self.pt_wise.weight, self.pt_wise.bias)

@@ -814,7 +814,8 @@ def train_composite_forward(st, fm, dw_w, dw_b, pt_w, pt_b):
                 ops.copy_rect(fflat, (r0 * OW + c0) * N2, fb, nb, OH * OW * N2, r1 - r0, OW * N2, (c1 - c0) * N2, to_strided=True)
     finally:
         ops._PROFILE_LABEL = keep_label
-    st.comp = dict(A=A, Wf=Wf, Wb=Wb, Ufwd=Ufwd, Ut=Ut, K=K, N2=N2, mult=mult, masks=masks, classes=classes, vb=kept_vb, g=None, dUc=None, gb=None)
+    st.comp = dict(A=A, Wf=Wf, Wb=Wb, Ufwd=Ufwd, Ut=Ut, K=K, N2=N2, mult=mult, masks=masks, classes=classes, vb=kept_vb, g=None, dUc=None, gb=None, gf=None,
+                   dw_w=dw_w.detach(), pt_w=pt_w.detach())
     return f
 
 
@@ -868,9 +869,31 @@ def train_composite_backward(st, gf, dw_w, dw_b, pt_w, pt_b):
         grads = torch.autograd.grad([A2, c2], wanted, [dA, G])
     it = iter(grads)
     g_dw, g_dwb, g_pt, g_ptb, g_ob = [next(it) if t is not None else None for t in leaves]
-    cp['g'], cp['dUc'], cp['gb'] = per_chunk, dUc, g_ob
+    cp['g'], cp['dUc'], cp['gb'], cp['gf'] = per_chunk, dUc, g_ob, gf
     st.vx = None                                      # the transformed patches have served (forward GEMM, dW')
     return g_dw, g_dwb, g_pt, g_ptb
+
+
+def train_composite_fallback(st, gy):
+    """The convolution's backward node cannot take the composed reader's shares in the cell domain (two RoI poolings on an overlap
+    level: the dense kernels run): the reader's share of d/d(map) is formed in the pixel domain after all -- d/d(depthwise output) =
+    d/df pt (1x1 data gradient), scattered through the depthwise taps onto the pattern pixels of `gy` -- and the cell-domain shares
+    are dropped; the backward pass then proceeds exactly as without the composition.  -> gy (in place)."""
+    cp = st.comp
+    st.comp = None
+    if cp is None or cp['gf'] is None:
+        raise RuntimeError('the composed RPN reader of this demand-driven map has not been through its backward pass')
+    gf, dw_w, pt_w = cp['gf'], cp['dw_w'], cp['pt_w']
+    B, OH, OW, N2 = gf.shape
+    M_ = dw_w.shape[0]
+    gd = torch.empty((B * OH * OW, M_), device=gf.device, dtype=torch.float32)
+    ops.conv_dgrad(gf.reshape(-1, N2), pt_w.reshape(N2, M_), gd, B=1, H=B * OH * OW, W=1, Cin=M_, N=N2, g_ld=N2, w_ld=M_)
+    gy = gy.contiguous()
+    ops.dwconv3x3_bwd_acc(gd.view(B, OH, OW, M_), dw_w, cp['mult'], st.stride, gy)
+    for e in _ZERO_POOL.values():                # a persistent gradient map: the pattern pixels are part of its footprint now
+        if e['busy'] and e['buf'].data_ptr() == gy.data_ptr():
+            zero_note(e, lambda b_=e['buf'], s_=st.stride: ops.zero_pattern(b_, s_))
+    return gy
 
 
 def lazy_state(fm):

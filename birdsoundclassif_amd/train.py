@@ -113,6 +113,15 @@ class FusedAdamW(torch.optim.Optimizer):
             self._flat.append(dict(p=fp, g=fg, m=fm, v=fv, spans=spans))
         from .nets import _prep
         _prep.bump()
+        try:                                     # weight-gradient kernels may accumulate straight into these views (functional.grad_sink)
+            import weakref
+            from .nets import functional as Fn
+            for f in self._flat:
+                for (p, _, _) in (f['spans'] if f is not None else []):
+                    if p.is_cuda:
+                        Fn.GRAD_SINK[p.data_ptr()] = (weakref.ref(p), self._mark)
+        except (ImportError, OSError, RuntimeError):     # the CPU twin of the optimiser in the gloo tests: no HIP library, no sink
+            pass
 
     @staticmethod
     def _check_device(dev):
