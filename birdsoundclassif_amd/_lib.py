@@ -29,7 +29,8 @@ class GemmDesc(C.Structure):
                 ('alpha', C.c_float), ('act', C.c_int), ('shift_per_row', C.c_int),
                 ('up', C.c_void_p), ('up_H', C.c_int), ('up_W', C.c_int),
                 ('rows', C.c_void_p), ('rows_blocks', C.c_void_p),
-                ('rows_mode', C.c_int), ('rows_count', C.c_int), ('rows_TH', C.c_int), ('rows_TW', C.c_int)]
+                ('rows_mode', C.c_int), ('rows_count', C.c_int), ('rows_TH', C.c_int), ('rows_TW', C.c_int),
+                ('mask', C.c_void_p), ('mask_ld', C.c_int)]
 
 
 class RoiDesc(C.Structure):

@@ -526,9 +526,14 @@ extern "C" int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream) {
   p.x_ld = d->x_ld; p.w_ld = d->w_ld; p.y_ld = d->y_ld; p.res_ld = d->res_ld;
   p.alpha = d->alpha; p.act = d->act; p.shift_per_row = d->shift_per_row;
   if (p.w_ld < p.nk * BK) return NBM_EINVAL;  // every W row must hold nk*32 readable floats
+  if (d->mask) {
+    if (d->rows || d->groups != 1 || d->mask_ld < d->N) return NBM_EUNSUPPORTED;
+    p.mask = d->mask; p.mask_ld = d->mask_ld;
+  }
   p.vec_epi = ((d->N & 3) == 0 && (d->y_ld & 3) == 0 && (d->y_gs & 3) == 0 && nbm_aligned16(d->y) &&
                (!d->residual || ((d->res_ld & 3) == 0 && (d->res_gs & 3) == 0 && nbm_aligned16(d->residual))) &&
-               (!d->scale || nbm_aligned16(d->scale)) && (!d->shift || d->shift_per_row || nbm_aligned16(d->shift)))
+               (!d->scale || nbm_aligned16(d->scale)) && (!d->shift || d->shift_per_row || nbm_aligned16(d->shift)) &&
+               (!d->mask || ((d->mask_ld & 3) == 0 && nbm_aligned16(d->mask))))
                   ? 1 : 0;
   if ((d->w_ld & 3) || (d->w_gs & 3) || !nbm_aligned16(d->w)) return NBM_EALIGN;
   if (d->up) {
@@ -555,7 +560,7 @@ extern "C" int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream) {
   }
   // streaming form for 1x1 / stride 1 layers whose weights fit LDS (see stream1x1_kernel)
   const char* stream_env = getenv("NBM_STREAM1X1");          // read per call: the parity test flips it inside one process
-  if (!(stream_env && stream_env[0] == '0') && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && d->groups == 1 && fast && p.vec_epi && !d->up &&
+  if (!(stream_env && stream_env[0] == '0') && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && d->groups == 1 && fast && p.vec_epi && !d->up && !d->mask &&
       !d->shift_per_row && (d->N % 32) == 0 && p.M >= 8192) {
     StreamParams sp{d->x, d->w, d->y, d->scale, d->shift, d->residual, p.M, d->x_ld, d->w_ld, d->y_ld, d->res_ld, (p.M + 31) / 32,
                     d->alpha, d->act};

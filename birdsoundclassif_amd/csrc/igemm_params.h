@@ -26,6 +26,8 @@ struct IgemmParams {
   //                input patch (rows 2ty-1.., columns 2tx-1..; outside the image = none).
   //   rows_blocks (device, optional): number of leading 128-entry list blocks that are filled.
   const int* rows; const int* rows_blocks; int rows_mode, rows_TH, rows_TW;
+  // producer mask (vector and scalar epilogue, not ROWS): y = 0 where mask[m][n] <= 0 -- a 1x1 data gradient run as this forward GEMM
+  const float* mask; int mask_ld;
 };
 
 // igemm_split.hip: 256 x 128 tiles on the bf16 matrix pipe (fast gather, 16-byte epilogue, N > 64, nk > 8 only; the caller checks)

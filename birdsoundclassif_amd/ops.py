@@ -76,7 +76,7 @@ def lib():
 def gemm_conv(x, w, y, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, Ho=None, Wo=None,
               x_ld=None, w_ld=None, y_ld=None, scale=None, shift=None, residual=None, res_ld=None,
               groups=1, x_gs=0, w_gs=0, y_gs=0, res_gs=0, alpha=1.0, act=ACT_NONE, shift_per_row=False, up=None,
-              rows=None, rows_mode=0, rows_count=0, rows_blocks=None, rows_thw=(0, 0)):
+              rows=None, rows_mode=0, rows_count=0, rows_blocks=None, rows_thw=(0, 0), mask=None, mask_ld=None):
     """Raw call of nbm_gemm_conv (see include/nbm_hip.h for the exact semantics)."""
     Ho = (H + 2 * pad - kh) // stride + 1 if Ho is None else Ho
     Wo = (W + 2 * pad - kw) // stride + 1 if Wo is None else Wo
@@ -96,6 +96,8 @@ def gemm_conv(x, w, y, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, Ho=None,
     d.alpha, d.act, d.shift_per_row = float(alpha), int(act), int(bool(shift_per_row))
     if up is not None:                       # [B, up_H, up_W, N] coarse map merged in the epilogue
         d.up, d.up_H, d.up_W = _chk(up, name='up').data_ptr(), up.shape[1], up.shape[2]
+    if mask is not None:                     # producer mask: y = 0 where mask <= 0 (a 1x1 data gradient run as a forward GEMM)
+        d.mask, d.mask_ld = mask.data_ptr(), int(N if mask_ld is None else mask_ld)
     if rows is not None:                     # listed pixels only (the lateral of a demand-driven FPN level)
         d.rows, d.rows_mode, d.rows_count = rows.data_ptr(), int(rows_mode), int(rows_count)
         d.rows_blocks = rows_blocks.data_ptr() if rows_blocks is not None else None
@@ -780,10 +782,29 @@ def _bwd_desc(g, *, B, H, W, Cin, N, kh, kw, stride, pad, g_ld, groups=1, alpha=
     return d
 
 
+def split_nn():
+    """Deep-K 1x1 data gradients through nbm_gemm_conv's split-bf16 kernel (opt-in with NBM_SPLIT_BF16=1; NBM_SPLIT_NN=0 keeps them on
+    the fp32 data-gradient kernel)."""
+    return os.environ.get('NBM_SPLIT_BF16') == '1' and os.environ.get('NBM_SPLIT_NN', '1') != '0'
+
+
 def conv_dgrad(g, w, out, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, g_ld=None, w_ld=None, out_ld=None,
                a_scale=None, residual=None, mask=None, alpha=1.0, groups=1, g_gs=0, w_gs=0, out_gs=0, res_gs=0, residual2=None):
     """Raw nbm_conv_dgrad: out[B*H*W][Cin] = gather(g)[..][N] x W (see include/nbm_hip.h).  `residual2` [B, ceil(H/2), ceil(W/2),
     Cin]: added at the pixels with even row and column (a stride-2 shortcut's data gradient at its own resolution)."""
+    if (groups == 1 and kh == 1 and kw == 1 and stride == 1 and pad == 0 and residual2 is None and N > 256 and N % 32 == 0 and Cin > 64 and
+            Cin % 4 == 0 and split_nn()):
+        # opt-in (NBM_SPLIT_BF16=1, DESIGN 4e): a deep-K 1x1 data gradient IS the forward GEMM of the incoming gradient with the
+        # transposed weights (FrozenBN scale folded in), so it takes nbm_gemm_conv's split-bf16 kernel; shortcut gradient and ReLU mask
+        # ride in that kernel's epilogue (`residual`, `mask`).  The transposed copy is rebuilt per call ([N][Cin] -> [Cin][N], a few MB).
+        wl = kh * kw * Cin if w_ld is None else w_ld
+        wv = w.view(-1)[:N * wl].view(N, wl)[:, :Cin]
+        wt = (wv * a_scale[:N, None] if a_scale is not None else wv).t().contiguous()
+        with _timed(('dgrad', B, H, W, Cin, N, kh, stride, groups)):
+            gemm_conv(g, wt, out, B=B, H=H, W=W, Cin=N, N=Cin, x_ld=N if g_ld is None else g_ld, w_ld=N,
+                      y_ld=Cin if out_ld is None else out_ld, residual=residual, res_ld=Cin if residual is not None else None, alpha=alpha,
+                      mask=mask, mask_ld=Cin if mask is not None else None)
+        return out
     d = _bwd_desc(g, B=B, H=H, W=W, Cin=Cin, N=N, kh=kh, kw=kw, stride=stride, pad=pad,
                   g_ld=N if g_ld is None else g_ld, groups=groups, alpha=alpha)
     d.w, d.out = w.data_ptr(), out.data_ptr()

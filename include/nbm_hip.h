@@ -89,6 +89,13 @@ typedef struct nbm_gemm_desc {
   const int* rows;
   const int* rows_blocks;
   int rows_mode, rows_count, rows_TH, rows_TW;
+  /* Optional producer mask [M][mask_ld] (not with `rows`): y is zeroed where mask <= 0, after everything else -- the ReLU of the layer
+   * whose data gradient this launch computes (what autograd derives for reference train.py:212 through torchvision's Bottleneck): with
+   * the transposed, BatchNorm-scaled weights as `w` and the incoming gradient as `x`, a 1x1 data gradient IS this forward GEMM, which
+   * lets it take the split-bf16 form below (NBM_SPLIT_BF16=1; ops.conv_dgrad routes it).  One group; the 16-byte epilogue needs it
+   * 16-byte aligned with mask_ld % 4 == 0 (otherwise the scalar epilogue runs). */
+  const float* mask;
+  int mask_ld;
 } nbm_gemm_desc;
 
 /* Environment switch, read on every call: NBM_SPLIT_BF16=1 runs the deep-K launches (K = kh*kw*Cin > 256, N > 64, Cin % 32 == 0,

@@ -89,3 +89,61 @@ def test_split_with_fused_topdown_merge(monkeypatch):
     f32, split = both(monkeypatch, lambda: ops.conv2d(x, w, shift=b, alpha=2.0, up=coarse))
     assert float((split - f32).abs().max()) <= 2e-5 * (1 + float(f32.abs().max()))
     assert float((split - f32).abs().max()) > 0          # (the two kernels do differ in the last bits: the switch took effect)
+
+
+@pytest.mark.parametrize('cfg', [
+    # rows (B, H, W), Cin (= channels of dX), N (= channels of the incoming gradient = K), a_scale, residual, mask
+    ((2, 24, 32), 256, 1024, True, False, True),      # layer3 1x1 256->1024: K = 1024 (32 steps -> 4)
+    ((3, 17, 23), 200, 512, True, True, True),        # ragged rows and channels, shortcut gradient + ReLU mask
+    ((1, 40, 64), 1024, 1408, False, False, False),   # the attention [q|k|v] projection: plain GEMM, K = 1408 (44 -> 4)
+    ((2, 12, 16), 384, 288, False, True, False),      # K = 288 (9 steps -> 0): the shortest launch the split form takes
+])
+def test_split_data_gradient_against_float64_and_the_fp32_kernel(cfg, monkeypatch):
+    """NN form: a deep-K 1x1 data gradient dX = mask(alpha (G * a_scale) W + residual) run as the forward GEMM of G with
+    the transposed, scaled weights on the split-bf16 kernel (`ops.conv_dgrad`, NBM_SPLIT_BF16=1), against float64 and against the fp32
+    data-gradient kernel (`igemm_nn_kernel`) of the same call: error <= 1.05 x the fp32 kernel's."""
+    (B, H, W), Ci, N, use_scale, use_res, use_mask = cfg
+    M = B * H * W
+    g = rnd(('g', cfg), M, N).cuda()
+    w = (rnd(('w', cfg), N, Ci) * (2.0 / N) ** 0.5).cuda()                 # KRSC rows of a 1x1 convolution [N][Cin]
+    a_scale = (1 + 0.1 * rnd(('s', cfg), N)).cuda() if use_scale else None
+    res = rnd(('r', cfg), M, Ci).cuda() if use_res else None
+    mask = rnd(('m', cfg), M, Ci).cuda() if use_mask else None
+    ref = (g.double() * (a_scale.double()[None, :] if use_scale else 1.0)) @ w.double()
+    if use_res:
+        ref = ref + res.double()
+    if use_mask:
+        ref = ref * (mask > 0).double()
+
+    def run():
+        out = torch.empty((M, Ci), device='cuda')
+        ops.conv_dgrad(g, w, out, B=B, H=H, W=W, Cin=Ci, N=N, a_scale=a_scale, residual=res, mask=mask)
+        return out
+    f32, split = both(monkeypatch, run)
+    assert not torch.equal(f32, split)                                     # two kernels, two summation orders
+    e32, esp = (f32.double() - ref).abs(), (split.double() - ref).abs()
+    assert float(esp.max()) <= 2e-5 * (1 + float(ref.abs().max())), (cfg, float(esp.max()))
+    rms32, rmssp = float((e32 ** 2).mean().sqrt()), float((esp ** 2).mean().sqrt())
+    assert rmssp <= 1.05 * rms32 + 1e-9, f'{cfg}: split rms error {rmssp:.3e} vs fp32 kernel {rms32:.3e}'
+    if use_mask:
+        assert torch.equal(split == 0, f32 == 0) or float(((split == 0) != (f32 == 0)).float().mean()) < 1e-5
+    monkeypatch.setenv('NBM_SPLIT_NN', '0')                                # the switch keeps the call on the fp32 data-gradient kernel
+    assert torch.equal(run(), f32)
+
+
+def test_producer_mask_in_the_forward_epilogue_of_both_kernels(monkeypatch):
+    """`nbm_gemm_desc.mask` (include/nbm_hip.h): y = 0 where mask <= 0, after scale / shift / residual / activation -- on the fp32 kernel
+    (16-byte and scalar epilogue) and on the split kernel."""
+    for (M, K, N) in ((700, 512, 256), (333, 64, 130)):                   # deep K, N % 4 == 0  |  short K, scalar epilogue (N % 4 != 0)
+        x, w = rnd(('mx', M, K), M, K).cuda(), (rnd(('mw', N, K), N, K) * (1.0 / K) ** 0.5).cuda()
+        res, mask = rnd(('mr', M, N), M, N).cuda(), rnd(('mm', M, N), M, N).cuda()
+        ref = ((x.double() @ w.double().t()) * 0.5 + res.double()) * (mask > 0).double()
+
+        def run():
+            y = torch.empty((M, N), device='cuda')
+            ops.gemm_conv(x, w, y, B=1, H=M, W=1, Cin=K, N=N, residual=res, res_ld=N, alpha=0.5, mask=mask, mask_ld=N)
+            return y
+        f32, split = both(monkeypatch, run)
+        for got in (f32, split):
+            assert float((got.double() - ref).abs().max()) <= 2e-5 * (1 + float(ref.abs().max()))
+            assert torch.equal(got == 0, ref == 0) or float(((got == 0) != (ref == 0)).float().mean()) < 1e-4
