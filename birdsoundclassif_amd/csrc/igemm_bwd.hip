@@ -15,6 +15,7 @@
 // loads issued two tiles ahead and, like the LDS writes, scheduled between the MFMAs of the running K-step.
 #include <stdlib.h>
 #include "nbm_common.h"
+#include "igemm_split_tn.h"
 #include <type_traits>
 
 namespace {
@@ -780,10 +781,39 @@ extern "C" int nbm_conv_wgrad(const nbm_bwd_desc* d, void* stream) {
     const double fill = (double)wg / (double)(rounds * slots);
     if (fill > best + 0.005) { best = fill; splits = sp; }
   }
+  p.plain = (d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0) ? 1 : 0;
+  // opt-in (NBM_SPLIT_BF16=1): plain weight-gradient GEMMs (1x1 convolutions, nn.Linear, the grouped Winograd- / cell-domain
+  // products) with >= 192 rows and > 64 columns on the bf16 matrix pipe through split fp32 operands (igemm_split_tn.hip).  Read per call;
+  // chosen by the LAYER, never by the number of pixels.  The bias gradient is not produced there (the caller sums the columns of G).
+  {
+    const char* se = getenv("NBM_SPLIT_BF16");
+    const char* te = getenv("NBM_SPLIT_TN");
+    if (se && se[0] == '1' && !(te && te[0] == '0') && p.plain && !p.b_generic && !d->bias_grad && d->N >= 192 && d->Cin > 64 &&
+        (d->out_ld >= d->Cin) && (long long)32 * d->g_ld * 4 < 0x40000000ll && (long long)32 * d->x_ld * 4 < 0x40000000ll) {
+      nbm_igemm::SplitTnParams q{};
+      q.g = d->g; q.x = d->x; q.out = d->out; q.row_scale = d->row_scale;
+      q.g_gs = d->g_gs; q.x_gs = d->x_gs; q.out_gs = d->out_gs;
+      q.M = p.M; q.N = d->N; q.K = d->Cin; q.g_ld = d->g_ld; q.x_ld = d->x_ld; q.out_ld = d->out_ld; q.alpha = d->alpha;
+      q.n_tiles = (d->Cin + 127) / 128;
+      const int tiles_s = ((d->N + 255) / 256) * q.n_tiles * d->groups;
+      const int slots_s = 256;                                       // one workgroup per CU
+      const int max_sp = (p.M + 16 * 32 - 1) / (16 * 32);            // >= 32 K16 stages per split
+      int sp_best = 1;
+      double fill_best = -1.0;
+      for (int sp = 1; sp <= max_sp && (long long)sp * tiles_s <= 16ll * slots_s; ++sp) {
+        const long long wgs = (long long)sp * tiles_s;
+        const long long rounds = (wgs + slots_s - 1) / slots_s;
+        const double fill = (double)wgs / (double)(rounds * slots_s);
+        if (fill > fill_best + 0.005) { fill_best = fill; sp_best = sp; }
+      }
+      q.k_chunk = (((p.M + sp_best - 1) / sp_best) + 31) / 32 * 32;
+      const int sp_n = (p.M + q.k_chunk - 1) / q.k_chunk;
+      return nbm_igemm::split_tn_launch(q, sp_n, d->groups, st);
+    }
+  }
   p.k_chunk = (((p.M + splits - 1) / splits) + BK - 1) / BK * BK;
   splits = (p.M + p.k_chunk - 1) / p.k_chunk;
   dim3 grid(p.m_tiles * p.n_tiles, splits, d->groups);
-  p.plain = (d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0) ? 1 : 0;
   const bool same = !p.b_generic && d->stride == 1 && d->Ho == d->H && d->Wo == d->W && (d->Wo >= BK || p.plain) &&
                     (long long)BK * d->x_ld * 4 < 0x40000000ll;
   if (p.b_generic) hipLaunchKernelGGL((igemm_tn_kernel<64, B_GENERIC>), grid, dim3(256), 0, st, p);

@@ -782,6 +782,12 @@ def _bwd_desc(g, *, B, H, W, Cin, N, kh, kw, stride, pad, g_ld, groups=1, alpha=
     return d
 
 
+def split_tn():
+    """Plain weight-gradient GEMMs through the split-bf16 kernel (opt-in with NBM_SPLIT_BF16=1; NBM_SPLIT_TN=0 keeps them on the fp32
+    kernel).  The C side (nbm_conv_wgrad) applies the same switch and the same shape rule."""
+    return os.environ.get('NBM_SPLIT_BF16') == '1' and os.environ.get('NBM_SPLIT_TN', '1') != '0'
+
+
 def split_nn():
     """Deep-K 1x1 data gradients through nbm_gemm_conv's split-bf16 kernel (opt-in with NBM_SPLIT_BF16=1; NBM_SPLIT_NN=0 keeps them on
     the fp32 data-gradient kernel)."""
@@ -830,6 +836,11 @@ def conv_dgrad(g, w, out, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, g_ld=
 def conv_wgrad(g, x, out, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, g_ld=None, x_ld=None, out_ld=None,
                row_scale=None, alpha=1.0, groups=1, g_gs=0, x_gs=0, out_gs=0, bias_grad=None):
     """Raw nbm_conv_wgrad: out[N][kh*kw*Cin] += g^T x im2col(x); `out` must be zeroed (or hold a partial sum)."""
+    deferred_bias = None
+    if (bias_grad is not None and groups == 1 and kh == 1 and kw == 1 and stride == 1 and pad == 0 and N >= 192 and Cin > 64 and
+            Cin % 4 == 0 and split_tn()):
+        # the split-bf16 weight-gradient kernel (opt-in) does not sum the columns of G: the bias gradient comes from nbm_colsum
+        deferred_bias, bias_grad = bias_grad, None
     d = _bwd_desc(g, B=B, H=H, W=W, Cin=Cin, N=N, kh=kh, kw=kw, stride=stride, pad=pad,
                   g_ld=N if g_ld is None else g_ld, groups=groups, alpha=alpha)
     d.x, d.out = x.data_ptr(), out.data_ptr()
@@ -842,6 +853,9 @@ def conv_wgrad(g, x, out, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, g_ld=
         FLOPS[0] += 2.0 * B * d.Ho * d.Wo * N * kh * kw * Cin * groups
     with _timed(('wgrad', B, H, W, Cin, N, kh, stride, groups)):
         check(lib().nbm_conv_wgrad(C.byref(d), _stream()), 'nbm_conv_wgrad')
+    if deferred_bias is not None:
+        gl = N if g_ld is None else g_ld
+        deferred_bias += colsum(g.reshape(-1)[:B * H * W * gl].view(B * H * W, gl), N)
     return out
 
 

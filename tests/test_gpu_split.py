@@ -147,3 +147,47 @@ def test_producer_mask_in_the_forward_epilogue_of_both_kernels(monkeypatch):
         for got in (f32, split):
             assert float((got.double() - ref).abs().max()) <= 2e-5 * (1 + float(ref.abs().max()))
             assert torch.equal(got == 0, ref == 0) or float(((got == 0) != (ref == 0)).float().mean()) < 1e-4
+
+
+@pytest.mark.parametrize('cfg', [
+    # M (pixels), N (rows of dW = channels of G), K (columns = channels of X), groups, row_scale, bias
+    (24 * 64 * 2, 256, 1024, 1, True, False),      # layer3 1x1 1024->256
+    (3001, 200, 130 * 2, 1, True, True),           # ragged everything: pixels not a multiple of 16, N and K not multiples of the tile
+    (1536 * 2, 1408, 1024, 1, False, True),        # the attention [q|k|v] projection, bias through nbm_colsum
+    (700, 256, 448, 5, False, False),              # grouped (cell-domain planes): [5][M][N]^T [5][M][K]
+    (40000, 384, 256, 1, False, False),            # many splits
+])
+def test_split_weight_gradient_against_float64_and_the_fp32_kernel(cfg, monkeypatch):
+    """TN form: plain weight-gradient GEMMs dW = alpha row_scale G^T X on the bf16 matrix pipe through split fp32
+    operands (csrc/igemm_split_tn.hip: pixel-major LDS image, transposed reads), accumulated into a non-zero dW, against float64 and
+    against the fp32 kernel (`igemm_tn_kernel`) of the same call: error <= 1.05 x the fp32 kernel's."""
+    M, N, K, groups, use_scale, use_bias = cfg
+    g = rnd(('tg', cfg), groups, M, N).cuda()
+    x = torch.relu(rnd(('tx', cfg), groups, M, K)).cuda()
+    base = rnd(('tb', cfg), groups, N, K).cuda()
+    row_scale = (1 + 0.1 * rnd(('ts', cfg), N)).cuda() if use_scale else None
+    ref = torch.einsum('gmn,gmk->gnk', g.double(), x.double()) * 0.5
+    if use_scale:
+        ref = ref * row_scale.double()[None, :, None]
+    ref = ref + base.double()
+    bref = g.double().sum(1)[0] + 1.0 if use_bias else None
+
+    def run():
+        out = base.clone()
+        gb = torch.ones((N,), device='cuda') if use_bias else None
+        ops.conv_wgrad(g, x, out, B=1, H=M, W=1, Cin=K, N=N, groups=groups, g_gs=M * N, x_gs=M * K, out_gs=N * K, row_scale=row_scale,
+                       alpha=0.5, bias_grad=gb)
+        return out, gb
+    (f32, gb32), (split, gbsp) = both(monkeypatch, run)
+    assert not torch.equal(f32, split)
+    scale = float(ref.abs().max())
+    e32, esp = (f32.double() - ref).abs(), (split.double() - ref).abs()
+    assert float(esp.max()) <= 3e-5 * (1 + scale), (cfg, float(esp.max()), scale)
+    rms32, rmssp = float((e32 ** 2).mean().sqrt()), float((esp ** 2).mean().sqrt())
+    assert rmssp <= 1.05 * rms32 + 1e-9, f'{cfg}: split rms error {rmssp:.3e} vs fp32 kernel {rms32:.3e}'
+    if use_bias:
+        for gb in (gb32, gbsp):
+            assert float((gb.double() - bref).abs().max()) <= 1e-4 * (1 + float(bref.abs().max()))
+    monkeypatch.setenv('NBM_SPLIT_TN', '0')                                # the switch keeps the call on the fp32 kernel (atomics: not bit-stable)
+    again, _ = run()
+    assert float((again.double() - f32.double()).abs().max()) <= 1e-5 * (1 + scale)
