@@ -239,6 +239,26 @@ def train_bench(rank, world, dist, batch, steps, warmup, mix_steps=10):
         dtm, _ = timed([(i % 10) == 9 for i in range(mix_steps)])
         mix = {'steps': mix_steps, 'negative_every': 10, 'ms_per_step': dtm / mix_steps * 1e3,
                'clips_per_s': world * batch * mix_steps / dtm}
+    # opt-in mode beside the headline of this leg (never IN it): the same positive step with every deep-K GEMM -- forward, 1x1 data gradients,
+    # plain weight gradients -- on the bf16 matrix pipe through split fp32 operands (csrc/igemm_split.hip, igemm_split_tn.hip)
+    split_leg = None
+    if world == 1:
+        was = os.environ.get('NBM_SPLIT_BF16')
+        os.environ['NBM_SPLIT_BF16'] = '1'
+        try:
+            timed([False, False])
+            dts, _ = timed([False] * steps)
+            split_leg = {'default': False, 'switch': 'NBM_SPLIT_BF16=1', 'ms_per_step': dts / steps * 1e3, 'clips_per_s': batch * steps / dts,
+                         'steps': steps, 'what': 'forward deep-K GEMMs (igemm_split_kernel), deep-K 1x1 data gradients (the same kernel on '
+                                                 'transposed scaled weights, mask / shortcut in its epilogue), plain weight-gradient GEMMs with >= 192 '
+                                                 'rows (igemm_split_tn_kernel); everything else on the fp32 matrix instruction'}
+        except Exception as exc:
+            split_leg = {'error': f'{type(exc).__name__}: {exc}'[:300]}
+        finally:
+            if was is None:
+                os.environ.pop('NBM_SPLIT_BF16', None)
+            else:
+                os.environ['NBM_SPLIT_BF16'] = was
     if os.environ.get('NBM_BENCH_MEMLOG') == '1':
         st = torch.cuda.memory_stats()
         print(f'bench: train leg: alloc retries {st.get("num_alloc_retries")}, ooms {st.get("num_ooms")}, peak allocated '
@@ -250,7 +270,7 @@ def train_bench(rank, world, dist, batch, steps, warmup, mix_steps=10):
     exec_tflops = v / world * exec_gflop_per_clip / 1e3
     return {'value': v, 'unit': 'clips/s', 'batch_per_gpu': batch, 'distinct_images': batch, 'global_batch': world * batch, 'steps': steps,
             'ms_per_step': pos['ms_per_step'], 'ms_per_step_with_the_instruments_on': pos['ms_per_step_instrumented'],
-            'parallelism': f'dp{world}', 'per_rank': per_rank,
+            'parallelism': f'dp{world}', 'per_rank': per_rank, 'split_bf16': split_leg,
             'exchange': None if world == 1 else ('one all-reduce (AVG) per flat gradient buffer; the non-backbone buffer starts inside the backward '
                                                  'pass (hook on the backbone\'s last tap), the backbone buffer after it' if T.DP_OVERLAP else
                                                  'one all-reduce (AVG) per flat gradient buffer, after the backward pass'),

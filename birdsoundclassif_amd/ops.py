@@ -798,18 +798,20 @@ def conv_dgrad(g, w, out, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, g_ld=
                a_scale=None, residual=None, mask=None, alpha=1.0, groups=1, g_gs=0, w_gs=0, out_gs=0, res_gs=0, residual2=None):
     """Raw nbm_conv_dgrad: out[B*H*W][Cin] = gather(g)[..][N] x W (see include/nbm_hip.h).  `residual2` [B, ceil(H/2), ceil(W/2),
     Cin]: added at the pixels with even row and column (a stride-2 shortcut's data gradient at its own resolution)."""
-    if (groups == 1 and kh == 1 and kw == 1 and stride == 1 and pad == 0 and residual2 is None and N > 256 and N % 32 == 0 and Cin > 64 and
-            Cin % 4 == 0 and split_nn()):
+    if (kh == 1 and kw == 1 and stride == 1 and pad == 0 and residual2 is None and N > 256 and N % 32 == 0 and Cin > 64 and Cin % 4 == 0 and
+            (groups == 1 or (mask is None and a_scale is None)) and split_nn()):
         # opt-in (NBM_SPLIT_BF16=1, DESIGN 4e): a deep-K 1x1 data gradient IS the forward GEMM of the incoming gradient with the
         # transposed weights (FrozenBN scale folded in), so it takes nbm_gemm_conv's split-bf16 kernel; shortcut gradient and ReLU mask
         # ride in that kernel's epilogue (`residual`, `mask`).  The transposed copy is rebuilt per call ([N][Cin] -> [Cin][N], a few MB).
+        # The rule names the LAYER (K = N, the channel counts, the operands), never the number of rows or groups: the P V product of the
+        # attention (one group per image) takes the same kernel whatever the batch.
         wl = kh * kw * Cin if w_ld is None else w_ld
-        wv = w.view(-1)[:N * wl].view(N, wl)[:, :Cin]
-        wt = (wv * a_scale[:N, None] if a_scale is not None else wv).t().contiguous()
+        wv = w.as_strided((groups, N, Cin), (w_gs, wl, 1))         # (`w` may be a row / column slice of a wider matrix: only its pitches count)
+        wt = (wv * a_scale[None, :N, None] if a_scale is not None else wv).transpose(1, 2).contiguous()
         with _timed(('dgrad', B, H, W, Cin, N, kh, stride, groups)):
             gemm_conv(g, wt, out, B=B, H=H, W=W, Cin=N, N=Cin, x_ld=N if g_ld is None else g_ld, w_ld=N,
                       y_ld=Cin if out_ld is None else out_ld, residual=residual, res_ld=Cin if residual is not None else None, alpha=alpha,
-                      mask=mask, mask_ld=Cin if mask is not None else None)
+                      mask=mask, mask_ld=Cin if mask is not None else None, groups=groups, x_gs=g_gs, w_gs=Cin * N, y_gs=out_gs, res_gs=res_gs)
         return out
     d = _bwd_desc(g, B=B, H=H, W=W, Cin=Cin, N=N, kh=kh, kw=kw, stride=stride, pad=pad,
                   g_ld=N if g_ld is None else g_ld, groups=groups, alpha=alpha)

@@ -191,3 +191,22 @@ def test_split_weight_gradient_against_float64_and_the_fp32_kernel(cfg, monkeypa
     monkeypatch.setenv('NBM_SPLIT_TN', '0')                                # the switch keeps the call on the fp32 kernel (atomics: not bit-stable)
     again, _ = run()
     assert float((again.double() - f32.double()).abs().max()) <= 1e-5 * (1 + scale)
+
+
+def test_split_data_gradient_with_groups_is_chosen_by_the_layer_not_by_the_batch(monkeypatch):
+    """The attention's P V product (`ops.conv_dgrad`, one group per image): under NBM_SPLIT_BF16=1 an image's result must not depend on
+    how many images share the launch -- one group and four groups take the same (split) kernel."""
+    L, dv = 1536, 384
+    monkeypatch.setenv('NBM_SPLIT_BF16', '1')
+    pm = torch.softmax(rnd('pv-p', 4, L, L).cuda(), -1).contiguous()
+    v = rnd('pv-v', 4, L, dv + 64).cuda()                                   # V is a column slice of a wider [q|k|v] matrix
+    def run(b0, nb):
+        out = torch.empty((nb, L, dv), device='cuda')
+        ops.conv_dgrad(pm[b0:b0 + nb], v[b0:b0 + nb, :, 64:], out, B=1, H=L, W=1, Cin=dv, N=L, g_ld=L, w_ld=dv + 64, out_ld=dv, groups=nb,
+                       g_gs=L * L, w_gs=L * (dv + 64), out_gs=L * dv)
+        return out
+    four = run(0, 4)
+    for b in range(4):
+        assert torch.equal(run(b, 1)[0], four[b])
+    ref = torch.einsum('blm,bmc->blc', pm.double(), v[:, :, 64:].double())
+    assert float((four.double() - ref).abs().max()) <= 2e-6 * (1 + float(ref.abs().max()))
