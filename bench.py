@@ -410,6 +410,8 @@ def parse_args(argv=None):
                          '-- 160 ms of anchor targets at B = 128 -- is not hidden behind a previous step; 2-3 steps measured 470-500 ms / step '
                          'where 5-8 measure 427)')
     ap.add_argument('--no-train', action='store_true')
+    ap.add_argument('--tile-clips', dest='tile_clips', type=int, default=0,
+                    help='A/B switch: repeat the first N synthetic clips over the batch instead of B distinct clips (0 = distinct, the default)')
     ap.add_argument('--no-dense-reference', dest='no_dense_reference', action='store_true')
     ap.add_argument('--no-split-leg', dest='no_split_leg', action='store_true',
                     help='skip the extra detect leg with the deep-K GEMMs on the bf16 matrix pipe (split fp32 operands, opt-in mode)')
@@ -591,6 +593,8 @@ def main(argv=None):
     # B DISTINCT clips per rank: the batch-coupled minima of the proposal stage, the device RoI tile lists and the NMS launches see a
     # mixed batch (tests/test_gpu_fullsize.py checks the same 64 clips against the oracle)
     pcm_host = synth.clip_batch_pcm16(rank * B, B)
+    if a.tile_clips:                                          # A/B switch: the first `tile_clips` clips repeated (rounds 1-4 timed 8 tiled clips)
+        pcm_host = np.tile(pcm_host[:a.tile_clips], (-(-B // a.tile_clips), 1))[:B].copy()
     distinct_clips = len({bytes(r) for r in pcm_host})
     pcm = torch.from_numpy(pcm_host).cuda()
 
