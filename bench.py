@@ -33,9 +33,9 @@ sys.path.insert(0, ROOT)
 import numpy as np   # noqa: E402
 import torch         # noqa: E402
 
-PMC_DOMINANT = 'r04_pmc_dominant.json'    # committed rocprofv3 --pmc passes of `python bench.py` (scripts/pmc_dominant.py)
-PMC_WGRAD = 'r04_pmc_wgrad.json'          # ... of scripts/trainbench.py: the weight-gradient kernels (scripts/r04_profiles.sh)
-PMC_DGRAD = 'r04_pmc_dgrad.json'          # ... the data-gradient kernels
+PMC_DOMINANT = 'r05_pmc_dominant.json'    # committed rocprofv3 --pmc passes of `python bench.py` (scripts/pmc_dominant.py)
+PMC_WGRAD = 'r05_pmc_wgrad.json'          # ... of scripts/trainbench.py: the weight-gradient kernels (scripts/r04_profiles.sh)
+PMC_DGRAD = 'r05_pmc_dgrad.json'          # ... the data-gradient kernels
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 BF16_MFMA_PEAK_TFLOPS = 2500.0         # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16: 1024 FLOP/clk/SIMD), same guide
 FP64_MFMA_PEAK_TFLOPS = 78.6           # v_mfma_f64_16x16x4_f64: half the fp32 rate on this part (64 cycles / 2048 FLOP / SIMD)

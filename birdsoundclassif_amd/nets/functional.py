@@ -822,7 +822,8 @@ class RpnComposite(Function):
             ptr = ctx.fm_ptr
             if EARLY and ptr in _FPN_OUT and GRAD_SHARE:
                 acc = e = None
-                if (ondemand.ZERO_POOL and LAZY_DGRAD and LAZY_WGRAD and ondemand.CELL_BWD and st.sparse and st.keep and st.stride >= 5):
+                if (ondemand.ZERO_POOL and LAZY_DGRAD and LAZY_WGRAD and ondemand.CELL_BWD and st.keep and
+                        ((st.sparse and st.stride >= 5) or st.overlap)):
                     acc, e = ondemand.zero_acquire(ctx.fm_shape, gf.device, ('map-grad', st.stride))      # persistent zeros: no fill
                 if acc is None:
                     acc = torch.zeros(ctx.fm_shape, device=gf.device, dtype=torch.float32)
@@ -924,7 +925,9 @@ class RoiPool(Function):
         if ondemand.ZERO_POOL and GRAD_SHARE and LAZY_DGRAD and LAZY_WGRAD and ondemand.CELL_BWD:
             for i, f in enumerate(fmaps):
                 st = ondemand.lazy_state(f)
-                if st is not None and st.sparse and st.keep and st.stride >= 5:
+                # (an overlap level read by the composed RPN block, Fn.RpnComposite: nothing but the RoI windows is ever written to its
+                # gradient map either -- 3.15 GB at B = 128 that a fresh torch.zeros filled every step)
+                if st is not None and st.keep and ((st.sparse and st.stride >= 5) or (st.overlap and st.comp is not None)):
                     ctx.pooled[i] = st.stride
         _GRAD_ACC.clear()                      # nothing of an earlier step may survive into this one's backward pass
         ctx.save_for_backward(rois, level)
