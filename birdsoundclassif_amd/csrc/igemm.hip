@@ -594,6 +594,9 @@ extern "C" int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream) {
                 : launch<128, 128, 64, 64, A_GENERIC, EPI_STD>(p, d->groups, st);
   } else if (d->N > 32) {
     p.n_tiles = 1;
+    // (NEGATIVE, round 5: 256 x 64 tiles with a 64 x 64 patch per wave -- the fragment reuse of the 128 x 128 kernel -- on the layer1 3x3
+    // 64 -> 64 @94x256: two LDS stages / one workgroup per CU 1.30 ms against 1.14 at B = 64, one stage / two workgroups per CU 1.15:
+    // the 64-wide tile's time is not its LDS reads per MFMA)
     return fast ? launch<128, 64, 64, 32, A_FAST, EPI_STD>(p, d->groups, st)
                 : launch<128, 64, 64, 32, A_GENERIC, EPI_STD>(p, d->groups, st);
   } else {
