@@ -32,7 +32,7 @@ namespace {
 
 constexpr int BK = 32;
 constexpr int PITCH = 36;     // floats per LDS row (32 + 4 pad): conflict-free ds_read_b128
-constexpr int BM = 128;
+constexpr int LIST_BM = 128;     // tile rows of a workgroup's block where tile LISTS are involved (the lists come in 128-entry blocks)
 
 struct WinoFusedParams {
   const float* R; const float* U; float* y;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void wino23_rows_tiles_kernel(const float* __r
   const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
   f32x4* r4 = reinterpret_cast<f32x4*>(R);
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  if (n_blocks) n_entries = min(n_entries, *n_blocks * BM);
+  if (n_blocks) n_entries = min(n_entries, *n_blocks * LIST_BM);
   const long long total = (long long)n_entries * 4 * C4;
   for (long long idx = blockIdx.x * 256ll + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
     const int c = (int)(idx % C4);
@@ -133,9 +133,10 @@ __global__ __launch_bounds__(256) void wino23_rows_tiles_kernel(const float* __r
 
 // ABL: timing-only ablations for scripts/wino_fused_probe.py (results are wrong): 1 = no flush, 2 = no epilogue,
 // 4 = every workgroup reads the same L2-resident A tile
-template <int BN, int WN, int ABL = 0>
+// BM: tile rows of the block (128; 96 for dense launches whose 128-row blocks would leave the last round of resident workgroups
+// half empty -- one wave row of 96 x 32 patches, MT = 3, NT = 1; an output sums its planes and K-steps in the same order in every shape)
+template <int BM, int BN, int WM, int WN, int ABL = 0>
 __global__ __launch_bounds__(256, BN == 128 ? 1 : 2) void wino23_fused_kernel(const WinoFusedParams p) {
-  constexpr int WM = 64;
   constexpr int MT = WM / 32, NT = WN / 32;
   constexpr int WAVES_N = BN / WN;
   constexpr int AR = BM / 32, BR = BN / 32;
@@ -515,7 +516,7 @@ extern "C" int nbm_wino23_conv_fused_tiles(const float* R, const float* U, const
                                            const float* mask, int relu, int B, int H, int W, int C, int N, float* y,
                                            const int* tiles, int n_entries, const int* n_blocks, const unsigned* blk_info,
                                            void* stream) {
-  if (!tiles || n_entries < 0 || (n_entries % BM)) return NBM_EINVAL;
+  if (!tiles || n_entries < 0 || (n_entries % LIST_BM)) return NBM_EINVAL;
   if (n_entries == 0) return NBM_OK;
   return wino23_conv_fused_launch(R, U, scale, shift, mask, relu, B, H, W, C, N, y, tiles, n_entries, n_blocks, blk_info, 0,
                                   stream);
@@ -543,9 +544,9 @@ static int wino23_conv_fused_launch(const float* R, const float* U, const float*
   p.R = R; p.U = U; p.y = y; p.scale = scale; p.shift = shift; p.mask = mask; p.relu = relu;
   p.T = (int)T; p.N = N; p.C = C; p.nk = C / BK; p.H = H; p.W = W;
   p.r_gs = (long long)B * p.TH * p.WP * C; p.u_gs = N * C;
-  p.m_tiles = (int)((T + BM - 1) / BM);
+  p.m_tiles = (int)((T + LIST_BM - 1) / LIST_BM);
   p.tiles = tiles; p.n_blocks = n_blocks; p.blk_info = blk_info;
-  if (tiles) { p.T = n_entries; p.m_tiles = n_entries / BM; }
+  if (tiles) { p.T = n_entries; p.m_tiles = n_entries / LIST_BM; }
   hipStream_t st = (hipStream_t)stream;
   // `variant`: 0 = automatic, 128 / 64 = channel-tile width; anything else is refused.  The timing-only ablations of
   // scripts/wino_fused_probe.py (variant + 1000 * ABL: WRONG results by design) exist only in a -DNBM_ABLATE build
@@ -558,19 +559,37 @@ static int wino23_conv_fused_launch(const float* R, const float* U, const float*
   if (variant != 0 && variant != 64 && variant != 128) return NBM_EINVAL;
   const bool wide = variant == 128 || (variant == 0 && N % 128 == 0);
   p.n_tiles = wide ? (N + 127) / 128 : (N + 63) / 64;
+  // Dense launches of the wide shape run ONE workgroup per CU, in rounds of `cus` workgroups: 96-row blocks where they finish sooner than
+  // 128-row blocks (256 -> 256 @24x64 at B = 64: 384 blocks = 1.5 rounds of 128 rows against 512 blocks = 2 rounds of 96; 512 -> 512
+  // @12x32: 192 of 256 CUs busy against all of them with 3/4 of the work each).  The 96-row shape stages 1.17 x the operand rows per
+  // MFMA: it has to win by more than `pen` (measured, scripts/wino_fused_one.py).  NBM_WINO_BM = 128 / 96 forces a shape (experiments).
+  int bm = LIST_BM;
+  if (wide && !tiles) {
+    const char* fe = getenv("NBM_WINO_BM");                 // read per call: the parity test flips it inside one process
+    const int force = fe ? atoi(fe) : 0;
+    static const int cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+                                return n > 0 ? n : 256; }();
+    const long long nt = p.n_tiles;
+    const long long r128 = ((T + 127) / 128 * nt + cus - 1) / cus, r96 = ((T + 95) / 96 * nt + cus - 1) / cus;
+    if (force == 96 || (force == 0 && r96 * 96 * 108 < r128 * 128 * 100)) bm = 96;
+    if (force == 128) bm = 128;
+    p.m_tiles = (int)((T + bm - 1) / bm);
+  }
   const dim3 grid((n_blocks ? (p.m_tiles + 7) / 8 * 8 : p.m_tiles) * p.n_tiles), block(256);
-#define NBM_WF(BN_, WN_, A_) hipLaunchKernelGGL((wino23_fused_kernel<BN_, WN_, A_>), grid, block, 0, st, p)
+#define NBM_WF(BM_, BN_, WM_, WN_, A_) hipLaunchKernelGGL((wino23_fused_kernel<BM_, BN_, WM_, WN_, A_>), grid, block, 0, st, p)
 #ifdef NBM_ABLATE
   if (wide) {
-    switch (abl) { case 0: NBM_WF(128, 64, 0); break; case 1: NBM_WF(128, 64, 1); break; case 2: NBM_WF(128, 64, 2); break;
-                   case 3: NBM_WF(128, 64, 3); break; case 7: NBM_WF(128, 64, 7); break; default: return NBM_EINVAL; }
+    switch (abl) { case 0: NBM_WF(128, 128, 64, 64, 0); break; case 1: NBM_WF(128, 128, 64, 64, 1); break; case 2: NBM_WF(128, 128, 64, 64, 2); break;
+                   case 3: NBM_WF(128, 128, 64, 64, 3); break; case 7: NBM_WF(128, 128, 64, 64, 7); break; default: return NBM_EINVAL; }
   } else {
-    switch (abl) { case 0: NBM_WF(64, 32, 0); break; case 1: NBM_WF(64, 32, 1); break; case 2: NBM_WF(64, 32, 2); break;
-                   case 3: NBM_WF(64, 32, 3); break; case 7: NBM_WF(64, 32, 7); break; default: return NBM_EINVAL; }
+    switch (abl) { case 0: NBM_WF(128, 64, 64, 32, 0); break; case 1: NBM_WF(128, 64, 64, 32, 1); break; case 2: NBM_WF(128, 64, 64, 32, 2); break;
+                   case 3: NBM_WF(128, 64, 64, 32, 3); break; case 7: NBM_WF(128, 64, 64, 32, 7); break; default: return NBM_EINVAL; }
   }
 #else
   (void)abl;
-  if (wide) NBM_WF(128, 64, 0); else NBM_WF(64, 32, 0);
+  if (!wide) NBM_WF(128, 64, 64, 32, 0);
+  else if (bm == 96) NBM_WF(96, 128, 96, 32, 0);
+  else NBM_WF(128, 128, 64, 64, 0);
 #endif
 #undef NBM_WF
   return nbm_launch_status();

@@ -348,6 +348,35 @@ def test_c_abi_from_plain_c(tmp_path):
     assert 'max |err|' in out.stdout
 
 
+def test_winograd_fused_block_shapes_give_the_same_bits(monkeypatch):
+    """The fused F(2x2,3x3) kernel in its 96-row block shape (chosen for dense launches whose 128-row blocks leave the last round of
+    workgroups half empty, csrc/wino_fused.hip) against the 128-row shape: every output sums its planes and K-steps in the same order, so
+    the results are the same BITS -- ragged tile counts, odd map sizes, both epilogue flavours -- and both are a convolution (float64)."""
+    from birdsoundclassif_amd.nets import _prep
+
+    def nrm(key, *shape):
+        return synth.normal(key, int(np.prod(shape))).reshape(shape)
+
+    for B, H, W, Ci, Co, relu in ((3, 24, 64, 128, 256, True), (2, 11, 13, 96, 128, False), (5, 12, 32, 160, 384, True), (1, 6, 10, 64, 128, False)):
+        x = torch.from_numpy(nrm(('wfx', B, H, Ci), B, H, W, Ci).astype(np.float32)).cuda()
+        w = torch.from_numpy((nrm(('wfw', Co, Ci), Co, Ci, 3, 3) * (2.0 / (9 * Ci)) ** 0.5).astype(np.float32))
+        b = torch.from_numpy((0.1 * nrm(('wfb', Co), Co)).astype(np.float32)).cuda()
+        mask = torch.from_numpy(nrm(('wfm', B, H, Co), B, H, W, Co).astype(np.float32)).cuda() if relu else None
+        U = _prep.wino23(w.cuda())
+        outs = {}
+        for bm in ('128', '96'):
+            monkeypatch.setenv('NBM_WINO_BM', bm)
+            outs[bm] = ops.conv3x3_winograd(x, U, b, relu=relu, mask=mask)
+        monkeypatch.delenv('NBM_WINO_BM')
+        auto = ops.conv3x3_winograd(x, U, b, relu=relu, mask=mask)
+        assert torch.equal(outs['128'], outs['96']) and torch.equal(auto, outs['128']), (B, H, W, Ci, Co)
+        ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double(), b.double().cpu(), padding=1)
+        if relu:
+            ref = F.relu(ref) * (mask.permute(0, 3, 1, 2).cpu() > 0)
+        err = (outs['96'].permute(0, 3, 1, 2).cpu().double() - ref).abs().max().item()
+        assert err <= 5e-6 * max(1.0, ref.abs().max().item()), (err, B, H, W, Ci, Co)
+
+
 def test_winograd_weight_transform_kernels():
     """nbm_wino_weight / nbm_wino_weight_grad vs the float64 definition U = G g G^T, dW = G^T dU G (both tile sizes, the
     rotated / channel-swapped / scaled form of the data-gradient weights, the row scale of the gradient)."""
