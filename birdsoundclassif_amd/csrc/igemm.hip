@@ -137,11 +137,13 @@ __global__ __launch_bounds__(256, BM > 128 ? 1 : STAGES == 1 ? 3 : 2) void igemm
     a_rel[i] = ((unsigned)(a_base[i] - blk_base) + c4 * 4) * 4u;   // bytes; rows ascend with m: never negative
     unsigned long long mk = 0ull;
     if constexpr (AMODE == A_FAST) {
-      if (a_ok[i])
-        for (int r = 0; r < p.kh; ++r)
-          for (int s2 = 0; s2 < p.kw; ++s2)
-            if ((unsigned)(a_iy0[i] + r) < (unsigned)p.H && (unsigned)(a_ix0[i] + s2) < (unsigned)p.W)
-              mk |= 1ull << (r * p.kw + s2);
+      // rows and columns of the filter that land inside the image, then their product -- selects only: as a kh x kw nest of data-dependent
+      // branches this loop was the longest part of the tile prologue (cycle counters of the data-gradient twin, round 5)
+      unsigned rowm = 0u, colm = 0u;
+      for (int r = 0; r < p.kh; ++r) rowm |= ((unsigned)(a_iy0[i] + r) < (unsigned)p.H ? 1u : 0u) << r;
+      for (int s2 = 0; s2 < p.kw; ++s2) colm |= ((unsigned)(a_ix0[i] + s2) < (unsigned)p.W ? 1u : 0u) << s2;
+      for (int r = 0; r < p.kh; ++r) mk |= ((rowm >> r) & 1u) ? (unsigned long long)colm << (r * p.kw) : 0ull;
+      mk = a_ok[i] ? mk : 0ull;
     }
     a_taps[i] = mk;
   }
@@ -597,6 +599,15 @@ extern "C" int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream) {
     // (NEGATIVE, round 5: 256 x 64 tiles with a 64 x 64 patch per wave -- the fragment reuse of the 128 x 128 kernel -- on the layer1 3x3
     // 64 -> 64 @94x256: two LDS stages / one workgroup per CU 1.30 ms against 1.14 at B = 64, one stage / two workgroups per CU 1.15:
     // the 64-wide tile's time is not its LDS reads per MFMA)
+    // single LDS stage / three workgroups per CU for the 64-wide tile up to K = 32 * s1_n64 (NBM_S1_N64; 0 = never): this tile spends half the
+    // MFMA cycles per K-step of the 128-wide one, so its prologue / epilogue weigh double and the third workgroup pays up to K = 576 (layer1's
+    // 3x3 64 -> 64 @94x256: 1.075 -> 0.99 ms at B = 64, 2.05 -> 1.83 at B = 128; same K order, same bits)
+    static const int s1_n64 = getenv("NBM_S1_N64") ? atoi(getenv("NBM_S1_N64")) : 20;
+    if (fast && p.vec_epi && p.nk <= s1_n64) {
+      dim3 grid(p.m_tiles * p.n_tiles, 1, d->groups);
+      hipLaunchKernelGGL((igemm_kernel<128, 64, 64, 32, A_FAST, EPI_STD, 1>), grid, dim3(256), 0, st, p);
+      return nbm_launch_status();
+    }
     return fast ? launch<128, 64, 64, 32, A_FAST, EPI_STD>(p, d->groups, st)
                 : launch<128, 64, 64, 32, A_GENERIC, EPI_STD>(p, d->groups, st);
   } else {

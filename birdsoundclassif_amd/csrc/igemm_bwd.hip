@@ -48,6 +48,9 @@ struct BwdParams {
   int ph_tiles[4];           //   M tiles of each class; tile_m = 4 * (tile within class) + class, so the four classes of
                              //   one image region run side by side and fill the same DRAM pages together
   int ablate;                // NN, timing-only build (-DNBM_ABLATE_NN, `make ablate_nn`; never shipped): NBM_NN_ABLATE bits, see ABL_*
+  // NN: launch-invariant divisors of the row decode (nbm_fastdiv, nbm_common.h): pixels per image and row width of the (parity class's)
+  // pixel grid, the stride, and the full grid again for the half-resolution residual
+  nbm_fastdiv fd_hw[4], fd_w[4], fd_st, fd_HW, fd_W;
 };
 
 // Attribution of igemm_nn_kernel's time (scripts/dgrad_ablate.py -> profiles/r05_dgrad_attribution.txt).  Each bit
@@ -56,8 +59,14 @@ enum { ABL_NO_MASK = 1, ABL_NO_RESIDUAL = 2, ABL_NO_ASCALE = 4, /* 8: was the ta
        ABL_NO_LOADS = 64, ABL_NO_LDS_WRITES = 128 };
 #ifdef NBM_ABLATE_NN
 #define NBM_ABL(p, bit) (((p).ablate & (bit)) != 0)
+// per parity class (0 when not phased): cycles in prologue / K loop / epilogue, tiles (thread 0 of every workgroup; clock64)
+__device__ unsigned long long nbm_nn_dbg[20];   // [class][address arithmetic | first loads + LDS write | K loop | epilogue], [16 + class] tiles
+#define NBM_DBG_T(var) const long long var = clock64()
+#define NBM_DBG_ADD(slot, v) do { if (threadIdx.x == 0) atomicAdd(&nbm_nn_dbg[slot], (unsigned long long)(v)); } while (0)
 #else
 #define NBM_ABL(p, bit) false
+#define NBM_DBG_T(var)
+#define NBM_DBG_ADD(slot, v)
 #endif
 
 __device__ __forceinline__ int xcd_tile(int nwg, int bid) {
@@ -86,6 +95,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
   float* Bs = lds + STAGES * BM * PITCH;
   if constexpr (STAGES == 2) nbm_stagger_priority();
 
+  NBM_DBG_T(dbg_t0);
   const int wg = xcd_tile(gridDim.x, blockIdx.x);
   const int tile_m = wg / p.n_tiles, tile_n = wg - tile_m * p.n_tiles;
   const int bm0 = tile_m * BM, bn0 = tile_n * BN;
@@ -97,7 +107,10 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
   const int lrow = lane & 31, lh = lane >> 5;
   const int st = p.stride;
-  const int frm = (p.kh - 1) / st, fsm = (p.kw - 1) / st;      // largest tap shift in G rows / columns
+  // v / stride for v >= 0 through a host-prepared multiplier: a 32-bit division by a run-time value is ~35 vector instructions, and the
+  // tap loop of the prologue did 4 of them per (row, tap) (144 per thread for a 3x3), `load_tiles` 2 per K-step, the row decode 2 per row
+  auto divst = [&](int v) -> int { return (int)nbm_fdiv((unsigned)v, p.fd_st); };
+  const int frm = divst(p.kh - 1), fsm = divst(p.kw - 1);      // largest tap shift in G rows / columns
 
   // Row -> input pixel.  Plain: row q = bm0 + r enumerates (b, iy, ix) row-major.  Phased (stride 2): a pixel only
   // receives the taps with r = (iy + pad) mod 2, s = (ix + pad) mod 2, so the M tiles are grouped by that parity class;
@@ -113,11 +126,12 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
     Hp = (p.H - y0 + 1) >> 1; Wp = (p.W - x0 + 1) >> 1;
     rows_here = p.B * Hp * Wp;
   }
+  const nbm_fastdiv dv_hw = p.fd_hw[p.phased ? (tile_m & 3) : 0], dv_w = p.fd_w[p.phased ? (tile_m & 3) : 0];
   auto decode = [&](int q, int& b, int& iy, int& ix) -> bool {
     const bool ok = q < rows_here;
     const int qq = ok ? q : 0, hw = Hp * Wp;
-    b = qq / hw;
-    const int rem = qq - b * hw, u = rem / Wp, v = rem - u * Wp;
+    b = (int)nbm_fdiv((unsigned)qq, dv_hw);
+    const int rem = qq - b * hw, u = (int)nbm_fdiv((unsigned)rem, dv_w), v = rem - u * Wp;
     iy = p.phased ? 2 * u + y0 : u;
     ix = p.phased ? 2 * v + x0 : v;
     return ok;
@@ -135,24 +149,31 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
     // column 0 of the first row's G row: with stride > 1 two consecutive input rows can map to the SAME G row, so the
     // first pixel of the tile is not necessarily the smallest address (offsets must stay non-negative)
     (void)ix;
-    blk_base = ((long long)(b * p.Ho + (iy + p.pad) / st) * p.Wo) * p.g_ld;
+    blk_base = ((long long)(b * p.Ho + divst(iy + p.pad)) * p.Wo) * p.g_ld;
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int b, iy, ix;
     const bool ok = decode(q0 + r0 + 32 * i, b, iy, ix);
-    const int fy = (iy + p.pad) / st, fx = (ix + p.pad) / st;
+    const int fy = divst(iy + p.pad), fx = divst(ix + p.pad);
     const int py = (iy + p.pad) - fy * st, px = (ix + p.pad) - fx * st;
     const long long base = ((long long)(b * p.Ho + fy) * p.Wo + fx) * p.g_ld;
     a_rel[i] = ((unsigned)(base - blk_base) + c4 * 4) * 4u;
+    // taps that reach this pixel: filter rows r with r = py (mod stride) whose G row fy - r / stride exists, likewise columns, then their
+    // product -- selects only (as a kh x kw nest of data-dependent branches this was the longest part of the tile prologue: 28 k of the
+    // 37 k cycles in front of the first load of a 3x3 tile, cycle counters of the `ablate_nn` build, round 5)
     unsigned long long mk = 0ull;
-    if (ok)
-      for (int r = 0; r < p.kh; ++r)
-        for (int s = 0; s < p.kw; ++s) {
-          const int oy = fy - r / st, ox = fx - s / st;
-          if (r % st == py && s % st == px && oy >= 0 && oy < p.Ho && ox >= 0 && ox < p.Wo) mk |= 1ull << (r * p.kw + s);
-        }
-    a_taps[i] = mk;
+    unsigned rowm = 0u, colm = 0u;
+    for (int r = 0; r < p.kh; ++r) {
+      const int rq = divst(r);
+      rowm |= ((r - rq * st == py && (unsigned)(fy - rq) < (unsigned)p.Ho) ? 1u : 0u) << r;
+    }
+    for (int s = 0; s < p.kw; ++s) {
+      const int sq = divst(s);
+      colm |= ((s - sq * st == px && (unsigned)(fx - sq) < (unsigned)p.Wo) ? 1u : 0u) << s;
+    }
+    for (int r = 0; r < p.kh; ++r) mk |= ((rowm >> r) & 1u) ? (unsigned long long)colm << (r * p.kw) : 0ull;
+    a_taps[i] = ok ? mk : 0ull;
   }
   const long long maxoff = ((long long)frm * p.Wo + fsm) * p.g_ld;
   const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(gg + blk_base - maxoff, 0x7ffffff0u);
@@ -176,7 +197,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
     if (NBM_ABL(p, ABL_NO_LOADS) && abl_loads_done >= 2) return;           // operands stay what the first two loads fetched
     ++abl_loads_done;
     const int tap = cur_r * p.kw + cur_s;
-    const unsigned a_soff = (unsigned)((maxoff - ((long long)(cur_r / st) * p.Wo + cur_s / st) * p.g_ld + cur_n0) * 4);
+    const unsigned a_soff = (unsigned)((maxoff - ((long long)divst(cur_r) * p.Wo + divst(cur_s)) * p.g_ld + cur_n0) * 4);
     const unsigned b_soff = (unsigned)(((long long)cur_n0 * p.w_row + (long long)tap * p.Cin) * 4);
 #pragma unroll
     for (int i = 0; i < 4; ++i) ra[i] = buf_load4(rsrc_a, ((a_taps[i] >> tap) & 1ull) ? a_rel[i] : OOB, a_soff);
@@ -230,6 +251,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
   const int n_r = r_begin < p.kh ? (p.kh - r_begin + t_step - 1) / t_step : 0;
   const int n_s = s_begin < p.kw ? (p.kw - s_begin + t_step - 1) / t_step : 0;
   const int nk = ((p.N + BK - 1) / BK) * n_r * n_s;          // 0: no tap reaches this parity class, dX = residual
+  NBM_DBG_T(dbg_t0b);
   if constexpr (STAGES == 2) {
     if (nk > 0) {
       load_tiles();
@@ -238,6 +260,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
     if (nk > 1) load_tiles();
   }
 
+  NBM_DBG_T(dbg_t1);
   auto k_step = [&](int kt, auto store_c, auto load_c) {
     constexpr bool STORE = decltype(store_c)::value, LOAD = decltype(load_c)::value;
     const int cur = kt & 1;
@@ -294,6 +317,11 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
     }
   }
   __syncthreads();
+  NBM_DBG_T(dbg_t2);
+#ifdef NBM_ABLATE_NN
+  const int dbg_c = p.phased ? 4 * (tile_m & 3) : 0;
+  NBM_DBG_ADD(dbg_c, dbg_t0b - dbg_t0); NBM_DBG_ADD(dbg_c + 1, dbg_t1 - dbg_t0b); NBM_DBG_ADD(dbg_c + 2, dbg_t2 - dbg_t1); NBM_DBG_ADD(16 + dbg_c / 4, 1);
+#endif
 
   float* __restrict__ og = p.out + (long long)grp * p.out_gs;
   const float* __restrict__ rg = (p.residual && !NBM_ABL(p, ABL_NO_RESIDUAL)) ? p.residual + (long long)grp * p.res_gs : nullptr;
@@ -369,8 +397,8 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
           v[0] += q[0]; v[1] += q[1]; v[2] += q[2]; v[3] += q[3];
         }
         if (r2_) {          // the data gradient of a 1x1 / stride-2 shortcut, kept at its own (half) resolution
-          const int hw = p.H * p.W, b_ = (int)(m / hw), rem_ = (int)(m - (long long)b_ * hw);
-          const int iy_ = rem_ / p.W, ix_ = rem_ - iy_ * p.W;
+          const int hw = p.H * p.W, b_ = (int)nbm_fdiv((unsigned)m, p.fd_HW), rem_ = (int)(m - (long long)b_ * hw);
+          const int iy_ = (int)nbm_fdiv((unsigned)rem_, p.fd_W), ix_ = rem_ - iy_ * p.W;
           if (!((iy_ | ix_) & 1)) {
             const long long m2 = ((long long)b_ * ((p.H + 1) >> 1) + (iy_ >> 1)) * ((p.W + 1) >> 1) + (ix_ >> 1);
             const f32x4 q = *reinterpret_cast<const f32x4*>(r2_ + m2 * p.res2_ld + c);
@@ -385,6 +413,10 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
         if (!NBM_ABL(p, ABL_NO_STORE) || v[0] == 1.2345e-30f) *reinterpret_cast<f32x4*>(og + (long long)m * p.out_ld + c) = v;
       }
     }
+#ifdef NBM_ABLATE_NN
+    __syncthreads();
+    NBM_DBG_ADD(dbg_c + 3, clock64() - dbg_t2);
+#endif
     return;
   }
 #pragma unroll
@@ -401,8 +433,8 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
         float v = acc[i][j][e] * p.alpha;
         if (rg) v += rg[(long long)m * p.res_ld + c];
         if (r2_) {
-          const int hw = p.H * p.W, b_ = (int)(m / hw), rem_ = (int)(m - (long long)b_ * hw);
-          const int iy_ = rem_ / p.W, ix_ = rem_ - iy_ * p.W;
+          const int hw = p.H * p.W, b_ = (int)nbm_fdiv((unsigned)m, p.fd_HW), rem_ = (int)(m - (long long)b_ * hw);
+          const int iy_ = (int)nbm_fdiv((unsigned)rem_, p.fd_W), ix_ = rem_ - iy_ * p.W;
           if (!((iy_ | ix_) & 1))
             v += r2_[(((long long)b_ * ((p.H + 1) >> 1) + (iy_ >> 1)) * ((p.W + 1) >> 1) + (ix_ >> 1)) * p.res2_ld + c];
         }
@@ -673,6 +705,17 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(const BwdParams p) {
 
 }  // namespace
 
+#ifdef NBM_ABLATE_NN
+// timing-only build: read and clear the per-class cycle counters of igemm_nn_kernel (scripts/dgrad_ablate.py)
+extern "C" int nbm_nn_dbg_read(unsigned long long* host20) {
+  unsigned long long z[20] = {0};
+  if (hipMemcpyFromSymbol(host20, HIP_SYMBOL(nbm_nn_dbg), sizeof(z)) != hipSuccess) return -4;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(nbm_nn_dbg), z, sizeof(z)) != hipSuccess) return -4;
+  return NBM_OK;
+}
+#endif
+
+
 static int fill_common(const nbm_bwd_desc* d, BwdParams& p) {
   if (!d || !d->g || !d->out) return NBM_EINVAL;
   if (d->B <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->N <= 0 || d->kh <= 0 || d->kw <= 0 || d->stride <= 0 ||
@@ -718,14 +761,20 @@ extern "C" int nbm_conv_dgrad(const nbm_bwd_desc* d, void* stream) {
                (!d->mask || ((d->mask_ld & 3) == 0 && nbm_aligned16(d->mask))) &&
                (!d->residual2 || ((d->res2_ld & 3) == 0 && nbm_aligned16(d->residual2)))) ? 1 : 0;
   p.m_tiles = (p.M + 127) / 128;
+  p.fd_st = nbm_fastdiv_make((unsigned)d->stride);
+  p.fd_HW = p.fd_hw[0] = nbm_fastdiv_make((unsigned)(d->H * d->W));
+  p.fd_W = p.fd_w[0] = nbm_fastdiv_make((unsigned)d->W);
   if (d->stride == 2) {                  // group the M tiles by parity class (see igemm_nn_kernel)
     p.phased = 1;
     int tmax = 0;
     for (int ph = 0; ph < 4; ++ph) {
       const int y0 = ((ph >> 1) + d->pad) & 1, x0 = ((ph & 1) + d->pad) & 1;
-      const long long rows = (long long)d->B * ((d->H - y0 + 1) >> 1) * ((d->W - x0 + 1) >> 1);
+      const int Hp = (d->H - y0 + 1) >> 1, Wp = (d->W - x0 + 1) >> 1;
+      const long long rows = (long long)d->B * Hp * Wp;
       p.ph_tiles[ph] = (int)((rows + 127) / 128);
       if (p.ph_tiles[ph] > tmax) tmax = p.ph_tiles[ph];
+      p.fd_hw[ph] = nbm_fastdiv_make((unsigned)(Hp * Wp));     // (an empty class: no tile of it gets past its early exit)
+      p.fd_w[ph] = nbm_fastdiv_make((unsigned)Wp);
     }
     p.m_tiles = 4 * tmax;
   }
@@ -735,7 +784,14 @@ extern "C" int nbm_conv_dgrad(const nbm_bwd_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   // short K (<= 8 steps of 32) and a 16-byte epilogue: the three-workgroups-per-CU variant (see the template comment)
   static const int shortk_max = getenv("NBM_NN_SHORTK_MAX") ? atoi(getenv("NBM_NN_SHORTK_MAX")) : 8;   // 0 disables
-  const bool shortk = !p.phased && p.vec_epi && ((d->N + BK - 1) / BK) * d->kh * d->kw <= shortk_max;
+  // stride 2 (phased): a tile's K loop visits its parity class's taps only -- (N / 32) x {1, 2, 2, 4} steps for a 3x3
+  // (the largest class's step count decides: 128 -> 128 @94x256, steps 4 / 8 / 8 / 16: 3.61 -> 3.46 ms at B = 128 on the single-stage kernel)
+  static const int shortk_ph = getenv("NBM_NN_SHORTK_PHASED") ? atoi(getenv("NBM_NN_SHORTK_PHASED")) : 16;
+  const int ph_max = ((d->N + BK - 1) / BK) * ((d->kh + 1) / 2) * ((d->kw + 1) / 2);
+  // the 64-wide tile spends half the MFMA cycles per K-step: its prologue / epilogue weigh double, and the third workgroup pays up to
+  // K = 576 (layer1's 3x3 64 -> 64 @94x256 at B = 128: 2.39 -> 2.15 ms, round 5)
+  const int shortk_lim = d->Cin <= 64 && shortk_max ? (shortk_max > 20 ? shortk_max : 20) : shortk_max;
+  const bool shortk = p.vec_epi && (p.phased ? ph_max <= shortk_ph : ((d->N + BK - 1) / BK) * d->kh * d->kw <= shortk_lim);
   if (d->Cin > 64) {
     p.n_tiles = (d->Cin + 127) / 128;
     const dim3 grid(p.m_tiles * p.n_tiles, 1, d->groups);

@@ -92,11 +92,11 @@ __global__ __launch_bounds__(256, 1) void igemm_split_kernel(const IgemmParams p
     const long long base = ((long long)(b * p.H + iy0) * p.W + ix0) * p.x_ld;
     rel[c] = ((unsigned)(base - blk_base) + e * 8) * 4u;       // rows ascend with m: never negative
     unsigned long long mk = 0ull;
-    if (ok)
-      for (int r = 0; r < p.kh; ++r)
-        for (int s2 = 0; s2 < p.kw; ++s2)
-          if ((unsigned)(iy0 + r) < (unsigned)p.H && (unsigned)(ix0 + s2) < (unsigned)p.W) mk |= 1ull << (r * p.kw + s2);
-    taps[c] = mk;
+    unsigned rowm = 0u, colm = 0u;                     // (selects only, as in igemm.hip)
+    for (int r = 0; r < p.kh; ++r) rowm |= ((unsigned)(iy0 + r) < (unsigned)p.H ? 1u : 0u) << r;
+    for (int s2 = 0; s2 < p.kw; ++s2) colm |= ((unsigned)(ix0 + s2) < (unsigned)p.W ? 1u : 0u) << s2;
+    for (int r = 0; r < p.kh; ++r) mk |= ((rowm >> r) & 1u) ? (unsigned long long)colm << (r * p.kw) : 0ull;
+    taps[c] = ok ? mk : 0ull;
     wofs[c] = slot(r0 + 128 * c, e);
   }
   {

@@ -22,7 +22,11 @@ LAUNCHES = [
     ('layer3 1x1 256->1024 (G 1024 -> dX 256) + mask', 24, 64, 256, 1024, 1, 1, True, False, True, None),
     ('FPN lateral 1x1 256->384 @94x256 (G 384 -> dX 256) + residual', 94, 256, 256, 384, 1, 1, False, True, False, None),
     ('attention [q|k|v] 1024->1408 (G 1408 -> dX 1024), plain GEMM', 1536 * B, 1, 1024, 1408, 1, 1, False, False, False, 1),
+    ('layer2.0 3x3 s2 128->128 @94x256 (by parity class) + mask', 94, 256, 128, 128, 3, 2, True, False, True, None),
+    ('layer3.0 3x3 s2 256->256 @47x128 (by parity class) + mask', 47, 128, 256, 256, 3, 2, True, False, True, None),
 ]
+if len(sys.argv) > 3:
+    LAUNCHES = [l for l in LAUNCHES if sys.argv[3] in l[0]]
 BITS = [(0, 'nothing removed'), (1, '- mask'), (2, '- residual(s)'), (4, '- a_scale multiply'), (16, '- global stores'),
         (32, '- whole epilogue'), (64, '- global loads (main loop)'), (128, '- LDS writes (main loop)'), (192, '- loads - LDS writes'),
         (224, 'MFMA + LDS reads + barriers only')]
@@ -48,7 +52,7 @@ hdr = f'{"launch":<66}' + ''.join(f'{name[:22]:>24}' for _, name in (BITS if abl
 print(hdr)
 for label, H, W, Cin, N, k, stride, sc, res, msk, b1 in LAUNCHES:
     Bn = b1 or B
-    Ho, Wo = (H + stride - 1) // stride, (W + stride - 1) // stride
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
     g = torch.randn((Bn, Ho, Wo, N), device='cuda') * 0.1
     w = torch.randn((N, k * k * Cin), device='cuda') * 0.05
     out = torch.empty((Bn, H, W, Cin), device='cuda')
@@ -63,6 +67,26 @@ for label, H, W, Cin, N, k, stride, sc, res, msk, b1 in LAUNCHES:
                                           w_ld=w.shape[1], a_scale=a_scale, residual=residual, mask=mask))
         cells.append(f'{ms:8.3f} ({gflop / ms:5.1f} TF/s)')
     os.environ['NBM_NN_ABLATE'] = '0'
+    if ablate_build and os.environ.get('NBM_NN_CYCLES'):
+        # cycle counters of the instrumented build (thread 0 of every workgroup, clock64): per parity class (class 0 when not phased)
+        import ctypes as C
+        from birdsoundclassif_amd import _lib
+        L = _lib.load()
+        buf = (C.c_ulonglong * 20)()
+        L.nbm_nn_dbg_read(buf)                                       # clear
+        for bits in (0, 224):
+            os.environ['NBM_NN_ABLATE'] = str(bits)
+            ops.conv_dgrad(g.view(-1, N), w, out, B=Bn, H=H, W=W, Cin=Cin, N=N, kh=k, kw=k, stride=stride, pad=k // 2, g_ld=N,
+                           w_ld=w.shape[1], a_scale=a_scale, residual=residual, mask=mask)
+            torch.cuda.synchronize()
+            L.nbm_nn_dbg_read(buf)
+            for c in range(4):
+                adr, ld, loop, epi = (int(buf[4 * c + i]) for i in range(4))
+                n = int(buf[16 + c])
+                if n:
+                    print(f'      ablate={bits:<3d} class {c}: {n:6d} tiles, cycles per tile: address arithmetic {adr / n:8.0f}  first loads + LDS write {ld / n:8.0f}  '
+                          f'K loop {loop / n:8.0f}  epilogue {epi / n:8.0f}')
+        os.environ['NBM_NN_ABLATE'] = '0'
     gb = (g.numel() + out.numel() + (residual.numel() if res else 0) + (mask.numel() if msk else 0)) * 4 / 1e9
     print(f'{label:<66}' + ''.join(f'{c:>24}' for c in cells) + f'   [{gb:.2f} GB mandatory -> {gb / 5.0:.2f} ms at 5 TB/s; {gflop / PEAK:.2f} ms at the MFMA peak]')
     del g, w, out, residual, mask
