@@ -74,8 +74,8 @@ __global__ __launch_bounds__(256, BM > 128 ? 1 : STAGES == 1 ? 3 : 2) void igemm
     const int t = p.rows[m >> 4];
     if (t < 0) return -1;
     const int thw = p.rows_TH * p.rows_TW, k = m & 15;
-    const int b = t / thw, rem = t - b * thw;
-    const int ty = rem / p.rows_TW, tx = rem - ty * p.rows_TW;
+    const int b = (int)nbm_fdiv((unsigned)t, p.fd_rows_thw), rem = t - b * thw;
+    const int ty = (int)nbm_fdiv((unsigned)rem, p.fd_rows_tw), tx = rem - ty * p.rows_TW;
     const int y = 2 * ty - 1 + (k >> 2), x = 2 * tx - 1 + (k & 3);
     if ((unsigned)y >= (unsigned)p.H || (unsigned)x >= (unsigned)p.W) return -1;
     return ((long long)b * p.H + y) * p.W + x;
@@ -112,12 +112,12 @@ __global__ __launch_bounds__(256, BM > 128 ? 1 : STAGES == 1 ? 3 : 2) void igemm
   long long blk_base = 0;
   if constexpr (ROWS) {           // base = start of the image of the block's first listed entry (a block spans <= 2 images)
     const int e0 = p.rows[p.rows_mode == 2 ? bm0 >> 4 : bm0];
-    const int b = p.rows_mode == 2 ? e0 / (p.rows_TH * p.rows_TW) : e0 / p.HoWo;
+    const int b = (int)nbm_fdiv((unsigned)e0, p.rows_mode == 2 ? p.fd_rows_thw : p.fd_howo);
     blk_base = (long long)b * p.HoWo * p.x_ld;
   } else {
     const int m0 = bm0 < p.M ? bm0 : 0;
-    const int b = m0 / p.HoWo, rem = m0 - b * p.HoWo;
-    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    const int b = (int)nbm_fdiv((unsigned)m0, p.fd_howo), rem = m0 - b * p.HoWo;
+    const int oy = (int)nbm_fdiv((unsigned)rem, p.fd_wo), ox = rem - oy * p.Wo;
     blk_base = ((long long)(b * p.H + oy * p.stride - p.pad) * p.W + (ox * p.stride - p.pad)) * p.x_ld;
   }
 #pragma unroll
@@ -129,8 +129,9 @@ __global__ __launch_bounds__(256, BM > 128 ? 1 : STAGES == 1 ? 3 : 2) void igemm
       if (a_ok[i]) { mm = row_pixel(m); a_ok[i] = mm >= 0; }
       if (!a_ok[i]) mm = blk_base / p.x_ld;
     }
-    const int b = (int)(mm / p.HoWo), rem = (int)(mm - (long long)b * p.HoWo);
-    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    // (pixel indices fit 31 bits: M is an int; a 64-bit division here was ~150 instructions per row)
+    const int b = (int)nbm_fdiv((unsigned)mm, p.fd_howo), rem = (int)(mm - (long long)b * p.HoWo);
+    const int oy = (int)nbm_fdiv((unsigned)rem, p.fd_wo), ox = rem - oy * p.Wo;
     a_iy0[i] = oy * p.stride - p.pad;
     a_ix0[i] = ox * p.stride - p.pad;
     a_base[i] = ((long long)(b * p.H + a_iy0[i]) * p.W + a_ix0[i]) * p.x_ld;
@@ -525,6 +526,7 @@ extern "C" int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream) {
   p.nk = (p.K + BK - 1) / BK;
   p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad;
   p.Ho = d->Ho; p.Wo = d->Wo; p.HoWo = d->Ho * d->Wo;
+  p.fd_howo = nbm_fastdiv_make((unsigned)p.HoWo); p.fd_wo = nbm_fastdiv_make((unsigned)p.Wo);
   p.x_ld = d->x_ld; p.w_ld = d->w_ld; p.y_ld = d->y_ld; p.res_ld = d->res_ld;
   p.alpha = d->alpha; p.act = d->act; p.shift_per_row = d->shift_per_row;
   if (p.w_ld < p.nk * BK) return NBM_EINVAL;  // every W row must hold nk*32 readable floats
@@ -555,6 +557,7 @@ extern "C" int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream) {
     if (d->rows_mode == 2 && (d->rows_TH != (d->H + 1) / 2 || d->rows_TW != (d->W + 1) / 2)) return NBM_EINVAL;
     if (2ll * d->H * d->W * d->x_ld * 4 > 0x7fffffffll) return NBM_EUNSUPPORTED;
     p.rows = d->rows; p.rows_blocks = d->rows_blocks; p.rows_mode = d->rows_mode; p.rows_TH = d->rows_TH; p.rows_TW = d->rows_TW;
+    p.fd_rows_thw = nbm_fastdiv_make((unsigned)(d->rows_TH * d->rows_TW)); p.fd_rows_tw = nbm_fastdiv_make((unsigned)d->rows_TW);
     p.M = d->rows_count;
     p.m_tiles = p.M / BM;
     p.n_tiles = (d->N + 127) / 128;

@@ -51,6 +51,7 @@ struct BwdParams {
   // NN: launch-invariant divisors of the row decode (nbm_fastdiv, nbm_common.h): pixels per image and row width of the (parity class's)
   // pixel grid, the stride, and the full grid again for the half-resolution residual
   nbm_fastdiv fd_hw[4], fd_w[4], fd_st, fd_HW, fd_W;
+  nbm_fastdiv fd_howo, fd_wo;   // TN: output pixels per image, output row width
 };
 
 // Attribution of igemm_nn_kernel's time (scripts/dgrad_ablate.py -> profiles/r05_dgrad_attribution.txt).  Each bit
@@ -508,9 +509,9 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(const BwdParams p) {
 #pragma unroll
   for (int i = 0; i < BPASS; ++i) {
     const int m = m_begin + br0 + BROWS * i;
-    b_b[i] = m / HoWo;
+    b_b[i] = (int)nbm_fdiv((unsigned)m, p.fd_howo);
     const int rem = m - b_b[i] * HoWo;
-    b_oy[i] = rem / p.Wo;
+    b_oy[i] = (int)nbm_fdiv((unsigned)rem, p.fd_wo);
     b_ox[i] = rem - b_oy[i] * p.Wo;
   }
   int kt_load = 0;
@@ -554,9 +555,9 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(const BwdParams p) {
           if (b_ox[i] >= p.Wo) { b_ox[i] -= p.Wo; if (++b_oy[i] == p.Ho) { b_oy[i] = 0; ++b_b[i]; } }
         } else {
           const int mn = m + BK;
-          b_b[i] = mn / HoWo;
+          b_b[i] = (int)nbm_fdiv((unsigned)mn, p.fd_howo);
           const int rem = mn - b_b[i] * HoWo;
-          b_oy[i] = rem / p.Wo;
+          b_oy[i] = (int)nbm_fdiv((unsigned)rem, p.fd_wo);
           b_ox[i] = rem - b_oy[i] * p.Wo;
         }
       }
@@ -566,8 +567,8 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(const BwdParams p) {
         const int m = mbase + br0 + BROWS * i;
         f32x4 v = zero4;
         if (m < m_end) {
-          const int b = m / HoWo, rem = m - b * HoWo;
-          const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+          const int b = (int)nbm_fdiv((unsigned)m, p.fd_howo), rem = m - b * HoWo;
+          const int oy = (int)nbm_fdiv((unsigned)rem, p.fd_wo), ox = rem - oy * p.Wo;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int j = j0 + bc * 4 + e;
@@ -729,6 +730,7 @@ static int fill_common(const nbm_bwd_desc* d, BwdParams& p) {
   p.g_gs = d->g_gs; p.w_gs = d->w_gs; p.x_gs = d->x_gs; p.out_gs = d->out_gs; p.res_gs = d->res_gs;
   p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.N = d->N; p.kh = d->kh; p.kw = d->kw;
   p.stride = d->stride; p.pad = d->pad; p.Ho = d->Ho; p.Wo = d->Wo;
+  p.fd_howo = nbm_fastdiv_make((unsigned)(d->Ho * d->Wo)); p.fd_wo = nbm_fastdiv_make((unsigned)d->Wo);
   p.g_ld = d->g_ld; p.w_ld = d->w_ld; p.x_ld = d->x_ld; p.out_ld = d->out_ld; p.res_ld = d->res_ld; p.mask_ld = d->mask_ld;
   p.alpha = d->alpha;
   p.bias_grad = d->bias_grad;

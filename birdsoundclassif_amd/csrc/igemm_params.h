@@ -28,6 +28,9 @@ struct IgemmParams {
   const int* rows; const int* rows_blocks; int rows_mode, rows_TH, rows_TW;
   // producer mask (vector and scalar epilogue, not ROWS): y = 0 where mask[m][n] <= 0 -- a 1x1 data gradient run as this forward GEMM
   const float* mask; int mask_ld;
+  // launch-invariant divisors of the row decode (nbm_fastdiv, nbm_common.h): output pixels per image, output row width, and the tile grid
+  // of rows_mode 2
+  nbm_fastdiv fd_howo, fd_wo, fd_rows_thw, fd_rows_tw;
 };
 
 // igemm_split.hip: 256 x 128 tiles on the bf16 matrix pipe (fast gather, 16-byte epilogue, N > 64, nk > 8 only; the caller checks)

@@ -74,8 +74,8 @@ __global__ __launch_bounds__(256, 1) void igemm_split_kernel(const IgemmParams p
   long long blk_base;
   {
     const int m0 = bm0 < p.M ? bm0 : 0;
-    const int b = m0 / p.HoWo, rem = m0 - b * p.HoWo;
-    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    const int b = (int)nbm_fdiv((unsigned)m0, p.fd_howo), rem = m0 - b * p.HoWo;
+    const int oy = (int)nbm_fdiv((unsigned)rem, p.fd_wo), ox = rem - oy * p.Wo;
     blk_base = ((long long)(b * p.H + oy * p.stride - p.pad) * p.W + (ox * p.stride - p.pad)) * p.x_ld;
   }
   unsigned rel[CH];                                  // byte offset of the chunk inside its buffer resource (A: relative to blk_base)
@@ -86,8 +86,8 @@ __global__ __launch_bounds__(256, 1) void igemm_split_kernel(const IgemmParams p
     const int m = bm0 + r0 + 128 * c;
     const bool ok = m < p.M;
     const long long mm = ok ? m : 0;
-    const int b = (int)(mm / p.HoWo), rem = (int)(mm - (long long)b * p.HoWo);
-    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    const int b = (int)nbm_fdiv((unsigned)mm, p.fd_howo), rem = (int)(mm - (long long)b * p.HoWo);
+    const int oy = (int)nbm_fdiv((unsigned)rem, p.fd_wo), ox = rem - oy * p.Wo;
     const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
     const long long base = ((long long)(b * p.H + iy0) * p.W + ix0) * p.x_ld;
     rel[c] = ((unsigned)(base - blk_base) + e * 8) * 4u;       // rows ascend with m: never negative

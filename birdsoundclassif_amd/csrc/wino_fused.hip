@@ -41,6 +41,7 @@ struct WinoFusedParams {
   int u_gs;                     // floats between planes of U (= N * C)
   int T, N, C, nk;
   int H, W, TH, TW, THW, WP;
+  nbm_fastdiv fd_thw, fd_tw;      // tile id -> (image, tile row, tile column) without run-time divisions (nbm_common.h)
   int m_tiles, n_tiles, relu;
   // Optional tile list (demand-driven evaluation, see nbm_wino23_conv_fused_tiles): m_tiles * 128 entries, entry = linear
   // tile id (b * THW + ty * TW + tx) ascending inside a 128-entry block, or -1 (only at the end of a block).  n_blocks
@@ -182,16 +183,16 @@ __global__ __launch_bounds__(256, BN == 128 ? 1 : 2) void wino23_fused_kernel(co
   long long blk_base;
   {
     const int t = bm0 < p.T ? tile_of(bm0) : 0;
-    const int bi = t / p.THW, rem = t - bi * p.THW;
-    const int ty = rem / p.TW, tx = rem - ty * p.TW;
+    const int bi = (int)nbm_fdiv((unsigned)t, p.fd_thw), rem = t - bi * p.THW;
+    const int ty = (int)nbm_fdiv((unsigned)rem, p.fd_tw), tx = rem - ty * p.TW;
     blk_base = (((long long)bi * p.TH + ty) * p.WP + 2 * tx) * p.C;
   }
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
     const int t = bm0 + r0 + 32 * i < p.T ? tile_of(bm0 + r0 + 32 * i) : -1;
     if (t >= 0) {
-      const int bi = t / p.THW, rem = t - bi * p.THW;
-      const int ty = rem / p.TW, tx = rem - ty * p.TW;
+      const int bi = (int)nbm_fdiv((unsigned)t, p.fd_thw), rem = t - bi * p.THW;
+      const int ty = (int)nbm_fdiv((unsigned)rem, p.fd_tw), tx = rem - ty * p.TW;
       const long long off = (((long long)bi * p.TH + ty) * p.WP + 2 * tx) * p.C - blk_base;   // rows ascend with t
       a_rel[i] = (unsigned)((off + c4 * 4) * 4);
     } else {
@@ -409,8 +410,8 @@ __global__ __launch_bounds__(256, BN == 128 ? 1 : 2) void wino23_fused_kernel(co
     const int t = bm0 + tid < p.T ? tile_of(bm0 + tid) : -1;
     long long v = -1;
     if (t >= 0) {
-      const int bi = t / p.THW, rem = t - bi * p.THW;
-      const int ty = rem / p.TW, tx = rem - ty * p.TW;
+      const int bi = (int)nbm_fdiv((unsigned)t, p.fd_thw), rem = t - bi * p.THW;
+      const int ty = (int)nbm_fdiv((unsigned)rem, p.fd_tw), tx = rem - ty * p.TW;
       const long long pix = (p.relu & 4) ? (long long)(bm0 + tid) * 4 : ((long long)bi * p.H + 2 * ty) * p.W + 2 * tx;
       v = (pix << 2) | (2 * ty + 1 < p.H ? 2 : 0) | (2 * tx + 1 < p.W ? 1 : 0);
     }
@@ -533,6 +534,7 @@ static int wino23_conv_fused_launch(const float* R, const float* U, const float*
     return NBM_EALIGN;
   WinoFusedParams p{};
   p.TH = (H + 1) >> 1; p.TW = (W + 1) >> 1; p.THW = p.TH * p.TW; p.WP = 2 * p.TW + 2;
+  p.fd_thw = nbm_fastdiv_make((unsigned)p.THW); p.fd_tw = nbm_fastdiv_make((unsigned)p.TW);
   const long long T = (long long)B * p.THW;
   // 32-bit byte offsets inside the kernel: the rows of one 128-tile block (<= 128 image rows of R apart), one row
   // combination of R behind the block base, and the whole of U
