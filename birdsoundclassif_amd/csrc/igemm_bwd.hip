@@ -61,7 +61,7 @@ enum { ABL_NO_MASK = 1, ABL_NO_RESIDUAL = 2, ABL_NO_ASCALE = 4, /* 8: was the ta
 #ifdef NBM_ABLATE_NN
 #define NBM_ABL(p, bit) (((p).ablate & (bit)) != 0)
 // per parity class (0 when not phased): cycles in prologue / K loop / epilogue, tiles (thread 0 of every workgroup; clock64)
-__device__ unsigned long long nbm_nn_dbg[20];   // [class][address arithmetic | first loads + LDS write | K loop | epilogue], [16 + class] tiles
+__device__ unsigned long long nbm_nn_dbg[24];   // [class][address arithmetic | first loads + LDS write | K loop | epilogue], [16 + class] tiles; [20..23] weight-gradient kernel: prologue | K loop | epilogue (atomics) | tiles
 #define NBM_DBG_T(var) const long long var = clock64()
 #define NBM_DBG_ADD(slot, v) do { if (threadIdx.x == 0) atomicAdd(&nbm_nn_dbg[slot], (unsigned long long)(v)); } while (0)
 #else
@@ -464,6 +464,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(const BwdParams p) {
   float* As = lds;                    // [2][32][AP]   G tile:  pixel-major, n contiguous
   float* Bs = lds + 2 * BK * AP;      // [2][32][BP]   X tile:  pixel-major, c contiguous
 
+  NBM_DBG_T(dbg_t0);
   const int wg = xcd_tile(gridDim.x, blockIdx.x);
   const int tile_m = wg / p.n_tiles, tile_n = wg - tile_m * p.n_tiles;
   const int bm0 = tile_m * BM;                      // n0
@@ -671,6 +672,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(const BwdParams p) {
     mfma_group(Ab, Bb, 2);
     mfma_group(Ab, Bb, 3);
   };
+  NBM_DBG_T(dbg_t1);
   {
     using T = std::true_type;
     using F = std::false_type;
@@ -679,6 +681,7 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(const BwdParams p) {
     if (nk >= 2) { k_step(kt, T{}, F{}); ++kt; }
     k_step(kt, F{}, F{});
   }
+  NBM_DBG_T(dbg_t2);
 
   if (do_bias) {
     const int n = bm0 + (tid % BM);
@@ -702,15 +705,19 @@ __global__ __launch_bounds__(256, 2) void igemm_tn_kernel(const BwdParams p) {
         atomicAdd(og + (long long)n * p.out_ld + col, v);
       }
   }
+#ifdef NBM_ABLATE_NN
+  __syncthreads();
+  NBM_DBG_ADD(20, dbg_t1 - dbg_t0); NBM_DBG_ADD(21, dbg_t2 - dbg_t1); NBM_DBG_ADD(22, clock64() - dbg_t2); NBM_DBG_ADD(23, 1);
+#endif
 }
 
 }  // namespace
 
 #ifdef NBM_ABLATE_NN
 // timing-only build: read and clear the per-class cycle counters of igemm_nn_kernel (scripts/dgrad_ablate.py)
-extern "C" int nbm_nn_dbg_read(unsigned long long* host20) {
-  unsigned long long z[20] = {0};
-  if (hipMemcpyFromSymbol(host20, HIP_SYMBOL(nbm_nn_dbg), sizeof(z)) != hipSuccess) return -4;
+extern "C" int nbm_nn_dbg_read(unsigned long long* host24) {
+  unsigned long long z[24] = {0};
+  if (hipMemcpyFromSymbol(host24, HIP_SYMBOL(nbm_nn_dbg), sizeof(z)) != hipSuccess) return -4;
   if (hipMemcpyToSymbol(HIP_SYMBOL(nbm_nn_dbg), z, sizeof(z)) != hipSuccess) return -4;
   return NBM_OK;
 }
@@ -830,6 +837,9 @@ extern "C" int nbm_conv_wgrad(const nbm_bwd_desc* d, void* stream) {
   // round among those with >= 8 K-steps per split and <= 16 rounds; ties go to fewer splits (fewer atomics).
   const int tiles = p.m_tiles * p.n_tiles * d->groups;
   const int max_splits = (p.M + 8 * BK - 1) / (8 * BK);
+  // (512 = 256 CUs x the two workgroups of the 128 x 128 instantiation.  The narrower instantiations hold 3 or 4 per CU; sizing the rounds
+  // for 768 / 1024 was measured in round 5 and changes nothing -- 2.161 vs 2.155 ms on layer1's 3x3: a CU with fewer workgroups left runs
+  // them faster, the matrix pipe is what they share -- scripts/wgrad_cycles.py)
   const int slots = 512;
   int splits = 1;
   double best = -1.0;
