@@ -894,8 +894,8 @@ def main(argv=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # roofline of the dominant kernel = igemm_kernel<128,128,64,64,A_FAST,EPI_STD,2> (csrc/igemm.hip), the deep-K instantiation of
-    # the implicit-GEMM kernel: every launch of a step that nbm_gemm_conv dispatches to it -- the ResNet 1x1 / strided 3x3 layers
+    # roofline of the dominant kernel = igemm_h16_kernel<3> (csrc/igemm_h16.hip; round 5: the half-step form of
+    # igemm_kernel<128,128,64,64,A_FAST,EPI_STD,2>, csrc/igemm.hip), the deep-K kernel of the implicit GEMM: every launch of a step that nbm_gemm_conv dispatches to it -- the ResNet 1x1 / strided 3x3 layers
     # with K > 256, the attention GEMMs, the FPN laterals of levels 1-4 and the launches of the composed RPN reader (FPN levels 0 and
     # 1 on demand).  `achieved` = MFMA FLOPs these launches EXECUTE (2 * M * N * K * groups) over their HIP-event
     # time on the launch stream inside the timed loop; avg_launch_ms is what rocprofv3 --stats reports as the kernel's average.
@@ -925,8 +925,9 @@ def main(argv=None):
             slot[1] += g
             slot[2] += 1
         top = sorted(big.items(), key=lambda kv: -kv[1][0])[:4]
-        roof = {'bound': 'mfma', 'kernel': 'igemm_kernel<128,128,64,64,A_FAST,EPI_STD,STAGES=2>: fp32-MFMA implicit GEMM, deep-K '
-                                           'instantiation (128x128x32 tiles, double-buffered LDS, fused epilogue); all its launches of a '
+        roof = {'bound': 'mfma', 'kernel': 'igemm_h16_kernel<3> (csrc/igemm_h16.hip): fp32-MFMA implicit GEMM, the deep-K kernel (128x128 tiles, '
+                                           'double-buffered half-step LDS stages, three workgroups per CU, fused epilogue; the same products in the same '
+                                           'order as igemm_kernel<128,128,64,64,A_FAST,EPI_STD,2>, which NBM_H16=0 selects); all its launches of a '
                                            'step: ResNet 1x1 / strided 3x3 layers with K > 256, attention, FPN laterals, the 5x5 / stride-S '
                                            'launches of the RPN reader composed with the output convolution of the on-demand FPN levels (DESIGN 4f)',
                 'achieved': ach, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP32_MFMA_PEAK_TFLOPS,

@@ -590,6 +590,14 @@ extern "C" int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream) {
     static const int split_min_nk = getenv("NBM_SPLIT_MIN_NK") ? atoi(getenv("NBM_SPLIT_MIN_NK")) : 9;      // experiment switch (>= 3)
     if (split_env && split_env[0] == '1' && fast && p.vec_epi && p.nk >= (split_min_nk < 3 ? 3 : split_min_nk) && d->kh * d->kw < 63)
       return nbm_igemm::split_launch(p, d->groups, st);
+    // deep K: half-step LDS stages, three workgroups per CU (igemm_h16.hip: the same products in the same order as the two-stage kernel below,
+    // 2-14 % faster launch by launch at B = 64, scripts/h16_probe.py).  NBM_H16 = 0: the two-stage kernel; 3 (default) / 4: workgroups per CU;
+    // from NBM_H16_MIN_NK K-steps up (default 9: up to 8 the single-stage kernel below stays)
+    const char* h16_env = getenv("NBM_H16");                   // read per call: the parity test flips it inside one process
+    const int h16 = h16_env ? atoi(h16_env) : 3;
+    const char* h16_min_env = getenv("NBM_H16_MIN_NK");
+    const int h16_min = h16_min_env ? atoi(h16_min_env) : 9;
+    if (h16 && fast && p.vec_epi && p.nk >= h16_min && d->kh * d->kw < 63) return nbm_igemm::h16_launch(p, d->groups, h16, st);
     // short K and a 16-byte epilogue: the three-workgroups-per-CU variant (see the template comment)
     static const int shortk_max = getenv("NBM_SHORTK_MAX") ? atoi(getenv("NBM_SHORTK_MAX")) : 8;   // 0 disables
     if (fast && p.vec_epi && p.nk <= shortk_max)

@@ -36,4 +36,8 @@ struct IgemmParams {
 // igemm_split.hip: 256 x 128 tiles on the bf16 matrix pipe (fast gather, 16-byte epilogue, N > 64, nk > 8 only; the caller checks)
 int split_launch(const IgemmParams& p, int groups, hipStream_t st);
 
+// igemm_h16.hip: the 128 x 128 tile with half-step LDS stages, `occ` (3 or 4) workgroups per CU (fast gather, 16-byte epilogue, N > 64; same bits as
+// igemm_kernel<128,128,...>)
+int h16_launch(const IgemmParams& p, int groups, int occ, hipStream_t st);
+
 }  // namespace nbm_igemm

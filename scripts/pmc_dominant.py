@@ -27,7 +27,7 @@ f, nf, grid = per_launch(dF, 'FETCH_SIZE')
 w, nw, _ = per_launch(dW, 'WRITE_SIZE')
 mf, _, _ = per_launch(dM, 'SQ_VALU_MFMA_BUSY_CYCLES')
 ga, _, _ = per_launch(dM, 'GRBM_GUI_ACTIVE')
-res = {'kernel': sub, 'kernel_family': 'igemm deep-K' if 'igemm_kernel<128, 128, 64, 64, 0, 0, 2, false>' in sub else sub.split('<')[0], 'what': label, 'launches': mode, 'lazy_finest': True, 'launches_averaged': nf, 'grid_size_threads': grid, 'executed_GFLOP': gflop,
+res = {'kernel': sub, 'kernel_family': 'igemm deep-K' if ('igemm_kernel<128, 128, 64, 64, 0, 0, 2, false>' in sub or 'igemm_h16_kernel' in sub) else sub.split('<')[0], 'what': label, 'launches': mode, 'lazy_finest': True, 'launches_averaged': nf, 'grid_size_threads': grid, 'executed_GFLOP': gflop,
        'FETCH_SIZE_KB_per_launch': f, 'WRITE_SIZE_KB_per_launch': w,
        'fetch_bytes_raw': f * 1024, 'fetch_bytes_corrected_x2': 2 * f * 1024, 'write_bytes': w * 1024,
        'traffic_bytes_per_launch': 2 * f * 1024 + w * 1024,

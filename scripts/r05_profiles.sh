@@ -47,7 +47,7 @@ if [ $PART = all ] || [ $PART = bench ]; then
 fi
 if [ $PART = all ] || [ $PART = pmc_detect ]; then
   GF=$(python3 -c "import json,sys; print(json.loads(open('$O/bench_default.json').read().strip().splitlines()[-1])['roofline']['executed_GFLOP_per_launch'])" 2>/dev/null || echo 0)
-  python3 $R/scripts/pmc_dominant.py $O/pmc_dominant.json "igemm_kernel<128, 128, 64, 64, 0, 0, 2, false>" $GF $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_MFMA "igemm_kernel<128,128,64,64,A_FAST,EPI_STD,2>, mean over all launches of the B = 64 detect step (FPN levels 0 and 1 on demand)" all > /dev/null
+  python3 $R/scripts/pmc_dominant.py $O/pmc_dominant.json "igemm_h16_kernel" $GF $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_MFMA "igemm_h16_kernel<3> (the deep-K kernel; half-step form of igemm_kernel<128,128,64,64,A_FAST,EPI_STD,2>), mean over all launches of the B = 64 detect step (FPN levels 0 and 1 on demand)" all > /dev/null
   python3 $R/scripts/pmc_dominant.py $O/pmc_split.json "igemm_split_kernel" 0 $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_MFMA "igemm_split_kernel<REM> (opt-in NBM_SPLIT_BF16=1: the split_bf16 leg of the same command), mean over all its launches of B = 64 detect steps" all > /dev/null
   python3 $R/scripts/pmc_dominant.py $O/pmc_fused.json "wino23_fused_kernel" 0 $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_MFMA "wino23_fused_kernel (both block shapes: 128 x 128 and 96 x 128), mean over all launches of the B = 64 detect step" all > /dev/null
   for d in pmc_FETCH_SIZE pmc_WRITE_SIZE pmc_MFMA; do

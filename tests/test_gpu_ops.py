@@ -348,6 +348,61 @@ def test_c_abi_from_plain_c(tmp_path):
     assert 'max |err|' in out.stdout
 
 
+@pytest.mark.parametrize('cfg', [
+    # B, H, W, Cin, Cout, k, stride, pad, groups      (K / 32 >= 9: the launches the deep-K kernel gets)
+    (2, 24, 32, 512, 256, 1, 1, 0, 1),
+    (3, 17, 23, 1024, 200, 1, 1, 0, 1),        # ragged M (1173 rows) and N
+    (2, 21, 19, 128, 128, 3, 2, 1, 1),         # taps at the image border, stride 2
+    (2, 12, 14, 512, 1024, 1, 2, 0, 1),        # 1x1 stride 2
+    (1, 25, 33, 384, 256, 3, 1, 1, 1),         # 3x3 stride 1
+    (1, 9, 11, 64, 192, 5, 4, 2, 1),           # 5x5 / stride 4 / pad 2 (the composed RPN reader's launches)
+    (1, 1, 300, 320, 96, 1, 1, 0, 3),          # grouped plain GEMM (three groups of [300 x 320] x [96 x 320]^T)
+])
+def test_half_step_kernel_gives_the_bits_of_the_two_stage_kernel(cfg, monkeypatch):
+    """csrc/igemm_h16.hip (half-step LDS stages, three workgroups per CU; library default for deep K) against igemm_kernel<128,128,...>
+    (NBM_H16=0): the same products in the same order -- bit for bit, with every epilogue operand in play -- and a convolution (float64)."""
+    B, H, W, Ci, Co, k, st, pad, G = cfg
+
+    def nrm(key, *shape, scale=1.0):
+        return torch.from_numpy((synth.normal((key, cfg), int(np.prod(shape))) * scale).astype(np.float32).reshape(shape))
+
+    if G == 1:
+        x = F.relu(nrm('hx', B, Ci, H, W))
+        w = nrm('hw', Co, Ci, k, k, scale=(2.0 / (Ci * k * k)) ** 0.5)
+        sc, sh = 1 + 0.1 * nrm('hs', Co), 0.1 * nrm('hb', Co)
+        ref = F.conv2d(x.double(), w.double(), stride=st, padding=pad)
+        res = nrm('hr', *ref.shape)
+        mask = nrm('hm', *ref.shape)
+        ref = F.relu(ref * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1) + res.double()) * (mask > 0)
+        xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+        wd = w.permute(0, 2, 3, 1).reshape(Co, -1).contiguous().cuda()
+        rd, md = res.permute(0, 2, 3, 1).contiguous().cuda(), mask.permute(0, 2, 3, 1).contiguous().cuda()
+        Ho, Wo = ref.shape[2:]
+
+        def run():
+            y = torch.empty((B, Ho, Wo, Co), device='cuda')
+            ops.gemm_conv(xd, wd, y, B=B, H=H, W=W, Cin=Ci, N=Co, kh=k, kw=k, stride=st, pad=pad, Ho=Ho, Wo=Wo, w_ld=wd.shape[1],
+                          scale=sc.cuda(), shift=sh.cuda(), residual=rd, act=ops.ACT_RELU, mask=md, mask_ld=Co)
+            return y
+        ref = ref.permute(0, 2, 3, 1)
+    else:
+        a = nrm('ga', G, W, Ci).cuda()
+        bm = nrm('gb', G, Co, Ci, scale=(1.0 / Ci) ** 0.5).cuda()
+        ref = torch.einsum('gmk,gnk->gmn', a.double().cpu(), bm.double().cpu())
+
+        def run():
+            return ops.bgemm_nt(a, bm)
+    outs = {}
+    for mode in ('0', '3'):
+        monkeypatch.setenv('NBM_H16', mode)
+        outs[mode] = run()
+    monkeypatch.delenv('NBM_H16')
+    default = run()
+    assert torch.equal(outs['0'], outs['3']) and torch.equal(default, outs['3']), cfg
+    err = float((outs['3'].cpu().double() - ref).abs().max())
+    assert err <= 2e-5 * (1 + float(ref.abs().max())), (cfg, err)
+
+
 def test_winograd_fused_block_shapes_give_the_same_bits(monkeypatch):
     """The fused F(2x2,3x3) kernel in its 96-row block shape (chosen for dense launches whose 128-row blocks leave the last round of
     workgroups half empty, csrc/wino_fused.hip) against the 128-row shape: every output sums its planes and K-steps in the same order, so
