@@ -87,13 +87,21 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsi
 // bottlenecks, whose time is the dX / shortcut-gradient / ReLU-mask traffic of the epilogue, not MFMA): one LDS buffer (35 KB)
 // and an epilogue staged in two halves, so THREE workgroups fit a CU and their load / compute / store phases overlap -- the same
 // trade as igemm.hip's STAGES = 1 forward variant.
-template <int BN, int STAGES = 2>
-__global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(const BwdParams p) {
+// HS (round 5, STAGES = 2 only): HALF-STEP LDS stages like igemm_h16.hip -- a stage holds 16 of the 32 K values of a step (A rows of 20
+// floats, 16 B rows), the epilogue goes out in two halves like the single-stage form's, and THREE workgroups share a CU.  Half-step h
+// holds k = 8h .. 8h + 7 (A columns / B rows 0..7, fed by lanes 0..31) and k = 16 + 8h .. (columns / rows 8..15, lanes 32..63): its two
+// MFMA groups are groups 2h, 2h + 1 of the full step -- the same products in the same order, the same bits.
+template <int BN, int STAGES = 2, bool HS = false>
+__global__ __launch_bounds__(256, (STAGES == 1 || HS) ? 3 : 2) void igemm_nn_kernel(const BwdParams p) {
+  static_assert(!HS || STAGES == 2, "half-step stages are a form of the two-stage pipeline");
   constexpr int BM = 128, WM = 64, WN = BN / 2, MT = 2, NT = WN / 32;
   constexpr int BP = BN + 4;                                   // K-major B tile pitch
-  __shared__ __attribute__((aligned(16))) float lds[STAGES * (BM * PITCH + BK * BP)];
+  constexpr int KS = HS ? 16 : BK;                             // K values per LDS stage
+  constexpr int AP = HS ? 20 : PITCH;                          // A tile pitch (16 + 4 / 32 + 4 floats)
+  constexpr int NG = KS / 8;                                   // MFMA groups (4 k-pairs each) per stage
+  __shared__ __attribute__((aligned(16))) float lds[STAGES * (BM * AP + KS * BP)];
   float* As = lds;
-  float* Bs = lds + STAGES * BM * PITCH;
+  float* Bs = lds + STAGES * BM * AP;
   if constexpr (STAGES == 2) nbm_stagger_priority();
 
   NBM_DBG_T(dbg_t0);
@@ -138,11 +146,14 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
     return ok;
   };
 
-  // A staging: 128 rows x 8 chunks of 16 B.  Row i gathers G at (b, fy - r/st, fx - s/st) for the taps whose parity
+  // A staging: 128 rows x 8 (half-step: 4) chunks of 16 B.  Row i gathers G at (b, fy - r/st, fx - s/st) for the taps whose parity
   // matches; offsets are relative to a block-uniform base shifted by the largest tap so that they stay non-negative.
-  const int c4 = tid & 7, r0 = tid >> 3;
-  unsigned a_rel[4];
-  unsigned long long a_taps[4];
+  constexpr int ACH = KS / 4, ARPP = 256 / ACH, AR = BM / ARPP;      // chunks per row, rows per pass, rows per thread
+  const int c4 = tid % ACH, r0 = tid / ACH;
+  // first K value (of the 32 of a step) of this thread's chunk: 4 c4, or -- half-step -- 0, 4, 16, 20 (+ 8 h)
+  const int koff = HS ? (c4 < 2 ? 4 * c4 : 16 + 4 * (c4 - 2)) : 4 * c4;
+  unsigned a_rel[AR];
+  unsigned long long a_taps[AR];
   long long blk_base;
   {
     int b, iy, ix;
@@ -153,13 +164,13 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
     blk_base = ((long long)(b * p.Ho + divst(iy + p.pad)) * p.Wo) * p.g_ld;
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < AR; ++i) {
     int b, iy, ix;
-    const bool ok = decode(q0 + r0 + 32 * i, b, iy, ix);
+    const bool ok = decode(q0 + r0 + ARPP * i, b, iy, ix);
     const int fy = divst(iy + p.pad), fx = divst(ix + p.pad);
     const int py = (iy + p.pad) - fy * st, px = (ix + p.pad) - fx * st;
     const long long base = ((long long)(b * p.Ho + fy) * p.Wo + fx) * p.g_ld;
-    a_rel[i] = ((unsigned)(base - blk_base) + c4 * 4) * 4u;
+    a_rel[i] = ((unsigned)(base - blk_base) + koff) * 4u;
     // taps that reach this pixel: filter rows r with r = py (mod stride) whose G row fy - r / stride exists, likewise columns, then their
     // product -- selects only (as a kh x kw nest of data-dependent branches this was the longest part of the tile prologue: 28 k of the
     // 37 k cycles in front of the first load of a 3x3 tile, cycle counters of the `ablate_nn` build, round 5)
@@ -180,31 +191,36 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
   const __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc(gg + blk_base - maxoff, 0x7ffffff0u);
 
   // B staging (K-major): 32 rows x BN/4 chunks; thread -> rows rk0 + (256/(BN/4)) * i
-  constexpr int BCH = BN / 4, BROWS = 256 / BCH, BPASS = BK / BROWS;
+  constexpr int BCH = BN / 4, BROWS = 256 / BCH, BPASS = KS / BROWS;
   const int bc = tid % BCH, rk0 = tid / BCH;
   unsigned b_rel[BPASS];
 #pragma unroll
-  for (int i = 0; i < BPASS; ++i)
-    b_rel[i] = (bn0 + bc * 4 < p.Cin) ? (unsigned)((rk0 + BROWS * i) * p.w_row + bn0 + bc * 4) * 4u : OOB;
+  for (int i = 0; i < BPASS; ++i) {
+    const int j = rk0 + BROWS * i;                               // LDS row; half-step: rows 8..15 hold k = 16 + (row - 8) (+ 8 h)
+    const int kk = HS ? (j < 8 ? j : j + 8) : j;
+    b_rel[i] = (bn0 + bc * 4 < p.Cin) ? (unsigned)(kk * p.w_row + bn0 + bc * 4) * 4u : OOB;
+  }
   // rows n >= N fall outside the resource and read zeros
   const long long wbytes = (long long)p.N * p.w_row * 4;
   const __amdgpu_buffer_rsrc_t rsrc_b = make_rsrc(wg_, (unsigned)(wbytes < 0x7ffffff0ll ? wbytes : 0x7ffffff0ll));
 
-  f32x4 ra[4], rb[BPASS], rsc = {1.f, 1.f, 1.f, 1.f};
-  int cur_r = r_begin, cur_s = s_begin, cur_n0 = 0;
+  f32x4 ra[AR], rb[BPASS], rsc = {1.f, 1.f, 1.f, 1.f};
+  int cur_r = r_begin, cur_s = s_begin, cur_n0 = 0, cur_h = 0;
 
   int abl_loads_done = 0;
   auto load_tiles = [&]() {
     if (NBM_ABL(p, ABL_NO_LOADS) && abl_loads_done >= 2) return;           // operands stay what the first two loads fetched
     ++abl_loads_done;
     const int tap = cur_r * p.kw + cur_s;
-    const unsigned a_soff = (unsigned)((maxoff - ((long long)divst(cur_r) * p.Wo + divst(cur_s)) * p.g_ld + cur_n0) * 4);
-    const unsigned b_soff = (unsigned)(((long long)cur_n0 * p.w_row + (long long)tap * p.Cin) * 4);
+    const int n0h = cur_n0 + 8 * cur_h;                                    // (half-step: the second half starts 8 K values further)
+    const unsigned a_soff = (unsigned)((maxoff - ((long long)divst(cur_r) * p.Wo + divst(cur_s)) * p.g_ld + n0h) * 4);
+    const unsigned b_soff = (unsigned)(((long long)n0h * p.w_row + (long long)tap * p.Cin) * 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = buf_load4(rsrc_a, ((a_taps[i] >> tap) & 1ull) ? a_rel[i] : OOB, a_soff);
+    for (int i = 0; i < AR; ++i) ra[i] = buf_load4(rsrc_a, ((a_taps[i] >> tap) & 1ull) ? a_rel[i] : OOB, a_soff);
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) rb[i] = buf_load4(rsrc_b, b_rel[i], b_soff);
-    if (p.a_scale && !NBM_ABL(p, ABL_NO_ASCALE)) rsc = *reinterpret_cast<const f32x4*>(p.a_scale + cur_n0 + c4 * 4);
+    if (p.a_scale && !NBM_ABL(p, ABL_NO_ASCALE)) rsc = *reinterpret_cast<const f32x4*>(p.a_scale + n0h + koff);
+    if (HS && (cur_h ^= 1) != 0) return;                                   // the other half of the same (tap, 32-wide K) step comes next
     cur_s += t_step;
     if (cur_s >= p.kw) { cur_s = s_begin; cur_r += t_step; if (cur_r >= p.kh) { cur_r = r_begin; cur_n0 += BK; } }
   };
@@ -213,14 +229,14 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
     if (NBM_ABL(p, ABL_NO_LDS_WRITES) && abl_writes_done >= 2) return;
     ++abl_writes_done;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < AR; ++i) {
       f32x4 v = ra[i];
       if (!NBM_ABL(p, ABL_NO_ASCALE)) { v[0] *= rsc[0]; v[1] *= rsc[1]; v[2] *= rsc[2]; v[3] *= rsc[3]; }
-      *reinterpret_cast<f32x4*>(As + (buf * BM + r0 + 32 * i) * PITCH + c4 * 4) = v;
+      *reinterpret_cast<f32x4*>(As + (buf * BM + r0 + ARPP * i) * AP + c4 * 4) = v;
     }
 #pragma unroll
     for (int i = 0; i < BPASS; ++i)
-      *reinterpret_cast<f32x4*>(Bs + (buf * BK + rk0 + BROWS * i) * BP + bc * 4) = rb[i];
+      *reinterpret_cast<f32x4*>(Bs + (buf * KS + rk0 + BROWS * i) * BP + bc * 4) = rb[i];
   };
 
   f32x16 acc[MT][NT];
@@ -235,7 +251,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
     f32x4 a[MT];
     float b[NT][4];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * PITCH + q * 4);
+    for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * AP + q * 4);
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -253,12 +269,13 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
   const int n_s = s_begin < p.kw ? (p.kw - s_begin + t_step - 1) / t_step : 0;
   const int nk = ((p.N + BK - 1) / BK) * n_r * n_s;          // 0: no tap reaches this parity class, dX = residual
   NBM_DBG_T(dbg_t0b);
+  const int n_st = HS ? 2 * nk : nk;                             // LDS stages of the K loop
   if constexpr (STAGES == 2) {
-    if (nk > 0) {
+    if (n_st > 0) {
       load_tiles();
       store_lds(0);
     }
-    if (nk > 1) load_tiles();
+    if (n_st > 1) load_tiles();
   }
 
   NBM_DBG_T(dbg_t1);
@@ -266,15 +283,15 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
     constexpr bool STORE = decltype(store_c)::value, LOAD = decltype(load_c)::value;
     const int cur = kt & 1;
     __syncthreads();
-    const float* Ab = As + (cur * BM + wm0 + lrow) * PITCH + lh * 16;
-    const float* Bb = Bs + (cur * BK + lh * 16) * BP + wn0 + lrow;
+    const float* Ab = As + (cur * BM + wm0 + lrow) * AP + lh * (KS / 2);
+    const float* Bb = Bs + (cur * KS + lh * (KS / 2)) * BP + wn0 + lrow;
     mfma_group(Ab, Bb, 0);
     if constexpr (STORE) {
       store_lds(cur ^ 1);
       __builtin_amdgcn_sched_group_barrier(0x100, MT + 4 * NT, 0);
 #pragma unroll
-      for (int z = 0; z < 4 + BPASS; ++z) {
-        __builtin_amdgcn_sched_group_barrier(0x008, (4 * MT * NT) / (4 + BPASS), 0);
+      for (int z = 0; z < AR + BPASS; ++z) {
+        __builtin_amdgcn_sched_group_barrier(0x008, (4 * MT * NT) / (AR + BPASS), 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
         __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
       }
@@ -285,23 +302,25 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
       load_tiles();
       __builtin_amdgcn_sched_group_barrier(0x100, MT + 4 * NT, 0);
 #pragma unroll
-      for (int z = 0; z < 4 + BPASS; ++z) {
-        __builtin_amdgcn_sched_group_barrier(0x008, (4 * MT * NT) / (4 + BPASS), 0);
+      for (int z = 0; z < AR + BPASS; ++z) {
+        __builtin_amdgcn_sched_group_barrier(0x008, (4 * MT * NT) / (AR + BPASS), 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    mfma_group(Ab, Bb, 2);
-    mfma_group(Ab, Bb, 3);
+    if constexpr (NG == 4) {
+      mfma_group(Ab, Bb, 2);
+      mfma_group(Ab, Bb, 3);
+    }
   };
   if constexpr (STAGES == 2) {
     using T = std::true_type;
     using F = std::false_type;
     int kt = 0;
-    for (; kt + 2 < nk; ++kt) k_step(kt, T{}, T{});
-    if (nk >= 2) { k_step(kt, T{}, F{}); ++kt; }
-    if (nk >= 1) k_step(kt, F{}, F{});
+    for (; kt + 2 < n_st; ++kt) k_step(kt, T{}, T{});
+    if (n_st >= 2) { k_step(kt, T{}, F{}); ++kt; }
+    if (n_st >= 1) k_step(kt, F{}, F{});
   } else {
     // short K: load -> LDS -> MFMA, the next tile's loads in flight during the MFMAs; the other two workgroups of the CU cover
     // the barriers
@@ -348,9 +367,9 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void igemm_nn_kernel(cons
   if (p.vec_epi) {
     // accumulator tile -> LDS -> 16-byte residual / mask loads and stores (see igemm.hip)
     constexpr int CP = BN + 4;
-    constexpr int HALVES = STAGES == 1 ? BM / WM : 1;          // the single-stage LDS holds WM rows of the tile at a time
+    constexpr int HALVES = (STAGES == 1 || HS) ? BM / WM : 1;  // the single-stage / half-step LDS holds WM rows of the tile at a time
     constexpr int HROWS = BM / HALVES;
-    static_assert(HROWS * CP <= STAGES * (BM * PITCH + BK * BP), "epilogue tile must fit the operand buffers");
+    static_assert(HROWS * CP <= STAGES * (BM * AP + KS * BP), "epilogue tile must fit the operand buffers");
     float* Cs = lds;
     constexpr int CH = BN / 4, RPP = 256 / CH;
     const int cc = tid % CH, rr = tid / CH;
@@ -801,15 +820,21 @@ extern "C" int nbm_conv_dgrad(const nbm_bwd_desc* d, void* stream) {
   // K = 576 (layer1's 3x3 64 -> 64 @94x256 at B = 128: 2.39 -> 2.15 ms, round 5)
   const int shortk_lim = d->Cin <= 64 && shortk_max ? (shortk_max > 20 ? shortk_max : 20) : shortk_max;
   const bool shortk = p.vec_epi && (p.phased ? ph_max <= shortk_ph : ((d->N + BK - 1) / BK) * d->kh * d->kw <= shortk_lim);
+  // deep K: the half-step form of the two-stage kernel (three workgroups per CU, same bits; NBM_NN_H16=0: the two-stage kernel).  Read per
+  // call: the parity test flips it inside one process.
+  const char* hs_env = getenv("NBM_NN_H16");
+  const bool hs = !(hs_env && hs_env[0] == '0') && p.vec_epi;
   if (d->Cin > 64) {
     p.n_tiles = (d->Cin + 127) / 128;
     const dim3 grid(p.m_tiles * p.n_tiles, 1, d->groups);
     if (shortk) hipLaunchKernelGGL((igemm_nn_kernel<128, 1>), grid, dim3(256), 0, st, p);
+    else if (hs) hipLaunchKernelGGL((igemm_nn_kernel<128, 2, true>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((igemm_nn_kernel<128, 2>), grid, dim3(256), 0, st, p);
   } else {
     p.n_tiles = 1;
     const dim3 grid(p.m_tiles, 1, d->groups);
     if (shortk) hipLaunchKernelGGL((igemm_nn_kernel<64, 1>), grid, dim3(256), 0, st, p);
+    else if (hs) hipLaunchKernelGGL((igemm_nn_kernel<64, 2, true>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((igemm_nn_kernel<64, 2>), grid, dim3(256), 0, st, p);
   }
   return nbm_launch_status();

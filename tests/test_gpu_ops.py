@@ -403,6 +403,49 @@ def test_half_step_kernel_gives_the_bits_of_the_two_stage_kernel(cfg, monkeypatc
     assert err <= 2e-5 * (1 + float(ref.abs().max())), (cfg, err)
 
 
+@pytest.mark.parametrize('cfg', [
+    # B, H, W, Cin (channels of dX), N (channels of G), k, stride     -- launches the two-stage data-gradient kernel used to get
+    (2, 24, 32, 256, 1024, 1, 1),          # deep 1x1, 128-wide tile
+    (3, 17, 23, 200, 512, 1, 1),           # ragged rows (1173) and columns
+    (1, 25, 33, 256, 384, 3, 1),           # 3x3 stride 1
+    (2, 21, 19, 256, 256, 3, 2),           # stride 2 by parity class, odd map, 8..32 steps per class
+    (2, 20, 24, 64, 96, 3, 1),             # 64-wide tile beyond the single-stage limit (27 steps)
+    (2, 16, 20, 48, 704, 1, 1),            # 64-wide tile, 22 steps, ragged columns
+])
+def test_half_step_data_gradient_gives_the_bits_of_the_two_stage_kernel(cfg, monkeypatch):
+    """`igemm_nn_kernel<BN, 2, true>` (half-step LDS stages, three or more workgroups per CU; library default for the deep-K data
+    gradients) against the two-stage kernel (NBM_NN_H16=0) with every epilogue operand in play (BatchNorm scale on G, shortcut gradient,
+    ReLU mask): the same products in the same order, bit for bit -- and the gradient of a convolution (float64)."""
+    B, H, W, Ci, N, k, st = cfg
+    pad = k // 2
+
+    def nrm(key, *shape, scale=1.0):
+        return torch.from_numpy((synth.normal((key, cfg), int(np.prod(shape))) * scale).astype(np.float32).reshape(shape))
+
+    x = nrm('dx', B, Ci, H, W).double().requires_grad_(True)
+    w = nrm('dw', N, Ci, k, k, scale=(2.0 / (Ci * k * k)) ** 0.5)
+    sc = 1 + 0.1 * nrm('ds', N)
+    y = F.conv2d(x, w.double(), stride=st, padding=pad) * sc.double().view(1, -1, 1, 1)
+    g = nrm('dg', *y.shape, scale=0.1)
+    y.backward(g.double())
+    res, mask = nrm('dr', B, Ci, H, W), nrm('dm', B, Ci, H, W)
+    ref = ((x.grad + res.double()) * (mask > 0)).permute(0, 2, 3, 1)
+    gd = g.permute(0, 2, 3, 1).reshape(-1, N).contiguous().cuda()
+    wk = w.permute(0, 2, 3, 1).reshape(N, -1).contiguous().cuda()
+    rd, md = res.permute(0, 2, 3, 1).contiguous().cuda(), mask.permute(0, 2, 3, 1).contiguous().cuda()
+    outs = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('NBM_NN_H16', mode)
+        out = torch.empty((B, H, W, Ci), device='cuda')
+        ops.conv_dgrad(gd, wk, out, B=B, H=H, W=W, Cin=Ci, N=N, kh=k, kw=k, stride=st, pad=pad, g_ld=N, w_ld=wk.shape[1], a_scale=sc.cuda(),
+                       residual=rd, mask=md)
+        outs[mode] = out
+    monkeypatch.delenv('NBM_NN_H16')
+    assert torch.equal(outs['0'], outs['1']), cfg
+    err = float((outs['1'].cpu().double() - ref).abs().max())
+    assert err <= 2e-5 * (1 + float(ref.abs().max())), (cfg, err)
+
+
 def test_winograd_fused_block_shapes_give_the_same_bits(monkeypatch):
     """The fused F(2x2,3x3) kernel in its 96-row block shape (chosen for dense launches whose 128-row blocks leave the last round of
     workgroups half empty, csrc/wino_fused.hip) against the 128-row shape: every output sums its planes and K-steps in the same order, so
