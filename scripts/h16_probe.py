@@ -30,7 +30,7 @@ for label, H, W, Cin, N, k, st, res, relu, b1 in SHAPES:
     r = torch.randn(Bn, Ho, Wo, N, device='cuda') if res else None
     gf = 2.0 * Bn * Ho * Wo * N * k * k * Cin / 1e9
     outs, cells = [], []
-    for mode in ('0', '3'):
+    for mode in ('0', os.environ.get('H16_PROBE_MODE', '3')):
         os.environ['NBM_H16'] = mode
         f = lambda: ops.conv2d(x, w, k, k, st, k // 2, scale=sc, shift=sh, residual=r, act=ops.ACT_RELU if relu else ops.ACT_NONE)
         outs.append(f())
