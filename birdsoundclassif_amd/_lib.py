@@ -30,7 +30,7 @@ class GemmDesc(C.Structure):
                 ('up', C.c_void_p), ('up_H', C.c_int), ('up_W', C.c_int),
                 ('rows', C.c_void_p), ('rows_blocks', C.c_void_p),
                 ('rows_mode', C.c_int), ('rows_count', C.c_int), ('rows_TH', C.c_int), ('rows_TW', C.c_int),
-                ('mask', C.c_void_p), ('mask_ld', C.c_int)]
+                ('mask', C.c_void_p), ('mask_ld', C.c_int), ('bits_out', C.c_void_p)]
 
 
 class RoiDesc(C.Structure):
@@ -58,7 +58,8 @@ class BwdDesc(C.Structure):
                 ('B', C.c_int), ('H', C.c_int), ('W', C.c_int), ('Cin', C.c_int), ('N', C.c_int),
                 ('kh', C.c_int), ('kw', C.c_int), ('stride', C.c_int), ('pad', C.c_int), ('Ho', C.c_int), ('Wo', C.c_int),
                 ('g_ld', C.c_int), ('w_ld', C.c_int), ('x_ld', C.c_int), ('out_ld', C.c_int), ('res_ld', C.c_int),
-                ('mask_ld', C.c_int), ('alpha', C.c_float), ('bias_grad', C.c_void_p), ('residual2', C.c_void_p), ('res2_ld', C.c_int)]
+                ('mask_ld', C.c_int), ('alpha', C.c_float), ('bias_grad', C.c_void_p), ('residual2', C.c_void_p), ('res2_ld', C.c_int),
+                ('mask_bits', C.c_void_p)]
 
 
 _P, _I, _L, _F, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64

@@ -332,6 +332,7 @@ __global__ __launch_bounds__(256, BM > 128 ? 1 : STAGES == 1 ? 3 : 2) void igemm
 struct StreamParams {
   const float* x; const float* w; float* y; const float* scale; const float* shift; const float* residual;
   int M, x_ld, w_ld, y_ld, res_ld, m_tiles; float alpha; int act;
+  unsigned* bits_out; int n_words;      // optional: (y > 0) bits, n_words = N_total / 32 words per row (nbm_gemm_desc.bits_out)
 };
 constexpr int SPITCH = 36;
 // NTG: 32-wide channel blocks per accumulation group; WAVES per workgroup.  Two schedules, both aimed at keeping every wave's memory
@@ -349,6 +350,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void stream1x1_kernel(const StreamPa
   static_assert(NT % NTG == 0 && (!CHUNKED || NTG == NT), "groups");
   __shared__ __attribute__((aligned(16))) float Ws[N * WP];
   __shared__ __attribute__((aligned(16))) float Stg[WAVES][32 * SPITCH];
+  __shared__ __attribute__((aligned(16))) unsigned Bw[WAVES][32 * NT];       // (y > 0) words of a wave's 32-row tile (bits_out)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, lh = lane >> 5;
   // blockIdx.y = slice of N output channels (layers whose whole weight matrix does not fit LDS: every slice streams the rows again --
   // through L2, the slices of a tile run side by side -- and owns its columns of the output / residual)
@@ -472,9 +474,37 @@ __global__ __launch_bounds__(WAVES * 64, 1) void stream1x1_kernel(const StreamPa
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
           }
+          if (p.bits_out) {                          // the 8 lanes of a row (er) hold its 32 channels of block jj: one word
+            const int grp8 = 8 * er;                 // this row's byte of the wave-wide comparison masks: bit 8 e + q <-> channel 4 q + e
+            const unsigned wb = ((unsigned)(__builtin_amdgcn_ballot_w64(v[0] > 0.f) >> grp8) & 0xffu) |
+                                (((unsigned)(__builtin_amdgcn_ballot_w64(v[1] > 0.f) >> grp8) & 0xffu) << 8) |
+                                (((unsigned)(__builtin_amdgcn_ballot_w64(v[2] > 0.f) >> grp8) & 0xffu) << 16) |
+                                (((unsigned)(__builtin_amdgcn_ballot_w64(v[3] > 0.f) >> grp8) & 0xffu) << 24);
+            if (ec == 0) Bw[wave][r * NT + jj] = wb;        // written out row-contiguous once the tile is complete (below)
+          }
           *reinterpret_cast<f32x4*>(p.y + (long long)m * p.y_ld + n) = v;
         }
       }
+    }
+    if (p.bits_out) {
+      // the tile's 32 x NT words in pieces of NT / 2 consecutive words per lane: word by word from the lanes that formed them, these
+      // stores were 4 useful bytes per 32-byte sector (64 -> 256 @94x256 at B = 128: 1.47 -> 1.69 ms with the bits, round 5)
+      static_assert(NT >= 2 && NT % 2 == 0, "two lanes per tile row");
+      constexpr int WPL = NT / 2;                              // words per lane
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      const int r = lane >> 1, j0 = (lane & 1) * WPL;
+      const int m = m0 + r;
+      if (m < p.M) {
+        unsigned* dst = p.bits_out + (long long)m * p.n_words + (n_off >> 5) + j0;
+        const unsigned* src = Bw[wave] + r * NT + j0;
+        if constexpr (WPL == 4) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+        else if constexpr (WPL == 2) *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(src);
+        else {
+#pragma unroll
+          for (int q = 0; q < WPL; ++q) dst[q] = src[q];
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
   }
 }
@@ -540,6 +570,10 @@ extern "C" int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream) {
                (!d->mask || ((d->mask_ld & 3) == 0 && nbm_aligned16(d->mask))))
                   ? 1 : 0;
   if ((d->w_ld & 3) || (d->w_gs & 3) || !nbm_aligned16(d->w)) return NBM_EALIGN;
+  if (d->bits_out) {              // (y > 0) bits: written by the vector epilogue, whole 32-channel words
+    if (!p.vec_epi || (d->N & 31) || d->groups != 1 || d->rows) return NBM_EUNSUPPORTED;
+    p.bits_out = d->bits_out;
+  }
   if (d->up) {
     if (!p.vec_epi || d->groups != 1 || d->up_H <= 0 || d->up_W <= 0 || !nbm_aligned16(d->up)) return NBM_EUNSUPPORTED;
     p.up = d->up; p.up_H = d->up_H; p.up_W = d->up_W;
@@ -568,7 +602,7 @@ extern "C" int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream) {
   if (!(stream_env && stream_env[0] == '0') && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && d->groups == 1 && fast && p.vec_epi && !d->up && !d->mask &&
       !d->shift_per_row && (d->N % 32) == 0 && p.M >= 8192) {
     StreamParams sp{d->x, d->w, d->y, d->scale, d->shift, d->residual, p.M, d->x_ld, d->w_ld, d->y_ld, d->res_ld, (p.M + 31) / 32,
-                    d->alpha, d->act};
+                    d->alpha, d->act, d->bits_out, d->N >> 5};
     const int k32 = d->Cin / 32, nt = d->N / 32;
     // 64 -> 256 without a residual is write-bound and gains nothing (0.78 ms either way at B = 64): tiled kernel
     if (k32 == 2 && nt == 8 && d->residual) return launch_stream<2, 8, 4, 8, 1>(sp, st);

@@ -30,6 +30,7 @@ struct BwdParams {
   const float* row_scale;    // TN: per-n multiplier of dW rows or null
   const float* residual;     // NN: added to dX (gradient accumulation) or null
   const float* mask;         // NN: forward output of the producer; dX is zeroed where mask <= 0 (ReLU) or null
+  const unsigned* mask_bits; // NN: the same mask as bits, [M][Cin / 32] words (nbm_gemm_desc.bits_out of the producer), or null
   const float* residual2;    // NN: a HALF-resolution map [B][ceil(H/2)][ceil(W/2)][Cin] added at the pixels with even iy and ix, or null
   int res2_ld;
   long long g_gs, w_gs, x_gs, out_gs, res_gs;
@@ -345,7 +346,8 @@ __global__ __launch_bounds__(256, (STAGES == 1 || HS) ? 3 : 2) void igemm_nn_ker
 
   float* __restrict__ og = p.out + (long long)grp * p.out_gs;
   const float* __restrict__ rg = (p.residual && !NBM_ABL(p, ABL_NO_RESIDUAL)) ? p.residual + (long long)grp * p.res_gs : nullptr;
-  const float* __restrict__ mk_ = NBM_ABL(p, ABL_NO_MASK) ? nullptr : p.mask;
+  const unsigned* __restrict__ mb_ = NBM_ABL(p, ABL_NO_MASK) ? nullptr : p.mask_bits;     // the mask as bits takes precedence
+  const float* __restrict__ mk_ = (NBM_ABL(p, ABL_NO_MASK) || mb_) ? nullptr : p.mask;
   const float* __restrict__ r2_ = NBM_ABL(p, ABL_NO_RESIDUAL) ? nullptr : p.residual2;
   if (NBM_ABL(p, ABL_NO_EPILOGUE)) {                                       // keep the accumulators alive: a store that never happens
     float t = 0.f;
@@ -381,7 +383,8 @@ __global__ __launch_bounds__(256, (STAGES == 1 || HS) ? 3 : 2) void igemm_nn_ker
       // residual / mask values of this thread's rows: requested before the accumulators go through LDS (inside the row loop, behind
       // its exit test, they were 2 NR dependent round trips at the end of every tile -- igemm.hip)
       f32x4 rq[NR], mq[NR];
-      const bool pre = c < p.Cin && (rg || mk_);
+      unsigned mw[NR];                                          // mask words (Cin % 32 == 0: the word of channels c .. c + 3 of the row)
+      const bool pre = c < p.Cin && (rg || mk_ || mb_);
       if (pre) {
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
@@ -389,6 +392,7 @@ __global__ __launch_bounds__(256, (STAGES == 1 || HS) ? 3 : 2) void igemm_nn_ker
           const long long m = out_pixel(qq);
           if (rg) rq[k] = *reinterpret_cast<const f32x4*>(rg + m * p.res_ld + c);
           if (mk_) mq[k] = *reinterpret_cast<const f32x4*>(mk_ + m * p.mask_ld + c);
+          if (mb_) mw[k] = mb_[m * (p.Cin >> 5) + (c >> 5)];
         }
       }
       if (HALVES == 1 || wm0 == half * HROWS) {
@@ -430,6 +434,11 @@ __global__ __launch_bounds__(256, (STAGES == 1 || HS) ? 3 : 2) void igemm_nn_ker
 #pragma unroll
           for (int e = 0; e < 4; ++e) if (!(q[e] > 0.f)) v[e] = 0.f;
         }
+        if (mb_) {
+          const unsigned by = mw[k] >> ((c >> 2) & 7);        // bit 8 e + q of the word <-> channel 4 q + e (nbm_hip.h)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (!((by >> (8 * e)) & 1u)) v[e] = 0.f;
+        }
         if (!NBM_ABL(p, ABL_NO_STORE) || v[0] == 1.2345e-30f) *reinterpret_cast<f32x4*>(og + (long long)m * p.out_ld + c) = v;
       }
     }
@@ -459,6 +468,7 @@ __global__ __launch_bounds__(256, (STAGES == 1 || HS) ? 3 : 2) void igemm_nn_ker
             v += r2_[(((long long)b_ * ((p.H + 1) >> 1) + (iy_ >> 1)) * ((p.W + 1) >> 1) + (ix_ >> 1)) * p.res2_ld + c];
         }
         if (mk_ && !(mk_[(long long)m * p.mask_ld + c] > 0.f)) v = 0.f;
+        if (mb_ && !((mb_[m * (p.Cin >> 5) + (c >> 5)] >> (8 * (c & 3) + ((c >> 2) & 7))) & 1u)) v = 0.f;
         og[(long long)m * p.out_ld + c] = v;
       }
   }
@@ -775,6 +785,10 @@ extern "C" int nbm_conv_dgrad(const nbm_bwd_desc* d, void* stream) {
   if (d->out_ld < d->Cin || (d->residual && d->res_ld < d->Cin) || (d->mask && d->mask_ld < d->Cin)) return NBM_EINVAL;
   if (d->residual2 && (d->stride != 1 || d->groups != 1 || d->res2_ld < d->Cin)) return NBM_EINVAL;
   if (d->a_scale && (d->N & 31)) return NBM_EINVAL;
+  if (d->mask_bits) {                    // the ReLU mask as bits: whole 32-channel words, one group
+    if ((d->Cin & 31) || d->groups != 1) return NBM_EUNSUPPORTED;
+    p.mask_bits = d->mask_bits;
+  }
   // the gather window of one 128-row tile (+ one image boundary) must stay inside the 2 GB buffer resource
   {
     const long long row = (long long)d->Wo * d->g_ld * 4;                  // bytes per G image row

@@ -28,6 +28,8 @@ struct IgemmParams {
   const int* rows; const int* rows_blocks; int rows_mode, rows_TH, rows_TW;
   // producer mask (vector and scalar epilogue, not ROWS): y = 0 where mask[m][n] <= 0 -- a 1x1 data gradient run as this forward GEMM
   const float* mask; int mask_ld;
+  // one bit per stored output element, (y > 0), 32 channels per word (vector epilogue, N % 32 == 0, one group, not ROWS) -- or null
+  unsigned* bits_out;
   // launch-invariant divisors of the row decode (nbm_fastdiv, nbm_common.h): output pixels per image, output row width, and the tile grid
   // of rows_mode 2
   nbm_fastdiv fd_howo, fd_wo, fd_rows_thw, fd_rows_tw;

@@ -53,6 +53,36 @@ def grad_sink(param, rows, cols):
     return g.view(rows, cols), (lambda q=q, mark=e[1]: mark(q))
 
 
+# The ReLU mask of a bottleneck's output as BITS (round 5): the epilogue that stores y = relu(...) also stores (y > 0), 32 channels per word
+# (`nbm_gemm_desc.bits_out`); the next block's first data-gradient kernel, whose epilogue zeroes d/dx where its input was <= 0, then reads
+# 1/32 of the bytes it read from y itself (`nbm_bwd_desc.mask_bits`) -- those kernels run at the HBM roof through exactly these bytes
+# (profiles/r05_dgrad_attribution.txt).  The bits belong to the tensor OBJECT that the forward pass produced (same storage, same version).
+RELU_BITS = os.environ.get('NBM_RELU_BITS', '1') != '0'
+_RELU_BITS = {}         # data_ptr of a ReLU output -> (weakref to it, its version, int32 bits [numel / 32])
+
+
+def _relu_bits_forget(ptr, ident):
+    e = _RELU_BITS.get(ptr)
+    if e is not None and id(e[2]) == ident:
+        del _RELU_BITS[ptr]
+
+
+def relu_bits_note(y, bits):
+    _RELU_BITS[y.data_ptr()] = (weakref.ref(y), y._version, bits)
+    weakref.finalize(y, _relu_bits_forget, y.data_ptr(), id(bits))
+
+
+def relu_bits_of(t):
+    """The (t > 0) bits written together with `t`, or None."""
+    e = _RELU_BITS.get(t.data_ptr()) if RELU_BITS else None
+    if e is None:
+        return None
+    q = e[0]()
+    if q is None or q.data_ptr() != t.data_ptr() or q.shape != t.shape or t._version != e[1]:
+        return None
+    return e[2]
+
+
 def _w_to_ref_layout(gw, weight):
     """KRSC gradient rows [N, >=K] -> the parameter's own layout."""
     if weight.dim() == 2:
@@ -429,7 +459,15 @@ class Bottleneck(Function):
         else:
             a2 = ops.conv2d(a1, _prep.krsc(w2), 3, 3, stride, 1, scale=s2, shift=b2, act=ACT_RELU)
         idt = x if wd is None else ops.conv2d(x, _prep.krsc(wd), 1, 1, stride, 0, scale=sd, shift=bd)
-        y = ops.conv2d(a2, _prep.krsc(w3), scale=s3, shift=b3, residual=idt, act=ACT_RELU)
+        # a backward pass may follow: the epilogue also writes (y > 0) as bits for the NEXT block's data gradient (relu_bits_note)
+        N3 = w3.shape[0]
+        bits = None
+        if RELU_BITS and any(ctx.needs_input_grad) and N3 % 32 == 0:
+            bits = torch.empty((a2.shape[0] * a2.shape[1] * a2.shape[2] * (N3 // 32),), device=x.device, dtype=torch.int32)
+        y = ops.conv2d(a2, _prep.krsc(w3), scale=s3, shift=b3, residual=idt, act=ACT_RELU, bits_out=bits)
+        if bits is not None:
+            relu_bits_note(y, bits)
+        ctx.x_bits = relu_bits_of(x)             # this block's input as bits, if its producer wrote them
         ctx.save_for_backward(x, a1, a2, y, w1, w2, w3, wd, s1, s2, s3, sd)
         ctx.cfg = (stride, mask_input, mask_gy, wino)
         # first block of a stage: its input is a backbone tap that the FPN lateral reads too -- the lateral's backward pass runs
@@ -501,8 +539,9 @@ class Bottleneck(Function):
         gx = None
         if need[0]:
             gx = torch.empty_like(x)
+            masked = mask_input or premask
             ops.conv_dgrad(g1r, k1, gx, B=B, H=H, W=W, Cin=Cin, N=P, g_ld=P, w_ld=k1.shape[1], a_scale=s1, residual=gid,
-                           residual2=gid2, mask=x if mask_input or premask else None)
+                           residual2=gid2, mask=x if masked else None, mask_bits=ctx.x_bits if masked else None)
             if premask:
                 _PREMASKED[x.data_ptr()] = (gx.data_ptr(), gx._version)
         return (gx, gw1, gw2, gw3, gwd) + (None,) * 11

@@ -76,8 +76,9 @@ def lib():
 def gemm_conv(x, w, y, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, Ho=None, Wo=None,
               x_ld=None, w_ld=None, y_ld=None, scale=None, shift=None, residual=None, res_ld=None,
               groups=1, x_gs=0, w_gs=0, y_gs=0, res_gs=0, alpha=1.0, act=ACT_NONE, shift_per_row=False, up=None,
-              rows=None, rows_mode=0, rows_count=0, rows_blocks=None, rows_thw=(0, 0), mask=None, mask_ld=None):
-    """Raw call of nbm_gemm_conv (see include/nbm_hip.h for the exact semantics)."""
+              rows=None, rows_mode=0, rows_count=0, rows_blocks=None, rows_thw=(0, 0), mask=None, mask_ld=None, bits_out=None):
+    """Raw call of nbm_gemm_conv (see include/nbm_hip.h for the exact semantics).  `bits_out` (int32 [M * N / 32]): one bit per stored
+    output element, (y > 0) -- the ReLU mask of the consumer's data gradient (`conv_dgrad(mask_bits=)`)."""
     Ho = (H + 2 * pad - kh) // stride + 1 if Ho is None else Ho
     Wo = (W + 2 * pad - kw) // stride + 1 if Wo is None else Wo
     d = GemmDesc()
@@ -98,6 +99,9 @@ def gemm_conv(x, w, y, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, Ho=None,
         d.up, d.up_H, d.up_W = _chk(up, name='up').data_ptr(), up.shape[1], up.shape[2]
     if mask is not None:                     # producer mask: y = 0 where mask <= 0 (a 1x1 data gradient run as a forward GEMM)
         d.mask, d.mask_ld = mask.data_ptr(), int(N if mask_ld is None else mask_ld)
+    if bits_out is not None:
+        assert bits_out.dtype == torch.int32 and bits_out.is_contiguous() and bits_out.numel() * 32 >= B * Ho * Wo * N and N % 32 == 0
+        d.bits_out = bits_out.data_ptr()
     if rows is not None:                     # listed pixels only (the lateral of a demand-driven FPN level)
         d.rows, d.rows_mode, d.rows_count = rows.data_ptr(), int(rows_mode), int(rows_count)
         d.rows_blocks = rows_blocks.data_ptr() if rows_blocks is not None else None
@@ -126,7 +130,7 @@ def gemm_conv(x, w, y, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, Ho=None,
 
 
 def conv2d(x, w, kh=1, kw=1, stride=1, pad=0, scale=None, shift=None, residual=None, act=ACT_NONE,
-           alpha=1.0, out=None, w_ld=None, up=None):
+           alpha=1.0, out=None, w_ld=None, up=None, bits_out=None):
     """x [B,H,W,Cin] NHWC, w [N, w_ld>=kh*kw*Cin] (KRSC rows) -> [B,Ho,Wo,N]; `up` [B,h,w,N]: + bilinear(up)."""
     _chk(x, name='x'), _chk(w, name='w')
     B, H, W, Cin = x.shape
@@ -139,7 +143,7 @@ def conv2d(x, w, kh=1, kw=1, stride=1, pad=0, scale=None, shift=None, residual=N
         assert residual.shape == y.shape
     gemm_conv(x, w, y, B=B, H=H, W=W, Cin=Cin, N=N, kh=kh, kw=kw, stride=stride, pad=pad, Ho=Ho, Wo=Wo,
               w_ld=w.shape[1] if w_ld is None else w_ld, scale=scale, shift=shift, residual=residual,
-              alpha=alpha, act=act, up=up)
+              alpha=alpha, act=act, up=up, bits_out=bits_out)
     return y
 
 
@@ -795,7 +799,8 @@ def split_nn():
 
 
 def conv_dgrad(g, w, out, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, g_ld=None, w_ld=None, out_ld=None,
-               a_scale=None, residual=None, mask=None, alpha=1.0, groups=1, g_gs=0, w_gs=0, out_gs=0, res_gs=0, residual2=None):
+               a_scale=None, residual=None, mask=None, alpha=1.0, groups=1, g_gs=0, w_gs=0, out_gs=0, res_gs=0, residual2=None,
+               mask_bits=None):
     """Raw nbm_conv_dgrad: out[B*H*W][Cin] = gather(g)[..][N] x W (see include/nbm_hip.h).  `residual2` [B, ceil(H/2), ceil(W/2),
     Cin]: added at the pixels with even row and column (a stride-2 shortcut's data gradient at its own resolution)."""
     if (kh == 1 and kw == 1 and stride == 1 and pad == 0 and residual2 is None and N > 256 and N % 32 == 0 and Cin > 64 and Cin % 4 == 0 and
@@ -823,6 +828,10 @@ def conv_dgrad(g, w, out, *, B, H, W, Cin, N, kh=1, kw=1, stride=1, pad=0, g_ld=
     d.res_ld = Cin if residual is not None else 0
     d.mask = mask.data_ptr() if mask is not None else None
     d.mask_ld = Cin if mask is not None else 0
+    if mask_bits is not None and groups == 1 and Cin % 32 == 0:
+        # the same mask as one bit per element (written by the producer's epilogue, `gemm_conv(bits_out=)`): 1/32 of the bytes
+        assert mask_bits.dtype == torch.int32 and mask_bits.numel() * 32 >= B * H * W * Cin
+        d.mask_bits, d.mask, d.mask_ld = mask_bits.data_ptr(), None, 0
     if residual2 is not None:
         if groups != 1 or tuple(residual2.shape) != (B, (H + 1) // 2, (W + 1) // 2, Cin) or kh != 1 or stride != 1:
             raise ValueError('conv_dgrad: residual2 must be [B, ceil(H/2), ceil(W/2), Cin] of a 1x1 / stride-1 data gradient')

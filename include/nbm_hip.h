@@ -96,6 +96,11 @@ typedef struct nbm_gemm_desc {
    * 16-byte aligned with mask_ld % 4 == 0 (otherwise the scalar epilogue runs). */
   const float* mask;
   int mask_ld;
+  /* Optional (round 5): one BIT per output element, (stored y > 0), 32 channels per word -- bits_out[m * (N / 32) + n / 32], bit
+   * 8 (n % 4) + (n % 32) / 4 (the four comparison masks of a 16-byte lane group side by side: no bit shuffling in the epilogue) --
+   * written by the same epilogue (vector epilogue, N % 32 == 0, one group, not with `rows`; otherwise NBM_EUNSUPPORTED).  The ReLU mask of
+   * the consumer's data gradient (nbm_bwd_desc.mask_bits) at 1/32 of the bytes of re-reading y. */
+  unsigned* bits_out;
 } nbm_gemm_desc;
 
 /* Environment switch, read on every call: NBM_SPLIT_BF16=1 runs the deep-K launches (K = kh*kw*Cin > 256, N > 64, Cin % 32 == 0,
@@ -453,6 +458,9 @@ typedef struct nbm_bwd_desc {
                             the pixels with even iy and ix -- the data gradient of the block's 1x1 / stride-2 shortcut
                             (torchvision Bottleneck.downsample), which is non-zero only there -- or NULL                    */
   int res2_ld;
+  const unsigned* mask_bits;/* dgrad (round 5): the ReLU mask as BITS instead of `mask` -- [M][Cin / 32] words, bit c % 32 of word
+                            m * (Cin / 32) + c / 32 (bit order of nbm_gemm_desc.bits_out) set where the producer's output was > 0 -- or NULL.
+                            Cin % 32 == 0, one group; takes precedence over `mask`.                                          */
 } nbm_bwd_desc;
 
 /* dX[b][iy][ix][c] = alpha * sum_{r,s,n} g[b][(iy+pad-r)/stride][(ix+pad-s)/stride][n] * a_scale[n] * W[n][r][s][c]

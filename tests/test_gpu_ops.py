@@ -446,6 +446,52 @@ def test_half_step_data_gradient_gives_the_bits_of_the_two_stage_kernel(cfg, mon
     assert err <= 2e-5 * (1 + float(ref.abs().max())), (cfg, err)
 
 
+@pytest.mark.parametrize('cfg', [
+    # B, H, W, Cin, N, residual     -- one launch per kernel that finishes a bottleneck: streaming 1x1 (K = 64 / sliced 128 / 256), single-stage,
+    (2, 70, 64, 64, 256, True),     # half-step deep K
+    (2, 70, 64, 128, 512, True),
+    (2, 70, 64, 256, 1024, True),
+    (3, 17, 23, 256, 96, False),    # single-stage tiled kernel (M < 8192: not the streaming form), 96 = 3 words per row
+    (1, 24, 32, 512, 2048, True),
+])
+def test_relu_bits_of_the_forward_epilogues_and_their_use_as_data_gradient_mask(cfg):
+    """`nbm_gemm_desc.bits_out`: the epilogue that stores y also stores (y > 0), 32 channels per word -- checked against y itself for every
+    kernel that finishes a ResNet bottleneck; `nbm_bwd_desc.mask_bits`: the data gradient masked by those bits is, bit for bit, the one
+    masked by y."""
+    B, H, W, Ci, N, with_res = cfg
+
+    def nrm(key, *shape, scale=1.0):
+        return torch.from_numpy((synth.normal((key, cfg), int(np.prod(shape))) * scale).astype(np.float32).reshape(shape)).cuda()
+
+    x = torch.relu(nrm('bx', B, H, W, Ci))
+    w = nrm('bw', N, Ci, scale=(2.0 / Ci) ** 0.5)
+    sc, sh = 1 + 0.1 * nrm('bs', N), 0.1 * nrm('bb', N)
+    res = nrm('br', B, H, W, N) if with_res else None
+    bits = torch.full((B * H * W * N // 32,), -1, device='cuda', dtype=torch.int32)
+    y = ops.conv2d(x, w, scale=sc, shift=sh, residual=res, act=ops.ACT_RELU, bits_out=bits)
+    y0 = ops.conv2d(x, w, scale=sc, shift=sh, residual=res, act=ops.ACT_RELU)
+    assert torch.equal(y, y0)
+    want = (y.view(-1, 32) > 0).to(torch.int64)
+    pos = torch.tensor([8 * (ch % 4) + ch // 4 for ch in range(32)], device='cuda')       # bit of channel ch within its word (nbm_hip.h)
+    packed = (want << pos).sum(1)
+    packed = torch.where(packed >= 2 ** 31, packed - 2 ** 32, packed).to(torch.int32)
+    assert torch.equal(bits, packed), cfg
+    assert 0.2 < float(want.float().mean()) < 0.8                  # (the mask is not trivial)
+    # consumer: d/dy of a following 1x1 (y [.., N] -> P channels), masked by y / by the bits
+    P = 64
+    g = nrm('bg', B * H * W, P, scale=0.1)
+    wk = nrm('bk', P, N, scale=(2.0 / N) ** 0.5)
+    a_scale = 1 + 0.1 * nrm('ba', P)
+    short = nrm('bh', B, H, W, N)
+    outs = []
+    for kw in (dict(mask=y), dict(mask=y, mask_bits=bits)):
+        out = torch.empty((B, H, W, N), device='cuda')
+        ops.conv_dgrad(g, wk, out, B=B, H=H, W=W, Cin=N, N=P, g_ld=P, w_ld=N, a_scale=a_scale, residual=short, **kw)
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1]), cfg
+    assert float((outs[1] == 0).float().mean()) > 0.15
+
+
 def test_winograd_fused_block_shapes_give_the_same_bits(monkeypatch):
     """The fused F(2x2,3x3) kernel in its 96-row block shape (chosen for dense launches whose 128-row blocks leave the last round of
     workgroups half empty, csrc/wino_fused.hip) against the 128-row shape: every output sums its planes and K-steps in the same order, so
