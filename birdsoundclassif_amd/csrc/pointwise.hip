@@ -459,7 +459,7 @@ __global__ void pair_softmax_kernel(const float* __restrict__ x, long long n_pix
 
 }  // namespace
 
-extern "C" const char* nbm_version(void) { return "nbm_hip 0.3 (gfx950)"; }
+extern "C" const char* nbm_version(void) { return "nbm_hip 0.4 (gfx950)"; }
 
 extern "C" int nbm_graph_census(void* graph, long long counts[6]) {
   if (!graph || !counts) return NBM_EINVAL;
