@@ -549,6 +549,27 @@ extern "C" int nbm_gemm_conv(const nbm_gemm_desc* d, void* stream) {
   if ((d->H + 2 * d->pad - d->kh) / d->stride + 1 != d->Ho || (d->W + 2 * d->pad - d->kw) / d->stride + 1 != d->Wo)
     return NBM_EINVAL;
   if (d->x_ld < d->Cin || d->y_ld < d->N || (d->residual && d->res_ld < d->N)) return NBM_EINVAL;
+  // An output width 64 past a multiple of 128 (the cell-domain data-gradient planes of the deferred lateral: 256 -> 448): the last 128-wide
+  // tile would be half padding -- the first N - 64 channels on 128-wide tiles, the last 64 on the 64-wide kernel.  Every output element is the
+  // same sum in the same order either way (round 5; weight-gradient twin: nbm_conv_wgrad).
+  {
+    static const int tail_split = getenv("NBM_NT_TAIL") ? atoi(getenv("NBM_NT_TAIL")) : 1;
+    if (tail_split && d->N > 128 && (d->N & 127) == 64 && !d->rows && !d->up && !d->bits_out && !d->shift_per_row && (d->Cin % BK) == 0 &&
+        d->kh * d->kw * d->Cin > 256) {
+      nbm_gemm_desc a = *d, b = *d;
+      const int n0 = d->N - 64;
+      a.N = n0;
+      b.N = 64;
+      b.w = d->w + (long long)n0 * d->w_ld;
+      b.y = d->y + n0;
+      if (d->scale) b.scale = d->scale + n0;
+      if (d->shift) b.shift = d->shift + n0;
+      if (d->residual) b.residual = d->residual + n0;
+      if (d->mask) b.mask = d->mask + n0;
+      const int rc = nbm_gemm_conv(&a, stream);
+      return rc ? rc : nbm_gemm_conv(&b, stream);
+    }
+  }
   IgemmParams p{};
   p.x = d->x; p.w = d->w; p.y = d->y; p.scale = d->scale; p.shift = d->shift; p.residual = d->residual;
   p.x_gs = d->x_gs; p.w_gs = d->w_gs; p.y_gs = d->y_gs; p.res_gs = d->res_gs;

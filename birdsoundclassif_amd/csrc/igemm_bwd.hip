@@ -863,6 +863,23 @@ extern "C" int nbm_conv_wgrad(const nbm_bwd_desc* d, void* stream) {
   p.b_generic = ((d->Cin & 3) || (d->x_ld & 3) || (d->x_gs & 3) || !nbm_aligned16(d->x)) ? 1 : 0;
   const int taps = d->kh * d->kw;
   if (d->out_ld < taps * d->Cin) return NBM_EINVAL;
+  // Plain GEMMs whose column count is 64 past a multiple of 128 (the cell-domain planes of the deferred lateral: [T][256]^T x [T][448]): the
+  // 128-wide tiles would multiply 64 columns of padding in the last tile (1 / 8 of the MFMA work of 448 columns: 110 against 122 TF/s for
+  // the 384-column twin, round 5) -- the first Cin - 64 columns on 128-wide tiles, the last 64 on the 64-wide kernel.  Same sums per element
+  // (the split over the pixels is chosen per launch; the atomics make the order free anyway).
+  {
+    static const int tail_split = getenv("NBM_TN_TAIL") ? atoi(getenv("NBM_TN_TAIL")) : 1;
+    if (tail_split && taps == 1 && d->stride == 1 && d->pad == 0 && !p.b_generic && d->Cin > 128 && (d->Cin & 127) == 64) {
+      nbm_bwd_desc a = *d, b = *d;
+      a.Cin = d->Cin - 64;
+      b.Cin = 64;
+      b.x = d->x + (d->Cin - 64);
+      b.out = d->out + (d->Cin - 64);
+      b.bias_grad = nullptr;                                   // (the column sums of G come from the first launch)
+      rc = nbm_conv_wgrad(&a, stream);
+      return rc ? rc : nbm_conv_wgrad(&b, stream);
+    }
+  }
   p.M = d->B * d->Ho * d->Wo;
   const bool narrow_m = d->N <= 64 && !p.b_generic;            // 64-row dW tiles: no MFMA spent on the zero half of a 128-row G tile
   p.m_tiles = narrow_m ? 1 : (d->N + 127) / 128;
