@@ -457,7 +457,13 @@ class Bottleneck(Function):
         if wino:              # 3x3 / stride 1 with >= 128 channels: Winograd, FrozenBN + ReLU in the output transform
             a2 = ops.conv3x3_winograd(a1, _prep.wino23(w2), b2, scale=s2, relu=True)
         else:
-            a2 = ops.conv2d(a1, _prep.krsc(w2), 3, 3, stride, 1, scale=s2, shift=b2, act=ACT_RELU)
+            # (direct 3x3: its epilogue can write the ReLU bits of a2 too -- the mask of conv3's data gradient, 1/6 of that launch's bytes)
+            P_ = w2.shape[0]
+            ctx.a2_bits = None
+            if RELU_BITS and any(ctx.needs_input_grad) and P_ % 32 == 0:
+                Ho_, Wo_ = (a1.shape[1] + 2 - 3) // stride + 1, (a1.shape[2] + 2 - 3) // stride + 1
+                ctx.a2_bits = torch.empty((a1.shape[0] * Ho_ * Wo_ * (P_ // 32),), device=x.device, dtype=torch.int32)
+            a2 = ops.conv2d(a1, _prep.krsc(w2), 3, 3, stride, 1, scale=s2, shift=b2, act=ACT_RELU, bits_out=ctx.a2_bits)
         idt = x if wd is None else ops.conv2d(x, _prep.krsc(wd), 1, 1, stride, 0, scale=sd, shift=bd)
         # a backward pass may follow: the epilogue also writes (y > 0) as bits for the NEXT block's data gradient (relu_bits_note)
         N3 = w3.shape[0]
@@ -500,7 +506,8 @@ class Bottleneck(Function):
 
         gw3 = wgrad(g3r, a2, k3, w3, s3, B=B, H=Ho, W=Wo, Cin=P, N=N3) if need[3] else None
         g2 = torch.empty_like(a2)
-        ops.conv_dgrad(g3r, k3, g2, B=B, H=Ho, W=Wo, Cin=P, N=N3, g_ld=N3, w_ld=k3.shape[1], a_scale=s3, mask=a2)
+        ops.conv_dgrad(g3r, k3, g2, B=B, H=Ho, W=Wo, Cin=P, N=N3, g_ld=N3, w_ld=k3.shape[1], a_scale=s3, mask=a2,
+                       mask_bits=getattr(ctx, 'a2_bits', None))
         g2r = g2.view(-1, P)
         geom2 = dict(B=B, H=H, W=W, Cin=P, N=P, kh=3, kw=3, stride=stride, pad=1)
         if wino:              # both gradients of the 3x3 in the Winograd domain (F(4x4,3x3)); BN scale folded into the weights

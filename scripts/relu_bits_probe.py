@@ -43,3 +43,21 @@ for label, H, W, P in (('layer1 64->256', 94, 256, 64), ('layer2 128->512', 47, 
     t0 = t(lambda: ops.conv2d(x, w, scale=sc, shift=sh, residual=res, act=ops.ACT_RELU, out=y))
     t1 = t(lambda: ops.conv2d(x, w, scale=sc, shift=sh, residual=res, act=ops.ACT_RELU, out=y, bits_out=bits))
     print(f'{label:<18} forward {t0:.3f} ms   with bits_out {t1:.3f} ms', flush=True)
+
+# the inner mask of layer1: 3x3 64 -> 64 (+ BN + ReLU) writes a2 (+ bits); conv3's data gradient (G 256 -> dX 64) masks by a2
+H, W, P = 94, 256, 64
+x = torch.relu(torch.randn(B, H, W, P, device='cuda'))
+w = torch.randn(P, 9 * P, device='cuda') * 0.05
+sc, sh = torch.rand(P, device='cuda') + 0.5, torch.randn(P, device='cuda')
+y = torch.empty(B, H, W, P, device='cuda')
+bits = torch.empty(B * H * W * P // 32, device='cuda', dtype=torch.int32)
+t0 = t(lambda: ops.conv2d(x, w, 3, 3, 1, 1, scale=sc, shift=sh, act=ops.ACT_RELU, out=y))
+t1 = t(lambda: ops.conv2d(x, w, 3, 3, 1, 1, scale=sc, shift=sh, act=ops.ACT_RELU, out=y, bits_out=bits))
+print(f'layer1 3x3 64->64  forward {t0:.3f} ms   with bits_out {t1:.3f} ms', flush=True)
+g = torch.randn(B * H * W, 4 * P, device='cuda') * 0.1
+wk = torch.randn(4 * P, P, device='cuda') * 0.05
+s3 = torch.rand(4 * P, device='cuda') + 0.5
+out = torch.empty(B, H, W, P, device='cuda')
+t0 = t(lambda: ops.conv_dgrad(g, wk, out, B=B, H=H, W=W, Cin=P, N=4 * P, g_ld=4 * P, w_ld=P, a_scale=s3, mask=y))
+t1 = t(lambda: ops.conv_dgrad(g, wk, out, B=B, H=H, W=W, Cin=P, N=4 * P, g_ld=4 * P, w_ld=P, a_scale=s3, mask=y, mask_bits=bits))
+print(f'layer1 64->256 data gradient (G 256 -> dX 64): mask from a2 {t0:.3f} ms   as bits {t1:.3f} ms', flush=True)
