@@ -371,8 +371,11 @@ __global__ __launch_bounds__(256, (STAGES == 1 || HS) ? 3 : 2) void igemm_nn_ker
     constexpr int CP = BN + 4;
     constexpr int HALVES = (STAGES == 1 || HS) ? BM / WM : 1;  // the single-stage / half-step LDS holds WM rows of the tile at a time
     constexpr int HROWS = BM / HALVES;
-    static_assert(HROWS * CP <= STAGES * (BM * AP + KS * BP), "epilogue tile must fit the operand buffers");
+    static_assert(HROWS * CP + 2 * HROWS <= STAGES * (BM * AP + KS * BP), "epilogue tile + row table must fit the operand buffers");
     float* Cs = lds;
+    // stride 2: the output pixel of a tile row (parity-class sub-grid -> image) is decoded ONCE per row into LDS, not by each of the row's
+    // BN / 4 threads in the prefetch AND in the store loop (two fast divisions + the parity arithmetic per call; round 5)
+    long long* const Rm = reinterpret_cast<long long*>(lds + HROWS * CP);     // [HROWS]; HROWS * CP is even
     constexpr int CH = BN / 4, RPP = 256 / CH;
     const int cc = tid % CH, rr = tid / CH;
     const int c = bn0 + cc * 4;
@@ -380,6 +383,13 @@ __global__ __launch_bounds__(256, (STAGES == 1 || HS) ? 3 : 2) void igemm_nn_ker
 #pragma unroll
     for (int half = 0; half < HALVES; ++half) {
       if (HALVES > 1 && half) __syncthreads();                  // the previous half has been read
+      if (p.phased) {
+        if (tid < HROWS) Rm[tid] = out_pixel(min(q0 + half * HROWS + tid, rows_here - 1));
+        __syncthreads();
+      }
+      auto row_out = [&](int rl) -> long long {                 // output pixel of row rl of this half (clamped to the last row of the class)
+        return p.phased ? Rm[rl] : (long long)min(q0 + half * HROWS + rl, rows_here - 1);
+      };
       // residual / mask values of this thread's rows: requested before the accumulators go through LDS (inside the row loop, behind
       // its exit test, they were 2 NR dependent round trips at the end of every tile -- igemm.hip)
       f32x4 rq[NR], mq[NR];
@@ -388,8 +398,7 @@ __global__ __launch_bounds__(256, (STAGES == 1 || HS) ? 3 : 2) void igemm_nn_ker
       if (pre) {
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
-          const int qq = min(q0 + half * HROWS + rr + k * RPP, rows_here - 1);
-          const long long m = out_pixel(qq);
+          const long long m = row_out(min(rr + k * RPP, HROWS - 1));
           if (rg) rq[k] = *reinterpret_cast<const f32x4*>(rg + m * p.res_ld + c);
           if (mk_) mq[k] = *reinterpret_cast<const f32x4*>(mk_ + m * p.mask_ld + c);
           if (mb_) mw[k] = mb_[m * (p.Cin >> 5) + (c >> 5)];
@@ -412,7 +421,7 @@ __global__ __launch_bounds__(256, (STAGES == 1 || HS) ? 3 : 2) void igemm_nn_ker
         if (rl >= HROWS) break;
         const int r = half * HROWS + rl;
         if (q0 + r >= rows_here) break;
-        const long long m = out_pixel(q0 + r);
+        const long long m = row_out(rl);
         f32x4 v = *reinterpret_cast<const f32x4*>(Cs + rl * CP + cc * 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
