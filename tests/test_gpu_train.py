@@ -481,6 +481,22 @@ def test_fused_bottleneck_chain_backward(P):
         for k in ('w1', 'w2', 'w3', 'wd'):
             if ws[k] is not None:
                 close(wdv[k].grad, ws[k].grad, 5e-5, f'bottleneck {bi} d{k}')
+    # the ReLU masks as bits (functional.RELU_BITS: written by the blocks' forward epilogues, read by the next block's data gradient) or
+    # read from the activations themselves: the same d/dx, bit for bit
+    assert Fn.RELU_BITS
+    Fn.RELU_BITS = False
+    try:
+        xd2 = nhwc(x).requires_grad_(True)
+        hd2 = xd2
+        for bi, ((ws, aff, s), wdv) in enumerate(zip(blocks, dev)):
+            a = {k: (v[0].cuda(), v[1].cuda()) for k, v in aff.items()}
+            sd, bd = a['d'] if wdv['wd'] is not None else (None, None)
+            hd2 = Fn.Bottleneck.apply(hd2, wdv['w1'], wdv['w2'], wdv['w3'], wdv['wd'], *a['1'], *a['2'], *a['3'], sd, bd, s,
+                                      True, bi == 2)
+        hd2.backward(nhwc(go))
+    finally:
+        Fn.RELU_BITS = True
+    assert torch.equal(hd2, hd) and torch.equal(xd2.grad, xd.grad)
 
 
 @pytest.mark.parametrize('override,expect', [
